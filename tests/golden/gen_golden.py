@@ -1,0 +1,419 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by IMPORTING the reference's own Python.
+
+Runs only in the build container (needs /root/reference; the GPU box never sees it).
+    python tests/golden/gen_golden.py
+The fixtures are plain data (inputs + the reference's outputs); no reference source is copied.
+
+What is pinned: A1 A2 A3 (action chain, float32 bit patterns and the
+force/torque values handed to the Bullet C-API), A6 (observation packing), A7 A8 A9 (reward,
+termination, truncation, post-step/reset bookkeeping incl. quirks Q1-Q5), A10
+(normalize.NormalizeObservation), A12 (tracks), N1 (the GAE lines of cleanRLPPO.py).
+What is NOT pinned: A4/A5's Bullet half -- the fake pybullet integrates with the oracle's own
+restatement (tests/golden/_ref_stubs.py), so closed-loop fixtures validate everything AROUND
+the integrator, not the integrator.
+
+SB3's SubprocVecEnv worker and Monitor are not in the tree either; `RefVec` below restates
+their auto-reset/episode-statistics semantics from memory [3P-recall] around the real
+reference env + the real reference normalize.NormalizeObservation.
+"""
+import os
+import sys
+import textwrap
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+from oracle import oracle as O          # noqa: E402
+import _ref_stubs                        # noqa: E402
+
+pb = _ref_stubs.install(O.lib())
+os.chdir(REF)                            # the reference opens "Sol/resources/..." relative to cwd
+sys.path.insert(0, REF)
+import io                                # noqa: E402
+import contextlib                        # noqa: E402
+
+with contextlib.redirect_stdout(io.StringIO()):
+    from Sol.Model.Environments.PBDroneEnv import PBDroneEnv      # noqa: E402
+    from Sol.Model.Environments import normalize as ref_normalize  # noqa: E402
+    from Sol.Utilities import Waypoints                            # noqa: E402
+    from Sol.PyBullet.enums import ActionType                      # noqa: E402
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def make_ref_env(targets, spawn, dim, circle, max_steps=4096, threshold=0.3):
+    """PBDroneEnv exactly as PBDroneSimulator.make_env builds it (PBDroneSimulator.py:154-171)."""
+    return quiet(PBDroneEnv, target_points=targets, threshold=threshold, discount=0.999, max_steps=max_steps,
+                 act=ActionType.THRUST, gui=False, initial_xyzs=spawn, save_folder=None, aviary_dim=dim,
+                 random_spawn=False, cylinder=True, circle=circle, include_distance=True,
+                 normalize_actions=True, collect_rollouts=False)
+
+
+def track_circle(n):
+    wp, spawn, dim = Waypoints.circle(radius=1, num_points=n, height=1)
+    targets = [np.array(w) for w in wp]
+    targets.pop(0)                       # PBDroneSimulator.py:129-130 (circle tracks drop the first point)
+    return targets, spawn, dim, True
+
+
+def track_reaching():
+    wp, spawn, dim = Waypoints.reaching()
+    return [np.array(w) for w in wp], spawn, dim, False
+
+
+def internals(env):
+    e = env
+    return dict(pos=e.pos[0].copy(), quat=e.quat[0].copy(), rpy=e.rpy[0].copy(), vel=e.vel[0].copy(),
+                ang_v=e.ang_v[0].copy(), cur_pos=np.array(e._current_position, dtype=np.float64).copy(),
+                cur_vel=np.array(e.current_vel, dtype=np.float64), cur_ang_v=np.array(e.current_ang_v, dtype=np.float64),
+                prev_vel=np.array(e.prev_vel, dtype=np.float64), prev_ang_v=np.array(e.prev_ang_v, dtype=np.float64),
+                d=float(e._distance_to_target), d_prev=float(e._prev_distance_to_target),
+                idx=int(e._current_target_index), just_found=int(e.just_found), is_done=int(e._is_done),
+                steps=int(e._steps))
+
+
+INT_KEYS = ("pos", "quat", "rpy", "vel", "ang_v", "cur_pos", "cur_vel", "cur_ang_v", "prev_vel", "prev_ang_v",
+            "d", "d_prev", "idx", "just_found", "is_done", "steps")
+
+
+class RefVec:
+    """[3P-recall] SubprocVecEnv worker + Monitor around the real reference env (+ real normaliser)."""
+
+    def __init__(self, mk, n, normalize_obs):
+        self.raw, self.envs = [], []
+        for i in range(n):
+            env = mk()
+            quiet(env.reset, seed=i)                         # make_env: env.reset(seed=seed+rank)
+            self.raw.append(env)
+            self.envs.append(ref_normalize.NormalizeObservation(env) if normalize_obs else env)
+        self.rewards = [[] for _ in range(n)]
+
+    def reset(self):
+        out = []
+        for i, env in enumerate(self.envs):
+            obs, _ = quiet(env.reset)
+            self.rewards[i] = []
+            out.append(np.asarray(obs))
+        return np.stack(out)
+
+    def step(self, actions):
+        n = len(self.envs)
+        res = dict(obs=np.zeros((n, 13), np.float64), reward=np.zeros(n, np.float64), done=np.zeros(n, np.uint8),
+                   truncated=np.zeros(n, np.uint8), terminated=np.zeros(n, np.uint8),
+                   found_targets=np.zeros(n, np.int32), terminal_obs=np.zeros((n, 13), np.float64),
+                   ep_ret=np.zeros(n, np.float64), ep_len=np.zeros(n, np.int32))
+        for i, env in enumerate(self.envs):
+            obs, r, term, trunc, info = quiet(env.step, actions[i])
+            self.rewards[i].append(float(r))                                 # Monitor.step
+            done = bool(term or trunc)
+            res["reward"][i] = r
+            res["done"][i] = done
+            res["terminated"][i] = bool(term)
+            res["truncated"][i] = bool(trunc and not term)                   # info["TimeLimit.truncated"]
+            res["found_targets"][i] = info["found_targets"]
+            if done:
+                res["ep_ret"][i] = sum(self.rewards[i])                      # Monitor: ep_rew = sum(self.rewards)
+                res["ep_len"][i] = len(self.rewards[i])
+                res["terminal_obs"][i] = obs                                 # info["terminal_observation"]
+                obs, _ = quiet(env.reset)
+                self.rewards[i] = []
+            res["obs"][i] = obs
+        return res
+
+
+# --------------------------------------------------------------------------------------
+def gen_constants_and_actions(out):
+    targets, spawn, dim, circle = track_circle(4)
+    env = make_ref_env(targets, spawn, dim, circle)
+    consts = dict(M=env.M, L=env.L, KF=env.KF, KM=env.KM, IXX=env.J[0, 0], IYY=env.J[1, 1], IZZ=env.J[2, 2],
+                  PWM2RPM_SCALE=env.PWM2RPM_SCALE, PWM2RPM_CONST=env.PWM2RPM_CONST, MIN_PWM=env.MIN_PWM,
+                  MAX_PWM=env.MAX_PWM, G=env.G, GRAVITY=env.GRAVITY, HOVER_RPM=env.HOVER_RPM, MAX_RPM=env.MAX_RPM,
+                  PYB_TIMESTEP=env.PYB_TIMESTEP, PYB_STEPS_PER_CTRL=env.PYB_STEPS_PER_CTRL,
+                  max_target_dist=env._max_target_dist)
+    a_low, a_high = env.physical_action_bounds
+    rng = np.random.default_rng(7)
+    acts = np.concatenate([
+        np.linspace(-1, 1, 2001), np.arange(0.0895, 0.0976, 1e-5), rng.uniform(-1, 1, 4000),
+        0.0922 + 0.003 * rng.standard_normal(4000), [0.0, 1.0, -1.0, 0.092227, 1e-30, -1e-30, 5.0, -5.0],
+    ]).astype(np.float32)
+    acts = acts[: (len(acts) // 4) * 4].reshape(-1, 4)
+    resc = np.stack([env.rescale_action(a) for a in acts])
+    rpm = np.stack([env._preprocessAction(r) for r in resc])
+    assert resc.dtype == np.float32 and rpm.dtype == np.float32
+    forces = np.zeros((len(acts), 4))
+    zt = np.zeros(len(acts))
+    cl = pb._clients[env.CLIENT]
+    kinds = set()
+    for k, r in enumerate(rpm):
+        cl["applied"].clear()
+        env._physics(r, 0)
+        for kind, link, tname, val in cl["applied"]:
+            kinds.add(tname)
+            if kind == "F":
+                forces[k, link] = val
+            else:
+                zt[k] = val
+    out["actions"] = dict(actions=acts, rescaled=resc, rpm=rpm, forces=forces, z_torque=zt,
+                          a_low=np.float32(a_low[0]), a_high=np.float32(a_high[0]),
+                          api_scalar_types=np.array(sorted(kinds)),
+                          **{"const_" + k: np.float64(v) for k, v in consts.items()})
+
+
+def gen_tracks(out):
+    d = {}
+    for name, fn in (("circle4", lambda: Waypoints.circle(1, 4, 1)), ("circle6", lambda: Waypoints.circle(1, 6, 1)),
+                     ("reaching", Waypoints.reaching), ("up", Waypoints.up),
+                     ("half_up_forward", Waypoints.half_up_forward), ("up_circle", Waypoints.up_circle),
+                     ("up_sharp_back_turn", Waypoints.up_sharp_back_turn)):
+        wp, spawn, dim = fn()
+        d[name + "_waypoints"] = np.array(wp, dtype=np.float64)
+        d[name + "_spawn"] = np.array(spawn, dtype=np.float64).reshape(-1)
+        d[name + "_dim"] = np.array(dim, dtype=np.float64)
+    out["tracks"] = d
+
+
+def gen_obs_pack(out):
+    """A6: random kinematic states -> _computeObs (teacher-forced through the fake Bullet getters)."""
+    rng = np.random.default_rng(11)
+    res = {}
+    for tname, mk in (("circle", lambda: track_circle(4)), ("race", track_reaching)):
+        targets, spawn, dim, circle = mk()
+        env = make_ref_env(targets, spawn, dim, circle)
+        cl = pb._clients[env.CLIENT]
+        n = 600
+        pos = rng.uniform(-5, 5, (n, 3))
+        quat = rng.standard_normal((n, 4))
+        quat /= np.linalg.norm(quat, axis=1, keepdims=True)
+        vel = rng.standard_normal((n, 3)) * np.array([4, 4, 2])
+        ang = rng.standard_normal((n, 3)) * 5
+        ang[::50] = 0.0                                       # zero angular velocity stays zero
+        vel[1::50] = [3.0, -3.0, 1.0]                         # clip edges
+        quat[2::50] = [0, np.sin(np.pi / 4), 0, np.cos(np.pi / 4)]   # gimbal-lock branch of the Euler conversion
+        quat[3::50] = [0, -np.sin(np.pi / 4), 0, np.cos(np.pi / 4)]
+        dist = rng.uniform(0, 6, n)
+        obs = np.zeros((n, 13), np.float32)
+        rpy = np.zeros((n, 3))
+        for k in range(n):
+            cl["pos"], cl["quat"], cl["vel"], cl["ang_v"] = pos[k].copy(), quat[k].copy(), vel[k].copy(), ang[k].copy()
+            env._updateAndStoreKinematicInformation()
+            env._distance_to_target = np.float64(dist[k])
+            o = env._computeObs()
+            assert o.dtype == np.float32
+            obs[k] = o
+            rpy[k] = env.rpy[0]
+        res.update({tname + "_pos": pos, tname + "_quat": quat, tname + "_vel": vel, tname + "_ang_v": ang,
+                    tname + "_dist": dist, tname + "_obs": obs, tname + "_rpy": rpy})
+    out["obs_pack"] = res
+
+
+def run_closed_loop(mk_track, n, T, action_fn, normalize_obs, max_steps, seed):
+    targets, spawn, dim, circle = mk_track()
+    vec = RefVec(lambda: make_ref_env(targets, spawn, dim, circle, max_steps=max_steps), n, normalize_obs)
+    rng = np.random.default_rng(seed)
+    rec = dict(reset_obs=vec.reset().astype(np.float64))
+    keys = ("obs", "reward", "done", "truncated", "terminated", "found_targets", "terminal_obs", "ep_ret", "ep_len")
+    steps = {k: [] for k in keys}
+    ints = {k: [] for k in INT_KEYS}
+    actions = []
+    for t in range(T):
+        a = action_fn(rng, t, n).astype(np.float32)
+        actions.append(a)
+        r = vec.step(a)
+        for k in keys:
+            steps[k].append(r[k])
+        cur = [internals(e) for e in vec.raw]
+        for k in INT_KEYS:
+            ints[k].append(np.stack([np.asarray(c[k]) for c in cur]))
+    rec["actions"] = np.stack(actions)
+    for k in keys:
+        rec[k] = np.stack(steps[k])
+    for k in INT_KEYS:
+        rec["int_" + k] = np.stack(ints[k])
+    rec["waypoints"] = np.array(targets, dtype=np.float64)
+    rec["spawn"] = np.array(spawn, dtype=np.float64).reshape(-1)
+    rec["dim"] = np.array(dim, dtype=np.float64)
+    rec["circle"] = np.int32(circle)
+    rec["max_steps"] = np.int32(max_steps)
+    rec["normalize_obs"] = np.int32(normalize_obs)
+    if normalize_obs:
+        rec["rms_mean"] = np.stack([e.obs_rms.mean for e in vec.envs])
+        rec["rms_var"] = np.stack([e.obs_rms.var for e in vec.envs])
+        rec["rms_count"] = np.array([e.obs_rms.count for e in vec.envs])
+    return rec
+
+
+def a_uniform(rng, t, n):
+    return rng.uniform(-1, 1, (n, 4))
+
+
+def a_hover(rng, t, n):
+    return 0.0922 + 0.003 * rng.standard_normal((n, 4))
+
+
+def a_mixed(rng, t, n):
+    a = 0.0922 + 0.002 * rng.standard_normal((n, 4))
+    a[: n // 2] += 0.0004 * np.sin(t / 15.0 + np.arange(n // 2))[:, None] * np.array([1, -1, -1, 1])
+    return a
+
+
+def gen_closed_loop(out):
+    out["traj_circle_uniform"] = run_closed_loop(lambda: track_circle(4), 8, 300, a_uniform, False, 4096, 1)
+    out["traj_circle_hover"] = run_closed_loop(lambda: track_circle(4), 8, 400, a_hover, False, 150, 2)
+    out["traj_race_uniform"] = run_closed_loop(track_reaching, 8, 300, a_uniform, False, 4096, 3)
+    out["traj_race_mixed_norm"] = run_closed_loop(track_reaching, 8, 400, a_mixed, True, 120, 4)
+    out["traj_circle6_norm"] = run_closed_loop(lambda: track_circle(6), 4, 300, a_hover, True, 4096, 5)
+
+
+# --------------------------------------------------------------------------------------
+def scripted_path(targets, spawn, rng, per_seg, lateral, drift, n_laps=1, arc=False):
+    """Positions that follow spawn -> wp0 -> wp1 ... with lateral noise and an optional growing drift
+    (along the unit circle at z=1 when `arc`, so a circle track's torus corridor is respected)."""
+    pts = [np.array(spawn, dtype=np.float64).reshape(3)] + [np.array(t, dtype=np.float64) for t in targets]
+    pos = []
+    k = 0
+    for _ in range(n_laps):
+        for a, b in zip(pts[:-1], pts[1:]):
+            for s in range(per_seg):
+                u = (s + 1) / per_seg
+                p = a + (b - a) * u
+                if arc:
+                    th0, th1 = np.arctan2(a[1], a[0]), np.arctan2(b[1], b[0])
+                    th = th0 + ((th1 - th0) % (2 * np.pi)) * u
+                    p = np.array([np.cos(th), np.sin(th), 1.0])
+                p = p + lateral * rng.standard_normal(3) + drift * k * np.array([0.3, -0.2, 0.1])
+                pos.append(p)
+                k += 1
+    return np.array(pos)
+
+
+def run_scripted(mk_track, per_seg, lateral, drift, max_steps, seed, n_after=40):
+    """Teacher-forced: the fake Bullet is frozen and its state is written before every step, so the
+    reference's reward/termination/bookkeeping code sees a chosen kinematic sequence."""
+    targets, spawn, dim, circle = mk_track()
+    env = make_ref_env(targets, spawn, dim, circle, max_steps=max_steps)
+    cl = pb._clients[env.CLIENT]
+    quiet(env.reset, seed=0)
+    quiet(env.reset)
+    rng = np.random.default_rng(seed)
+    path = scripted_path(targets, spawn, rng, per_seg, lateral, drift, arc=bool(circle))
+    path = np.concatenate([path, path[-1] + np.cumsum(0.02 * rng.standard_normal((n_after, 3)), axis=0)])
+    T = len(path)
+    vel = np.gradient(path, 1 / 240.0, axis=0) * rng.uniform(0.5, 1.5, (T, 1))
+    heading = np.arctan2(vel[:, 1], vel[:, 0]) + 0.15 * rng.standard_normal(T)
+    pitch = 0.2 * rng.standard_normal(T)
+    roll = 0.2 * rng.standard_normal(T)
+    ang = rng.standard_normal((T, 3)) * rng.choice([0.05, 2.0, 40.0], (T, 1))
+    vel[rng.random(T) < 0.1] *= 40.0                          # velocity jumps -> smoothness penalties
+    quat = np.array([pb.getQuaternionFromEuler([roll[t], pitch[t], heading[t]]) for t in range(T)])
+    rec = {k: [] for k in ("obs", "reward", "terminated", "truncated", "found_targets", "reset_obs")}
+    ints = {k: [] for k in INT_KEYS}
+    cl["frozen"] = True
+    for t in range(T):
+        cl["pos"], cl["quat"], cl["vel"], cl["ang_v"] = path[t].copy(), quat[t].copy(), vel[t].copy(), ang[t].copy()
+        # freeze: write the state AFTER the (no-op) stepSimulation by patching it in place
+        obs, r, term, trunc, info = quiet(env.step, np.full(4, 0.0922, np.float32))
+        rec["obs"].append(obs)
+        rec["reward"].append(float(r))
+        rec["terminated"].append(bool(term))
+        rec["truncated"].append(bool(trunc))
+        rec["found_targets"].append(info["found_targets"])
+        if term or trunc:
+            o, _ = quiet(env.reset)
+            rec["reset_obs"].append(o)
+        else:
+            rec["reset_obs"].append(np.zeros(13, np.float32))
+        cur = internals(env)
+        for k in INT_KEYS:
+            ints[k].append(np.asarray(cur[k]))
+    res = dict(pos=path, quat=quat, vel=vel, ang_v=ang, waypoints=np.array(targets, dtype=np.float64),
+               spawn=np.array(spawn, dtype=np.float64).reshape(-1), dim=np.array(dim, dtype=np.float64),
+               circle=np.int32(circle), max_steps=np.int32(max_steps))
+    for k, v in rec.items():
+        res[k] = np.array(v)
+    for k, v in ints.items():
+        res["int_" + k] = np.stack(v)
+    return res
+
+
+def gen_scripted(out):
+    out["script_circle_follow"] = run_scripted(lambda: track_circle(4), 40, 0.03, 0.0, 4096, 21)
+    out["script_circle_drift"] = run_scripted(lambda: track_circle(4), 30, 0.05, 0.004, 4096, 22)
+    out["script_circle_trunc"] = run_scripted(lambda: track_circle(4), 40, 0.02, 0.0, 37, 23)
+    out["script_race_follow"] = run_scripted(track_reaching, 60, 0.04, 0.0, 4096, 24)
+    out["script_race_drift"] = run_scripted(track_reaching, 40, 0.08, 0.001, 4096, 25)
+    out["script_race_trunc"] = run_scripted(track_reaching, 50, 0.03, 0.0, 61, 26)
+    up = lambda: ([np.array(w) for w in Waypoints.up()[0]], np.array([Waypoints.up()[1]]), Waypoints.up()[2], False)  # noqa: E731
+    out["script_up_follow"] = run_scripted(up, 30, 0.02, 0.0, 4096, 27)
+
+
+def gen_normalize(out):
+    """A10 alone: a 300-long observation stream through normalize.NormalizeObservation.normalize."""
+    class _E:
+        observation_space = _ref_stubs.Box(-np.ones(13), np.ones(13), dtype=np.float32)
+    w = ref_normalize.NormalizeObservation(_E())
+    rng = np.random.default_rng(31)
+    x = (rng.standard_normal((300, 13)) * rng.uniform(0.01, 3, 13) + rng.uniform(-1, 1, 13)).astype(np.float32)
+    x[:, 4] = 0.0
+    y = np.stack([w.normalize(np.array([o]))[0] for o in x])
+    out["normalize"] = dict(x=x, y=y, mean=w.obs_rms.mean, var=w.obs_rms.var, count=np.float64(w.obs_rms.count))
+
+
+def gen_gae(out):
+    """N1: execute the reference's GAE lines (cleanRLPPO.py:234-248) on random buffers."""
+    import torch
+    src = open(os.path.join(REF, "Sol/Model/Algorithms/cleanRLPPO.py")).read().splitlines()
+    block = textwrap.dedent("\n".join(src[233:248]))          # lines 234..248, 1-based
+    assert "lastgaelam" in block and "returns = advantages + values" in block
+    rng = np.random.default_rng(41)
+    T, N = 33, 17
+
+    class _Args:
+        num_steps, gamma, gae_lambda = T, 0.99, 0.95
+
+    class _Agent:
+        def __init__(self, v):
+            self.v = v
+
+        def get_value(self, obs):
+            return self.v
+
+    rewards = torch.tensor(rng.standard_normal((T, N)).astype(np.float32))
+    values = torch.tensor(rng.standard_normal((T, N)).astype(np.float32))
+    dones = torch.tensor((rng.random((T, N)) < 0.1).astype(np.float32))
+    next_done = torch.tensor((rng.random(N) < 0.1).astype(np.float32))
+    next_value = torch.tensor(rng.standard_normal(N).astype(np.float32))
+    ns = dict(torch=torch, args=_Args, agent=_Agent(next_value), next_obs=None, rewards=rewards, values=values,
+              dones=dones, next_done=next_done, device="cpu")
+    exec(block, ns)
+    out["gae"] = dict(rewards=rewards.numpy(), values=values.numpy(), dones=dones.numpy().astype(np.uint8),
+                      next_done=next_done.numpy().astype(np.uint8), next_value=next_value.numpy(),
+                      gamma=np.float64(0.99), gae_lambda=np.float64(0.95),
+                      advantages=ns["advantages"].numpy(), returns=ns["returns"].numpy())
+
+
+def main():
+    out = {}
+    gen_constants_and_actions(out)
+    gen_tracks(out)
+    gen_obs_pack(out)
+    gen_closed_loop(out)
+    gen_scripted(out)
+    gen_normalize(out)
+    gen_gae(out)
+    for name, d in out.items():
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **d)
+        print(f"{name:28s} {os.path.getsize(path) / 1024:8.1f} KiB")
+
+
+if __name__ == "__main__":
+    main()
