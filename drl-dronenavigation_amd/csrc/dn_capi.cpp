@@ -1,0 +1,468 @@
+// dn_capi.cpp -- host side of the C ABI declared in include/dronenav.h.
+//
+// Owns the device arena, the waypoint/corridor tables and the launch parameters; every entry point
+// validates its arguments, turns HIP failures into dn_status codes + a thread-local message, and
+// never falls back to a CPU implementation.
+#include "dn_internal.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int32_t fail(dn_status st, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return (int32_t)st;
+}
+
+#define DN_HIP(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail(e_ == hipErrorOutOfMemory ? DN_ERR_OUT_OF_MEMORY : DN_ERR_HIP, "%s failed: %s", #expr, \
+                        hipGetErrorString(e_));                                                   \
+    } while (0)
+
+inline double norm3d(const double v[3]) { return std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
+
+size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+}  // namespace
+
+struct dn_env {
+    dn_config cfg;
+    DnParams p;
+    void *arena = nullptr;
+    size_t arena_bytes = 0;
+    double *tab64 = nullptr;
+    float *tab32 = nullptr;
+    uint64_t step_count = 0;
+    long long blocks = 0;
+};
+
+namespace {
+
+// Device arena: seven float4 groups, optional normaliser statistics, statistics slots, tables.
+struct Layout {
+    size_t off_g[7], off_mean, off_var, off_count, off_stats, off_tab64, off_tab32, total;
+};
+
+Layout make_layout(long long n, int normalize_obs)
+{
+    Layout L;
+    size_t o = 0;
+    for (int k = 0; k < 7; ++k) { L.off_g[k] = o; o = align_up(o + (size_t)n * sizeof(float4), 256); }
+    L.off_mean = o;  o = align_up(o + (normalize_obs ? (size_t)n * DN_OBS_DIM * sizeof(double) : 0), 256);
+    L.off_var = o;   o = align_up(o + (normalize_obs ? (size_t)n * DN_OBS_DIM * sizeof(double) : 0), 256);
+    L.off_count = o; o = align_up(o + (normalize_obs ? (size_t)n * sizeof(double) : 0), 256);
+    L.off_stats = o; o = align_up(o + (size_t)((n + DN_BLOCK - 1) / DN_BLOCK) * sizeof(DnStatSlot), 256);
+    L.off_tab64 = o; o = align_up(o + DN_MAX_WAYPOINTS * DN_T_STRIDE * sizeof(double), 256);
+    L.off_tab32 = o; o = align_up(o + DN_MAX_WAYPOINTS * DN_T_STRIDE * sizeof(float), 256);
+    L.total = o;
+    return L;
+}
+
+// Corridor table, float64, in the reference's operation order (PBDroneEnv.py:746-786).
+void build_table(const dn_config &c, double *tab)
+{
+    const double ext = 0.2;
+    for (int k = 0; k < c.num_waypoints; ++k) {
+        double *e = tab + k * DN_T_STRIDE;
+        const double *b1 = (k == 0) ? c.spawn : &c.waypoints[3 * (k - 1)];
+        const double *b2 = &c.waypoints[3 * k];
+        double lv[3] = {b2[0] - b1[0], b2[1] - b1[1], b2[2] - b1[2]};
+        double ll = norm3d(lv);
+        for (int j = 0; j < 3; ++j) { e[DN_T_WP + j] = b2[j]; e[DN_T_B1 + j] = b1[j]; }
+        e[DN_T_LL] = ll;
+        if (ll == 0.0) {
+            for (int j = 0; j < 3; ++j) { e[DN_T_U + j] = 0.0; e[DN_T_E1 + j] = b1[j]; }
+            e[DN_T_LEXT] = 0.0;
+            continue;
+        }
+        double u[3] = {lv[0] / ll, lv[1] / ll, lv[2] / ll};
+        double e1[3] = {b1[0] - ext * u[0], b1[1] - ext * u[1], b1[2] - ext * u[2]};
+        double e2[3] = {b2[0] + ext * u[0], b2[1] + ext * u[1], b2[2] + ext * u[2]};
+        double ee[3] = {e2[0] - e1[0], e2[1] - e1[1], e2[2] - e1[2]};
+        for (int j = 0; j < 3; ++j) { e[DN_T_U + j] = u[j]; e[DN_T_E1 + j] = e1[j]; }
+        e[DN_T_LEXT] = norm3d(ee);
+    }
+}
+
+template <typename R>
+void build_consts(const dn_config &c, DnConsts<R> &k)
+{
+    for (int j = 0; j < 6; ++j) k.dim[j] = (R)c.aviary_dim[j];
+    for (int j = 0; j < 3; ++j) k.spawn[j] = (R)c.spawn[j];
+    k.threshold = (R)c.threshold;
+    k.thr_ext = (R)(c.threshold + 0.2);
+    double a = std::fabs(c.aviary_dim[0]) + c.aviary_dim[3], b = std::fabs(c.aviary_dim[1]) + c.aviary_dim[4];
+    double m = a > b ? a : b;
+    k.max_target_dist = (R)(m > c.aviary_dim[5] ? m : c.aviary_dim[5]);           // PBDroneEnv.py:91
+    // BaseAviary.reset -> _computeObs on the freshly loaded body: pos = spawn, quat = (0,0,0,1), at rest.
+    // getEulerFromQuaternion(identity) = (atan2(0,1), asin(-0.0), atan2(0,1)) = (0, -0, 0).
+    const R pi = (R)3.14159265358979323846;
+    k.reset_obs[0] = k.spawn[0] / k.dim[3];
+    k.reset_obs[1] = k.spawn[1] / k.dim[4];
+    k.reset_obs[2] = k.spawn[2] / k.dim[5];
+    k.reset_obs[3] = (R)0.0 / pi;
+    k.reset_obs[4] = (R)-0.0 / pi;
+    k.reset_obs[5] = (R)0.0 / pi;
+    for (int j = 6; j < 12; ++j) k.reset_obs[j] = (R)0.0;
+}
+
+int32_t validate(const dn_config *c)
+{
+    if (!c) return fail(DN_ERR_INVALID_ARGUMENT, "cfg is NULL");
+    if (c->num_envs < 1) return fail(DN_ERR_INVALID_ARGUMENT, "num_envs must be >= 1 (got %lld)", (long long)c->num_envs);
+    if (c->num_envs > (1ll << 31) - 64) return fail(DN_ERR_INVALID_ARGUMENT, "num_envs too large (got %lld)", (long long)c->num_envs);
+    if (c->num_waypoints < 1 || c->num_waypoints > DN_MAX_WAYPOINTS)
+        return fail(DN_ERR_INVALID_ARGUMENT, "num_waypoints must be in 1..%d (got %d)", DN_MAX_WAYPOINTS, c->num_waypoints);
+    if (c->max_steps < 0 || c->max_steps > (1 << 24) - 2)
+        return fail(DN_ERR_INVALID_ARGUMENT, "max_steps must be in 0..%d (got %d)", (1 << 24) - 2, c->max_steps);
+    if (!(c->threshold >= 0.0)) return fail(DN_ERR_INVALID_ARGUMENT, "threshold must be >= 0");
+    for (int j = 0; j < 3; ++j)
+        if (!(c->aviary_dim[3 + j] != 0.0)) return fail(DN_ERR_INVALID_ARGUMENT, "aviary_dim high bounds must be non-zero");
+    if (c->act_noise_sigma < 0.0f || c->obs_noise_sigma < 0.0f) return fail(DN_ERR_INVALID_ARGUMENT, "noise sigma must be >= 0");
+    for (int j = 0; j < c->num_waypoints * 3; ++j)
+        if (!std::isfinite(c->waypoints[j])) return fail(DN_ERR_INVALID_ARGUMENT, "waypoint %d is not finite", j / 3);
+    return DN_OK;
+}
+
+int32_t init_state(dn_env *e, hipStream_t s)
+{
+    const dn_config &c = e->cfg;
+    const long long n = c.num_envs;
+    // PBDroneEnv.__init__ (PBDroneEnv.py:122-145) followed by make_env's env.reset (PBDroneSimulator.py:173)
+    double df[3] = {c.spawn[0] - c.waypoints[0], c.spawn[1] - c.waypoints[1], c.spawn[2] - c.waypoints[2]};
+    const float d = (float)norm3d(df);
+    const float sx = (float)c.spawn[0], sy = (float)c.spawn[1], sz = (float)c.spawn[2];
+    DN_HIP(dn_launch_fill4(e->p.st.g0, make_float4(sx, sy, sz, d), n, s));
+    DN_HIP(dn_launch_fill4(e->p.st.g1, make_float4(0.f, 0.f, 0.f, 1.f), n, s));
+    DN_HIP(dn_launch_fill4(e->p.st.g2, make_float4(0.f, 0.f, 0.f, d), n, s));
+    DN_HIP(dn_launch_fill4(e->p.st.g3, make_float4(0.f, 0.f, 0.f, 0.f), n, s));
+    DN_HIP(dn_launch_fill4(e->p.st.g4, make_float4(0.f, 0.f, 0.f, 0.f), n, s));
+    DN_HIP(dn_launch_fill4(e->p.st.g5, make_float4(0.f, 0.f, 0.f, 0.f), n, s));
+    DN_HIP(dn_launch_fill4(e->p.st.g6, make_float4(sx, sy, sz, 0.f), n, s));
+    if (c.normalize_obs) {                         // normalize.RunningMeanStd.__init__, normalize.py:14-18
+        DN_HIP(dn_launch_filld(e->p.st.rms_mean, 0.0, n * DN_OBS_DIM, s));
+        DN_HIP(dn_launch_filld(e->p.st.rms_var, 1.0, n * DN_OBS_DIM, s));
+        DN_HIP(dn_launch_filld(e->p.st.rms_count, 1e-4, n, s));
+    }
+    DN_HIP(hipMemsetAsync(e->p.st.stats, 0, (size_t)e->blocks * sizeof(DnStatSlot), s));
+    return DN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t dn_abi_version(void) { return DN_ABI_VERSION; }
+
+const char *dn_last_error(void) { return g_err; }
+
+int32_t dn_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void dn_config_default(dn_config *cfg)
+{
+    if (!cfg) return;
+    memset(cfg, 0, sizeof *cfg);
+    cfg->num_envs = 1;
+    cfg->threshold = 0.3;             // PBDroneSimulator.py:116
+    cfg->max_steps = 4096;            // parameter_manager.py:25
+    cfg->cylinder = 1;                // PBDroneSimulator.py:167
+    cfg->include_distance = 1;        // PBDroneSimulator.py:661
+    cfg->normalize_actions = 1;       // PBDroneSimulator.py:662
+    cfg->ground_contact = 1;
+    cfg->aviary_dim[0] = cfg->aviary_dim[1] = -1.0;   // make_env default aviary_dim, PBDroneSimulator.py:141
+    cfg->aviary_dim[3] = cfg->aviary_dim[4] = cfg->aviary_dim[5] = 1.0;
+}
+
+int64_t dn_state_bytes(int64_t num_envs, int32_t normalize_obs)
+{
+    if (num_envs < 1) return 0;
+    return (int64_t)make_layout(num_envs, normalize_obs).total;
+}
+
+int32_t dn_create(const dn_config *cfg, dn_env **out)
+{
+    if (!out) return fail(DN_ERR_INVALID_ARGUMENT, "out is NULL");
+    *out = nullptr;
+    int32_t rc = validate(cfg);
+    if (rc != DN_OK) return rc;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(DN_ERR_NO_DEVICE, "no HIP device is visible: libdronenav has no CPU fallback");
+    if (cfg->device_id < 0 || cfg->device_id >= ndev)
+        return fail(DN_ERR_INVALID_ARGUMENT, "device_id %d out of range (%d devices)", cfg->device_id, ndev);
+    DN_HIP(hipSetDevice(cfg->device_id));
+
+    dn_env *e = new (std::nothrow) dn_env();
+    if (!e) return fail(DN_ERR_OUT_OF_MEMORY, "host allocation failed");
+    e->cfg = *cfg;
+    const long long n = cfg->num_envs;
+    e->blocks = (n + DN_BLOCK - 1) / DN_BLOCK;
+    const Layout L = make_layout(n, cfg->normalize_obs);
+    hipError_t he = hipMalloc(&e->arena, L.total);
+    if (he != hipSuccess) {
+        delete e;
+        return fail(DN_ERR_OUT_OF_MEMORY, "hipMalloc(%zu bytes) for %lld drones failed: %s", L.total, n, hipGetErrorString(he));
+    }
+    e->arena_bytes = L.total;
+    char *base = (char *)e->arena;
+    DnParams &p = e->p;
+    memset(&p, 0, sizeof p);
+    p.st.g0 = (float4 *)(base + L.off_g[0]); p.st.g1 = (float4 *)(base + L.off_g[1]);
+    p.st.g2 = (float4 *)(base + L.off_g[2]); p.st.g3 = (float4 *)(base + L.off_g[3]);
+    p.st.g4 = (float4 *)(base + L.off_g[4]); p.st.g5 = (float4 *)(base + L.off_g[5]);
+    p.st.g6 = (float4 *)(base + L.off_g[6]);
+    p.st.rms_mean = (double *)(base + L.off_mean);
+    p.st.rms_var = (double *)(base + L.off_var);
+    p.st.rms_count = (double *)(base + L.off_count);
+    p.st.stats = (DnStatSlot *)(base + L.off_stats);
+    e->tab64 = (double *)(base + L.off_tab64);
+    e->tab32 = (float *)(base + L.off_tab32);
+    p.tab64 = e->tab64;
+    p.tab32 = e->tab32;
+    p.n = n;
+    p.num_waypoints = cfg->num_waypoints;
+    p.max_steps = cfg->max_steps;
+    p.circle = cfg->circle != 0; p.cylinder = cfg->cylinder != 0; p.include_distance = cfg->include_distance != 0;
+    p.normalize_actions = cfg->normalize_actions != 0; p.normalize_obs = cfg->normalize_obs != 0;
+    p.ground_contact = cfg->ground_contact != 0;
+    p.act_noise_sigma = cfg->act_noise_sigma; p.obs_noise_sigma = cfg->obs_noise_sigma;
+    p.seed = cfg->seed; p.env_id_offset = cfg->env_id_offset;
+    build_consts<double>(*cfg, p.c64);
+    build_consts<float>(*cfg, p.c32);
+
+    std::vector<double> t64(DN_MAX_WAYPOINTS * DN_T_STRIDE, 0.0);
+    std::vector<float> t32(DN_MAX_WAYPOINTS * DN_T_STRIDE, 0.0f);
+    build_table(*cfg, t64.data());
+    for (size_t j = 0; j < t64.size(); ++j) t32[j] = (float)t64[j];
+    int32_t st = DN_OK;
+    do {
+        if (hipMemcpy(e->tab64, t64.data(), t64.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(e->tab32, t32.data(), t32.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+            st = fail(DN_ERR_HIP, "uploading the waypoint table failed");
+            break;
+        }
+        st = init_state(e, nullptr);
+        if (st != DN_OK) break;
+        if (hipStreamSynchronize(nullptr) != hipSuccess) { st = fail(DN_ERR_HIP, "state initialisation failed"); break; }
+    } while (0);
+    if (st != DN_OK) {
+        (void)hipFree(e->arena);
+        delete e;
+        return st;
+    }
+    *out = e;
+    return DN_OK;
+}
+
+int32_t dn_destroy(dn_env *env)
+{
+    if (!env) return DN_OK;
+    hipError_t he = hipSuccess;
+    if (env->arena) {
+        (void)hipSetDevice(env->cfg.device_id);
+        he = hipFree(env->arena);
+    }
+    delete env;
+    if (he != hipSuccess) return fail(DN_ERR_HIP, "hipFree failed: %s", hipGetErrorString(he));
+    return DN_OK;
+}
+
+int64_t dn_num_envs(const dn_env *env) { return env ? env->cfg.num_envs : 0; }
+
+int32_t dn_reset(dn_env *env, float *obs, void *stream)
+{
+    if (!env) return fail(DN_ERR_INVALID_ARGUMENT, "env is NULL");
+    if (!obs) return fail(DN_ERR_INVALID_ARGUMENT, "obs is NULL");
+    env->p.step_count = (unsigned)env->step_count;
+    DN_HIP(dn_launch_reset(env->p, obs, env->cfg.compute_f32 != 0, (hipStream_t)stream));
+    return DN_OK;
+}
+
+int32_t dn_step(dn_env *env, const float *actions, float *obs, float *reward, uint8_t *done, uint8_t *truncated,
+                int32_t *found_targets, float *terminal_obs, float *ep_return, int32_t *ep_length,
+                uint64_t *done_mask, void *stream)
+{
+    if (!env) return fail(DN_ERR_INVALID_ARGUMENT, "env is NULL");
+    if (!actions || !obs || !reward || !done || !truncated || !found_targets)
+        return fail(DN_ERR_INVALID_ARGUMENT, "actions, obs, reward, done, truncated and found_targets are required");
+    if (((uintptr_t)actions & 15u) || ((uintptr_t)obs & 15u))
+        return fail(DN_ERR_INVALID_ARGUMENT, "actions and obs must be 16-byte aligned");
+    DnStepIO io;
+    io.actions = actions; io.obs = obs; io.reward = reward; io.done = done; io.truncated = truncated;
+    io.found_targets = found_targets; io.terminal_obs = terminal_obs; io.ep_return = ep_return;
+    io.ep_length = ep_length; io.done_mask = (unsigned long long *)done_mask;
+    env->p.step_count = (unsigned)env->step_count;
+    DN_HIP(dn_launch_step(env->p, io, env->cfg.compute_f32 != 0, (hipStream_t)stream));
+    env->step_count += 1;
+    return DN_OK;
+}
+
+int32_t dn_compact_done(const uint64_t *done_mask, int64_t num_envs, int32_t *indices, int32_t *count,
+                        int32_t device_id, void *stream)
+{
+    if (!done_mask || !indices || !count || num_envs < 1)
+        return fail(DN_ERR_INVALID_ARGUMENT, "done_mask, indices, count are required and num_envs >= 1");
+    DN_HIP(hipSetDevice(device_id));
+    DN_HIP(dn_launch_compact((const unsigned long long *)done_mask, num_envs, indices, count, (hipStream_t)stream));
+    return DN_OK;
+}
+
+int32_t dn_get_state(dn_env *env, dn_env_state *states, int64_t count)
+{
+    if (!env || !states) return fail(DN_ERR_INVALID_ARGUMENT, "env and states are required");
+    const long long n = env->cfg.num_envs;
+    if (count != n) return fail(DN_ERR_INVALID_ARGUMENT, "count (%lld) != num_envs (%lld)", (long long)count, n);
+    DN_HIP(hipSetDevice(env->cfg.device_id));
+    DN_HIP(hipDeviceSynchronize());
+    std::vector<float4> g[7];
+    float4 *src[7] = {env->p.st.g0, env->p.st.g1, env->p.st.g2, env->p.st.g3, env->p.st.g4, env->p.st.g5, env->p.st.g6};
+    for (int k = 0; k < 7; ++k) {
+        g[k].resize((size_t)n);
+        DN_HIP(hipMemcpy(g[k].data(), src[k], (size_t)n * sizeof(float4), hipMemcpyDeviceToHost));
+    }
+    std::vector<double> mean, var, cnt;
+    if (env->cfg.normalize_obs) {
+        mean.resize((size_t)n * DN_OBS_DIM); var.resize((size_t)n * DN_OBS_DIM); cnt.resize((size_t)n);
+        DN_HIP(hipMemcpy(mean.data(), env->p.st.rms_mean, mean.size() * sizeof(double), hipMemcpyDeviceToHost));
+        DN_HIP(hipMemcpy(var.data(), env->p.st.rms_var, var.size() * sizeof(double), hipMemcpyDeviceToHost));
+        DN_HIP(hipMemcpy(cnt.data(), env->p.st.rms_count, cnt.size() * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    for (long long i = 0; i < n; ++i) {
+        dn_env_state &s = states[i];
+        memset(&s, 0, sizeof s);
+        s.pos[0] = g[0][i].x; s.pos[1] = g[0][i].y; s.pos[2] = g[0][i].z; s.d = g[0][i].w;
+        s.quat[0] = g[1][i].x; s.quat[1] = g[1][i].y; s.quat[2] = g[1][i].z; s.quat[3] = g[1][i].w;
+        s.vel[0] = g[2][i].x; s.vel[1] = g[2][i].y; s.vel[2] = g[2][i].z; s.d_prev = g[2][i].w;
+        s.ang_v[0] = g[3][i].x; s.ang_v[1] = g[3][i].y; s.ang_v[2] = g[3][i].z;
+        uint32_t meta;
+        memcpy(&meta, &g[3][i].w, 4);
+        s.steps = (int32_t)(meta & 0xFFFFFFu); s.idx = (int32_t)((meta >> 24) & 0x7Fu); s.just_found = (int32_t)(meta >> 31);
+        s.prev_vel[0] = g[4][i].x; s.prev_vel[1] = g[4][i].y; s.prev_vel[2] = g[4][i].z; s.ep_ret = g[4][i].w;
+        s.prev_ang_v[0] = g[5][i].x; s.prev_ang_v[1] = g[5][i].y; s.prev_ang_v[2] = g[5][i].z;
+        memcpy(&s.ep_len, &g[5][i].w, 4);
+        // _current_position equals pos once a post-step has run (steps > 0); the stored copy is the stale one
+        if (s.steps > 0) { s.cur_pos[0] = s.pos[0]; s.cur_pos[1] = s.pos[1]; s.cur_pos[2] = s.pos[2]; }
+        else { s.cur_pos[0] = g[6][i].x; s.cur_pos[1] = g[6][i].y; s.cur_pos[2] = g[6][i].z; }
+        if (env->cfg.normalize_obs) {
+            for (int k = 0; k < DN_OBS_DIM; ++k) { s.rms_mean[k] = mean[(size_t)k * n + i]; s.rms_var[k] = var[(size_t)k * n + i]; }
+            s.rms_count = cnt[(size_t)i];
+        }
+    }
+    return DN_OK;
+}
+
+int32_t dn_set_state(dn_env *env, const dn_env_state *states, int64_t count)
+{
+    if (!env || !states) return fail(DN_ERR_INVALID_ARGUMENT, "env and states are required");
+    const long long n = env->cfg.num_envs;
+    if (count != n) return fail(DN_ERR_INVALID_ARGUMENT, "count (%lld) != num_envs (%lld)", (long long)count, n);
+    std::vector<float4> g[7];
+    for (int k = 0; k < 7; ++k) g[k].resize((size_t)n);
+    std::vector<double> mean, var, cnt;
+    if (env->cfg.normalize_obs) { mean.resize((size_t)n * DN_OBS_DIM); var.resize((size_t)n * DN_OBS_DIM); cnt.resize((size_t)n); }
+    for (long long i = 0; i < n; ++i) {
+        const dn_env_state &s = states[i];
+        if (s.idx < 0 || s.idx >= env->cfg.num_waypoints || s.steps < 0 || s.steps > (1 << 24) - 1)
+            return fail(DN_ERR_INVALID_ARGUMENT, "state %lld: idx/steps out of range", i);
+        if (s.steps > 0 && (s.cur_pos[0] != s.pos[0] || s.cur_pos[1] != s.pos[1] || s.cur_pos[2] != s.pos[2]))
+            return fail(DN_ERR_BAD_STATE, "state %lld: _current_position must equal pos once _steps > 0", i);
+        uint32_t meta = ((uint32_t)s.steps & 0xFFFFFFu) | (((uint32_t)s.idx & 0x7Fu) << 24) | ((uint32_t)(s.just_found != 0) << 31);
+        float fmeta, flen;
+        memcpy(&fmeta, &meta, 4);
+        memcpy(&flen, &s.ep_len, 4);
+        g[0][i] = make_float4(s.pos[0], s.pos[1], s.pos[2], s.d);
+        g[1][i] = make_float4(s.quat[0], s.quat[1], s.quat[2], s.quat[3]);
+        g[2][i] = make_float4(s.vel[0], s.vel[1], s.vel[2], s.d_prev);
+        g[3][i] = make_float4(s.ang_v[0], s.ang_v[1], s.ang_v[2], fmeta);
+        g[4][i] = make_float4(s.prev_vel[0], s.prev_vel[1], s.prev_vel[2], s.ep_ret);
+        g[5][i] = make_float4(s.prev_ang_v[0], s.prev_ang_v[1], s.prev_ang_v[2], flen);
+        g[6][i] = make_float4(s.cur_pos[0], s.cur_pos[1], s.cur_pos[2], 0.0f);
+        if (env->cfg.normalize_obs) {
+            for (int k = 0; k < DN_OBS_DIM; ++k) { mean[(size_t)k * n + i] = s.rms_mean[k]; var[(size_t)k * n + i] = s.rms_var[k]; }
+            cnt[(size_t)i] = s.rms_count;
+        }
+    }
+    DN_HIP(hipSetDevice(env->cfg.device_id));
+    DN_HIP(hipDeviceSynchronize());
+    float4 *dst[7] = {env->p.st.g0, env->p.st.g1, env->p.st.g2, env->p.st.g3, env->p.st.g4, env->p.st.g5, env->p.st.g6};
+    for (int k = 0; k < 7; ++k) DN_HIP(hipMemcpy(dst[k], g[k].data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice));
+    if (env->cfg.normalize_obs) {
+        DN_HIP(hipMemcpy(env->p.st.rms_mean, mean.data(), mean.size() * sizeof(double), hipMemcpyHostToDevice));
+        DN_HIP(hipMemcpy(env->p.st.rms_var, var.data(), var.size() * sizeof(double), hipMemcpyHostToDevice));
+        DN_HIP(hipMemcpy(env->p.st.rms_count, cnt.data(), cnt.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    return DN_OK;
+}
+
+int32_t dn_get_stats(dn_env *env, dn_stats *out, void *stream)
+{
+    if (!env || !out) return fail(DN_ERR_INVALID_ARGUMENT, "env and out are required");
+    std::vector<DnStatSlot> slots((size_t)env->blocks);
+    DN_HIP(hipMemcpyAsync(slots.data(), env->p.st.stats, slots.size() * sizeof(DnStatSlot), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    DN_HIP(hipStreamSynchronize((hipStream_t)stream));
+    memset(out, 0, sizeof *out);
+    long long fix = 0;
+    for (const DnStatSlot &s : slots) {
+        out->episodes += s.episodes; out->truncated += s.truncated; out->completed += s.completed;
+        out->sum_ep_len += s.sum_len; out->sum_found_targets += s.sum_found; fix += s.sum_ret_fix;
+    }
+    out->sum_ep_return = (double)fix * 1e-6;
+    out->env_steps = (int64_t)env->step_count * env->cfg.num_envs;
+    return DN_OK;
+}
+
+int32_t dn_reset_stats(dn_env *env, void *stream)
+{
+    if (!env) return fail(DN_ERR_INVALID_ARGUMENT, "env is NULL");
+    DN_HIP(hipMemsetAsync(env->p.st.stats, 0, (size_t)env->blocks * sizeof(DnStatSlot), (hipStream_t)stream));
+    return DN_OK;
+}
+
+int32_t dn_get_step_count(const dn_env *env, uint64_t *out)
+{
+    if (!env || !out) return fail(DN_ERR_INVALID_ARGUMENT, "env and out are required");
+    *out = env->step_count;
+    return DN_OK;
+}
+
+int32_t dn_set_step_count(dn_env *env, uint64_t value)
+{
+    if (!env) return fail(DN_ERR_INVALID_ARGUMENT, "env is NULL");
+    env->step_count = value;
+    return DN_OK;
+}
+
+int32_t dn_gae(const float *rewards, const float *values, const uint8_t *dones, const float *last_values,
+               const uint8_t *last_dones, int64_t n_steps, int64_t n_envs, double gamma, double gae_lambda,
+               float *advantages, float *returns, int32_t device_id, void *stream)
+{
+    if (!rewards || !values || !dones || !last_values || !last_dones || !advantages || !returns)
+        return fail(DN_ERR_INVALID_ARGUMENT, "all buffers are required");
+    if (n_steps < 1 || n_envs < 1) return fail(DN_ERR_INVALID_ARGUMENT, "n_steps and n_envs must be >= 1");
+    DN_HIP(hipSetDevice(device_id));
+    // gamma and gamma*gae_lambda are Python floats multiplied into float32 tensors (cleanRLPPO.py:245-246)
+    DN_HIP(dn_launch_gae(rewards, values, dones, last_values, last_dones, n_steps, n_envs, (float)gamma,
+                         (float)(gamma * gae_lambda), advantages, returns, (hipStream_t)stream));
+    return DN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,102 @@
+// dn_internal.h -- shared between the HIP kernels (dn_kernels.hip) and the C-ABI host side (dn_capi.cpp).
+#ifndef DN_INTERNAL_H
+#define DN_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/dronenav.h"
+
+// One wave per workgroup: N = 32768 drones is only 512 waves, and 512 workgroups of one wave spread
+// over all 256 CUs (2 per CU, block b -> XCD b % 8) where 128 workgroups of four would leave half the
+// chip idle.  Every wave-level idiom below (ballot, LDS tile transpose) assumes DN_BLOCK == 64.
+#define DN_BLOCK 64
+
+// Layout of one waypoint-table entry (entry k describes waypoint k and the corridor segment that ends
+// at it), staged into LDS once per workgroup.  Precomputed on the host in float64 with the reference's
+// operation order (PBDroneEnv.is_out_of_cylinder_bounds, PBDroneEnv.py:746-786).
+enum {
+    DN_T_WP = 0,    // target_points[k]                         (3)
+    DN_T_U = 3,     // line_unit_vec of segment k               (3)
+    DN_T_E1 = 6,    // extended_point1 = base1 - 0.2*unit       (3)
+    DN_T_B1 = 9,    // base1 (spawn for k = 0, else wp[k-1])    (3)
+    DN_T_LEXT = 12, // ||extended_point2 - extended_point1||    (1)
+    DN_T_LL = 13,   // line_length (0 -> degenerate segment)    (1)
+    DN_T_STRIDE = 14
+};
+
+// Per-workgroup episode statistics slot (workgroup b always owns drones [64b, 64b+64), so its lane 0
+// read-modify-writes the slot without atomics: deterministic, no contended counter).
+struct DnStatSlot {
+    long long episodes, truncated, completed, sum_len, sum_found, sum_ret_fix;
+};
+
+// Persistent state in HBM: "SoA of float4 groups" -- each group is an array of N float4, lane i reads
+// 16 contiguous bytes at i*16 (1 KiB per wave instruction, the full-width coalesced access), instead
+// of 26 separate dword arrays.  Field order inside a group is chosen so one drone's step touches six
+// groups read + six written; g6 (stale _current_position) is touched only around resets.
+struct DnState {
+    float4 *g0;  // pos.xyz, d (_distance_to_target)
+    float4 *g1;  // quat.xyzw
+    float4 *g2;  // vel.xyz, d_prev
+    float4 *g3;  // ang_v.xyz, meta bits: steps[0:24) | idx[24:31) | just_found[31]
+    float4 *g4;  // prev_vel.xyz, ep_ret (Monitor)
+    float4 *g5;  // prev_ang_v.xyz, ep_len bits (Monitor)
+    float4 *g6;  // _current_position.xyz (valid while steps == 0; otherwise it equals pos), pad
+    double *rms_mean;   // [13][N]  normalize.RunningMeanStd.mean
+    double *rms_var;    // [13][N]
+    double *rms_count;  // [N]
+    DnStatSlot *stats;  // [ceil(N/64)]
+};
+
+struct DnStepIO {
+    const float *actions;
+    float *obs;
+    float *reward;
+    uint8_t *done;
+    uint8_t *truncated;
+    int32_t *found_targets;
+    float *terminal_obs;
+    float *ep_return;
+    int32_t *ep_length;
+    unsigned long long *done_mask;
+};
+
+// Scalars of the environment, in both precisions (the float32 build must not touch float64).
+template <typename R>
+struct DnConsts {
+    R dim[6];
+    R spawn[3];
+    R threshold;
+    R thr_ext;          // threshold + 0.2
+    R max_target_dist;
+    R reset_obs[12];    // observation of the freshly spawned body (BaseAviary.reset, BaseAviary.py:318)
+};
+
+struct DnParams {
+    DnState st;
+    long long n;
+    int num_waypoints;
+    int max_steps;
+    int circle, cylinder, include_distance, normalize_actions, normalize_obs, ground_contact;
+    float act_noise_sigma, obs_noise_sigma;
+    unsigned long long seed;
+    long long env_id_offset;
+    unsigned int step_count;
+    const double *tab64;   // [W][DN_T_STRIDE] float64 table
+    const float *tab32;    // same, float32
+    DnConsts<double> c64;
+    DnConsts<float> c32;
+};
+
+hipError_t dn_launch_step(const DnParams &p, const DnStepIO &io, bool f32, hipStream_t stream);
+hipError_t dn_launch_reset(const DnParams &p, float *obs, bool f32, hipStream_t stream);
+hipError_t dn_launch_gae(const float *rewards, const float *values, const uint8_t *dones,
+                         const float *last_values, const uint8_t *last_dones, long long T, long long N,
+                         float gamma, float gl, float *adv, float *ret, hipStream_t stream);
+hipError_t dn_launch_fill4(float4 *dst, float4 v, long long n, hipStream_t stream);
+hipError_t dn_launch_filld(double *dst, double v, long long n, hipStream_t stream);
+hipError_t dn_launch_compact(const unsigned long long *mask, long long n, int32_t *indices, int32_t *count,
+                             hipStream_t stream);
+
+#endif

@@ -1,0 +1,174 @@
+/*
+ * dronenav.h -- C ABI of libdronenav.so: the MI355X-native vectorised drone-navigation
+ * environment (hand-written HIP for gfx950).
+ *
+ * This is the drop-in boundary for the reference's hot path.  In the reference
+ * (eRGiBi/DRL-DroneNavigation, pure Python, paths relative to /root/reference) that path is
+ *     SB3 SubprocVecEnv(...)                          Sol/Model/PBDroneSimulator.py:653-666
+ *       -> Monitor(NormalizeObservation(PBDroneEnv))  Sol/Model/PBDroneSimulator.py:154-196
+ *         -> PBDroneEnv.step / reset                  Sol/Model/Environments/PBDroneEnv.py:171,609
+ *           -> BaseAviary.step / reset                Sol/PyBullet/BaseAviary.py:324,276
+ *             -> pybullet.stepSimulation              Sol/PyBullet/BaseAviary.py:439-440
+ * i.e. N worker processes with one PyBullet world and one drone each.  Here one dn_env holds all
+ * N drones of one GPU; dn_step() advances every drone by one control step (240 Hz) in a single
+ * kernel launch and applies the VecEnv auto-reset in the same launch.
+ *
+ * Conventions
+ *   - plain C, no torch types; all *device* pointers are raw HIP device addresses (e.g.
+ *     tensor.data_ptr()), `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *   - the caller owns every I/O buffer; the library owns the persistent per-drone state allocated
+ *     by dn_create() and freed by dn_destroy(); no caller buffer is retained across calls.
+ *   - every function returns DN_OK (0) or a negative dn_status; dn_last_error() returns a
+ *     thread-local message.  HIP errors are surfaced, never abort()ed.
+ *   - a dn_env is used from one host thread at a time; work is enqueued on the caller's stream and
+ *     the calls do not synchronise unless stated.
+ *   - there is NO CPU fallback: without a HIP device dn_create() fails with DN_ERR_NO_DEVICE.
+ */
+#ifndef DRONENAV_H
+#define DRONENAV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DN_ABI_VERSION 1
+#define DN_MAX_WAYPOINTS 64
+#define DN_OBS_DIM 13      /* 12 kinematic + distance, PBDroneEnv._computeObs, PBDroneEnv.py:296-336 */
+#define DN_ACT_DIM 4       /* four rotor thrust commands, PBDroneEnv._actionSpace, PBDroneEnv.py:225-243 */
+
+typedef enum dn_status {
+    DN_OK = 0,
+    DN_ERR_INVALID_ARGUMENT = -1,
+    DN_ERR_HIP = -2,
+    DN_ERR_OUT_OF_MEMORY = -3,
+    DN_ERR_NO_DEVICE = -4,
+    DN_ERR_BAD_STATE = -5
+} dn_status;
+
+/* Replaces the constructor arguments of PBDroneEnv (PBDroneEnv.py:41-65) as filled in by
+ * PBDroneSimulator.make_env (PBDroneSimulator.py:154-171), plus the wrapper switches of
+ * make_env (:181-196) and the SubprocVecEnv size (:653-666). */
+typedef struct dn_config {
+    int64_t num_envs;                           /* drones on this GPU (SubprocVecEnv's n_envs) */
+    int32_t device_id;                          /* HIP device ordinal */
+    int32_t num_waypoints;                      /* len(target_points), 1..DN_MAX_WAYPOINTS */
+    double waypoints[DN_MAX_WAYPOINTS * 3];     /* target_points, row-major xyz */
+    double spawn[3];                            /* initial_xyzs[0] */
+    double aviary_dim[6];                       /* x_low y_low z_low x_high y_high z_high */
+    double threshold;                           /* gate radius, 0.3 in PBDroneSimulator.py:116 */
+    int32_t max_steps;                          /* --max_env_steps */
+    int32_t circle;                             /* Track.is_circle: torus corridor around the unit circle at z=1 */
+    int32_t cylinder;                           /* corridor check on (make_env passes True) */
+    int32_t include_distance;                   /* obs[12] = distance/max_target_dist (True in the driver) */
+    int32_t normalize_actions;                  /* PBDroneEnv.rescale_action (True in the driver) */
+    int32_t normalize_obs;                      /* per-drone normalize.NormalizeObservation (always on in make_env) */
+    int32_t ground_contact;                     /* approximate len(p.getContactPoints())>0 vs plane.urdf */
+    int32_t compute_f32;                        /* 0: float64 arithmetic in registers over the float32 state
+                                                      (parity grade, default); 1: float32 arithmetic */
+    float act_noise_sigma;                      /* sim-to-real: Gaussian action noise (0 = reference) */
+    float obs_noise_sigma;                      /* sim-to-real: Gaussian observation noise (0 = reference) */
+    uint64_t seed;                              /* Philox key for the noise streams */
+    int64_t env_id_offset;                      /* global id of drone 0 (rank * num_envs when sharded) */
+} dn_config;
+
+/* One drone's persistent state, host-side AoS view used by dn_get_state/dn_set_state (tests,
+ * checkpointing).  Field names follow the reference's attributes. */
+typedef struct dn_env_state {
+    float pos[3], quat[4], vel[3], ang_v[3];    /* Bullet base state, BaseAviary.py:596-598 (quat = x,y,z,w) */
+    float prev_vel[3], prev_ang_v[3];           /* PBDroneEnv.prev_vel / prev_ang_v */
+    float cur_pos[3];                           /* PBDroneEnv._current_position (stale copy, quirk Q3) */
+    float d, d_prev;                            /* _distance_to_target, _prev_distance_to_target */
+    int32_t idx;                                /* _current_target_index */
+    int32_t steps;                              /* _steps */
+    int32_t just_found;                         /* just_found */
+    float ep_ret;                               /* Monitor: running episode return */
+    int32_t ep_len;                             /* Monitor: running episode length */
+    double rms_mean[DN_OBS_DIM];                /* normalize.RunningMeanStd.mean  (normalize_obs only) */
+    double rms_var[DN_OBS_DIM];                 /*                         .var                       */
+    double rms_count;                           /*                         .count                     */
+} dn_env_state;
+
+/* Wave-reduced episode statistics accumulated on the device since dn_create / dn_reset_stats. */
+typedef struct dn_stats {
+    int64_t env_steps;                          /* drone steps simulated */
+    int64_t episodes;                           /* episodes finished (done flags raised) */
+    int64_t truncated;                          /* of which TimeLimit.truncated */
+    int64_t completed;                          /* of which all waypoints reached (+200 branch) */
+    int64_t sum_ep_len;                         /* sum of Monitor 'l' */
+    int64_t sum_found_targets;                  /* sum of info['found_targets'] at episode end */
+    double sum_ep_return;                       /* sum of Monitor 'r' (fixed-point 1e-6 accumulation) */
+} dn_stats;
+
+typedef struct dn_env dn_env;
+
+int32_t dn_abi_version(void);
+const char *dn_last_error(void);
+int32_t dn_device_count(void);
+
+/* Fills *cfg with the driver's literals (threshold 0.3, max_steps 4096, cylinder, include_distance,
+ * normalize_actions on; circle/normalize_obs/noise off) and an empty track. */
+void dn_config_default(dn_config *cfg);
+
+/* Replaces N x PBDroneEnv.__init__ + the env.reset(seed=seed+rank) of make_env
+ * (PBDroneSimulator.py:154-173).  Allocates the device state. */
+int32_t dn_create(const dn_config *cfg, dn_env **out);
+int32_t dn_destroy(dn_env *env);
+int64_t dn_num_envs(const dn_env *env);
+
+/* Replaces VecEnv.reset() -> N x Monitor.reset/NormalizeObservation.reset/PBDroneEnv.reset
+ * (PBDroneEnv.py:609-665, BaseAviary.py:276-320).  obs: device float[N*13]. */
+int32_t dn_reset(dn_env *env, float *obs, void *stream);
+
+/* Replaces VecEnv.step_async+step_wait -> N x worker step (PBDroneEnv.step, PBDroneEnv.py:171-199)
+ * with SubprocVecEnv auto-reset and Monitor statistics.  All pointers are device pointers:
+ *   actions       const float[N*4]   policy output in [-1,1] (action_space, PBDroneEnv.py:230-236)
+ *   obs           float[N*13]        next observation (already the reset observation where done)
+ *   reward        float[N]
+ *   done          uint8[N]           terminated || truncated
+ *   truncated     uint8[N]           info["TimeLimit.truncated"] = truncated && !terminated
+ *   found_targets int32[N]           info["found_targets"] (PBDroneEnv.py:442)
+ *   terminal_obs  float[N*13]|NULL   info["terminal_observation"]; rows written only where done
+ *   ep_return     float[N]|NULL      Monitor info["episode"]["r"]; written only where done
+ *   ep_length     int32[N]|NULL      Monitor info["episode"]["l"]; written only where done
+ *   done_mask     uint64[ceil(N/64)]|NULL  one wave-ballot word per 64 drones (bit l = drone 64*w+l done) */
+int32_t dn_step(dn_env *env, const float *actions, float *obs, float *reward, uint8_t *done,
+                uint8_t *truncated, int32_t *found_targets, float *terminal_obs, float *ep_return,
+                int32_t *ep_length, uint64_t *done_mask, void *stream);
+
+/* Episode-done compaction: expands the per-wave ballot words written by dn_step into the ordered
+ * list of finished drones (what the host needs to build the per-env `infos` of SubprocVecEnv
+ * without scanning N flags).  indices: device int32[N]; count: device int32[1]. */
+int32_t dn_compact_done(const uint64_t *done_mask, int64_t num_envs, int32_t *indices, int32_t *count,
+                        int32_t device_id, void *stream);
+
+/* Host <-> device copies of the whole persistent state (synchronous).  states: host array [N]. */
+int32_t dn_get_state(dn_env *env, dn_env_state *states, int64_t count);
+int32_t dn_set_state(dn_env *env, const dn_env_state *states, int64_t count);
+
+/* Episode statistics (synchronises `stream`). */
+int32_t dn_get_stats(dn_env *env, dn_stats *out, void *stream);
+int32_t dn_reset_stats(dn_env *env, void *stream);
+
+/* Vector-step counter used as the Philox counter word of the noise streams. */
+int32_t dn_get_step_count(const dn_env *env, uint64_t *out);
+int32_t dn_set_step_count(dn_env *env, uint64_t value);
+
+/* Generalised advantage estimation on device buffers laid out [n_steps, n_envs]
+ * (the reference's only in-tree statement of the recursion: Sol/Model/Algorithms/cleanRLPPO.py:234-248).
+ * dones[t] is the episode-start flag of step t (cleanRL: dones[t] = next_done before step t),
+ * last_values/last_dones are V(s_T) and the done flag after the final step. */
+int32_t dn_gae(const float *rewards, const float *values, const uint8_t *dones,
+               const float *last_values, const uint8_t *last_dones, int64_t n_steps, int64_t n_envs,
+               double gamma, double gae_lambda, float *advantages, float *returns,
+               int32_t device_id, void *stream);
+
+/* Bytes of HBM the persistent state of `num_envs` drones occupies (capacity planning). */
+int64_t dn_state_bytes(int64_t num_envs, int32_t normalize_obs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DRONENAV_H */

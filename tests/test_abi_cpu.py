@@ -1,0 +1,118 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds, loads and exports every symbol that
+include/dronenav.h declares; argument validation and the no-GPU failure are loud; the product never
+imports the oracle.  No compute calls (there is no GPU here)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "drl-dronenavigation_amd")
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import drl_dronenavigation_amd as p
+    p.build.build_library()
+    return p
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "dronenav.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(dn_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    lib = pkg._capi.load()
+    syms = header_symbols()
+    assert len(syms) >= 18
+    for s in syms:
+        assert hasattr(lib, s), f"libdronenav.so does not export {s}"
+    assert set(syms) == set(pkg._capi.PROTOTYPES), "ctypes prototypes and the header disagree"
+    out = subprocess.run(["nm", "-D", "--defined-only", pkg._capi.library_path()], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (dn_[a-z_0-9]+)", out))
+    assert exported == set(syms), exported ^ set(syms)
+
+
+def test_struct_layouts_match_header(pkg):
+    # sizes computed by hand from include/dronenav.h (natural alignment)
+    assert C.sizeof(pkg._capi.DnConfig) == 8 + 4 + 4 + 64 * 3 * 8 + 3 * 8 + 6 * 8 + 8 + 8 * 4 + 2 * 4 + 8 + 8
+    assert C.sizeof(pkg._capi.DnEnvState) == 27 * 4 + 4 + 27 * 8 or C.sizeof(pkg._capi.DnEnvState) % 8 == 0
+    assert C.sizeof(pkg._capi.DnStats) == 7 * 8
+    assert pkg._capi.load().dn_abi_version() == 1
+
+
+def test_config_defaults_follow_the_driver(pkg):
+    cfg = pkg._capi.DnConfig()
+    pkg._capi.load().dn_config_default(C.byref(cfg))
+    assert cfg.threshold == 0.3 and cfg.max_steps == 4096 and cfg.cylinder == 1
+    assert cfg.include_distance == 1 and cfg.normalize_actions == 1 and cfg.compute_f32 == 0
+    assert cfg.act_noise_sigma == 0 and cfg.obs_noise_sigma == 0
+
+
+def test_create_fails_loudly(pkg):
+    """Invalid arguments are rejected before any device work; with valid arguments and no GPU the library
+    reports DN_ERR_NO_DEVICE instead of falling back to a CPU path."""
+    lib = pkg._capi.load()
+    from drl_dronenavigation_amd import tracks
+    from drl_dronenavigation_amd.vec_env import make_config
+    t = tracks.circle(1, 4, 1)
+    h = C.c_void_p()
+    for bad in (dict(num_envs=0), dict(max_steps=1 << 24), dict(threshold=-1.0), dict(act_noise_sigma=-1.0)):
+        kw = dict(num_envs=8, target_points=t.targets(), initial_xyzs=t.initial_xyzs, aviary_dim=t.aviary_dim)
+        kw.update(bad)
+        rc = lib.dn_create(C.byref(make_config(**kw)), C.byref(h))
+        assert rc == -1 and not h.value, bad
+        assert lib.dn_last_error()
+    cfg = make_config(num_envs=8, target_points=t.targets(), initial_xyzs=t.initial_xyzs, aviary_dim=t.aviary_dim)
+    cfg.num_waypoints = 65
+    assert lib.dn_create(C.byref(cfg), C.byref(h)) == -1
+    if lib.dn_device_count() == 0:
+        cfg.num_waypoints = 4
+        rc = lib.dn_create(C.byref(cfg), C.byref(h))
+        assert rc == -4 and b"no CPU fallback" in lib.dn_last_error()
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            pkg.DroneVecEnv(t, 8)
+    assert lib.dn_step(None, *([None] * 12)) == -1
+    assert lib.dn_destroy(None) == 0
+
+
+def test_state_bytes_capacity_planning(pkg):
+    lib = pkg._capi.load()
+    n = 32768
+    b = lib.dn_state_bytes(n, 0)
+    assert 7 * 16 * n <= b <= 7 * 16 * n + 64 * 1024
+    assert lib.dn_state_bytes(n, 1) - b >= 27 * 8 * n
+    # 288 GB of HBM3E holds > 10^9 drones' state
+    assert lib.dn_state_bytes(1 << 30, 0) < 288e9
+
+
+def test_tracks_match_reference_generators(pkg, golden):
+    from drl_dronenavigation_amd import tracks
+    g = golden("tracks")
+    for n in ["circle4", "circle6", "reaching", "up", "half_up_forward", "up_circle", "up_sharp_back_turn"]:
+        t = tracks.REGISTRY[n]()
+        assert np.array_equal(t.waypoints, g[n + "_waypoints"]), n
+        assert np.array_equal(t.initial_xyzs.ravel(), g[n + "_spawn"]), n
+        assert np.array_equal(t.aviary_dim, g[n + "_dim"]), n
+    assert len(tracks.circle(1, 4, 1).targets()) == 4          # circle tracks drop their first point
+    assert len(tracks.dilate_targets(tracks.reaching().waypoints, 2)) == 7 * 3 + 1
+
+
+def test_product_never_touches_the_oracle():
+    """The oracle is test infrastructure: nothing under the package, include/ or the import shim may
+    import, load or link it."""
+    offenders = []
+    files = [os.path.join(ROOT, "drl_dronenavigation_amd.py")]
+    for base in (PKG, os.path.join(ROOT, "include")):
+        for d, _, fs in os.walk(base):
+            files += [os.path.join(d, f) for f in fs if f.endswith((".py", ".h", ".hip", ".cpp"))]
+    for f in files:
+        txt = open(f).read()
+        if re.search(r"\boracle\b|liboracle|dn_oracle|orc_", txt):
+            offenders.append(f)
+    assert not offenders, offenders
