@@ -65,7 +65,7 @@ PROTOTYPES = {
     "dn_destroy": (_I32, [_VP]),
     "dn_num_envs": (_I64, [_VP]),
     "dn_reset": (_I32, [_VP, _VP, _VP]),
-    "dn_step": (_I32, [_VP] * 13),
+    "dn_step": (_I32, [_VP] * 12),
     "dn_compact_done": (_I32, [_VP, _I64, _VP, _VP, _I32, _VP]),
     "dn_get_state": (_I32, [_VP, _VP, _I64]),
     "dn_set_state": (_I32, [_VP, _VP, _I64]),
@@ -94,6 +94,14 @@ def load():
         raise DroneNavLibraryError(
             f"{path} is missing: run `python __graft_entry__.py` (or drl-dronenavigation_amd/build.py) to compile "
             "the HIP kernels with hipcc.  This package has no CPU fallback.")
+    # PyTorch-ROCm wheels bundle their own libamdhip64 (same SONAME as /opt/rocm's).  The device pointers
+    # handed across the C ABI come from torch's allocator, so both must share ONE HIP runtime instance:
+    # import torch first, and the dynamic loader resolves our NEEDED libamdhip64.so.7 to the copy torch
+    # already mapped.  (Pure-C users link against the system runtime as usual.)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     try:
         lib = C.CDLL(path)
     except OSError as exc:

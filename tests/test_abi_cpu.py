@@ -77,7 +77,7 @@ def test_create_fails_loudly(pkg):
         assert rc == -4 and b"no CPU fallback" in lib.dn_last_error()
         with pytest.raises(RuntimeError, match="no CPU fallback"):
             pkg.DroneVecEnv(t, 8)
-    assert lib.dn_step(None, *([None] * 12)) == -1
+    assert lib.dn_step(None, *([None] * 11)) == -1
     assert lib.dn_destroy(None) == 0
 
 

@@ -50,8 +50,14 @@ def gpu_state_to_oracle(st, envs, step_count):
 
 
 def actions_mixed(rng, n):
-    """Half bang-bang U(-1,1) (crashes within tens of steps), half hover + noise (long flights)."""
-    a = np.where(rng.random((n, 1)) < 0.5, rng.uniform(-1, 1, (n, 4)), 0.0922 + 0.003 * rng.standard_normal((n, 4)))
+    """Even drones: bang-bang U(-1,1) (crash within tens of steps, BASELINE config 2's stream); odd drones:
+    hover + noise, 0.0922 + 0.003 N(0,1) (long flights, truncation, gate passes); one step in eight the two
+    regimes swap so that hovering drones get kicked."""
+    bang = rng.uniform(-1, 1, (n, 4))
+    hover = 0.0922 + 0.003 * rng.standard_normal((n, 4))
+    swap = rng.random((n, 1)) < 0.125
+    even = (np.arange(n) % 2 == 0)[:, None]
+    a = np.where(even ^ swap, bang, hover)
     return a.astype(np.float32)
 
 
@@ -63,12 +69,13 @@ def compare_step(out, ref, tag, obs_atol=1e-5):
     assert np.array_equal(done.cpu().numpy(), ref["done"]), f"{tag}: done"
     assert np.array_equal(info["truncated"].cpu().numpy(), ref["truncated"]), f"{tag}: TimeLimit.truncated"
     assert np.array_equal(info["found_targets"].cpu().numpy(), ref["found_targets"]), f"{tag}: waypoint index"
-    np.testing.assert_allclose(obs.cpu().numpy(), ref["obs"], rtol=0, atol=obs_atol, err_msg=f"{tag}: obs")
+    k = obs.shape[1]                       # 12 columns when include_distance is off
+    np.testing.assert_allclose(obs.cpu().numpy(), ref["obs"][:, :k], rtol=0, atol=obs_atol, err_msg=f"{tag}: obs")
     # reward carries 3000*(d_prev - d)/25: 1e-5 relative + 1e-5 absolute
     np.testing.assert_allclose(rew.cpu().numpy(), ref["reward"], rtol=1e-5, atol=1e-5, err_msg=f"{tag}: reward")
     dn = ref["done"].astype(bool)
     if dn.any():
-        np.testing.assert_allclose(info["terminal_obs"].cpu().numpy()[dn], ref["terminal_obs"][dn], rtol=0,
+        np.testing.assert_allclose(info["terminal_obs"].cpu().numpy()[dn], ref["terminal_obs"][dn][:, :k], rtol=0,
                                    atol=obs_atol, err_msg=f"{tag}: terminal_observation")
         assert np.array_equal(info["ep_length"].cpu().numpy()[dn], ref["ep_len"][dn]), f"{tag}: episode l"
         np.testing.assert_allclose(info["ep_return"].cpu().numpy()[dn], ref["ep_ret"][dn], rtol=1e-5, atol=1e-4,
@@ -76,18 +83,18 @@ def compare_step(out, ref, tag, obs_atol=1e-5):
     return int(dn.sum())
 
 
-@pytest.mark.parametrize("track_name,n,T,norm", [("circle4", 4096, 120, False), ("reaching", 4096, 100, False),
-                                                 ("circle4", 1024, 80, True)])
+@pytest.mark.parametrize("track_name,n,T,norm", [("circle4", 4096, 260, False), ("reaching", 4096, 260, False),
+                                                 ("circle4", 1024, 200, True)])
 def test_teacher_forced_vs_oracle(track_name, n, T, norm):
     """BASELINE config 2: every step starts both sides from the GPU's float32 state; the reference-grade
     float64 oracle then has to agree on state (1e-5), done and waypoint index (exact)."""
     track = _tracks().REGISTRY[track_name]()
-    env, ora = make_pair(track, n, f32_state=False, max_steps=60, normalize_obs=norm)
+    env, ora = make_pair(track, n, f32_state=False, max_steps=110, normalize_obs=norm)
     env.reset_tensor()
     ora.reset()
     rng = np.random.default_rng(1)
     dev = torch.device("cuda:0")
-    n_done = n_found = 0
+    n_done = n_found = n_crash = 0
     max_state_err = 0.0
     for t in range(T):
         st = env.get_state()
@@ -98,6 +105,7 @@ def test_teacher_forced_vs_oracle(track_name, n, T, norm):
         ref = ora.step(a)
         n_done += compare_step(out, ref, f"{track_name} t={t}")
         n_found += int((ref["found_targets"] > 0).sum())
+        n_crash += int((ref["reward"] == -10.0 / 1).sum())
         st2 = env.get_state()
         for k in STATE_F32:
             err = np.abs(st2[k].astype(np.float64) - ora.envs[k]).max()
@@ -109,6 +117,7 @@ def test_teacher_forced_vs_oracle(track_name, n, T, norm):
             np.testing.assert_allclose(st2["rms_mean"], ora.envs["rms_mean"], rtol=1e-12, atol=1e-14)
             np.testing.assert_allclose(st2["rms_var"], ora.envs["rms_var"], rtol=1e-12, atol=1e-14)
     assert n_done > n // 4, "the auto-reset path must be exercised"
+    assert n_crash > n // 8 and n_done > n_crash, "both crashes (-10) and truncations must occur"
     print(f"{track_name}: {n_done} episodes, max |state err| = {max_state_err:.3e}")
     env.close()
 
@@ -159,7 +168,14 @@ def test_golden_fixtures_teacher_forced(golden, name):
         assert np.array_equal(info["truncated"].cpu().numpy(), g["truncated"][t]), (name, t)
         assert np.array_equal(info["found_targets"].cpu().numpy(), g["found_targets"][t]), (name, t)
         # float32 state teacher-forced from float64 internals: 1e-5 on obs, 1e-4 on the 120x-amplified reward
-        np.testing.assert_allclose(obs.cpu().numpy(), g["obs"][t], rtol=0, atol=2e-5 if norm else 1e-5)
+        # (the reference turns ang_v into a UNIT vector, so where |ang_v| is tiny the float32 rounding of the
+        #  teacher-forced input, 6e-8 absolute, is divided by |ang_v|: those three columns get 2e-7/|ang_v|)
+        atol = np.full((n, 13), 1e-4 if norm else 1e-5)   # normalised obs are divided by a running std << 1
+        if not norm:
+            wn = np.linalg.norm(g["int_ang_v"][t], axis=1, keepdims=True)
+            atol[:, 9:12] = np.maximum(1e-5, 2e-7 / np.maximum(wn, 1e-30))
+        err = np.abs(obs.cpu().numpy().astype(np.float64) - g["obs"][t])
+        assert (err <= atol).all(), (name, t, float((err - atol).max()))
         np.testing.assert_allclose(rew.cpu().numpy(), g["reward"][t], rtol=1e-4, atol=1e-4)
         # load the reference's own post-step state for the next step
         st = env.get_state()
@@ -175,11 +191,11 @@ def test_golden_fixtures_teacher_forced(golden, name):
 def test_ragged_sizes(n):
     """Ragged last tile (N not a multiple of the 64-lane wave) and the single-drone case."""
     track = _tracks().circle(1, 4, 1)
-    env, ora = make_pair(track, n, f32_state=True, max_steps=20, normalize_obs=True)
+    env, ora = make_pair(track, n, f32_state=True, max_steps=120, normalize_obs=True)
     np.testing.assert_allclose(env.reset(), ora.reset(), rtol=0, atol=1e-6)
     rng = np.random.default_rng(n)
     dev = torch.device("cuda:0")
-    for t in range(50):
+    for t in range(170):
         a = actions_mixed(rng, n)
         compare_step(env.step_tensor(torch.from_numpy(a).to(dev)), ora.step(a), f"n={n} t={t}")
     env.close()
@@ -244,7 +260,7 @@ def test_noise_streams_match_oracle():
 
 
 def test_float32_compute_mode_tolerance():
-    """The float32-arithmetic build is a speed option, held to 1e-4 (teacher-forced) instead of 1e-5."""
+    """The float32-arithmetic build is a speed option, held to 5e-4 (teacher-forced) instead of 1e-5."""
     track = _tracks().circle(1, 4, 1)
     n = 2048
     env, ora = make_pair(track, n, f32_state=False, max_steps=60, normalize_obs=False, compute_dtype="float32")
@@ -260,7 +276,7 @@ def test_float32_compute_mode_tolerance():
         ref = ora.step(a)
         same = done.cpu().numpy() == ref["done"]
         mism += int((~same).sum())
-        np.testing.assert_allclose(obs.cpu().numpy()[same], ref["obs"][same], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(obs.cpu().numpy()[same], ref["obs"][same], rtol=0, atol=5e-4)
     assert mism <= n * 60 * 1e-4, f"{mism} done flags differ"
     env.close()
 
@@ -269,14 +285,14 @@ def test_sb3_step_surface_and_infos():
     """reset()/step() NumPy surface: shapes, dtypes and the info keys SB3 and the reference read."""
     track = _tracks().circle(1, 4, 1)
     n = 130
-    env, ora = make_pair(track, n, f32_state=True, max_steps=15, normalize_obs=True)
+    env, ora = make_pair(track, n, f32_state=True, max_steps=90, normalize_obs=True)
     obs = env.reset()
     assert obs.shape == (n, 13) and obs.dtype == np.float32
     np.testing.assert_allclose(obs, ora.reset(), rtol=0, atol=1e-6)
     assert env.observation_space.shape == (13,) and env.action_space.shape == (4,)
     rng = np.random.default_rng(6)
     seen_trunc = seen_term = False
-    for t in range(40):
+    for t in range(220):
         a = actions_mixed(rng, n)
         obs, rew, done, infos = env.step(a)
         ref = ora.step(a)
@@ -336,7 +352,8 @@ def test_full_size_properties():
         runs.append((st.copy(), float(rew_sum), s))
         env.close()
     assert runs[0][1] == runs[1][1] and runs[0][2] == runs[1][2]
-    assert runs[0][0].tobytes() == runs[1][0].tobytes(), "two identical runs must be bit-identical"
+    for k in runs[0][0].dtype.names:
+        assert np.ascontiguousarray(runs[0][0][k]).tobytes() == np.ascontiguousarray(runs[1][0][k]).tobytes(), k
 
 
 def test_gae_kernel_matches_reference_recursion(golden):
