@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/s of the HIP drone-navigation environment on N MI355X of one node.
+
+Contract (see the task brief): `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver
+launches it under torch.distributed.run (one rank per GPU, RCCL).  A "step" is one pass of the hot path
+(dn_step: one kernel launch advancing every drone by one 240 Hz control step, auto-reset included) over
+one batch of synthetic actions that is already resident in HBM.  W untimed steps, then EXACTLY K timed
+steps bracketed by barrier + synchronize, MAX over ranks, one JSON line from rank 0.
+
+Workload = BASELINE.json configs[2]: 32 768 drones per GPU on the 8-gate race track
+(`Waypoints.reaching()`), norm_rew off, positional observation; actions U(-1,1)^4 float32 from a seeded
+generator (the bang-bang regime that exercises the auto-reset path constantly).
+The path shards embarrassingly (no data-path collective): weak scaling, 32 768 drones per rank.
+
+Extra objects on the JSON line:
+  roofline     -- HBM roofline of the step kernel: 288 algorithmic bytes per drone-step x
+                  drones per launch / average launch-to-launch time measured with HIP events on the launch
+                  stream over the timed region; peak 8 TB/s (MI355X_MICROARCH.md).
+  cpu_baseline -- the CPU oracle (a port; the reference's PyBullet path cannot run here) timed on this
+                  box's host cores on a bounded sample of the same workload, rank 0, N = 1 only.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+ALGO_BYTES_PER_ENV_STEP = 288          # state R+W 104, bookkeeping R+W 106, action 16, outputs 62
+HBM_PEAK_GBPS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20000)
+    ap.add_argument("--warmup", type=int, default=2000)
+    ap.add_argument("--num-envs", type=int, default=32768, help="drones per GPU")
+    ap.add_argument("--track", default="reaching")
+    ap.add_argument("--compute-dtype", default="float64", choices=["float64", "float32"])
+    ap.add_argument("--normalize-obs", action="store_true", help="fuse the per-drone NormalizeObservation (+432 B)")
+    ap.add_argument("--mode", default="many", choices=["many", "single", "graph"],
+                    help="many: one dn_step_many call; single: K python-level dn_step calls; graph: hipGraph replay")
+    ap.add_argument("--action-batches", type=int, default=64, help="distinct resident action batches cycled")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(track, num_envs, max_steps, seconds):
+    """Time the CPU oracle (test infrastructure used here only as the reported baseline) on all host cores."""
+    import numpy as np
+    from oracle import oracle as O
+    cores = os.cpu_count() or 1
+    cfg = O.make_config(track.targets(), track.initial_xyzs, track.aviary_dim, circle=track.is_circle,
+                        max_steps=max_steps, normalize_obs=False)
+    rng = np.random.default_rng(1)
+    acts = rng.uniform(-1, 1, (16, num_envs, 4)).astype(np.float32)
+    res = {}
+    for label, threads, budget in (("all", cores, seconds * 0.75), ("one", 1, seconds * 0.25)):
+        env = O.OracleVecEnv(cfg, num_envs, threads=threads)
+        env.reset()
+        env.step(acts[0])
+        t0 = time.perf_counter()
+        env.step(acts[1])
+        per = max(time.perf_counter() - t0, 1e-6)
+        k = max(2, int(budget / per))
+        t0 = time.perf_counter()
+        for t in range(k):
+            env.step(acts[t % len(acts)])
+        dt = time.perf_counter() - t0
+        res[label] = dict(value=num_envs * k / dt, steps=k, seconds=dt, threads=threads)
+    return {"value": round(res["all"]["value"], 1), "unit": "env-steps/s", "cores": res["all"]["threads"],
+            "kind": "port",
+            "sample": f"{num_envs} drones x {res['all']['steps']} vector steps ({res['all']['seconds']:.1f} s) of the same "
+                      f"workload through oracle/dn_oracle.c (OpenMP, float64)",
+            "single_thread_value": round(res["one"]["value"], 1)}
+
+
+def main():
+    args = parse()
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import drl_dronenavigation_amd as pkg
+    from drl_dronenavigation_amd import tracks
+    track = tracks.REGISTRY[args.track]()
+    n, K, W = args.num_envs, args.steps, args.warmup
+    max_steps = 4096                                      # --max_env_steps default, parameter_manager.py:25
+    env = pkg.DroneVecEnv(track, n, max_steps=max_steps, normalize_obs=args.normalize_obs,
+                          compute_dtype=args.compute_dtype, env_id_offset=rank * n, device=dev)
+    env.reset_tensor()
+
+    # synthetic actions resident in HBM before the timed region: U(-1,1)^4 float32, seeded per global drone id
+    A = max(1, min(args.action_batches, K))
+    g = torch.Generator(device="cpu").manual_seed(1 + rank)
+    acts = (torch.rand((A, n, 4), generator=g, dtype=torch.float32) * 2 - 1).to(dev)
+    lib = pkg._capi.load()
+    stream = torch.cuda.current_stream(dev)
+    sptr = C.c_void_p(stream.cuda_stream)
+    h = env._handle
+    o = dict(obs=torch.empty((A, n, 13), dtype=torch.float32, device=dev), reward=torch.empty((A, n), device=dev),
+             done=torch.empty((A, n), dtype=torch.uint8, device=dev), trunc=torch.empty((A, n), dtype=torch.uint8, device=dev),
+             found=torch.empty((A, n), dtype=torch.int32, device=dev))
+
+    def run_many(k):
+        """k steps as ceil(k/A) dn_step_many calls over the A resident action batches."""
+        done = 0
+        while done < k:
+            c = min(A, k - done)
+            pkg._capi.check(lib.dn_step_many(h, c, acts.data_ptr(), o["obs"].data_ptr(), o["reward"].data_ptr(),
+                                             o["done"].data_ptr(), o["trunc"].data_ptr(), o["found"].data_ptr(),
+                                             None, None, None, None, sptr))
+            done += c
+
+    ptrs = [(acts[j].data_ptr(), o["obs"][j].data_ptr(), o["reward"][j].data_ptr(), o["done"][j].data_ptr(),
+             o["trunc"][j].data_ptr(), o["found"][j].data_ptr()) for j in range(A)]
+
+    def run_single(k):
+        for t in range(k):
+            p = ptrs[t % A]
+            rc = lib.dn_step(h, p[0], p[1], p[2], p[3], p[4], p[5], None, None, None, None, sptr)
+            if rc:
+                pkg._capi.check(rc)
+
+    graph = None
+    if args.mode == "graph":
+        # capture A back-to-back launches once; replay ceil(K/A) times (K is rounded to a multiple of A)
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(stream)
+        with torch.cuda.stream(side):
+            sp = C.c_void_p(side.cuda_stream)
+            pkg._capi.check(lib.dn_step_many(h, A, acts.data_ptr(), o["obs"].data_ptr(), o["reward"].data_ptr(),
+                                             o["done"].data_ptr(), o["trunc"].data_ptr(), o["found"].data_ptr(),
+                                             None, None, None, None, sp))
+        stream.wait_stream(side)
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            sp = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            pkg._capi.check(lib.dn_step_many(h, A, acts.data_ptr(), o["obs"].data_ptr(), o["reward"].data_ptr(),
+                                             o["done"].data_ptr(), o["trunc"].data_ptr(), o["found"].data_ptr(),
+                                             None, None, None, None, sp))
+        if K % A or W % A:
+            raise SystemExit(f"--mode graph needs --steps and --warmup to be multiples of {A}")
+
+        def run_graph(k):
+            for _ in range(k // A):
+                graph.replay()
+    run = {"many": run_many, "single": run_single, "graph": run_graph if graph else None}[args.mode]
+
+    def barrier():
+        if dist is not None:
+            dist.barrier(device_ids=[local_rank])
+
+    run(W)
+    torch.cuda.synchronize(dev)
+    barrier()
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record(stream)
+    run(K)
+    e1.record(stream)
+    torch.cuda.synchronize(dev)
+    barrier()
+    torch.cuda.synchronize(dev)
+    wall = time.perf_counter() - t0
+    gpu_ms = e0.elapsed_time(e1)                          # HIP events on the launch stream, timed region only
+    if dist is not None:
+        tw = torch.tensor([wall, gpu_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        wall, gpu_ms = float(tw[0]), float(tw[1])
+    st = env.stats()
+
+    if rank == 0:
+        value = n * world * K / wall
+        launch_us = gpu_ms * 1e3 / K
+        achieved = ALGO_BYTES_PER_ENV_STEP * n / (launch_us * 1e-6) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):                          # per-launch HBM bytes from the committed rocprofv3 --pmc passes
+            try:
+                tj = json.load(open(tpath))
+                key = f"{args.track}_{n}_{args.compute_dtype}" + ("_norm" if args.normalize_obs else "")
+                traffic = tj.get(key, {}).get("bytes_per_launch")
+            except Exception:  # noqa: BLE001
+                traffic = None
+        line = {
+            "metric": "env_steps_per_sec", "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world,
+            "steps": K, "warmup": W, "ms_per_step": round(wall * 1e3 / K, 6), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64" if args.compute_dtype == "float64" else "f32", "data": "synthetic",
+            "config": {"workload": f"{n} drones/GPU, 8-gate race track (Waypoints.reaching), U(-1,1)^4 actions resident in HBM, "
+                                   f"norm_rew off, obs normaliser {'on' if args.normalize_obs else 'off'}, auto-reset on",
+                       "num_envs_per_gpu": n, "global_num_envs": n * world, "track": args.track,
+                       "state_dtype": "f32", "launch_mode": args.mode, "parallelism": f"env-shard x{world} (no data-path collective)",
+                       "episodes_finished_rank0": st["episodes"]},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
+                         "kernel": "dn_step_kernel<%s>" % ("double" if args.compute_dtype == "float64" else "float"),
+                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n,
+                         "avg_launch_us": round(launch_us, 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(track, n, max_steps, args.cpu_baseline_seconds)
+        print(json.dumps(line), flush=True)
+    env.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

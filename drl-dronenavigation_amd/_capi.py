@@ -66,6 +66,7 @@ PROTOTYPES = {
     "dn_num_envs": (_I64, [_VP]),
     "dn_reset": (_I32, [_VP, _VP, _VP]),
     "dn_step": (_I32, [_VP] * 12),
+    "dn_step_many": (_I32, [_VP, _I64] + [_VP] * 11),
     "dn_compact_done": (_I32, [_VP, _I64, _VP, _VP, _I32, _VP]),
     "dn_get_state": (_I32, [_VP, _VP, _I64]),
     "dn_set_state": (_I32, [_VP, _VP, _I64]),

@@ -316,6 +316,26 @@ int32_t dn_step(dn_env *env, const float *actions, float *obs, float *reward, ui
     return DN_OK;
 }
 
+int32_t dn_step_many(dn_env *env, int64_t k, const float *actions, float *obs, float *reward, uint8_t *done,
+                     uint8_t *truncated, int32_t *found_targets, float *terminal_obs, float *ep_return,
+                     int32_t *ep_length, uint64_t *done_mask, void *stream)
+{
+    if (!env) return fail(DN_ERR_INVALID_ARGUMENT, "env is NULL");
+    if (k < 1) return fail(DN_ERR_INVALID_ARGUMENT, "k must be >= 1 (got %lld)", (long long)k);
+    const long long n = env->cfg.num_envs;
+    if (k > 1 && (n & 3)) return fail(DN_ERR_INVALID_ARGUMENT, "dn_step_many needs num_envs %% 4 == 0 (got %lld)", n);
+    const long long words = (n + 63) / 64;
+    for (int64_t t = 0; t < k; ++t) {
+        int32_t rc = dn_step(env, actions + t * n * DN_ACT_DIM, obs + t * n * DN_OBS_DIM, reward + t * n, done + t * n,
+                             truncated + t * n, found_targets + t * n,
+                             terminal_obs ? terminal_obs + t * n * DN_OBS_DIM : nullptr,
+                             ep_return ? ep_return + t * n : nullptr, ep_length ? ep_length + t * n : nullptr,
+                             done_mask ? done_mask + t * words : nullptr, stream);
+        if (rc != DN_OK) return rc;
+    }
+    return DN_OK;
+}
+
 int32_t dn_compact_done(const uint64_t *done_mask, int64_t num_envs, int32_t *indices, int32_t *count,
                         int32_t device_id, void *stream)
 {

@@ -183,6 +183,37 @@ class DroneVecEnv(_VecEnvBase):
                 self._ep_len.data_ptr() if want_terminal else None,
                 self._done_mask.data_ptr(), self._stream()))
 
+    def rollout_tensor(self, actions, out=None, want_terminal=False):
+        """K open-loop control steps in one C call (dn_step_many).  `actions`: float32 CUDA tensor [K, N, 4].
+        Returns a dict of step-major device tensors (obs [K,N,13], reward [K,N], done [K,N] uint8,
+        truncated [K,N] uint8, found_targets [K,N] int32 and, if `want_terminal`, terminal_obs / ep_return /
+        ep_length / done_mask) -- the (n_steps, n_envs, ...) layout of a rollout buffer.  Pass the dict back as
+        `out` to reuse the buffers."""
+        if actions.device != self.device or actions.dtype != torch.float32 or actions.dim() != 3 \
+                or tuple(actions.shape[1:]) != (self.num_envs, ACT_DIM) or not actions.is_contiguous():
+            raise ValueError(f"actions must be a contiguous float32 [K, {self.num_envs}, {ACT_DIM}] tensor on {self.device}")
+        k, n, dev = actions.shape[0], self.num_envs, self.device
+        if out is None:
+            out = dict(obs=torch.empty((k, n, OBS_DIM), dtype=torch.float32, device=dev),
+                       reward=torch.empty((k, n), dtype=torch.float32, device=dev),
+                       done=torch.empty((k, n), dtype=torch.uint8, device=dev),
+                       truncated=torch.empty((k, n), dtype=torch.uint8, device=dev),
+                       found_targets=torch.empty((k, n), dtype=torch.int32, device=dev))
+            if want_terminal:
+                out.update(terminal_obs=torch.zeros((k, n, OBS_DIM), dtype=torch.float32, device=dev),
+                           ep_return=torch.zeros((k, n), dtype=torch.float32, device=dev),
+                           ep_length=torch.zeros((k, n), dtype=torch.int32, device=dev),
+                           done_mask=torch.zeros((k, (n + 63) // 64), dtype=torch.int64, device=dev))
+
+        def ptr(name):
+            return out[name].data_ptr() if name in out else None
+        with torch.cuda.device(self.device):
+            _capi.check(self._lib.dn_step_many(
+                self._handle, k, actions.data_ptr(), ptr("obs"), ptr("reward"), ptr("done"), ptr("truncated"),
+                ptr("found_targets"), ptr("terminal_obs"), ptr("ep_return"), ptr("ep_length"), ptr("done_mask"),
+                self._stream()))
+        return out
+
     def done_indices(self):
         """Ordered indices of the drones whose episode ended in the last step (device compaction of the
         per-wave ballot words), as a host int32 array."""

@@ -138,6 +138,14 @@ int32_t dn_step(dn_env *env, const float *actions, float *obs, float *reward, ui
                 uint8_t *truncated, int32_t *found_targets, float *terminal_obs, float *ep_return,
                 int32_t *ep_length, uint64_t *done_mask, void *stream);
 
+/* k consecutive control steps enqueued back-to-back (open-loop action sequences: replays, random-action
+ * collection, benchmarks).  Every buffer is step-major [k, N, ...] -- the (n_steps, n_envs, ...) layout of an
+ * SB3 RolloutBuffer -- with the same meaning and optionality as in dn_step; done_mask is [k, ceil(N/64)].
+ * N must be a multiple of 4 so that every step's obs slice stays 16-byte aligned. */
+int32_t dn_step_many(dn_env *env, int64_t k, const float *actions, float *obs, float *reward, uint8_t *done,
+                     uint8_t *truncated, int32_t *found_targets, float *terminal_obs, float *ep_return,
+                     int32_t *ep_length, uint64_t *done_mask, void *stream);
+
 /* Episode-done compaction: expands the per-wave ballot words written by dn_step into the ordered
  * list of finished drones (what the host needs to build the per-env `infos` of SubprocVecEnv
  * without scanning N flags).  indices: device int32[N]; count: device int32[1]. */
