@@ -108,6 +108,8 @@ void build_consts(const dn_config &c, DnConsts<R> &k)
     double a = std::fabs(c.aviary_dim[0]) + c.aviary_dim[3], b = std::fabs(c.aviary_dim[1]) + c.aviary_dim[4];
     double m = a > b ? a : b;
     k.max_target_dist = (R)(m > c.aviary_dim[5] ? m : c.aviary_dim[5]);           // PBDroneEnv.py:91
+    k.inv_max_target_dist = (R)1.0 / k.max_target_dist;
+    for (int j = 0; j < 3; ++j) k.inv_dim[j] = (R)1.0 / k.dim[3 + j];
     // BaseAviary.reset -> _computeObs on the freshly loaded body: pos = spawn, quat = (0,0,0,1), at rest.
     // getEulerFromQuaternion(identity) = (atan2(0,1), asin(-0.0), atan2(0,1)) = (0, -0, 0).
     const R pi = (R)3.14159265358979323846;

@@ -70,6 +70,8 @@ struct DnConsts {
     R threshold;
     R thr_ext;          // threshold + 0.2
     R max_target_dist;
+    R inv_max_target_dist;
+    R inv_dim[3];       // 1 / (x_high, y_high, z_high): position normalisation as a multiply
     R reset_obs[12];    // observation of the freshly spawned body (BaseAviary.reset, BaseAviary.py:318)
 };
 

@@ -38,6 +38,15 @@ template <typename R> struct K {
     static constexpr R MAX_COORD_VEL = R(100.0);                 // btMultiBody::m_maxCoordinateVelocity
     static constexpr R PI = R(3.14159265358979323846);
     static constexpr R COLL_R = R(0.06), COLL_H = R(0.025);      // cf2x.urdf:34
+    // Reciprocals of the constant divisors: x * (1/c) instead of x / c.  A float64 divide is a ~15-instruction
+    // dependent chain on gfx950; the product differs from the quotient by at most one float64 ulp (1e-16),
+    // eleven orders of magnitude inside the 1e-5 parity bar and invisible after the float32 store.
+    static constexpr R INV_M = R(1.0 / 0.027);
+    static constexpr R INV_IXX = R(1.0 / 1.4e-5), INV_IYY = R(1.0 / 1.4e-5), INV_IZZ = R(1.0 / 2.17e-5);
+    static constexpr R INV_PI = R(1.0 / 3.14159265358979323846);
+    static constexpr R THIRD = R(1.0 / 3.0);
+    static constexpr R INV_25 = R(1.0 / 25.0);
+    static constexpr R COS_10DEG = R(0.98480775301220805936674302458952);   // cos(np.radians(10))
 };
 constexpr float KF32 = (float)3.16e-10, KM32 = (float)7.94e-12;
 constexpr float PWM2RPM_SCALE32 = (float)0.2685, PWM2RPM_CONST32 = (float)4070.3;
@@ -171,8 +180,8 @@ DN_DEV bool has_collision(const DnParams &p, const DnConsts<R> &c, const R *tab,
     if (!p.cylinder) return false;
     if (p.circle) {                                   // :723-741, centre (0,0,1), radius 1
         R cx = px - R(0.0), cy = py - R(0.0), cz = R(0.0);
-        R n = norm3(cx, cy, cz);
-        R nx = cx / n * R(1.0), ny = cy / n * R(1.0), nz = cz / n * R(1.0);   // 0/0 -> NaN -> compare false
+        R rn = R(1.0) / norm3(cx, cy, cz);
+        R nx = cx * rn, ny = cy * rn, nz = cz * rn;    // radius 1; 0 * inf -> NaN -> the compare below is false
         R qx = R(0.0) + nx, qy = R(0.0) + ny, qz = R(1.0) + nz;
         return norm3(px - qx, py - qy, pz - qz) > c.threshold;
     }
@@ -188,17 +197,27 @@ DN_DEV bool has_collision(const DnParams &p, const DnConsts<R> &c, const R *tab,
     return norm3(px - qx, py - qy, pz - qz) > c.thr_ext;               // :786
 }
 
-// orientation_reward (PBDroneEnv.py:573-586) with get_forward_vector (:588-597)
+// orientation_reward (PBDroneEnv.py:573-586) with get_forward_vector (:588-597).  The reference tests
+// arccos(clip(f . t, -1, 1)) > radians(10); arccos is strictly decreasing, so that is f . t < cos(10 deg)
+// (NaN compares false on both forms) and the arccos is never evaluated.
 template <typename R>
 DN_DEV int orientation_reward(R fx, R fy, R fz, R px, R py, R pz, const R *wp)
 {
-    const R thr = R(10.0) * (K<R>::PI / R(180.0));
     R tx = wp[0] - px, ty = wp[1] - py, tz = wp[2] - pz;
-    R n = norm3(tx, ty, tz);
-    tx = tx / n; ty = ty / n; tz = tz / n;
-    R dot = fx * tx + fy * ty + fz * tz;
-    R ang = acos(clipv(dot, R(-1.0), R(1.0)));
-    return (ang > thr) ? -1 : 0;
+    R rn = R(1.0) / norm3(tx, ty, tz);
+    R dot = fx * (tx * rn) + fy * (ty * rn) + fz * (tz * rn);
+    return (clipv(dot, R(-1.0), R(1.0)) < K<R>::COS_10DEG) ? -1 : 0;
+}
+
+// sin(h)/h and cos(h) for the quaternion half-angle h = |w| dt / 2 <= pi/8 (Bullet clamps |w| dt at pi/4):
+// Taylor polynomials in h^2, truncation < 1e-18 on that interval, no range reduction needed.
+template <typename R> DN_DEV void sinc_cos_small(R h2, R &sinc, R &c)
+{
+    sinc = R(1.0) + h2 * (R(-1.0 / 6.0) + h2 * (R(1.0 / 120.0) + h2 * (R(-1.0 / 5040.0) + h2 * (R(1.0 / 362880.0) +
+           h2 * (R(-1.0 / 39916800.0) + h2 * (R(1.0 / 6227020800.0) + h2 * R(-1.0 / 1307674368000.0)))))));
+    c = R(1.0) + h2 * (R(-0.5) + h2 * (R(1.0 / 24.0) + h2 * (R(-1.0 / 720.0) + h2 * (R(1.0 / 40320.0) +
+        h2 * (R(-1.0 / 3628800.0) + h2 * (R(1.0 / 479001600.0) + h2 * (R(-1.0 / 87178291200.0) +
+        h2 * R(1.0 / 20922789888000.0))))))));
 }
 
 struct Meta {
@@ -255,13 +274,15 @@ DN_DEV void reset_obs(const DnParams &p, const DnConsts<R> &c, R d_last, float o
 {
 #pragma unroll
     for (int k = 0; k < 12; ++k) o[k] = (float)c.reset_obs[k];
-    o[12] = p.include_distance ? (float)clipv(d_last / c.max_target_dist, -(R)FLT_MAX, (R)FLT_MAX) : 0.0f;
+    o[12] = p.include_distance ? (float)clipv(d_last * c.inv_max_target_dist, -(R)FLT_MAX, (R)FLT_MAX) : 0.0f;
 }
 
 // =====================================================================================================
 // The step kernel.
 // =====================================================================================================
-template <typename R>
+// NORM / NOISE compile the optional per-drone observation normaliser and the Philox noise streams in or out:
+// the reference-default kernel <R, false, false> carries neither their registers nor their code.
+template <typename R, bool NORM, bool NOISE>
 __global__ __launch_bounds__(DN_BLOCK) void dn_step_kernel(const DnParams p, const DnStepIO io)
 {
     __shared__ R s_tab[DN_MAX_WAYPOINTS * DN_T_STRIDE];
@@ -281,7 +302,7 @@ __global__ __launch_bounds__(DN_BLOCK) void dn_step_kernel(const DnParams p, con
 
     const unsigned long long gid = (unsigned long long)(p.env_id_offset + i);
     float a[4] = {A.x, A.y, A.z, A.w};
-    if (p.act_noise_sigma > 0.0f) {
+    if (NOISE && p.act_noise_sigma > 0.0f) {
         float z[4];
         noise4(p.seed, gid, p.step_count, 0u, z);
 #pragma unroll
@@ -352,8 +373,8 @@ __global__ __launch_bounds__(DN_BLOCK) void dn_step_kernel(const DnParams p, con
         R Iwx = K<R>::IXX * wbx, Iwy = K<R>::IYY * wby, Iwz = K<R>::IZZ * wbz;
         R gx = wby * Iwz - wbz * Iwy, gy = wbz * Iwx - wbx * Iwz, gz = wbx * Iwy - wby * Iwx;
         R Tbx = tx - gx - Iwx * ka, Tby = ty - gy - Iwy * ka, Tbz = (R)zt32 - gz - Iwz * ka;
-        R abx = Fbx / K<R>::M, aby = Fby / K<R>::M, abz = Fbz / K<R>::M;
-        R dbx = Tbx / K<R>::IXX, dby = Tby / K<R>::IYY, dbz = Tbz / K<R>::IZZ;
+        R abx = Fbx * K<R>::INV_M, aby = Fby * K<R>::INV_M, abz = Fbz * K<R>::INV_M;
+        R dbx = Tbx * K<R>::INV_IXX, dby = Tby * K<R>::INV_IYY, dbz = Tbz * K<R>::INV_IZZ;
         // base -> world
         R awx = r00 * abx + r01 * aby + r02 * abz, awy = r10 * abx + r11 * aby + r12 * abz, awz = r20 * abx + r21 * aby + r22 * abz;
         R dwx = r00 * dbx + r01 * dby + r02 * dbz, dwy = r10 * dbx + r11 * dby + r12 * dbz, dwz = r20 * dbx + r21 * dby + r22 * dbz;
@@ -364,10 +385,12 @@ __global__ __launch_bounds__(DN_BLOCK) void dn_step_kernel(const DnParams p, con
         px += dt * vx; py += dt * vy; pz += dt * vz;                              // stepPositionsMultiDof
         R fAngle = norm3(wx, wy, wz);
         if (fAngle * dt > R(0.25) * K<R>::PI) fAngle = R(0.5) * (R(0.5) * K<R>::PI) / dt;
-        R k;
-        if (fAngle < R(0.001)) k = R(0.5) * dt - (dt * dt * dt) * R(0.020833333333) * fAngle * fAngle;
-        else k = sin(R(0.5) * fAngle * dt) / fAngle;
-        R ax = wx * k, ay = wy * k, az = wz * k, aw = cos(fAngle * dt * R(0.5));
+        // axis = w * sin(h)/|w| with h = |w| dt/2, i.e. w * (dt/2) * sinc(h): one formula covers Bullet's Taylor
+        // branch (|w| < 1e-3, identical to 1e-24) and its clamped branch, and needs no divide.
+        R hh = R(0.5) * fAngle * dt, sinc, aw;
+        sinc_cos_small<R>(hh * hh, sinc, aw);
+        R k = (R(0.5) * dt) * sinc;
+        R ax = wx * k, ay = wy * k, az = wz * k;
         R nx = aw * qx + ax * qw + ay * qz - az * qy;
         R ny = aw * qy + ay * qw + az * qx - ax * qz;
         R nz = aw * qz + az * qw + ax * qy - ay * qx;
@@ -377,16 +400,29 @@ __global__ __launch_bounds__(DN_BLOCK) void dn_step_kernel(const DnParams p, con
     }
 
     // ---- A5: p.getEulerFromQuaternion [3P-recall of pybullet.c] ------------------------------------------
-    R roll, pitch, yaw;
+    // get_forward_vector (PBDroneEnv.py:588-597) = (cos yaw cos pitch, sin yaw cos pitch, sin pitch) follows
+    // algebraically from the same quaternion terms: sin pitch = sarg, cos pitch = sqrt(1 - sarg^2) (pitch is an
+    // arcsine, so its cosine is non-negative), (cos yaw, sin yaw) = (yc, ys)/hypot(yc, ys) -- no sin/cos calls.
+    R roll, pitch, yaw, fwx, fwy, fwz;
     {
         R sqx = qx * qx, sqy = qy * qy, sqz = qz * qz, squ = qw * qw;
         R sarg = R(-2.0) * (qx * qz - qw * qy);
-        if (sarg <= R(-0.99999)) { roll = R(0.0); pitch = R(-0.5) * K<R>::PI; yaw = R(2.0) * atan2(qx, -qy); }
-        else if (sarg >= R(0.99999)) { roll = R(0.0); pitch = R(0.5) * K<R>::PI; yaw = R(2.0) * atan2(-qx, qy); }
-        else {
+        if (sarg <= R(-0.99999) || sarg >= R(0.99999)) {       // gimbal-lock branches: rare, keep them literal
+            roll = R(0.0);
+            if (sarg < R(0.0)) { pitch = R(-0.5) * K<R>::PI; yaw = R(2.0) * atan2(qx, -qy); }
+            else { pitch = R(0.5) * K<R>::PI; yaw = R(2.0) * atan2(-qx, qy); }
+            R cpit = cos(pitch);
+            fwx = cos(yaw) * cpit; fwy = sin(yaw) * cpit; fwz = sin(pitch);
+        } else {
+            R ys = R(2.0) * (qx * qy + qw * qz), yc = squ + sqx - sqy - sqz;
             roll = atan2(R(2.0) * (qy * qz + qw * qx), squ - sqx - sqy + sqz);
             pitch = asin(sarg);
-            yaw = atan2(R(2.0) * (qx * qy + qw * qz), squ + sqx - sqy - sqz);
+            yaw = atan2(ys, yc);
+            R cpit = sqrt(R(1.0) - sarg * sarg);
+            R hy = sqrt(ys * ys + yc * yc);
+            R cyaw = R(1.0), syaw = R(0.0);
+            if (hy > R(0.0)) { R rh = R(1.0) / hy; cyaw = yc * rh; syaw = ys * rh; }
+            fwx = cyaw * cpit; fwy = syaw * cpit; fwz = sarg;
         }
     }
     // rotation entry R[2][2] of the NEW attitude (ground-contact approximation only)
@@ -397,19 +433,19 @@ __global__ __launch_bounds__(DN_BLOCK) void dn_step_kernel(const DnParams p, con
     float o[DN_OBS_DIM];
     {
         const R fmax = (R)FLT_MAX;
-        o[0] = (float)clipv(px / c.dim[3], -fmax, fmax);
-        o[1] = (float)clipv(py / c.dim[4], -fmax, fmax);
-        o[2] = (float)clipv(pz / c.dim[5], -fmax, fmax);
-        o[3] = (float)(clipv(roll, -K<R>::PI, K<R>::PI) / K<R>::PI);
-        o[4] = (float)(clipv(pitch, -K<R>::PI, K<R>::PI) / K<R>::PI);
-        o[5] = (float)clipv(yaw / K<R>::PI, -fmax, fmax);
-        o[6] = (float)(clipv(vx, R(-3.0), R(3.0)) / R(3.0));
-        o[7] = (float)(clipv(vy, R(-3.0), R(3.0)) / R(3.0));
-        o[8] = (float)(clipv(vz, R(-1.0), R(1.0)) / R(3.0));
+        o[0] = (float)clipv(px * c.inv_dim[0], -fmax, fmax);
+        o[1] = (float)clipv(py * c.inv_dim[1], -fmax, fmax);
+        o[2] = (float)clipv(pz * c.inv_dim[2], -fmax, fmax);
+        o[3] = (float)(clipv(roll, -K<R>::PI, K<R>::PI) * K<R>::INV_PI);
+        o[4] = (float)(clipv(pitch, -K<R>::PI, K<R>::PI) * K<R>::INV_PI);
+        o[5] = (float)clipv(yaw * K<R>::INV_PI, -fmax, fmax);
+        o[6] = (float)(clipv(vx, R(-3.0), R(3.0)) * K<R>::THIRD);
+        o[7] = (float)(clipv(vy, R(-3.0), R(3.0)) * K<R>::THIRD);
+        o[8] = (float)(clipv(vz, R(-1.0), R(1.0)) * K<R>::THIRD);
         R nw = norm3(wx, wy, wz);
-        if (nw != R(0.0)) { o[9] = (float)(wx / nw); o[10] = (float)(wy / nw); o[11] = (float)(wz / nw); }
+        if (nw != R(0.0)) { R rw = R(1.0) / nw; o[9] = (float)(wx * rw); o[10] = (float)(wy * rw); o[11] = (float)(wz * rw); }
         else { o[9] = (float)wx; o[10] = (float)wy; o[11] = (float)wz; }
-        o[12] = p.include_distance ? (float)clipv(d_e / c.max_target_dist, -fmax, fmax) : 0.0f;
+        o[12] = p.include_distance ? (float)clipv(d_e * c.inv_max_target_dist, -fmax, fmax) : 0.0f;
     }
 
     // ---- A7 + A8: _computeReward (PBDroneEnv.py:475-571), _computeTerminated (:456-473) --------------------
@@ -422,8 +458,7 @@ __global__ __launch_bounds__(DN_BLOCK) void dn_step_kernel(const DnParams p, con
         reward = R(-10.0);
         terminated = true;
     } else {
-        R cyaw = cos(yaw), syaw = sin(yaw), cpit = cos(pitch), spit = sin(pitch);
-        R fx = cyaw * cpit, fy = syaw * cpit, fz = spit;
+        const R fx = fwx, fy = fwy, fz = fwz;
         if (d_e <= c.threshold) {                      // :539
             idx += 1;
             float r32 = 0.0f;
@@ -450,7 +485,7 @@ __global__ __launch_bounds__(DN_BLOCK) void dn_step_kernel(const DnParams p, con
             r = r + (lp + ap);                                                        // :558
             just_found = 0;
             d_prev = d_e;
-            reward = r / R(25.0);
+            reward = r * K<R>::INV_25;
             terminated = false;
         }
     }
@@ -476,9 +511,9 @@ __global__ __launch_bounds__(DN_BLOCK) void dn_step_kernel(const DnParams p, con
 
     // sensor noise / per-drone normaliser act on the step observation (which is also terminal_observation)
     double rms_count = 0.0;
-    if (p.normalize_obs) rms_count = p.st.rms_count[i];
-    if (p.obs_noise_sigma > 0.0f) add_obs_noise(p, gid, 1u, o);
-    if (p.normalize_obs) normalize_obs(p, i, active, rms_count, o);
+    if (NORM) rms_count = p.st.rms_count[i];
+    if (NOISE && p.obs_noise_sigma > 0.0f) add_obs_noise(p, gid, 1u, o);
+    if (NORM) normalize_obs(p, i, active, rms_count, o);
 
     const unsigned long long done_ballot = __ballot(done && active);
     if (done_ballot != 0ull) {                         // wave-uniform: most waves skip the whole reset path
@@ -498,8 +533,8 @@ __global__ __launch_bounds__(DN_BLOCK) void dn_step_kernel(const DnParams p, con
             else { const float4 G6 = p.st.g6[i]; cpx = G6.x; cpy = G6.y; cpz = G6.z; }
             if (active && !(terminated && m_e.steps == 0)) p.st.g6[i] = make_float4((float)cpx, (float)cpy, (float)cpz, 0.0f);
             reset_obs<R>(p, c, d, o);                                     // BaseAviary.py:318 before :617-658 (Q2)
-            if (p.obs_noise_sigma > 0.0f) add_obs_noise(p, gid, 5u, o);
-            if (p.normalize_obs) normalize_obs(p, i, active, rms_count, o);
+            if (NOISE && p.obs_noise_sigma > 0.0f) add_obs_noise(p, gid, 5u, o);
+            if (NORM) normalize_obs(p, i, active, rms_count, o);
             px = c.spawn[0]; py = c.spawn[1]; pz = c.spawn[2];
             qx = R(0.0); qy = R(0.0); qz = R(0.0); qw = R(1.0);
             vx = vy = vz = wx = wy = wz = R(0.0);
@@ -526,7 +561,7 @@ __global__ __launch_bounds__(DN_BLOCK) void dn_step_kernel(const DnParams p, con
             p.st.stats[blockIdx.x] = sl;
         }
     }
-    if (p.normalize_obs && active) p.st.rms_count[i] = rms_count;
+    if (NORM && active) p.st.rms_count[i] = rms_count;
 
     // ---- write back: state (6 x float4), scalars, observation tile ------------------------------------------
     if (active) {
@@ -680,8 +715,18 @@ hipError_t dn_launch_filld(double *dst, double v, long long n, hipStream_t strea
 hipError_t dn_launch_step(const DnParams &p, const DnStepIO &io, bool f32, hipStream_t stream)
 {
     const unsigned grid = (unsigned)((p.n + DN_BLOCK - 1) / DN_BLOCK);
-    if (f32) hipLaunchKernelGGL(dn_step_kernel<float>, dim3(grid), dim3(DN_BLOCK), 0, stream, p, io);
-    else hipLaunchKernelGGL(dn_step_kernel<double>, dim3(grid), dim3(DN_BLOCK), 0, stream, p, io);
+    const bool norm = p.normalize_obs != 0;
+    const bool noise = p.act_noise_sigma > 0.0f || p.obs_noise_sigma > 0.0f;
+#define DN_LAUNCH(R, NORM, NOISE) \
+    hipLaunchKernelGGL((dn_step_kernel<R, NORM, NOISE>), dim3(grid), dim3(DN_BLOCK), 0, stream, p, io)
+    if (f32) {
+        if (norm) { if (noise) DN_LAUNCH(float, true, true); else DN_LAUNCH(float, true, false); }
+        else { if (noise) DN_LAUNCH(float, false, true); else DN_LAUNCH(float, false, false); }
+    } else {
+        if (norm) { if (noise) DN_LAUNCH(double, true, true); else DN_LAUNCH(double, true, false); }
+        else { if (noise) DN_LAUNCH(double, false, true); else DN_LAUNCH(double, false, false); }
+    }
+#undef DN_LAUNCH
     return hipGetLastError();
 }
 

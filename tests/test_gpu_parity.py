@@ -64,7 +64,7 @@ def actions_mixed(rng, n):
 STATE_F32 = ("pos", "quat", "vel", "ang_v", "prev_vel", "prev_ang_v", "cur_pos", "d", "d_prev")
 
 
-def compare_step(out, ref, tag, obs_atol=1e-5):
+def compare_step(out, ref, tag, obs_atol=1e-5, rew_atol=1e-5):
     obs, rew, done, info = out
     assert np.array_equal(done.cpu().numpy(), ref["done"]), f"{tag}: done"
     assert np.array_equal(info["truncated"].cpu().numpy(), ref["truncated"]), f"{tag}: TimeLimit.truncated"
@@ -72,7 +72,7 @@ def compare_step(out, ref, tag, obs_atol=1e-5):
     k = obs.shape[1]                       # 12 columns when include_distance is off
     np.testing.assert_allclose(obs.cpu().numpy(), ref["obs"][:, :k], rtol=0, atol=obs_atol, err_msg=f"{tag}: obs")
     # reward carries 3000*(d_prev - d)/25: 1e-5 relative + 1e-5 absolute
-    np.testing.assert_allclose(rew.cpu().numpy(), ref["reward"], rtol=1e-5, atol=1e-5, err_msg=f"{tag}: reward")
+    np.testing.assert_allclose(rew.cpu().numpy(), ref["reward"], rtol=1e-5, atol=rew_atol, err_msg=f"{tag}: reward")
     dn = ref["done"].astype(bool)
     if dn.any():
         np.testing.assert_allclose(info["terminal_obs"].cpu().numpy()[dn], ref["terminal_obs"][dn][:, :k], rtol=0,
@@ -137,7 +137,10 @@ def test_free_running_vs_f32_state_oracle(track_name):
         a = actions_mixed(rng, n)
         out = env.step_tensor(torch.from_numpy(a).to(dev))
         ref = ora.step(a)
-        n_done += compare_step(out, ref, f"{track_name} free t={t}")
+        # free-running: the GPU's float64 arithmetic is not bit-identical to the oracle's (reciprocal multiplies,
+        # polynomial sin/cos), so a stored float32 may differ by an ulp; the reward amplifies a distance
+        # difference 120x (3000*(d_prev-d)/25), hence 1e-4 there.  Flags stay exact.
+        n_done += compare_step(out, ref, f"{track_name} free t={t}", rew_atol=1e-4)
     st = env.get_state()
     for k in STATE_F32:
         np.testing.assert_allclose(st[k], ora.envs[k], rtol=0, atol=1e-5, err_msg=k)
