@@ -326,15 +326,22 @@ int32_t dn_step_many(dn_env *env, int64_t k, const float *actions, float *obs, f
     if (k < 1) return fail(DN_ERR_INVALID_ARGUMENT, "k must be >= 1 (got %lld)", (long long)k);
     const long long n = env->cfg.num_envs;
     if (k > 1 && (n & 3)) return fail(DN_ERR_INVALID_ARGUMENT, "dn_step_many needs num_envs %% 4 == 0 (got %lld)", n);
-    const long long words = (n + 63) / 64;
-    for (int64_t t = 0; t < k; ++t) {
-        int32_t rc = dn_step(env, actions + t * n * DN_ACT_DIM, obs + t * n * DN_OBS_DIM, reward + t * n, done + t * n,
-                             truncated + t * n, found_targets + t * n,
-                             terminal_obs ? terminal_obs + t * n * DN_OBS_DIM : nullptr,
-                             ep_return ? ep_return + t * n : nullptr, ep_length ? ep_length + t * n : nullptr,
-                             done_mask ? done_mask + t * words : nullptr, stream);
-        if (rc != DN_OK) return rc;
-    }
+    if (k == 1)
+        return dn_step(env, actions, obs, reward, done, truncated, found_targets, terminal_obs, ep_return, ep_length,
+                       done_mask, stream);
+    if (!actions || !obs || !reward || !done || !truncated || !found_targets)
+        return fail(DN_ERR_INVALID_ARGUMENT, "actions, obs, reward, done, truncated and found_targets are required");
+    if (((uintptr_t)actions & 15u) || ((uintptr_t)obs & 15u))
+        return fail(DN_ERR_INVALID_ARGUMENT, "actions and obs must be 16-byte aligned");
+    if (k > (1 << 30)) return fail(DN_ERR_INVALID_ARGUMENT, "k too large");
+    // one fused launch: the state stays in registers for all k steps (dn_step_many_kernel)
+    DnStepIO io;
+    io.actions = actions; io.obs = obs; io.reward = reward; io.done = done; io.truncated = truncated;
+    io.found_targets = found_targets; io.terminal_obs = terminal_obs; io.ep_return = ep_return;
+    io.ep_length = ep_length; io.done_mask = (unsigned long long *)done_mask;
+    env->p.step_count = (unsigned)env->step_count;
+    DN_HIP(dn_launch_step_many(env->p, io, (int)k, env->cfg.compute_f32 != 0, (hipStream_t)stream));
+    env->step_count += (uint64_t)k;
     return DN_OK;
 }
 

@@ -92,6 +92,7 @@ struct DnParams {
 };
 
 hipError_t dn_launch_step(const DnParams &p, const DnStepIO &io, bool f32, hipStream_t stream);
+hipError_t dn_launch_step_many(const DnParams &p, const DnStepIO &io, int k, bool f32, hipStream_t stream);
 hipError_t dn_launch_reset(const DnParams &p, float *obs, bool f32, hipStream_t stream);
 hipError_t dn_launch_gae(const float *rewards, const float *values, const uint8_t *dones,
                          const float *last_values, const uint8_t *last_dones, long long T, long long N,

@@ -116,12 +116,12 @@ DN_DEV void noise4(unsigned long long seed, unsigned long long gid, unsigned ste
         z[2 * h + 1] = (float)(rad * sin(ang));
     }
 }
-DN_DEV void add_obs_noise(const DnParams &p, unsigned long long gid, unsigned stream0, float o[DN_OBS_DIM])
+DN_DEV void add_obs_noise(const DnParams &p, unsigned long long gid, unsigned step, unsigned stream0, float o[DN_OBS_DIM])
 {
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
         float z[4];
-        noise4(p.seed, gid, p.step_count, stream0 + (unsigned)b, z);
+        noise4(p.seed, gid, step, stream0 + (unsigned)b, z);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             if (4 * b + j < DN_OBS_DIM) {
@@ -281,30 +281,22 @@ DN_DEV void reset_obs(const DnParams &p, const DnConsts<R> &c, R d_last, float o
 // The step kernel.
 // =====================================================================================================
 // NORM / NOISE compile the optional per-drone observation normaliser and the Philox noise streams in or out:
-// the reference-default kernel <R, false, false> carries neither their registers nor their code.
+// the reference-default kernels <R, false, false> carry neither their registers nor their code.
+//
+// step_body advances ONE drone (this lane) by one control step.  The persistent state travels as the six
+// float4 groups G0..G5 exactly as they sit in HBM (float32), so the single-step kernel (load, step, store)
+// and the fused multi-step kernel (load, K x step, store) run the same arithmetic on the same roundings.
 template <typename R, bool NORM, bool NOISE>
-__global__ __launch_bounds__(DN_BLOCK) void dn_step_kernel(const DnParams p, const DnStepIO io)
+DN_DEV void step_body(const DnParams &p, const DnConsts<R> &c, const R *s_tab, float *s_tile, const DnStepIO &io,
+                      const unsigned step_count, const long long i, const long long tile_base, const int lane,
+                      const bool active, const float4 A, float4 &G0, float4 &G1, float4 &G2, float4 &G3, float4 &G4,
+                      float4 &G5)
 {
-    __shared__ R s_tab[DN_MAX_WAYPOINTS * DN_T_STRIDE];
-    __shared__ __attribute__((aligned(16))) float s_tile[DN_BLOCK * DN_OBS_DIM];
-
-    const int lane = threadIdx.x;
-    const long long tile_base = (long long)blockIdx.x * DN_BLOCK;
-    const long long i_raw = tile_base + lane;
-    const bool active = i_raw < p.n;
-    const long long i = active ? i_raw : p.n - 1;      // inactive lanes shadow the last drone, never store
-    const DnConsts<R> &c = consts<R>(p);
-
-    // ---- issue every load up front (6 x 16 B state + 16 B action per lane) ---------------------------
-    const float4 A = reinterpret_cast<const float4 *>(io.actions)[i];
-    const float4 G0 = p.st.g0[i], G1 = p.st.g1[i], G2 = p.st.g2[i], G3 = p.st.g3[i], G4 = p.st.g4[i], G5 = p.st.g5[i];
-    stage_table<R>(p, s_tab);
-
     const unsigned long long gid = (unsigned long long)(p.env_id_offset + i);
     float a[4] = {A.x, A.y, A.z, A.w};
     if (NOISE && p.act_noise_sigma > 0.0f) {
         float z[4];
-        noise4(p.seed, gid, p.step_count, 0u, z);
+        noise4(p.seed, gid, step_count, 0u, z);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float s = p.act_noise_sigma * z[j];
@@ -512,7 +504,7 @@ __global__ __launch_bounds__(DN_BLOCK) void dn_step_kernel(const DnParams p, con
     // sensor noise / per-drone normaliser act on the step observation (which is also terminal_observation)
     double rms_count = 0.0;
     if (NORM) rms_count = p.st.rms_count[i];
-    if (NOISE && p.obs_noise_sigma > 0.0f) add_obs_noise(p, gid, 1u, o);
+    if (NOISE && p.obs_noise_sigma > 0.0f) add_obs_noise(p, gid, step_count, 1u, o);
     if (NORM) normalize_obs(p, i, active, rms_count, o);
 
     const unsigned long long done_ballot = __ballot(done && active);
@@ -533,7 +525,7 @@ __global__ __launch_bounds__(DN_BLOCK) void dn_step_kernel(const DnParams p, con
             else { const float4 G6 = p.st.g6[i]; cpx = G6.x; cpy = G6.y; cpz = G6.z; }
             if (active && !(terminated && m_e.steps == 0)) p.st.g6[i] = make_float4((float)cpx, (float)cpy, (float)cpz, 0.0f);
             reset_obs<R>(p, c, d, o);                                     // BaseAviary.py:318 before :617-658 (Q2)
-            if (NOISE && p.obs_noise_sigma > 0.0f) add_obs_noise(p, gid, 5u, o);
+            if (NOISE && p.obs_noise_sigma > 0.0f) add_obs_noise(p, gid, step_count, 5u, o);
             if (NORM) normalize_obs(p, i, active, rms_count, o);
             px = c.spawn[0]; py = c.spawn[1]; pz = c.spawn[2];
             qx = R(0.0); qy = R(0.0); qz = R(0.0); qw = R(1.0);
@@ -563,14 +555,14 @@ __global__ __launch_bounds__(DN_BLOCK) void dn_step_kernel(const DnParams p, con
     }
     if (NORM && active) p.st.rms_count[i] = rms_count;
 
-    // ---- write back: state (6 x float4), scalars, observation tile ------------------------------------------
+    // ---- hand the state back as float32 groups; scalars and the observation tile go straight to HBM -----------
+    G0 = make_float4((float)px, (float)py, (float)pz, (float)d);
+    G1 = make_float4((float)qx, (float)qy, (float)qz, (float)qw);
+    G2 = make_float4((float)vx, (float)vy, (float)vz, (float)d_prev);
+    G3 = make_float4((float)wx, (float)wy, (float)wz, pack_meta(steps, idx, just_found));
+    G4 = make_float4((float)npvx, (float)npvy, (float)npvz, (float)ep_ret);
+    G5 = make_float4((float)npwx, (float)npwy, (float)npwz, __int_as_float(ep_len));
     if (active) {
-        p.st.g0[i] = make_float4((float)px, (float)py, (float)pz, (float)d);
-        p.st.g1[i] = make_float4((float)qx, (float)qy, (float)qz, (float)qw);
-        p.st.g2[i] = make_float4((float)vx, (float)vy, (float)vz, (float)d_prev);
-        p.st.g3[i] = make_float4((float)wx, (float)wy, (float)wz, pack_meta(steps, idx, just_found));
-        p.st.g4[i] = make_float4((float)npvx, (float)npvy, (float)npvz, (float)ep_ret);
-        p.st.g5[i] = make_float4((float)npwx, (float)npwy, (float)npwz, __int_as_float(ep_len));
         io.reward[i] = (float)reward;
         io.done[i] = (uint8_t)done;
         io.truncated[i] = (uint8_t)(truncated && !terminated);
@@ -578,6 +570,68 @@ __global__ __launch_bounds__(DN_BLOCK) void dn_step_kernel(const DnParams p, con
     }
     if (io.done_mask && lane == 0) io.done_mask[blockIdx.x] = done_ballot;
     store_obs_tile(s_tile, io.obs, tile_base, p.n, lane, active, o);
+}
+
+// One control step per launch: what VecEnv.step() maps to when a policy sits between steps.
+template <typename R, bool NORM, bool NOISE>
+__global__ __launch_bounds__(DN_BLOCK) void dn_step_kernel(const DnParams p, const DnStepIO io)
+{
+    __shared__ R s_tab[DN_MAX_WAYPOINTS * DN_T_STRIDE];
+    __shared__ __attribute__((aligned(16))) float s_tile[DN_BLOCK * DN_OBS_DIM];
+    const int lane = threadIdx.x;
+    const long long tile_base = (long long)blockIdx.x * DN_BLOCK;
+    const bool active = tile_base + lane < p.n;
+    const long long i = active ? tile_base + lane : p.n - 1;   // inactive lanes shadow the last drone, never store
+    // issue every load up front (6 x 16 B state + 16 B action per lane), then stage the table
+    const float4 A = reinterpret_cast<const float4 *>(io.actions)[i];
+    float4 G0 = p.st.g0[i], G1 = p.st.g1[i], G2 = p.st.g2[i], G3 = p.st.g3[i], G4 = p.st.g4[i], G5 = p.st.g5[i];
+    stage_table<R>(p, s_tab);
+    step_body<R, NORM, NOISE>(p, consts<R>(p), s_tab, s_tile, io, p.step_count, i, tile_base, lane, active, A,
+                              G0, G1, G2, G3, G4, G5);
+    if (active) {
+        p.st.g0[i] = G0; p.st.g1[i] = G1; p.st.g2[i] = G2; p.st.g3[i] = G3; p.st.g4[i] = G4; p.st.g5[i] = G5;
+    }
+}
+
+// K control steps per launch for open-loop action sequences (dn_step_many): the state is read once, stays in
+// registers for K steps and is written once; per step only the action (16 B) comes in and the outputs (62 B) go
+// out, and the K-1 kernel boundaries disappear.  Buffers are step-major [K, N, ...].
+template <typename R, bool NORM, bool NOISE>
+__global__ __launch_bounds__(DN_BLOCK) void dn_step_many_kernel(const DnParams p, const DnStepIO io0, const int k_steps)
+{
+    __shared__ R s_tab[DN_MAX_WAYPOINTS * DN_T_STRIDE];
+    __shared__ __attribute__((aligned(16))) float s_tile[DN_BLOCK * DN_OBS_DIM];
+    const int lane = threadIdx.x;
+    const long long tile_base = (long long)blockIdx.x * DN_BLOCK;
+    const bool active = tile_base + lane < p.n;
+    const long long i = active ? tile_base + lane : p.n - 1;
+    const float4 *act = reinterpret_cast<const float4 *>(io0.actions);
+    float4 A = act[i];
+    float4 G0 = p.st.g0[i], G1 = p.st.g1[i], G2 = p.st.g2[i], G3 = p.st.g3[i], G4 = p.st.g4[i], G5 = p.st.g5[i];
+    stage_table<R>(p, s_tab);
+    const long long n = p.n, words = (p.n + 63) / 64;
+#pragma clang loop unroll(disable)
+    for (int t = 0; t < k_steps; ++t) {
+        // prefetch the next step's action while this step computes
+        const float4 A_next = act[(long long)(t + 1 < k_steps ? t + 1 : t) * n + i];
+        DnStepIO io;
+        io.actions = nullptr;
+        io.obs = io0.obs + (long long)t * n * DN_OBS_DIM;
+        io.reward = io0.reward + (long long)t * n;
+        io.done = io0.done + (long long)t * n;
+        io.truncated = io0.truncated + (long long)t * n;
+        io.found_targets = io0.found_targets + (long long)t * n;
+        io.terminal_obs = io0.terminal_obs ? io0.terminal_obs + (long long)t * n * DN_OBS_DIM : nullptr;
+        io.ep_return = io0.ep_return ? io0.ep_return + (long long)t * n : nullptr;
+        io.ep_length = io0.ep_length ? io0.ep_length + (long long)t * n : nullptr;
+        io.done_mask = io0.done_mask ? io0.done_mask + (long long)t * words : nullptr;
+        step_body<R, NORM, NOISE>(p, consts<R>(p), s_tab, s_tile, io, p.step_count + (unsigned)t, i, tile_base, lane,
+                                  active, A, G0, G1, G2, G3, G4, G5);
+        A = A_next;
+    }
+    if (active) {
+        p.st.g0[i] = G0; p.st.g1[i] = G1; p.st.g2[i] = G2; p.st.g3[i] = G3; p.st.g4[i] = G4; p.st.g5[i] = G5;
+    }
 }
 
 // =====================================================================================================
@@ -601,7 +655,7 @@ __global__ __launch_bounds__(DN_BLOCK) void dn_reset_kernel(const DnParams p, fl
     float o[DN_OBS_DIM];
     reset_obs<R>(p, c, (R)G0.w, o);
     const unsigned long long gid = (unsigned long long)(p.env_id_offset + i);
-    if (p.obs_noise_sigma > 0.0f) add_obs_noise(p, gid, 5u, o);
+    if (p.obs_noise_sigma > 0.0f) add_obs_noise(p, gid, p.step_count, 5u, o);
     if (p.normalize_obs) {
         double cnt = p.st.rms_count[i];
         normalize_obs(p, i, active, cnt, o);
@@ -719,6 +773,24 @@ hipError_t dn_launch_step(const DnParams &p, const DnStepIO &io, bool f32, hipSt
     const bool noise = p.act_noise_sigma > 0.0f || p.obs_noise_sigma > 0.0f;
 #define DN_LAUNCH(R, NORM, NOISE) \
     hipLaunchKernelGGL((dn_step_kernel<R, NORM, NOISE>), dim3(grid), dim3(DN_BLOCK), 0, stream, p, io)
+    if (f32) {
+        if (norm) { if (noise) DN_LAUNCH(float, true, true); else DN_LAUNCH(float, true, false); }
+        else { if (noise) DN_LAUNCH(float, false, true); else DN_LAUNCH(float, false, false); }
+    } else {
+        if (norm) { if (noise) DN_LAUNCH(double, true, true); else DN_LAUNCH(double, true, false); }
+        else { if (noise) DN_LAUNCH(double, false, true); else DN_LAUNCH(double, false, false); }
+    }
+#undef DN_LAUNCH
+    return hipGetLastError();
+}
+
+hipError_t dn_launch_step_many(const DnParams &p, const DnStepIO &io, int k, bool f32, hipStream_t stream)
+{
+    const unsigned grid = (unsigned)((p.n + DN_BLOCK - 1) / DN_BLOCK);
+    const bool norm = p.normalize_obs != 0;
+    const bool noise = p.act_noise_sigma > 0.0f || p.obs_noise_sigma > 0.0f;
+#define DN_LAUNCH(R, NORM, NOISE) \
+    hipLaunchKernelGGL((dn_step_many_kernel<R, NORM, NOISE>), dim3(grid), dim3(DN_BLOCK), 0, stream, p, io, k)
     if (f32) {
         if (norm) { if (noise) DN_LAUNCH(float, true, true); else DN_LAUNCH(float, true, false); }
         else { if (noise) DN_LAUNCH(float, false, true); else DN_LAUNCH(float, false, false); }

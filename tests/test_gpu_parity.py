@@ -247,6 +247,45 @@ def test_many_waypoints_and_single_waypoint():
         env.close()
 
 
+@pytest.mark.parametrize("norm,noise", [(False, 0.0), (True, 0.01)])
+def test_fused_multi_step_equals_single_steps(norm, noise):
+    """dn_step_many (one launch, state in registers for K steps) must be bit-identical to K dn_step launches,
+    and both must match the oracle."""
+    pkg = _gpu()
+    track = _tracks().reaching()
+    n, K = 4096, 96
+    kw = dict(normalize_obs=norm, max_steps=40, obs_noise_sigma=noise, act_noise_sigma=noise / 10, seed=77)
+    env_a, ora = make_pair(track, n, f32_state=True, **kw)
+    env_b = pkg.DroneVecEnv(track, n, device="cuda:0", **kw)
+    env_a.reset()
+    env_b.reset()
+    ora.reset()
+    rng = np.random.default_rng(11)
+    acts = np.stack([actions_mixed(rng, n) for _ in range(K)])
+    dev = torch.device("cuda:0")
+    a_dev = torch.from_numpy(acts).to(dev)
+    out = env_b.rollout_tensor(a_dev, want_terminal=True)
+    n_done = 0
+    for t in range(K):
+        obs, rew, done, info = env_a.step_tensor(a_dev[t])
+        assert torch.equal(obs, out["obs"][t]) and torch.equal(rew, out["reward"][t]), t
+        assert torch.equal(done, out["done"][t]) and torch.equal(info["truncated"], out["truncated"][t]), t
+        assert torch.equal(info["found_targets"], out["found_targets"][t]), t
+        assert torch.equal(info["done_mask"], out["done_mask"][t]), t
+        d = done.bool()
+        assert torch.equal(info["terminal_obs"][d], out["terminal_obs"][t][d]), t
+        assert torch.equal(info["ep_length"][d], out["ep_length"][t][d]), t
+        n_done += compare_step((obs, rew, done, info), ora.step(acts[t]), f"fused t={t}", rew_atol=1e-4,
+                               obs_atol=1e-4 if norm else 1e-5)
+    assert n_done > n
+    sa, sb = env_a.get_state(), env_b.get_state()
+    for k in sa.dtype.names:
+        assert np.ascontiguousarray(sa[k]).tobytes() == np.ascontiguousarray(sb[k]).tobytes(), k
+    assert env_a.stats() == env_b.stats() and env_a.step_count == env_b.step_count == K
+    env_a.close()
+    env_b.close()
+
+
 def test_noise_streams_match_oracle():
     """Config 5 (sim-to-real): Philox-keyed action/observation noise; sigma = 0 is the reference."""
     track = _tracks().reaching()
