@@ -170,6 +170,15 @@ def main():
         if dist is not None:
             dist.barrier(device_ids=[local_rank])
 
+    def timed(fn, k):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(dev)
+        e0.record(stream)
+        fn(k)
+        e1.record(stream)
+        torch.cuda.synchronize(dev)
+        return e0.elapsed_time(e1) * 1e3 / k           # us per step on the GPU timeline
+
     run(W)
     torch.cuda.synchronize(dev)
     barrier()
@@ -189,17 +198,25 @@ def main():
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
         wall, gpu_ms = float(tw[0]), float(tw[1])
     st = env.stats()
+    # the other launch shape, outside the timed region, for the record: "single" = one dn_step launch per step
+    # (what a policy-in-the-loop VecEnv.step() costs), "many" = the fused K-step kernel
+    other = "single" if args.mode != "single" else "many"
+    k2 = max(A, min(K, 4096) // A * A)
+    other_us = timed({"single": run_single, "many": run_many}[other], k2)
 
     if rank == 0:
         value = n * world * K / wall
-        launch_us = gpu_ms * 1e3 / K
-        achieved = ALGO_BYTES_PER_ENV_STEP * n / (launch_us * 1e-6) / 1e9
+        step_us = gpu_ms * 1e3 / K
+        steps_per_launch = 1 if args.mode == "single" else A
+        launch_us = step_us * steps_per_launch
+        achieved = ALGO_BYTES_PER_ENV_STEP * n / (step_us * 1e-6) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):                          # per-launch HBM bytes from the committed rocprofv3 --pmc passes
             try:
                 tj = json.load(open(tpath))
-                key = f"{args.track}_{n}_{args.compute_dtype}" + ("_norm" if args.normalize_obs else "")
+                key = f"{args.track}_{n}_{args.compute_dtype}" + ("_norm" if args.normalize_obs else "") + \
+                    ("_single" if args.mode == "single" else f"_fused{A}")
                 traffic = tj.get(key, {}).get("bytes_per_launch")
             except Exception:  # noqa: BLE001
                 traffic = None
@@ -215,9 +232,14 @@ def main():
                        "episodes_finished_rank0": st["episodes"]},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
-                         "kernel": "dn_step_kernel<%s>" % ("double" if args.compute_dtype == "float64" else "float"),
-                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n,
-                         "avg_launch_us": round(launch_us, 4)},
+                         "kernel": "%s<%s>" % ("dn_step_kernel" if args.mode == "single" else "dn_step_many_kernel",
+                                               "double" if args.compute_dtype == "float64" else "float"),
+                         "env_steps_per_launch": n * steps_per_launch, "vector_steps_per_launch": steps_per_launch,
+                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n * steps_per_launch,
+                         "avg_launch_us": round(launch_us, 4), "us_per_vector_step": round(step_us, 4)},
+            "other_launch_shape": {"mode": other, "us_per_vector_step": round(other_us, 4),
+                                   "value": round(n * world / (other_us * 1e-6), 1),
+                                   "roofline_frac": round(ALGO_BYTES_PER_ENV_STEP * n / (other_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 5)},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(track, n, max_steps, args.cpu_baseline_seconds)

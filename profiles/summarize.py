@@ -49,7 +49,7 @@ def main(d):
                                  "and kernel_name like '%dn_%' group by kernel_name"):
             out.append(f"  {avg:14.2f} KB  x{n:6d}  {name}")
             vals[(ctr, name)] = avg
-    steps = [k[1] for k in vals if "dn_step_kernel" in k[1]]
+    steps = [k[1] for k in vals if "dn_step_kernel" in k[1] or "dn_step_many_kernel" in k[1]]
     for name in sorted(set(steps)):
         f, w = vals.get(("FETCH_SIZE", name)), vals.get(("WRITE_SIZE", name))
         if f is not None and w is not None:
