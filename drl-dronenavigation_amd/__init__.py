@@ -10,7 +10,8 @@ from . import _capi, build, tracks  # noqa: F401
 from ._capi import DroneNavError, DroneNavLibraryError  # noqa: F401
 from .tracks import Track  # noqa: F401
 
-__all__ = ["DroneVecEnv", "Track", "tracks", "gae", "DroneNavError", "DroneNavLibraryError", "make_config"]
+__all__ = ["DroneVecEnv", "Track", "tracks", "gae", "DroneNavError", "DroneNavLibraryError", "make_config",
+           "RolloutCollector", "ShardPlan", "all_gather_rollout"]
 
 
 def __getattr__(name):
@@ -19,7 +20,7 @@ def __getattr__(name):
     if name in ("DroneVecEnv", "gae", "make_config", "vec_env"):
         vec_env = importlib.import_module(__name__ + ".vec_env")
         return vec_env if name == "vec_env" else getattr(vec_env, name)
-    if name in ("collector", "RolloutCollector"):
+    if name in ("collector", "RolloutCollector", "ShardPlan", "all_gather_rollout"):
         collector = importlib.import_module(__name__ + ".collector")
         return collector if name == "collector" else getattr(collector, name)
     raise AttributeError(name)

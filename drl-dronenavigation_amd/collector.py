@@ -1,0 +1,136 @@
+"""Rollout collection over sharded drones: the host loop around the step kernel for BASELINE configs 3-5.
+
+What it stands in for in the reference: SB3 `OnPolicyAlgorithm.collect_rollouts` driving the
+`SubprocVecEnv` built at Sol/Model/PBDroneSimulator.py:653-666 (policy -> clip -> env.step -> buffer.add,
+then `compute_returns_and_advantage`), whose only in-tree statement of the advantage recursion is
+Sol/Model/Algorithms/cleanRLPPO.py:207-248.  Here every buffer stays on the GPU: the policy's output tensor is
+handed to `dn_step` by pointer, the rollout is laid out step-major [n_steps, N_local, ...] and the advantages
+come from the `dn_gae` kernel.
+
+Sharding: every drone is an independent world, so rank r of R owns the contiguous range
+[r*N_local, (r+1)*N_local) and stepping needs NO collective.  The one exchange is per rollout: where the
+learner draws its minibatches from the global batch (BASELINE config 4) the packed [2, n_steps, N_local]
+advantages/returns are all-gathered (RCCL `ncclAllGather` over xGMI when the process group's backend is
+"nccl"; the same call runs on gloo for the CPU tests).
+
+`ShardPlan` and `all_gather_rollout` are device-agnostic (plain torch.distributed); `RolloutCollector` needs
+the HIP environment and has no CPU path.
+"""
+from dataclasses import dataclass
+
+import torch
+
+
+@dataclass(frozen=True)
+class ShardPlan:
+    """Contiguous split of `global_num_envs` drones over `world_size` ranks."""
+    global_num_envs: int
+    world_size: int
+    rank: int
+
+    def __post_init__(self):
+        if self.world_size < 1 or not 0 <= self.rank < self.world_size:
+            raise ValueError(f"bad rank/world_size {self.rank}/{self.world_size}")
+        if self.global_num_envs < self.world_size or self.global_num_envs % self.world_size:
+            raise ValueError(f"global_num_envs ({self.global_num_envs}) must be a positive multiple of the world size "
+                             f"({self.world_size}): all_gather_into_tensor needs equal shards")
+
+    @property
+    def num_envs(self):
+        """Drones owned by this rank."""
+        return self.global_num_envs // self.world_size
+
+    @property
+    def env_id_offset(self):
+        """Global id of this rank's drone 0 (keys the Philox noise streams; dn_config.env_id_offset)."""
+        return self.rank * self.num_envs
+
+    def local_slice(self):
+        return slice(self.env_id_offset, self.env_id_offset + self.num_envs)
+
+    @classmethod
+    def from_env(cls, global_num_envs):
+        import os
+        return cls(int(global_num_envs), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")))
+
+
+def all_gather_rollout(advantages, returns, group=None):
+    """All-gather the per-rank [n_steps, N_local] advantages and returns into [n_steps, N_global] tensors whose
+    columns are in global drone order.  One collective for both arrays (packed [2, T, N_local] send buffer ->
+    [R*2, T, N_local] receive buffer), none at all for a single-rank job."""
+    import torch.distributed as dist
+    if advantages.shape != returns.shape or advantages.dim() != 2:
+        raise ValueError("advantages and returns must both be [n_steps, N_local]")
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return advantages, returns
+    world = dist.get_world_size(group)
+    T, n = advantages.shape
+    send = torch.stack((advantages, returns)).contiguous()                       # [2, T, n]
+    recv = torch.empty((world * 2, T, n), dtype=send.dtype, device=send.device)     # concatenated along dim 0
+    dist.all_gather_into_tensor(recv, send, group=group)
+    out = recv.view(world, 2, T, n).permute(1, 2, 0, 3).reshape(2, T, world * n)   # rank-major columns = global order
+    return out[0], out[1]
+
+
+class RolloutCollector:
+    """n_steps x (policy -> dn_step) on one GPU's shard, then GAE (+ optional all-gather).
+
+    policy(obs[N,13] f32) -> (actions[N,4] f32, values[N] f32, log_probs[N] f32), all on the env's device;
+    value_fn(obs) -> values[N] (defaults to the policy's second output).  Actions are clipped to the action
+    space before the step, as SB3 does.  `bootstrap_truncated` adds gamma * V(terminal_observation) to the reward
+    of drones whose episode hit the time limit (SB3's TimeLimit handling)."""
+
+    def __init__(self, env, policy, n_steps, *, value_fn=None, gamma=0.99, gae_lambda=0.95, bootstrap_truncated=True,
+                 gather=False, group=None):
+        from .vec_env import ACT_DIM, DroneVecEnv
+        if not isinstance(env, DroneVecEnv):
+            raise TypeError("RolloutCollector drives a DroneVecEnv (HIP); there is no CPU path")
+        self.env, self.policy, self.value_fn = env, policy, value_fn
+        self.n_steps, self.gamma, self.gae_lambda = int(n_steps), float(gamma), float(gae_lambda)
+        self.bootstrap_truncated, self.gather, self.group = bool(bootstrap_truncated), bool(gather), group
+        n, T, dev, f32 = env.num_envs, self.n_steps, env.device, torch.float32
+        self.buf = dict(
+            obs=torch.empty((T, n, env.obs_dim), dtype=f32, device=dev),
+            actions=torch.empty((T, n, ACT_DIM), dtype=f32, device=dev),
+            values=torch.empty((T, n), dtype=f32, device=dev), log_probs=torch.empty((T, n), dtype=f32, device=dev),
+            rewards=torch.empty((T, n), dtype=f32, device=dev),
+            episode_starts=torch.empty((T, n), dtype=torch.uint8, device=dev))
+        self._last_obs = env.reset_tensor().clone()
+        self._last_done = torch.ones(n, dtype=torch.uint8, device=dev)       # SB3: _last_episode_starts = True
+        self.num_timesteps = 0
+
+    def _values(self, obs):
+        if self.value_fn is not None:
+            return self.value_fn(obs).reshape(-1)
+        return self.policy(obs)[1].reshape(-1)
+
+    @torch.no_grad()
+    def collect(self):
+        """One rollout.  Returns the buffer dict plus `advantages`, `returns` ([n_steps, N_local]) and, with
+        `gather`, `advantages_global` / `returns_global` ([n_steps, N_global])."""
+        from .vec_env import gae
+        env, b = self.env, self.buf
+        obs, done = self._last_obs, self._last_done
+        for t in range(self.n_steps):
+            actions, values, log_probs = self.policy(obs)
+            b["obs"][t].copy_(obs)
+            b["episode_starts"][t].copy_(done)
+            b["values"][t].copy_(values.reshape(-1))
+            b["log_probs"][t].copy_(log_probs.reshape(-1))
+            b["actions"][t].copy_(actions)
+            clipped = b["actions"][t].clamp(-1.0, 1.0)
+            next_obs, reward, next_done, info = env.step_tensor(clipped, want_terminal=self.bootstrap_truncated)
+            if self.bootstrap_truncated:
+                # rows of terminal_obs are valid only where done; `truncated` is zero elsewhere
+                tv = self._values(torch.where(next_done.bool()[:, None], info["terminal_obs"], next_obs))
+                reward = reward + self.gamma * tv * info["truncated"].to(reward.dtype)
+            b["rewards"][t].copy_(reward)
+            obs, done = next_obs.clone(), next_done.clone()
+        self._last_obs, self._last_done = obs, done
+        self.num_timesteps += self.n_steps * env.num_envs
+        last_values = self._values(obs)
+        adv, ret = gae(b["rewards"], b["values"], b["episode_starts"], last_values, done, self.gamma, self.gae_lambda)
+        out = dict(b, advantages=adv, returns=ret, last_values=last_values, last_dones=done)
+        if self.gather:
+            out["advantages_global"], out["returns_global"] = all_gather_rollout(adv, ret, self.group)
+        return out

@@ -1,0 +1,107 @@
+"""Multi-rank path on CPU: world_size 2 over gloo (the GPU job uses the same calls over RCCL).
+
+Each rank steps its shard of drones with the CPU oracle standing in for the device (test infrastructure),
+computes GAE on the shard and all-gathers advantages/returns through the product's
+`collector.all_gather_rollout`; the gathered arrays must equal a single-process run over all drones --
+including the Philox noise streams, which are keyed by GLOBAL drone id (`env_id_offset`), so results cannot
+depend on how many ranks the drones are split over.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import oracle as O
+
+N_GLOBAL, T = 96, 40
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _run_shard(plan, acts_global):
+    """Oracle rollout of this rank's drones: rewards/values/episode-start flags [T, N_local] + GAE."""
+    from drl_dronenavigation_amd import tracks
+    track = tracks.reaching()
+    cfg = O.make_config(track.targets(), track.initial_xyzs, track.aviary_dim, circle=False, max_steps=25,
+                        f32_state=True, act_noise_sigma=0.002, obs_noise_sigma=0.01, seed=99,
+                        env_id_offset=plan.env_id_offset)
+    env = O.OracleVecEnv(cfg, plan.num_envs)
+    obs = env.reset()
+    n = plan.num_envs
+    rew = np.zeros((T, n), np.float32)
+    val = np.zeros((T, n), np.float32)
+    starts = np.zeros((T, n), np.uint8)
+    done = np.ones(n, np.uint8)
+    w = np.linspace(-1, 1, 13).astype(np.float32)            # a fixed linear "value function"
+    for t in range(T):
+        val[t] = obs @ w
+        starts[t] = done
+        out = env.step(acts_global[t, plan.local_slice()])
+        obs, done = out["obs"], out["done"]
+        rew[t] = out["reward"]
+    adv, ret = O.gae(rew, val, starts, obs @ w, done, 0.99, 0.95)
+    return adv, ret, int(done.sum())
+
+
+def _worker(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from drl_dronenavigation_amd.collector import ShardPlan, all_gather_rollout
+        plan = ShardPlan.from_env(N_GLOBAL)
+        assert (plan.rank, plan.world_size, plan.num_envs, plan.env_id_offset) == (rank, world, N_GLOBAL // world,
+                                                                                  rank * N_GLOBAL // world)
+        acts = np.load(os.path.join(tmp, "acts.npy"))
+        adv, ret, _ = _run_shard(plan, acts)
+        g_adv, g_ret = all_gather_rollout(torch.from_numpy(adv), torch.from_numpy(ret))
+        assert g_adv.shape == (T, N_GLOBAL) and g_ret.shape == (T, N_GLOBAL)
+        # every rank holds the full arrays, identical bits
+        chk = torch.stack((g_adv.double().sum(), g_ret.double().sum()))
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        assert torch.equal(lo, hi)
+        if rank == 0:
+            np.save(os.path.join(tmp, "adv.npy"), g_adv.numpy())
+            np.save(os.path.join(tmp, "ret.npy"), g_ret.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_rollout_all_gather_matches_single_process(tmp_path):
+    from drl_dronenavigation_amd.collector import ShardPlan
+    rng = np.random.default_rng(0)
+    acts = np.where(rng.random((T, N_GLOBAL, 1)) < 0.5, rng.uniform(-1, 1, (T, N_GLOBAL, 4)),
+                    0.0922 + 0.003 * rng.standard_normal((T, N_GLOBAL, 4))).astype(np.float32)
+    np.save(tmp_path / "acts.npy", acts)
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    adv1, ret1, n_done = _run_shard(ShardPlan(N_GLOBAL, 1, 0), acts)
+    assert n_done >= 0
+    adv2, ret2 = np.load(tmp_path / "adv.npy"), np.load(tmp_path / "ret.npy")
+    assert np.array_equal(adv1.view(np.uint32), adv2.view(np.uint32))
+    assert np.array_equal(ret1.view(np.uint32), ret2.view(np.uint32))
+    assert np.abs(adv1).max() > 0.1
+
+
+def test_shard_plan_validation():
+    from drl_dronenavigation_amd.collector import ShardPlan, all_gather_rollout
+    p = ShardPlan(262144, 8, 5)
+    assert p.num_envs == 32768 and p.env_id_offset == 5 * 32768 and p.local_slice() == slice(163840, 196608)
+    with pytest.raises(ValueError):
+        ShardPlan(100, 8, 0)
+    with pytest.raises(ValueError):
+        ShardPlan(64, 2, 2)
+    a = torch.zeros(3, 4)
+    assert all_gather_rollout(a, a)[0] is a            # no process group: identity, no collective
+    with pytest.raises(ValueError):
+        all_gather_rollout(a, torch.zeros(3, 5))

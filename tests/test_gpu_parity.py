@@ -433,3 +433,52 @@ def test_errors_are_loud():
         st["idx"] = 99
         env.set_state(st)
     env.close()
+
+
+def test_rollout_collector_matches_oracle_replay():
+    """collector.RolloutCollector (policy -> dn_step x n_steps -> dn_gae, SB3 truncation bootstrap) against an
+    oracle replay of the actions it took: rewards (incl. gamma*V(terminal_observation) on TimeLimit truncation),
+    episode-start flags and advantages."""
+    pkg = _gpu()
+    from drl_dronenavigation_amd.collector import RolloutCollector
+    track = _tracks().circle(1, 4, 1)
+    n, T, gamma, lam = 1024, 48, 0.99, 0.95
+    env, ora = make_pair(track, n, f32_state=True, max_steps=30, normalize_obs=False)
+    dev = env.device
+    g = torch.Generator(device="cpu").manual_seed(3)
+    w_pi = (torch.randn(13, 4, generator=g) * 0.01).to(dev)
+    w_v = torch.linspace(-1, 1, 13).to(dev)
+    noise = (0.003 * torch.randn(T * 3, n, 4, generator=g)).to(dev)
+    calls = [0]
+
+    def policy(obs):
+        hover = (torch.arange(n, device=dev) % 2 == 1)[:, None]
+        a = torch.where(hover, 0.0922 + noise[calls[0] % len(noise)], torch.tanh(obs @ w_pi * 50.0) * 1.5)
+        calls[0] += 1
+        return a, obs @ w_v, torch.zeros(n, device=dev)
+
+    col = RolloutCollector(env, policy, T, value_fn=lambda o: o @ w_v, gamma=gamma, gae_lambda=lam)
+    ora.reset()
+    last_done = np.ones(n, np.uint8)
+    n_trunc = 0
+    for it in range(2):
+        out = col.collect()
+        acts = out["actions"].cpu().numpy()
+        assert np.abs(acts).max() > 1.0, "the policy must exceed the action space so the clip matters"
+        rew = np.zeros((T, n), np.float32)
+        for t in range(T):
+            assert np.array_equal(out["episode_starts"][t].cpu().numpy(), last_done), (it, t)
+            ref = ora.step(np.clip(acts[t], -1, 1))
+            boot = gamma * (ref["terminal_obs"] @ w_v.cpu().numpy()) * ref["truncated"]
+            rew[t] = ref["reward"] + boot.astype(np.float32)
+            n_trunc += int(ref["truncated"].sum())
+            last_done = ref["done"]
+        np.testing.assert_allclose(out["rewards"].cpu().numpy(), rew, rtol=1e-5, atol=1e-4)
+        a_ref, r_ref = O.gae(out["rewards"].cpu().numpy(), out["values"].cpu().numpy(),
+                             out["episode_starts"].cpu().numpy(), out["last_values"].cpu().numpy(),
+                             out["last_dones"].cpu().numpy(), gamma, lam)
+        assert np.array_equal(out["advantages"].cpu().numpy().view(np.uint32), a_ref.view(np.uint32))
+        assert np.array_equal(out["returns"].cpu().numpy().view(np.uint32), r_ref.view(np.uint32))
+    assert n_trunc > 0, "TimeLimit truncations must occur so the bootstrap is exercised"
+    assert col.num_timesteps == 2 * T * n
+    env.close()
