@@ -105,6 +105,8 @@ void build_consts(const dn_config &c, DnConsts<R> &k)
     for (int j = 0; j < 3; ++j) k.spawn[j] = (R)c.spawn[j];
     k.threshold = (R)c.threshold;
     k.thr_ext = (R)(c.threshold + 0.2);
+    k.thr2 = (R)(c.threshold * c.threshold);
+    k.thr_ext2 = (R)((c.threshold + 0.2) * (c.threshold + 0.2));
     double a = std::fabs(c.aviary_dim[0]) + c.aviary_dim[3], b = std::fabs(c.aviary_dim[1]) + c.aviary_dim[4];
     double m = a > b ? a : b;
     k.max_target_dist = (R)(m > c.aviary_dim[5] ? m : c.aviary_dim[5]);           // PBDroneEnv.py:91
@@ -477,6 +479,18 @@ int32_t dn_set_step_count(dn_env *env, uint64_t value)
 {
     if (!env) return fail(DN_ERR_INVALID_ARGUMENT, "env is NULL");
     env->step_count = value;
+    return DN_OK;
+}
+
+int32_t dn_preprocess_action(const float *actions, int64_t num_envs, int32_t normalize_actions, float *rpm, float *forces,
+                             float *z_torque, int32_t device_id, void *stream)
+{
+    if (!actions || num_envs < 1) return fail(DN_ERR_INVALID_ARGUMENT, "actions is required and num_envs >= 1");
+    if (!rpm && !forces && !z_torque) return fail(DN_ERR_INVALID_ARGUMENT, "at least one output buffer is required");
+    if (((uintptr_t)actions & 15u) || ((uintptr_t)rpm & 15u) || ((uintptr_t)forces & 15u))
+        return fail(DN_ERR_INVALID_ARGUMENT, "actions, rpm and forces must be 16-byte aligned");
+    DN_HIP(hipSetDevice(device_id));
+    DN_HIP(dn_launch_action_chain(actions, num_envs, normalize_actions, rpm, forces, z_torque, (hipStream_t)stream));
     return DN_OK;
 }
 

@@ -69,6 +69,7 @@ struct DnConsts {
     R spawn[3];
     R threshold;
     R thr_ext;          // threshold + 0.2
+    R thr2, thr_ext2;   // squares of the two radii: corridor tests compare squared distances (no sqrt)
     R max_target_dist;
     R inv_max_target_dist;
     R inv_dim[3];       // 1 / (x_high, y_high, z_high): position normalisation as a multiply
@@ -97,6 +98,8 @@ hipError_t dn_launch_reset(const DnParams &p, float *obs, bool f32, hipStream_t 
 hipError_t dn_launch_gae(const float *rewards, const float *values, const uint8_t *dones,
                          const float *last_values, const uint8_t *last_dones, long long T, long long N,
                          float gamma, float gl, float *adv, float *ret, hipStream_t stream);
+hipError_t dn_launch_action_chain(const float *actions, long long n, int normalize_actions, float *rpm, float *forces,
+                                  float *z_torque, hipStream_t stream);
 hipError_t dn_launch_fill4(float4 *dst, float4 v, long long n, hipStream_t stream);
 hipError_t dn_launch_filld(double *dst, double v, long long n, hipStream_t stream);
 hipError_t dn_launch_compact(const unsigned long long *mask, long long n, int32_t *indices, int32_t *count,

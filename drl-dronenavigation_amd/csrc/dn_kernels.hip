@@ -62,28 +62,64 @@ template <typename T> DN_DEV T clipv(T x, T lo, T hi)
 template <typename R> DN_DEV R norm3(R a, R b, R c) { return sqrt(a * a + b * b + c * c); }
 
 // ---- A1-A3: float32 action chain ------------------------------------------------------------------
-DN_DEV float rotor_force_from_action(float a, bool normalize_actions, float &torque)
+// Bit-exact against numpy float32 (golden actions.npz).  IEEE divide and sqrt expand to 10 and 23 instructions on
+// gfx950 (scaling, fix-up); every divisor here is a constant and every operand range is known, so the chain uses
+//   a / c  =  q0 + fma(-q0, c, a) * RN(1/c),  q0 = a * RN(1/c)        (Markstein's correction, 3 instructions)
+//   sqrt   =  v_sqrt_f32 (1 ulp) + a one-ulp-down / one-ulp-up test with fma residuals
+// which tests/tools/check_action_chain_exact.c proves identical to the correctly rounded results for EVERY float32
+// input that can reach them (2.1e9 actions, 2e7 thrusts, 1e7 roots; exhaustive).  Clips are v_med3_f32; np.clip's
+// NaN propagation is restored by the final select.
+constexpr float DEN32 = A_HIGH32 - A_LOW32;
+constexpr float INV_DEN32 = 1.0f / DEN32, INV_KF32 = 1.0f / KF32, INV_SCALE32 = 1.0f / PWM2RPM_SCALE32;
+DN_DEV float div_const32(float a, float c, float inv_c)
+{
+    const float q0 = a * inv_c;
+    const float r = __builtin_fmaf(-q0, c, a);
+    return __builtin_fmaf(r, inv_c, q0);
+}
+DN_DEV float sqrt_rn32(float x)
+{
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float sm = __uint_as_float(__float_as_uint(s) - 1u), sp = __uint_as_float(__float_as_uint(s) + 1u);
+    const float rm = __builtin_fmaf(-sm, s, x), rp = __builtin_fmaf(-sp, s, x);
+    float out = rm <= 0.0f ? sm : s;
+    out = rp > 0.0f ? sp : out;
+    return out;
+}
+DN_DEV float rotor_force_from_action(float a, bool normalize_actions, float &torque, float *rpm_out = nullptr)
 {
     float cmd = a;
     if (normalize_actions) {                     // PBDroneEnv.rescale_action, PBDroneEnv.py:949-971
-        float num = a - A_LOW32;
-        float den = A_HIGH32 - A_LOW32;
-        float q = num / den;
-        float m = 2.0f * q;                      // (high - low) = 1 - (-1)
-        float r = -1.0f + m;
-        cmd = clipv(r, -1.0f, 1.0f);
+        const float ac = __builtin_amdgcn_fmed3f(a, -2.0f, 2.0f);   // beyond +-2 the result is saturated anyway
+        const float num = ac - A_LOW32;
+        const float q = div_const32(num, DEN32, INV_DEN32);
+        const float m = 2.0f * q;                // (high - low) = 1 - (-1)
+        const float r = -1.0f + m;
+        cmd = __builtin_amdgcn_fmed3f(r, -1.0f, 1.0f);
     }
-    float thrust = clipv(cmd, A_LOW32, A_HIGH32);    // PBDroneEnv._preprocessAction, PBDroneEnv.py:889
-    if (thrust < 0.0f) thrust = 0.0f;                // cmd2pwm, env_utils.py:29
-    float t = thrust / KF32;                         // env_utils.py:30 (n_motor = 1)
-    float s = sqrtf(t);
-    float pwm = (s - PWM2RPM_CONST32) / PWM2RPM_SCALE32;
-    pwm = clipv(pwm, MIN_PWM32, MAX_PWM32);          // env_utils.py:39
-    float r0 = PWM2RPM_SCALE32 * pwm;
-    float rpm = r0 + PWM2RPM_CONST32;                // pwm2rpm, env_utils.py:58
-    float sq = rpm * rpm;                            // BaseAviary._physics, BaseAviary.py:776-777
-    torque = sq * KM32;
-    return sq * KF32;
+    // PBDroneEnv._preprocessAction, PBDroneEnv.py:889.  The clip makes thrust >= a_low > 0, so cmd2pwm's
+    // maximum(thrust, 0) (env_utils.py:29) is the identity.
+    const float thrust = __builtin_amdgcn_fmed3f(cmd, A_LOW32, A_HIGH32);
+    const float t = div_const32(thrust, KF32, INV_KF32);             // env_utils.py:30 (n_motor = 1)
+    const float s = sqrt_rn32(t);
+    float pwm = div_const32(s - PWM2RPM_CONST32, PWM2RPM_SCALE32, INV_SCALE32);
+    pwm = __builtin_amdgcn_fmed3f(pwm, MIN_PWM32, MAX_PWM32);        // env_utils.py:39
+    const float r0 = PWM2RPM_SCALE32 * pwm;
+    const float rpm = r0 + PWM2RPM_CONST32;          // pwm2rpm, env_utils.py:58
+    const float sq = rpm * rpm;                      // BaseAviary._physics, BaseAviary.py:776-777
+    const bool nan = a != a;                         // np.clip / sqrt propagate NaN
+    if (rpm_out) *rpm_out = nan ? a : rpm;
+    torque = nan ? a : sq * KM32;
+    return nan ? a : sq * KF32;
+}
+
+DN_DEV float z_torque32(const float tq[4])
+{   // z_torque = -t0 + t1 - t2 + t3, left to right in float32 (BaseAviary.py:780)
+    float z = -tq[0];
+    z = z + tq[1];
+    z = z - tq[2];
+    z = z + tq[3];
+    return z;
 }
 
 // ---- noise (BASELINE config 5; sigma = 0 is the reference): Philox4x32-10 + float64 Box-Muller ------
@@ -114,6 +150,16 @@ DN_DEV void noise4(unsigned long long seed, unsigned long long gid, unsigned ste
         double ang = 2.0 * 3.14159265358979323846 * u2;
         z[2 * h] = (float)(rad * cos(ang));
         z[2 * h + 1] = (float)(rad * sin(ang));
+    }
+}
+DN_DEV void add_act_noise(const DnParams &p, unsigned long long gid, unsigned step, float a[4])
+{   // float32, unfused (its own function: the fused-multiply-add licence of step_body must not reach it)
+    float z[4];
+    noise4(p.seed, gid, step, 0u, z);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float s = p.act_noise_sigma * z[j];
+        a[j] = clipv(a[j] + s, -1.0f, 1.0f);
     }
 }
 DN_DEV void add_obs_noise(const DnParams &p, unsigned long long gid, unsigned step, unsigned stream0, float o[DN_OBS_DIM])
@@ -162,62 +208,139 @@ template <typename R> DN_DEV const DnConsts<R> &consts(const DnParams &p);
 template <> DN_DEV const DnConsts<double> &consts<double>(const DnParams &p) { return p.c64; }
 template <> DN_DEV const DnConsts<float> &consts<float>(const DnParams &p) { return p.c32; }
 
+// ---- arithmetic helpers ---------------------------------------------------------------------------
+// The float32 action chain above is evaluated operation by operation (file-wide -ffp-contract=off) because it
+// is bit-exact against the reference's numpy float32.  Everything from here on is float64 in registers over a
+// float32 state and is held to 1e-5 (flags exact); there a multiply-add may fuse (the difference is one float64
+// rounding, 1e-16) and divide / sqrt are replaced by the hardware seed (v_rcp_f64 / v_rsq_f64, ~2^-23) plus two
+// Newton steps: the operands are in benign ranges (no denormals, no overflow), so the scaling and fix-up code of
+// the IEEE library routines (3x the instructions) buys nothing.  The kernel is instruction-issue bound at
+// 32768 drones (one wave per SIMD), so the instruction count IS the step time.
+template <typename R> struct FM;
+template <> struct FM<double> {
+    static DN_DEV double rcp(double x)
+    {
+        double r = __builtin_amdgcn_rcp(x);
+        double e = __builtin_fma(-x, r, 1.0);
+        r = __builtin_fma(r, e, r);
+        e = __builtin_fma(-x, r, 1.0);
+        return __builtin_fma(r, e, r);
+    }
+    static DN_DEV double rsq(double x)         // x > 0; x == 0 gives NaN (callers compare / select afterwards)
+    {
+        double y = __builtin_amdgcn_rsq(x);
+        const double hx = 0.5 * x;
+        double e = __builtin_fma(-(hx * y), y, 0.5);
+        y = __builtin_fma(y, e, y);
+        e = __builtin_fma(-(hx * y), y, 0.5);
+        return __builtin_fma(y, e, y);
+    }
+    static DN_DEV double rsq_f32grade(double x)   // one Newton step: ~2^-45, for results that leave as float32
+    {
+        double y = __builtin_amdgcn_rsq(x);
+        double e = __builtin_fma(-(0.5 * x * y), y, 0.5);
+        return __builtin_fma(y, e, y);
+    }
+    static DN_DEV double sqrt0(double x)        // x >= 0, exact 0 allowed
+    {
+        double y = __builtin_amdgcn_rsq(x);
+        double g = x * y, h = 0.5 * y;
+        double r = __builtin_fma(-h, g, 0.5);
+        g = __builtin_fma(g, r, g);
+        h = __builtin_fma(h, r, h);
+        r = __builtin_fma(-h, g, 0.5);
+        g = __builtin_fma(g, r, g);
+        h = __builtin_fma(h, r, h);
+        const double d = __builtin_fma(-g, g, x);
+        g = __builtin_fma(d, h, g);
+        return x == 0.0 ? 0.0 : g;
+    }
+    static DN_DEV double fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+};
+template <> struct FM<float> {                  // speed option (compute_f32): hardware 1-ulp approximations
+    static DN_DEV float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+    static DN_DEV float rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+    static DN_DEV float rsq_f32grade(float x) { return __builtin_amdgcn_rsqf(x); }
+    static DN_DEV float sqrt0(float x) { return __builtin_amdgcn_sqrtf(x); }
+    static DN_DEV float fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+};
+
 // ---- A8: _has_collision_occurred (PBDroneEnv.py:678-707) + is_out_of_cylinder_bounds (:718-786) ----
+// The reference compares distances, norm(.) > radius; here the squared distance is compared with the squared
+// radius (no sqrt).  The two predicates differ only when the squared distance is within an ulp of the squared
+// radius (probability ~1e-16 per test); NaN compares false on both forms.
 template <typename R>
-DN_DEV bool has_collision(const DnParams &p, const DnConsts<R> &c, const R *tab, R px, R py, R pz, R r22, int idx)
-{
-    if (px > c.dim[3] || px < c.dim[0] || py > c.dim[4] || py < c.dim[1]) return true;
+DN_DEV bool collision_common(const DnParams &p, const DnConsts<R> &c, R px, R py, R pz, R r22)
+{   // everything in _has_collision_occurred that does not depend on the waypoint index
+#pragma clang fp contract(fast)
+    bool out = px > c.dim[3] || px < c.dim[0] || py > c.dim[4] || py < c.dim[1] || pz > c.dim[5];
     if (p.ground_contact) {
         // len(p.getContactPoints()) > 0 against plane.urdf, APPROXIMATED [3P-recall]: lowest point of the
-        // collision cylinder within Bullet's 0.02 contact-breaking threshold of z = 0.
-        R cz = fabs(r22);
+        // collision cylinder within Bullet's 0.02 contact-breaking threshold of z = 0:
+        //   pz - (H/2 |r22| + R sqrt(1 - r22^2)) <= 0.02   <=>   m <= 0  or  m^2 <= R^2 (1 - r22^2),
+        //   m = pz - H/2 |r22| - 0.02
         R s2 = R(1.0) - r22 * r22;
-        R s = s2 > R(0.0) ? sqrt(s2) : R(0.0);
-        R low = pz - (R(0.5) * K<R>::COLL_H * cz + K<R>::COLL_R * s);
-        if (low <= R(0.02)) return true;
+        s2 = s2 > R(0.0) ? s2 : R(0.0);
+        const R m = pz - R(0.5) * K<R>::COLL_H * fabs(r22) - R(0.02);
+        out = out || m <= R(0.0) || m * m <= (K<R>::COLL_R * K<R>::COLL_R) * s2;
     }
-    if (pz > c.dim[5]) return true;
-    if (!p.cylinder) return false;
-    if (p.circle) {                                   // :723-741, centre (0,0,1), radius 1
-        R cx = px - R(0.0), cy = py - R(0.0), cz = R(0.0);
-        R rn = R(1.0) / norm3(cx, cy, cz);
-        R nx = cx * rn, ny = cy * rn, nz = cz * rn;    // radius 1; 0 * inf -> NaN -> the compare below is false
-        R qx = R(0.0) + nx, qy = R(0.0) + ny, qz = R(1.0) + nz;
-        return norm3(px - qx, py - qy, pz - qz) > c.threshold;
+    if (p.cylinder && p.circle) {                     // :723-741, centre (0,0,1), radius 1
+        const R rn = FM<R>::rsq(px * px + py * py);   // 0 -> NaN -> the compare below is false, as in the reference
+        const R ex = px - px * rn, ey = py - py * rn, ez = pz - R(1.0);
+        out = out || (ex * ex + ey * ey + ez * ez) > c.thr2;
     }
+    return out;
+}
+template <typename R>
+DN_DEV bool outside_segment_corridor(const DnConsts<R> &c, const R *tab, R px, R py, R pz, int idx)
+{   // :746-786, the corridor around the segment that ends at waypoint idx (non-circle tracks)
+#pragma clang fp contract(fast)
     const R *e = tab + idx * DN_T_STRIDE;
-    if (e[DN_T_LL] == R(0.0))                          // :756-757
-        return norm3(px - e[DN_T_B1], py - e[DN_T_B1 + 1], pz - e[DN_T_B1 + 2]) > c.threshold;
-    R ux = e[DN_T_U], uy = e[DN_T_U + 1], uz = e[DN_T_U + 2];
-    R ex = e[DN_T_E1], ey = e[DN_T_E1 + 1], ez = e[DN_T_E1 + 2];
-    R dx = px - ex, dy = py - ey, dz = pz - ez;        // :776
+    const R ux = e[DN_T_U], uy = e[DN_T_U + 1], uz = e[DN_T_U + 2];
+    const R dx = px - e[DN_T_E1], dy = py - e[DN_T_E1 + 1], dz = pz - e[DN_T_E1 + 2];   // :776
     R proj = dx * ux + dy * uy + dz * uz;              // :778
     proj = clipv(proj, R(0.0), e[DN_T_LEXT]);          // :780
-    R qx = ex + proj * ux, qy = ey + proj * uy, qz = ez + proj * uz;   // :782
-    return norm3(px - qx, py - qy, pz - qz) > c.thr_ext;               // :786
+    // distance to the clamped projection (:782-786); a zero-length segment has u = 0, e1 = base1, lext = 0, so the
+    // same expression is |pos - base1|, which the reference tests against the bare threshold (:756-757)
+    const R qx = dx - proj * ux, qy = dy - proj * uy, qz = dz - proj * uz;
+    const R lim = e[DN_T_LL] == R(0.0) ? c.thr2 : c.thr_ext2;
+    return (qx * qx + qy * qy + qz * qz) > lim;
 }
 
 // orientation_reward (PBDroneEnv.py:573-586) with get_forward_vector (:588-597).  The reference tests
 // arccos(clip(f . t, -1, 1)) > radians(10); arccos is strictly decreasing, so that is f . t < cos(10 deg)
-// (NaN compares false on both forms) and the arccos is never evaluated.
+// (the clip cannot change the outcome because -1 < cos 10 deg < 1; NaN compares false on both forms).
 template <typename R>
 DN_DEV int orientation_reward(R fx, R fy, R fz, R px, R py, R pz, const R *wp)
 {
-    R tx = wp[0] - px, ty = wp[1] - py, tz = wp[2] - pz;
-    R rn = R(1.0) / norm3(tx, ty, tz);
-    R dot = fx * (tx * rn) + fy * (ty * rn) + fz * (tz * rn);
-    return (clipv(dot, R(-1.0), R(1.0)) < K<R>::COS_10DEG) ? -1 : 0;
+#pragma clang fp contract(fast)
+    const R tx = wp[0] - px, ty = wp[1] - py, tz = wp[2] - pz;
+    const R rn = FM<R>::rsq(tx * tx + ty * ty + tz * tz);
+    const R dot = (fx * tx + fy * ty + fz * tz) * rn;
+    return dot < K<R>::COS_10DEG ? -1 : 0;
 }
 
 // sin(h)/h and cos(h) for the quaternion half-angle h = |w| dt / 2 <= pi/8 (Bullet clamps |w| dt at pi/4):
-// Taylor polynomials in h^2, truncation < 1e-18 on that interval, no range reduction needed.
+// Taylor polynomials in h^2 (Horner, fused), truncation < 1e-17 on that interval, no range reduction needed.
 template <typename R> DN_DEV void sinc_cos_small(R h2, R &sinc, R &c)
 {
-    sinc = R(1.0) + h2 * (R(-1.0 / 6.0) + h2 * (R(1.0 / 120.0) + h2 * (R(-1.0 / 5040.0) + h2 * (R(1.0 / 362880.0) +
-           h2 * (R(-1.0 / 39916800.0) + h2 * (R(1.0 / 6227020800.0) + h2 * R(-1.0 / 1307674368000.0)))))));
-    c = R(1.0) + h2 * (R(-0.5) + h2 * (R(1.0 / 24.0) + h2 * (R(-1.0 / 720.0) + h2 * (R(1.0 / 40320.0) +
-        h2 * (R(-1.0 / 3628800.0) + h2 * (R(1.0 / 479001600.0) + h2 * (R(-1.0 / 87178291200.0) +
-        h2 * R(1.0 / 20922789888000.0))))))));
+    R s = R(-1.0 / 1307674368000.0);
+    s = FM<R>::fma(s, h2, R(1.0 / 6227020800.0));
+    s = FM<R>::fma(s, h2, R(-1.0 / 39916800.0));
+    s = FM<R>::fma(s, h2, R(1.0 / 362880.0));
+    s = FM<R>::fma(s, h2, R(-1.0 / 5040.0));
+    s = FM<R>::fma(s, h2, R(1.0 / 120.0));
+    s = FM<R>::fma(s, h2, R(-1.0 / 6.0));
+    sinc = FM<R>::fma(s, h2, R(1.0));
+    R k = R(1.0 / 20922789888000.0);
+    k = FM<R>::fma(k, h2, R(-1.0 / 87178291200.0));
+    k = FM<R>::fma(k, h2, R(1.0 / 479001600.0));
+    k = FM<R>::fma(k, h2, R(-1.0 / 3628800.0));
+    k = FM<R>::fma(k, h2, R(1.0 / 40320.0));
+    k = FM<R>::fma(k, h2, R(-1.0 / 720.0));
+    k = FM<R>::fma(k, h2, R(1.0 / 24.0));
+    k = FM<R>::fma(k, h2, R(-0.5));
+    c = FM<R>::fma(k, h2, R(1.0));
 }
 
 struct Meta {
@@ -237,25 +360,52 @@ DN_DEV float pack_meta(int steps, int idx, int just_found)
     return __uint_as_float(((unsigned)steps & 0xFFFFFFu) | (((unsigned)idx & 0x7Fu) << 24) | ((unsigned)just_found << 31));
 }
 
+// Block-relative output pointers of one control step.  Every pointer is uniform over the wave (an SGPR pair), so a
+// lane's access is "scalar base + 32-bit lane offset" (the saddr form of global_load/store) and the 64-bit
+// address arithmetic is done once per wave on the scalar unit instead of once per lane per access.
+struct StepOut {
+    float *obs;                    // [64][13] tile of this workgroup
+    float *reward;
+    uint8_t *done, *truncated;
+    int32_t *found;
+    float *terminal_obs;           // or nullptr
+    float *ep_return;              // or nullptr
+    int32_t *ep_length;            // or nullptr
+    unsigned long long *done_word; // this workgroup's ballot word, or nullptr
+};
+DN_DEV StepOut block_out(const DnStepIO &io, long long tile_base, long long step_off, long long word_off)
+{
+    StepOut o;
+    const long long e = step_off + tile_base;
+    o.obs = io.obs + e * DN_OBS_DIM;
+    o.reward = io.reward + e;
+    o.done = io.done + e;
+    o.truncated = io.truncated + e;
+    o.found = io.found_targets + e;
+    o.terminal_obs = io.terminal_obs ? io.terminal_obs + e * DN_OBS_DIM : nullptr;
+    o.ep_return = io.ep_return ? io.ep_return + e : nullptr;
+    o.ep_length = io.ep_length ? io.ep_length + e : nullptr;
+    o.done_word = io.done_mask ? io.done_mask + word_off + blockIdx.x : nullptr;
+    return o;
+}
+
 // Stores the wave's [64,13] observation tile: lanes park their 13 floats in LDS (stride 13 dwords: odd, so
 // conflict-free), then the wave streams the 3328 contiguous bytes out as float4 (ds_read_b128 +
 // global_store_dwordx4), i.e. 4 store instructions instead of 13 strided dword stores per destination.
-DN_DEV void store_obs_tile(float *s_tile, float *gdst, long long tile_base, long long n, int lane, bool active,
-                           const float o[DN_OBS_DIM])
+DN_DEV void store_obs_tile(float *s_tile, float *gtile, unsigned rows, unsigned lane, const float o[DN_OBS_DIM])
 {
 #pragma unroll
     for (int k = 0; k < DN_OBS_DIM; ++k) s_tile[lane * DN_OBS_DIM + k] = o[k];
     __syncthreads();
-    (void)active;
-    if (tile_base + DN_BLOCK <= n) {
-        float4 *g4 = reinterpret_cast<float4 *>(gdst + tile_base * DN_OBS_DIM);
+    if (rows == DN_BLOCK) {
+        float4 *g4 = reinterpret_cast<float4 *>(gtile);
         const float4 *s4 = reinterpret_cast<const float4 *>(s_tile);
 #pragma unroll
         for (int r = 0; r < 3; ++r) g4[r * 64 + lane] = s4[r * 64 + lane];
         if (lane < (DN_BLOCK * DN_OBS_DIM / 4 - 192)) g4[192 + lane] = s4[192 + lane];
     } else {
-        long long rem = (n - tile_base) * DN_OBS_DIM;      // ragged last tile
-        for (int e = lane; e < rem; e += DN_BLOCK) gdst[tile_base * DN_OBS_DIM + e] = s_tile[e];
+        const unsigned rem = rows * DN_OBS_DIM;            // ragged last tile
+        for (unsigned e = lane; e < rem; e += DN_BLOCK) gtile[e] = s_tile[e];
     }
 }
 
@@ -274,7 +424,7 @@ DN_DEV void reset_obs(const DnParams &p, const DnConsts<R> &c, R d_last, float o
 {
 #pragma unroll
     for (int k = 0; k < 12; ++k) o[k] = (float)c.reset_obs[k];
-    o[12] = p.include_distance ? (float)clipv(d_last * c.inv_max_target_dist, -(R)FLT_MAX, (R)FLT_MAX) : 0.0f;
+    o[12] = p.include_distance ? (float)(d_last * c.inv_max_target_dist) : 0.0f;
 }
 
 // =====================================================================================================
@@ -286,32 +436,30 @@ DN_DEV void reset_obs(const DnParams &p, const DnConsts<R> &c, R d_last, float o
 // step_body advances ONE drone (this lane) by one control step.  The persistent state travels as the six
 // float4 groups G0..G5 exactly as they sit in HBM (float32), so the single-step kernel (load, step, store)
 // and the fused multi-step kernel (load, K x step, store) run the same arithmetic on the same roundings.
+//
+// Algebra used to shorten Bullet's free-base step (A4) without changing what it computes beyond float64 rounding:
+//   * linear part: Bullet forms F_b = f_thrust_b + R^T (0,0,-M G) - M v_b (c + c |v_b|) in the body frame and
+//     rotates a_b = F_b / M back.  R R^T = 1 and |v_b| = |v|, so a = R[:,2] fz / M - (0,0,G) - v (c + c |v|).
+//   * the exponential-map quaternion update needs |w| only through (|w| dt / 2)^2 (sinc/cos are even), so no sqrt.
+//   * get_forward_vector (PBDroneEnv.py:588-597) = (cos yaw cos pitch, sin yaw cos pitch, sin pitch) is the first
+//     column of the rotation matrix of the (just normalised) quaternion: (1 - 2(y^2+z^2), 2(xy+wz), -2(xz-wy)).
 template <typename R, bool NORM, bool NOISE>
-DN_DEV void step_body(const DnParams &p, const DnConsts<R> &c, const R *s_tab, float *s_tile, const DnStepIO &io,
-                      const unsigned step_count, const long long i, const long long tile_base, const int lane,
-                      const bool active, const float4 A, float4 &G0, float4 &G1, float4 &G2, float4 &G3, float4 &G4,
-                      float4 &G5)
+DN_DEV void step_body(const DnParams &p, const DnConsts<R> &c, const R *s_tab, float *s_tile, const StepOut &out,
+                      float4 *g6_blk, const unsigned step_count, const long long tile_base, const unsigned li,
+                      const unsigned lane, const unsigned rows, const bool active, const float4 A, float4 &G0,
+                      float4 &G1, float4 &G2, float4 &G3, float4 &G4, float4 &G5)
 {
+#pragma clang fp contract(fast)
+    const long long i = tile_base + li;
     const unsigned long long gid = (unsigned long long)(p.env_id_offset + i);
     float a[4] = {A.x, A.y, A.z, A.w};
-    if (NOISE && p.act_noise_sigma > 0.0f) {
-        float z[4];
-        noise4(p.seed, gid, step_count, 0u, z);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float s = p.act_noise_sigma * z[j];
-            a[j] = clipv(a[j] + s, -1.0f, 1.0f);
-        }
-    }
+    if (NOISE && p.act_noise_sigma > 0.0f) add_act_noise(p, gid, step_count, a);
 
-    // ---- A1-A3 (float32) ---------------------------------------------------------------------------
+    // ---- A1-A3 (float32, unfused) ------------------------------------------------------------------
     float tq[4], f32[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) f32[j] = rotor_force_from_action(a[j], p.normalize_actions != 0, tq[j]);
-    float zt32 = -tq[0];
-    zt32 = zt32 + tq[1];
-    zt32 = zt32 - tq[2];
-    zt32 = zt32 + tq[3];                               // BaseAviary.py:780
+    const float zt32 = z_torque32(tq);                 // BaseAviary.py:780
 
     // ---- unpack the entry state -----------------------------------------------------------------------
     R px = G0.x, py = G0.y, pz = G0.z;
@@ -330,156 +478,166 @@ DN_DEV void step_body(const DnParams &p, const DnConsts<R> &c, const R *s_tab, f
     const R ang_ex = wx, ang_ey = wy, ang_ez = wz;     //                 (= current_ang_v)
 
     // ---- A4: p.stepSimulation, one free rigid body [3P-recall of Bullet3 btMultiBody] -------------------
-    R r00, r01, r02, r10, r11, r12, r20, r21, r22;
-    {
-        R dd = qx * qx + qy * qy + qz * qz + qw * qw;  // btMatrix3x3::setRotation
-        R s = R(2.0) / dd;
-        R xs = qx * s, ys = qy * s, zs = qz * s;
-        R wxs = qw * xs, wys = qw * ys, wzs = qw * zs;
-        R xx = qx * xs, xy = qx * ys, xz = qx * zs;
-        R yy = qy * ys, yz = qy * zs, zz = qz * zs;
-        r00 = R(1.0) - (yy + zz); r01 = xy - wzs;         r02 = xz + wys;
-        r10 = xy + wzs;         r11 = R(1.0) - (xx + zz); r12 = yz - wxs;
-        r20 = xz - wys;         r21 = yz + wxs;         r22 = R(1.0) - (xx + yy);
-    }
+    R w2;                                              // |w_new|^2, reused by the observation
     {
         const R dt = K<R>::DT;
-        // world -> base
-        R vbx = r00 * vx + r10 * vy + r20 * vz, vby = r01 * vx + r11 * vy + r21 * vz, vbz = r02 * vx + r12 * vy + r22 * vz;
-        R wbx = r00 * wx + r10 * wy + r20 * wz, wby = r01 * wx + r11 * wy + r21 * wz, wbz = r02 * wx + r12 * wy + r22 * wz;
-        R F0 = f32[0], F1 = f32[1], F2 = f32[2], F3 = f32[3];
-        R fz = F0 + F1 + F2 + F3;
-        // r x F with the prop offsets (+,-) (-,-) (-,+) (+,+) * 0.028 (cf2x.urdf:42,54,66,78)
-        R tx = R(0.0), ty = R(0.0);
-        tx += -K<R>::ARM * F0; ty -= K<R>::ARM * F0;
-        tx += -K<R>::ARM * F1; ty -= -K<R>::ARM * F1;
-        tx += K<R>::ARM * F2;  ty -= -K<R>::ARM * F2;
-        tx += K<R>::ARM * F3;  ty -= K<R>::ARM * F3;
-        const R gwz = -K<R>::G * K<R>::M;
-        R gbx = r00 * R(0.0) + r10 * R(0.0) + r20 * gwz, gby = r01 * R(0.0) + r11 * R(0.0) + r21 * gwz,
-          gbz = r02 * R(0.0) + r12 * R(0.0) + r22 * gwz;
-        R nv = norm3(vbx, vby, vbz), nw = norm3(wbx, wby, wbz);
-        R kl = K<R>::LIN_DAMP + K<R>::LIN_DAMP * nv;
-        R ka = K<R>::ANG_DAMP + K<R>::ANG_DAMP * nw;
-        R Fbx = gbx - K<R>::M * vbx * kl, Fby = gby - K<R>::M * vby * kl, Fbz = fz + gbz - K<R>::M * vbz * kl;
-        R Iwx = K<R>::IXX * wbx, Iwy = K<R>::IYY * wby, Iwz = K<R>::IZZ * wbz;
-        R gx = wby * Iwz - wbz * Iwy, gy = wbz * Iwx - wbx * Iwz, gz = wbx * Iwy - wby * Iwx;
-        R Tbx = tx - gx - Iwx * ka, Tby = ty - gy - Iwy * ka, Tbz = (R)zt32 - gz - Iwz * ka;
-        R abx = Fbx * K<R>::INV_M, aby = Fby * K<R>::INV_M, abz = Fbz * K<R>::INV_M;
-        R dbx = Tbx * K<R>::INV_IXX, dby = Tby * K<R>::INV_IYY, dbz = Tbz * K<R>::INV_IZZ;
-        // base -> world
-        R awx = r00 * abx + r01 * aby + r02 * abz, awy = r10 * abx + r11 * aby + r12 * abz, awz = r20 * abx + r21 * aby + r22 * abz;
-        R dwx = r00 * dbx + r01 * dby + r02 * dbz, dwy = r10 * dbx + r11 * dby + r12 * dbz, dwz = r20 * dbx + r21 * dby + r22 * dbz;
+        // btMatrix3x3::setRotation: s = 2 / |q|^2
+        const R s = R(2.0) * FM<R>::rcp(qx * qx + qy * qy + qz * qz + qw * qw);
+        const R xs = qx * s, ys = qy * s, zs = qz * s;
+        const R wxs = qw * xs, wys = qw * ys, wzs = qw * zs;
+        const R xx = qx * xs, xy = qx * ys, xz = qx * zs;
+        const R yy = qy * ys, yz = qy * zs, zz = qz * zs;
+        const R r00 = R(1.0) - (yy + zz), r01 = xy - wzs, r02 = xz + wys;
+        const R r10 = xy + wzs, r11 = R(1.0) - (xx + zz), r12 = yz - wxs;
+        const R r20 = xz - wys, r21 = yz + wxs, r22 = R(1.0) - (xx + yy);
+        // rotor thrusts along body z at the prop offsets (+,-) (-,-) (-,+) (+,+) * 0.028 (cf2x.urdf:42,54,66,78)
+        const R F0 = f32[0], F1 = f32[1], F2 = f32[2], F3 = f32[3];
+        const R fz = (F0 + F1) + (F2 + F3);
+        const R tx = K<R>::ARM * ((F2 + F3) - (F0 + F1));
+        const R ty = K<R>::ARM * ((F1 + F2) - (F0 + F3));
+        // linear: a = R[:,2] fz/M - (0,0,G) - v (c + c|v|)
+        const R kl = K<R>::LIN_DAMP + K<R>::LIN_DAMP * FM<R>::sqrt0(vx * vx + vy * vy + vz * vz);
+        const R fm = fz * K<R>::INV_M;
+        const R awx = r02 * fm - vx * kl, awy = r12 * fm - vy * kl, awz = (r22 * fm - K<R>::G) - vz * kl;
+        // angular, in the body frame: I dw = tau - w x (I w) - I w (c + c|w|)
+        const R wbx = r00 * wx + r10 * wy + r20 * wz, wby = r01 * wx + r11 * wy + r21 * wz, wbz = r02 * wx + r12 * wy + r22 * wz;
+        const R ka = K<R>::ANG_DAMP + K<R>::ANG_DAMP * FM<R>::sqrt0(wx * wx + wy * wy + wz * wz);
+        const R Iwx = K<R>::IXX * wbx, Iwy = K<R>::IYY * wby, Iwz = K<R>::IZZ * wbz;
+        const R gx = wby * Iwz - wbz * Iwy, gy = wbz * Iwx - wbx * Iwz, gz = wbx * Iwy - wby * Iwx;
+        const R dbx = (tx - gx - Iwx * ka) * K<R>::INV_IXX, dby = (ty - gy - Iwy * ka) * K<R>::INV_IYY,
+                dbz = ((R)zt32 - gz - Iwz * ka) * K<R>::INV_IZZ;
+        const R dwx = r00 * dbx + r01 * dby + r02 * dbz, dwy = r10 * dbx + r11 * dby + r12 * dbz, dwz = r20 * dbx + r21 * dby + r22 * dbz;
+        wx += dwx * dt; wy += dwy * dt; wz += dwz * dt;       // applyDeltaVeeMultiDof
+        vx += awx * dt; vy += awy * dt; vz += awz * dt;
+        // btMultiBody clamps every velocity coordinate at m_maxCoordinateVelocity; no reachable state gets there
+        // (thrust/weight = 5.5, damping), so test once per wave and clamp only then.  NaN stays NaN either way.
         const R mv = K<R>::MAX_COORD_VEL;
-        wx = clipv(wx + dwx * dt, -mv, mv); vx = clipv(vx + awx * dt, -mv, mv);   // applyDeltaVeeMultiDof
-        wy = clipv(wy + dwy * dt, -mv, mv); vy = clipv(vy + awy * dt, -mv, mv);
-        wz = clipv(wz + dwz * dt, -mv, mv); vz = clipv(vz + awz * dt, -mv, mv);
-        px += dt * vx; py += dt * vy; pz += dt * vz;                              // stepPositionsMultiDof
-        R fAngle = norm3(wx, wy, wz);
-        if (fAngle * dt > R(0.25) * K<R>::PI) fAngle = R(0.5) * (R(0.5) * K<R>::PI) / dt;
-        // axis = w * sin(h)/|w| with h = |w| dt/2, i.e. w * (dt/2) * sinc(h): one formula covers Bullet's Taylor
-        // branch (|w| < 1e-3, identical to 1e-24) and its clamped branch, and needs no divide.
-        R hh = R(0.5) * fAngle * dt, sinc, aw;
-        sinc_cos_small<R>(hh * hh, sinc, aw);
-        R k = (R(0.5) * dt) * sinc;
-        R ax = wx * k, ay = wy * k, az = wz * k;
-        R nx = aw * qx + ax * qw + ay * qz - az * qy;
-        R ny = aw * qy + ay * qw + az * qx - ax * qz;
-        R nz = aw * qz + az * qw + ax * qy - ay * qx;
-        R nw_ = aw * qw - ax * qx - ay * qy - az * qz;
-        R inv = R(1.0) / sqrt(nx * nx + ny * ny + nz * nz + nw_ * nw_);
+        const R big = fmax(fmax(fmax(fabs(wx), fabs(wy)), fmax(fabs(wz), fabs(vx))), fmax(fabs(vy), fabs(vz)));
+        if (big > mv) {
+            wx = clipv(wx, -mv, mv); wy = clipv(wy, -mv, mv); wz = clipv(wz, -mv, mv);
+            vx = clipv(vx, -mv, mv); vy = clipv(vy, -mv, mv); vz = clipv(vz, -mv, mv);
+        }
+        px += dt * vx; py += dt * vy; pz += dt * vz;          // stepPositionsMultiDof
+        // exponential map: Bullet clamps the angle rate, fAngle = min(|w|, (pi/4)/dt), and takes
+        // axis = w sin(h)/fAngle with h = fAngle dt/2, i.e. w (dt/2) sinc(h), and cos(h): both are even in h, so only
+        // h^2 = min(|w|^2 dt^2/4, (pi/8)^2) is needed and the sqrt of |w|^2 never is.  (Bullet's |w| < 1e-3 Taylor
+        // branch is the same function to 1e-24.)
+        w2 = wx * wx + wy * wy + wz * wz;
+        R h2 = (R(0.25) * dt * dt) * w2;
+        const R h2max = R(0.015625) * K<R>::PI * K<R>::PI;     // (pi/8)^2
+        h2 = h2 > h2max ? h2max : h2;
+        R sinc, aw;
+        sinc_cos_small<R>(h2, sinc, aw);
+        const R k = (R(0.5) * dt) * sinc;
+        const R ax = wx * k, ay = wy * k, az = wz * k;
+        const R nx = aw * qx + ax * qw + ay * qz - az * qy;
+        const R ny = aw * qy + ay * qw + az * qx - ax * qz;
+        const R nz = aw * qz + az * qw + ax * qy - ay * qx;
+        const R nw_ = aw * qw - ax * qx - ay * qy - az * qz;
+        const R inv = FM<R>::rsq(nx * nx + ny * ny + nz * nz + nw_ * nw_);
         qx = nx * inv; qy = ny * inv; qz = nz * inv; qw = nw_ * inv;
     }
 
     // ---- A5: p.getEulerFromQuaternion [3P-recall of pybullet.c] ------------------------------------------
-    // get_forward_vector (PBDroneEnv.py:588-597) = (cos yaw cos pitch, sin yaw cos pitch, sin pitch) follows
-    // algebraically from the same quaternion terms: sin pitch = sarg, cos pitch = sqrt(1 - sarg^2) (pitch is an
-    // arcsine, so its cosine is non-negative), (cos yaw, sin yaw) = (yc, ys)/hypot(yc, ys) -- no sin/cos calls.
-    R roll, pitch, yaw, fwx, fwy, fwz;
+    // The three angles only feed observation columns 3..5 (float32, bar 1e-5): the quaternion products are formed
+    // in R, the inverse trigonometry runs in float32 (atan2f ~1e-7 rad).  The forward vector feeds a compare and
+    // stays in R.
+    float roll32, pitch32, yaw32;
+    R fwx, fwy, fwz;
     {
-        R sqx = qx * qx, sqy = qy * qy, sqz = qz * qz, squ = qw * qw;
-        R sarg = R(-2.0) * (qx * qz - qw * qy);
+        const R sqx = qx * qx, sqy = qy * qy, sqz = qz * qz, squ = qw * qw;
+        const R sarg = R(-2.0) * (qx * qz - qw * qy);
+        const R ys = R(2.0) * (qx * qy + qw * qz), yc = squ + sqx - sqy - sqz;
         if (sarg <= R(-0.99999) || sarg >= R(0.99999)) {       // gimbal-lock branches: rare, keep them literal
-            roll = R(0.0);
+            R pitch, yaw;
+            roll32 = 0.0f;
             if (sarg < R(0.0)) { pitch = R(-0.5) * K<R>::PI; yaw = R(2.0) * atan2(qx, -qy); }
             else { pitch = R(0.5) * K<R>::PI; yaw = R(2.0) * atan2(-qx, qy); }
-            R cpit = cos(pitch);
+            const R cpit = cos(pitch);
             fwx = cos(yaw) * cpit; fwy = sin(yaw) * cpit; fwz = sin(pitch);
+            pitch32 = (float)pitch; yaw32 = (float)yaw;
         } else {
-            R ys = R(2.0) * (qx * qy + qw * qz), yc = squ + sqx - sqy - sqz;
-            roll = atan2(R(2.0) * (qy * qz + qw * qx), squ - sqx - sqy + sqz);
-            pitch = asin(sarg);
-            yaw = atan2(ys, yc);
-            R cpit = sqrt(R(1.0) - sarg * sarg);
-            R hy = sqrt(ys * ys + yc * yc);
-            R cyaw = R(1.0), syaw = R(0.0);
-            if (hy > R(0.0)) { R rh = R(1.0) / hy; cyaw = yc * rh; syaw = ys * rh; }
-            fwx = cyaw * cpit; fwy = syaw * cpit; fwz = sarg;
+            roll32 = atan2f((float)(R(2.0) * (qy * qz + qw * qx)), (float)(squ - sqx - sqy + sqz));
+            yaw32 = atan2f((float)ys, (float)yc);
+            // asin is ill-conditioned towards +-1: beyond 0.95 (pitch > 72 deg, rare) take the R-precision routine
+            if (fabs(sarg) > R(0.95)) pitch32 = (float)asin(sarg);
+            else pitch32 = asinf((float)sarg);
+            fwx = yc; fwy = ys; fwz = sarg;
         }
     }
-    // rotation entry R[2][2] of the NEW attitude (ground-contact approximation only)
-    const R r22n = R(1.0) - (qx * (qx * (R(2.0) / (qx * qx + qy * qy + qz * qz + qw * qw))) +
-                             qy * (qy * (R(2.0) / (qx * qx + qy * qy + qz * qz + qw * qw))));
+    // rotation entry R[2][2] of the NEW (unit) attitude, for the ground-contact approximation only
+    const R r22n = R(1.0) - R(2.0) * (qx * qx + qy * qy);
 
     // ---- A6: _computeObs (PBDroneEnv.py:296-336, :338-398), stale distance d_e (quirk Q1) -----------------
+    // The reference clips position / yaw / distance columns to the float32 range before the cast (:326); positions
+    // are bounded by the aviary box plus one step at the velocity cap, so those clips can never bind and are not
+    // evaluated.  clip(v, -3, 3)/3 is monotone, so it equals clip(float32(v/3), -1, 1) exactly.
     float o[DN_OBS_DIM];
     {
-        const R fmax = (R)FLT_MAX;
-        o[0] = (float)clipv(px * c.inv_dim[0], -fmax, fmax);
-        o[1] = (float)clipv(py * c.inv_dim[1], -fmax, fmax);
-        o[2] = (float)clipv(pz * c.inv_dim[2], -fmax, fmax);
-        o[3] = (float)(clipv(roll, -K<R>::PI, K<R>::PI) * K<R>::INV_PI);
-        o[4] = (float)(clipv(pitch, -K<R>::PI, K<R>::PI) * K<R>::INV_PI);
-        o[5] = (float)clipv(yaw * K<R>::INV_PI, -fmax, fmax);
-        o[6] = (float)(clipv(vx, R(-3.0), R(3.0)) * K<R>::THIRD);
-        o[7] = (float)(clipv(vy, R(-3.0), R(3.0)) * K<R>::THIRD);
-        o[8] = (float)(clipv(vz, R(-1.0), R(1.0)) * K<R>::THIRD);
-        R nw = norm3(wx, wy, wz);
-        if (nw != R(0.0)) { R rw = R(1.0) / nw; o[9] = (float)(wx * rw); o[10] = (float)(wy * rw); o[11] = (float)(wz * rw); }
-        else { o[9] = (float)wx; o[10] = (float)wy; o[11] = (float)wz; }
-        o[12] = p.include_distance ? (float)clipv(d_e * c.inv_max_target_dist, -fmax, fmax) : 0.0f;
+        const float inv_pi32 = (float)K<R>::INV_PI;
+        o[0] = (float)(px * c.inv_dim[0]);
+        o[1] = (float)(py * c.inv_dim[1]);
+        o[2] = (float)(pz * c.inv_dim[2]);
+        o[3] = roll32 * inv_pi32;
+        o[4] = pitch32 * inv_pi32;
+        o[5] = yaw32 * inv_pi32;
+        const float third32 = (float)K<R>::THIRD;
+        o[6] = clipv((float)(vx * K<R>::THIRD), -1.0f, 1.0f);
+        o[7] = clipv((float)(vy * K<R>::THIRD), -1.0f, 1.0f);
+        o[8] = clipv((float)(vz * K<R>::THIRD), -third32, third32);
+        if (w2 != R(0.0)) {                                   // ang_v / |ang_v|, zero stays zero (:383-384)
+            const R rw = FM<R>::rsq_f32grade(w2);
+            o[9] = (float)(wx * rw); o[10] = (float)(wy * rw); o[11] = (float)(wz * rw);
+        } else { o[9] = (float)wx; o[10] = (float)wy; o[11] = (float)wz; }
+        o[12] = p.include_distance ? (float)(d_e * c.inv_max_target_dist) : 0.0f;
     }
 
     // ---- A7 + A8: _computeReward (PBDroneEnv.py:475-571), _computeTerminated (:456-473) --------------------
+    // _computeReward evaluates _computeTerminated with the entry index (:489); after a gate pass BaseAviary.step
+    // evaluates it again with the advanced index (BaseAviary.py:448).  Only the segment corridor depends on the
+    // index, so the common part runs once and the segment test once per index that is actually needed; likewise the
+    // orientation term is evaluated once, against the waypoint the taken branch refers to.
     int idx = m_e.idx, just_found = m_e.just_found, is_done = 0;
     R d_prev = dprev_e;
     R reward;
-    const bool coll1 = has_collision<R>(p, c, s_tab, px, py, pz, r22n, idx);
+    const bool seg_track = p.cylinder && !p.circle;
+    const bool coll1 = collision_common<R>(p, c, px, py, pz, r22n) ||
+                       (seg_track && outside_segment_corridor<R>(c, s_tab, px, py, pz, idx));
+    const bool found_now = d_e <= c.threshold;         // :539
+    const bool last_gate = idx + 1 == p.num_waypoints;
+    const int idx_ori = (found_now && !last_gate) ? idx + 1 : idx;
+    const int ori = orientation_reward<R>(fwx, fwy, fwz, px, py, pz, s_tab + idx_ori * DN_T_STRIDE);
     bool terminated;
     if (coll1) {                                       // :489-490 (entry _is_done is always False here)
         reward = R(-10.0);
         terminated = true;
-    } else {
-        const R fx = fwx, fy = fwy, fz = fwz;
-        if (d_e <= c.threshold) {                      // :539
-            idx += 1;
-            float r32 = 0.0f;
-            if (idx == p.num_waypoints) { r32 = r32 + 200.0f; is_done = 1; }          // :542-546
-            else {
-                r32 = r32 + 75.0f;                                                    // :548-552
-                r32 = r32 + (float)(orientation_reward<R>(fx, fy, fz, px, py, pz, s_tab + idx * DN_T_STRIDE) * 5);
-                just_found = 1;
-            }
-            d_prev = d_e;
-            reward = (R)(r32 / 25.0f);
-            // second _computeTerminated (BaseAviary.py:448) sees the advanced index
-            terminated = is_done ? true : has_collision<R>(p, c, s_tab, px, py, pz, r22n, idx);
-        } else {
-            R r = R(0.0);
-            r = r + exp(R(-2.0) * d_e) * R(3.0);                                      // :555
-            r = r + (just_found ? R(0.0) : (dprev_e - d_e) * R(3000.0));              // :556
-            r = r + (R)(orientation_reward<R>(fx, fy, fz, px, py, pz, s_tab + idx * DN_T_STRIDE) * 3);   // :557
-            // smoothness_reward (:599-607) on the stale post-step copies (quirk Q4)
-            R la = norm3(vel_ex - pvx, vel_ey - pvy, vel_ez - pvz);
-            R aa = norm3(ang_ex - pwx, ang_ey - pwy, ang_ez - pwz);
-            R lp = (la > R(0.7)) ? -fabs(la) : R(0.0);
-            R ap = (aa > R(0.3)) ? -fabs(aa) : R(0.0);
-            r = r + (lp + ap);                                                        // :558
-            just_found = 0;
-            d_prev = d_e;
-            reward = r * K<R>::INV_25;
-            terminated = false;
+    } else if (found_now) {
+        idx += 1;
+        float r32 = 0.0f;
+        if (last_gate) { r32 = r32 + 200.0f; is_done = 1; terminated = true; }    // :542-546
+        else {
+            r32 = r32 + 75.0f;                                                    // :548-552
+            r32 = r32 + (float)(ori * 5);
+            just_found = 1;
+            // second _computeTerminated: the common part is already known to be false
+            terminated = seg_track && outside_segment_corridor<R>(c, s_tab, px, py, pz, idx);
         }
+        d_prev = d_e;
+        reward = (R)(r32 / 25.0f);
+    } else {
+        R r = R(3.0) * (R)expf((float)(R(-2.0) * d_e));                           // :555 (3/25 e^-2d: float32 exp is 1e-8 here)
+        r = r + (just_found ? R(0.0) : (dprev_e - d_e) * R(3000.0));              // :556
+        r = r + (R)(ori * 3);                                                     // :557
+        // smoothness_reward (:599-607) on the stale post-step copies (quirk Q4): -|dv| if |dv| > 0.7, -|dw| if > 0.3
+        const R lx = vel_ex - pvx, ly = vel_ey - pvy, lz = vel_ez - pvz;
+        const R ax_ = ang_ex - pwx, ay_ = ang_ey - pwy, az_ = ang_ez - pwz;
+        const R la2 = lx * lx + ly * ly + lz * lz, aa2 = ax_ * ax_ + ay_ * ay_ + az_ * az_;
+        if (la2 > R(0.7) * R(0.7)) r = r - FM<R>::sqrt0(la2);                     // needs > 160 m/s^2: rare
+        if (aa2 > R(0.3) * R(0.3)) r = r - FM<R>::sqrt0(aa2);
+        just_found = 0;
+        d_prev = d_e;
+        reward = r * K<R>::INV_25;
+        terminated = false;
     }
     const bool truncated = p.max_steps <= m_e.steps;   // :444-454, evaluated on the un-incremented _steps
     const int found = idx;
@@ -494,7 +652,8 @@ DN_DEV void step_body(const DnParams &p, const DnConsts<R> &c, const R *s_tab, f
         npvx = vel_ex; npvy = vel_ey; npvz = vel_ez;
         npwx = ang_ex; npwy = ang_ey; npwz = ang_ez;
         const R *wp = s_tab + idx * DN_T_STRIDE;
-        d = norm3(wp[0] - px, wp[1] - py, wp[2] - pz);
+        const R ex = wp[0] - px, ey = wp[1] - py, ez = wp[2] - pz;
+        d = FM<R>::sqrt0(ex * ex + ey * ey + ez * ez);
     }
 
     // ---- A11: Monitor + SubprocVecEnv worker ---------------------------------------------------------------
@@ -507,48 +666,63 @@ DN_DEV void step_body(const DnParams &p, const DnConsts<R> &c, const R *s_tab, f
     if (NOISE && p.obs_noise_sigma > 0.0f) add_obs_noise(p, gid, step_count, 1u, o);
     if (NORM) normalize_obs(p, i, active, rms_count, o);
 
+    // the advanced state as the float32 words that go back to HBM (w slots are filled in below)
+    float4 S0 = make_float4((float)px, (float)py, (float)pz, 0.0f);
+    float4 S1 = make_float4((float)qx, (float)qy, (float)qz, (float)qw);
+    float4 S2 = make_float4((float)vx, (float)vy, (float)vz, 0.0f);
+    float4 S3 = make_float4((float)wx, (float)wy, (float)wz, 0.0f);
+    float4 S4 = make_float4((float)npvx, (float)npvy, (float)npvz, 0.0f);
+    float4 S5 = make_float4((float)npwx, (float)npwy, (float)npwz, 0.0f);
+
     const unsigned long long done_ballot = __ballot(done && active);
-    if (done_ballot != 0ull) {                         // wave-uniform: most waves skip the whole reset path
+    if (done_ballot != 0ull) {                         // wave-uniform: waves without a finished drone skip all of this
+        const long long fix = llrint((double)ep_ret * 1e6);                       // Monitor 'r' in 1e-6 fixed point
         if (done) {
             if (active) {
-                if (io.terminal_obs) {
+                if (out.terminal_obs) {
 #pragma unroll
-                    for (int k = 0; k < DN_OBS_DIM; ++k) io.terminal_obs[i * DN_OBS_DIM + k] = o[k];
+                    for (int k = 0; k < DN_OBS_DIM; ++k) out.terminal_obs[li * DN_OBS_DIM + k] = o[k];
                 }
-                if (io.ep_return) io.ep_return[i] = (float)ep_ret;
-                if (io.ep_length) io.ep_length[i] = ep_len;
+                if (out.ep_return) out.ep_return[li] = (float)ep_ret;
+                if (out.ep_length) out.ep_length[li] = ep_len;
             }
             // PBDroneEnv.reset (:609-665): _current_position is NOT reset (quirk Q3)
             R cpx, cpy, cpz;
             if (!terminated) { cpx = px; cpy = py; cpz = pz; }            // post-step ran: it is the new position
             else if (m_e.steps > 0) { cpx = pos_ex; cpy = pos_ey; cpz = pos_ez; }
-            else { const float4 G6 = p.st.g6[i]; cpx = G6.x; cpy = G6.y; cpz = G6.z; }
-            if (active && !(terminated && m_e.steps == 0)) p.st.g6[i] = make_float4((float)cpx, (float)cpy, (float)cpz, 0.0f);
+            else { const float4 G6 = g6_blk[li]; cpx = G6.x; cpy = G6.y; cpz = G6.z; }
+            if (active && !(terminated && m_e.steps == 0)) g6_blk[li] = make_float4((float)cpx, (float)cpy, (float)cpz, 0.0f);
             reset_obs<R>(p, c, d, o);                                     // BaseAviary.py:318 before :617-658 (Q2)
             if (NOISE && p.obs_noise_sigma > 0.0f) add_obs_noise(p, gid, step_count, 5u, o);
             if (NORM) normalize_obs(p, i, active, rms_count, o);
-            px = c.spawn[0]; py = c.spawn[1]; pz = c.spawn[2];
-            qx = R(0.0); qy = R(0.0); qz = R(0.0); qw = R(1.0);
-            vx = vy = vz = wx = wy = wz = R(0.0);
-            npvx = npvy = npvz = npwx = npwy = npwz = R(0.0);
-            d = norm3(cpx - s_tab[0], cpy - s_tab[1], cpz - s_tab[2]);    // :651
+            // freshly loaded body at the spawn pose, at rest; selects act on the float32 words that go back to HBM
+            S0 = make_float4((float)c.spawn[0], (float)c.spawn[1], (float)c.spawn[2], 0.0f);
+            S1 = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+            S2 = S3 = S4 = S5 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            const R ex = cpx - s_tab[0], ey = cpy - s_tab[1], ez = cpz - s_tab[2];
+            d = FM<R>::sqrt0(ex * ex + ey * ey + ez * ez);                // :651
             d_prev = d;                                                   // :652
             idx = 0; steps = 0; just_found = 0;
             ep_ret = R(0.0); ep_len = 0;
         }
-        // wave-level reduction of the episode statistics -> this workgroup's slot (no atomics)
-        long long s_ep = done && active ? 1 : 0, s_tr = (done && active && truncated && !terminated) ? 1 : 0;
-        long long s_co = (done && active && is_done) ? 1 : 0;
-        long long s_len = done && active ? (long long)(eplen_e + 1) : 0, s_fd = done && active ? (long long)found : 0;
-        long long s_ret = done && active ? (long long)llrint((double)(epret_e + reward) * 1e6) : 0;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            s_ep += __shfl_xor(s_ep, off); s_tr += __shfl_xor(s_tr, off); s_co += __shfl_xor(s_co, off);
-            s_len += __shfl_xor(s_len, off); s_fd += __shfl_xor(s_fd, off); s_ret += __shfl_xor(s_ret, off);
+        // Episode statistics of this wave -> this workgroup's slot (no atomics, deterministic).  Counts are ballots
+        // + popcount on the scalar unit; the sums walk the set bits of the done ballot (typically one to three
+        // finished drones per wave-step) with v_readlane instead of a 6-stage cross-lane reduction of 64-bit values.
+        const long long n_trunc = __popcll(__ballot(done && active && truncated && !terminated));
+        const long long n_compl = __popcll(__ballot(done && active && is_done));
+        long long s_len = 0, s_fd = 0, s_ret = 0;
+        const int fix_lo = (int)(unsigned)(fix & 0xFFFFFFFFll), fix_hi = (int)(fix >> 32);
+        for (unsigned long long m = done_ballot; m != 0ull; m &= m - 1ull) {
+            const int l = __builtin_ctzll(m);
+            s_len += (long long)__builtin_amdgcn_readlane(eplen_e, l) + 1;
+            s_fd += (long long)__builtin_amdgcn_readlane(found, l);
+            const unsigned lo = (unsigned)__builtin_amdgcn_readlane(fix_lo, l);
+            const int hi = __builtin_amdgcn_readlane(fix_hi, l);
+            s_ret += (long long)(((unsigned long long)(unsigned)hi << 32) | lo);
         }
         if (lane == 0) {
             DnStatSlot sl = p.st.stats[blockIdx.x];
-            sl.episodes += s_ep; sl.truncated += s_tr; sl.completed += s_co;
+            sl.episodes += __popcll(done_ballot); sl.truncated += n_trunc; sl.completed += n_compl;
             sl.sum_len += s_len; sl.sum_found += s_fd; sl.sum_ret_fix += s_ret;
             p.st.stats[blockIdx.x] = sl;
         }
@@ -556,20 +730,29 @@ DN_DEV void step_body(const DnParams &p, const DnConsts<R> &c, const R *s_tab, f
     if (NORM && active) p.st.rms_count[i] = rms_count;
 
     // ---- hand the state back as float32 groups; scalars and the observation tile go straight to HBM -----------
-    G0 = make_float4((float)px, (float)py, (float)pz, (float)d);
-    G1 = make_float4((float)qx, (float)qy, (float)qz, (float)qw);
-    G2 = make_float4((float)vx, (float)vy, (float)vz, (float)d_prev);
-    G3 = make_float4((float)wx, (float)wy, (float)wz, pack_meta(steps, idx, just_found));
-    G4 = make_float4((float)npvx, (float)npvy, (float)npvz, (float)ep_ret);
-    G5 = make_float4((float)npwx, (float)npwy, (float)npwz, __int_as_float(ep_len));
+    S0.w = (float)d; S2.w = (float)d_prev; S3.w = pack_meta(steps, idx, just_found);
+    S4.w = (float)ep_ret; S5.w = __int_as_float(ep_len);
+    G0 = S0; G1 = S1; G2 = S2; G3 = S3; G4 = S4; G5 = S5;
     if (active) {
-        io.reward[i] = (float)reward;
-        io.done[i] = (uint8_t)done;
-        io.truncated[i] = (uint8_t)(truncated && !terminated);
-        io.found_targets[i] = found;
+        out.reward[li] = (float)reward;
+        out.done[li] = (uint8_t)done;
+        out.truncated[li] = (uint8_t)(truncated && !terminated);
+        out.found[li] = found;
     }
-    if (io.done_mask && lane == 0) io.done_mask[blockIdx.x] = done_ballot;
-    store_obs_tile(s_tile, io.obs, tile_base, p.n, lane, active, o);
+    if (out.done_word && lane == 0) *out.done_word = done_ballot;
+    store_obs_tile(s_tile, out.obs, rows, lane, o);
+}
+
+// Loads this lane's six state groups + nothing else; the block base is uniform, the lane offset 32-bit.
+struct BlockState {
+    float4 *g0, *g1, *g2, *g3, *g4, *g5, *g6;
+};
+DN_DEV BlockState block_state(const DnState &st, long long tile_base)
+{
+    BlockState b;
+    b.g0 = st.g0 + tile_base; b.g1 = st.g1 + tile_base; b.g2 = st.g2 + tile_base; b.g3 = st.g3 + tile_base;
+    b.g4 = st.g4 + tile_base; b.g5 = st.g5 + tile_base; b.g6 = st.g6 + tile_base;
+    return b;
 }
 
 // One control step per launch: what VecEnv.step() maps to when a policy sits between steps.
@@ -578,18 +761,23 @@ __global__ __launch_bounds__(DN_BLOCK) void dn_step_kernel(const DnParams p, con
 {
     __shared__ R s_tab[DN_MAX_WAYPOINTS * DN_T_STRIDE];
     __shared__ __attribute__((aligned(16))) float s_tile[DN_BLOCK * DN_OBS_DIM];
-    const int lane = threadIdx.x;
+    const unsigned lane = threadIdx.x;
     const long long tile_base = (long long)blockIdx.x * DN_BLOCK;
-    const bool active = tile_base + lane < p.n;
-    const long long i = active ? tile_base + lane : p.n - 1;   // inactive lanes shadow the last drone, never store
+    const long long left = p.n - tile_base;
+    const unsigned rows = left < DN_BLOCK ? (unsigned)left : DN_BLOCK;
+    const bool active = lane < rows;
+    const unsigned li = active ? lane : rows - 1;       // inactive lanes shadow the last drone, never store
+    __builtin_assume(li < DN_BLOCK);                    // lets the lane offset stay a 32-bit VGPR (saddr addressing)
+    const BlockState b = block_state(p.st, tile_base);
     // issue every load up front (6 x 16 B state + 16 B action per lane), then stage the table
-    const float4 A = reinterpret_cast<const float4 *>(io.actions)[i];
-    float4 G0 = p.st.g0[i], G1 = p.st.g1[i], G2 = p.st.g2[i], G3 = p.st.g3[i], G4 = p.st.g4[i], G5 = p.st.g5[i];
+    const float4 A = (reinterpret_cast<const float4 *>(io.actions) + tile_base)[li];
+    float4 G0 = b.g0[li], G1 = b.g1[li], G2 = b.g2[li], G3 = b.g3[li], G4 = b.g4[li], G5 = b.g5[li];
     stage_table<R>(p, s_tab);
-    step_body<R, NORM, NOISE>(p, consts<R>(p), s_tab, s_tile, io, p.step_count, i, tile_base, lane, active, A,
-                              G0, G1, G2, G3, G4, G5);
+    const StepOut out = block_out(io, tile_base, 0, 0);
+    step_body<R, NORM, NOISE>(p, consts<R>(p), s_tab, s_tile, out, b.g6, p.step_count, tile_base, li, lane, rows, active,
+                              A, G0, G1, G2, G3, G4, G5);
     if (active) {
-        p.st.g0[i] = G0; p.st.g1[i] = G1; p.st.g2[i] = G2; p.st.g3[i] = G3; p.st.g4[i] = G4; p.st.g5[i] = G5;
+        b.g0[li] = G0; b.g1[li] = G1; b.g2[li] = G2; b.g3[li] = G3; b.g4[li] = G4; b.g5[li] = G5;
     }
 }
 
@@ -601,36 +789,30 @@ __global__ __launch_bounds__(DN_BLOCK) void dn_step_many_kernel(const DnParams p
 {
     __shared__ R s_tab[DN_MAX_WAYPOINTS * DN_T_STRIDE];
     __shared__ __attribute__((aligned(16))) float s_tile[DN_BLOCK * DN_OBS_DIM];
-    const int lane = threadIdx.x;
+    const unsigned lane = threadIdx.x;
     const long long tile_base = (long long)blockIdx.x * DN_BLOCK;
-    const bool active = tile_base + lane < p.n;
-    const long long i = active ? tile_base + lane : p.n - 1;
-    const float4 *act = reinterpret_cast<const float4 *>(io0.actions);
-    float4 A = act[i];
-    float4 G0 = p.st.g0[i], G1 = p.st.g1[i], G2 = p.st.g2[i], G3 = p.st.g3[i], G4 = p.st.g4[i], G5 = p.st.g5[i];
+    const long long left = p.n - tile_base;
+    const unsigned rows = left < DN_BLOCK ? (unsigned)left : DN_BLOCK;
+    const bool active = lane < rows;
+    const unsigned li = active ? lane : rows - 1;
+    __builtin_assume(li < DN_BLOCK);
+    const BlockState b = block_state(p.st, tile_base);
+    const float4 *act = reinterpret_cast<const float4 *>(io0.actions) + tile_base;
+    float4 A = act[li];
+    float4 G0 = b.g0[li], G1 = b.g1[li], G2 = b.g2[li], G3 = b.g3[li], G4 = b.g4[li], G5 = b.g5[li];
     stage_table<R>(p, s_tab);
     const long long n = p.n, words = (p.n + 63) / 64;
 #pragma clang loop unroll(disable)
     for (int t = 0; t < k_steps; ++t) {
         // prefetch the next step's action while this step computes
-        const float4 A_next = act[(long long)(t + 1 < k_steps ? t + 1 : t) * n + i];
-        DnStepIO io;
-        io.actions = nullptr;
-        io.obs = io0.obs + (long long)t * n * DN_OBS_DIM;
-        io.reward = io0.reward + (long long)t * n;
-        io.done = io0.done + (long long)t * n;
-        io.truncated = io0.truncated + (long long)t * n;
-        io.found_targets = io0.found_targets + (long long)t * n;
-        io.terminal_obs = io0.terminal_obs ? io0.terminal_obs + (long long)t * n * DN_OBS_DIM : nullptr;
-        io.ep_return = io0.ep_return ? io0.ep_return + (long long)t * n : nullptr;
-        io.ep_length = io0.ep_length ? io0.ep_length + (long long)t * n : nullptr;
-        io.done_mask = io0.done_mask ? io0.done_mask + (long long)t * words : nullptr;
-        step_body<R, NORM, NOISE>(p, consts<R>(p), s_tab, s_tile, io, p.step_count + (unsigned)t, i, tile_base, lane,
-                                  active, A, G0, G1, G2, G3, G4, G5);
+        const float4 A_next = (act + (long long)(t + 1 < k_steps ? t + 1 : t) * n)[li];
+        const StepOut out = block_out(io0, tile_base, (long long)t * n, (long long)t * words);
+        step_body<R, NORM, NOISE>(p, consts<R>(p), s_tab, s_tile, out, b.g6, p.step_count + (unsigned)t, tile_base, li,
+                                  lane, rows, active, A, G0, G1, G2, G3, G4, G5);
         A = A_next;
     }
     if (active) {
-        p.st.g0[i] = G0; p.st.g1[i] = G1; p.st.g2[i] = G2; p.st.g3[i] = G3; p.st.g4[i] = G4; p.st.g5[i] = G5;
+        b.g0[li] = G0; b.g1[li] = G1; b.g2[li] = G2; b.g3[li] = G3; b.g4[li] = G4; b.g5[li] = G5;
     }
 }
 
@@ -640,14 +822,20 @@ __global__ __launch_bounds__(DN_BLOCK) void dn_step_many_kernel(const DnParams p
 template <typename R>
 __global__ __launch_bounds__(DN_BLOCK) void dn_reset_kernel(const DnParams p, float *obs)
 {
+#pragma clang fp contract(fast)
     __shared__ R s_tab[DN_MAX_WAYPOINTS * DN_T_STRIDE];
     __shared__ __attribute__((aligned(16))) float s_tile[DN_BLOCK * DN_OBS_DIM];
-    const int lane = threadIdx.x;
+    const unsigned lane = threadIdx.x;
     const long long tile_base = (long long)blockIdx.x * DN_BLOCK;
-    const bool active = tile_base + lane < p.n;
-    const long long i = active ? tile_base + lane : p.n - 1;
+    const long long left = p.n - tile_base;
+    const unsigned rows = left < DN_BLOCK ? (unsigned)left : DN_BLOCK;
+    const bool active = lane < rows;
+    const unsigned li = active ? lane : rows - 1;
+    __builtin_assume(li < DN_BLOCK);
+    const long long i = tile_base + li;
     const DnConsts<R> &c = consts<R>(p);
-    const float4 G0 = p.st.g0[i], G3 = p.st.g3[i], G6 = p.st.g6[i];
+    const BlockState b = block_state(p.st, tile_base);
+    const float4 G0 = b.g0[li], G3 = b.g3[li], G6 = b.g6[li];
     stage_table<R>(p, s_tab);
     const Meta m = unpack_meta(G3.w);
     R cpx, cpy, cpz;
@@ -661,17 +849,18 @@ __global__ __launch_bounds__(DN_BLOCK) void dn_reset_kernel(const DnParams p, fl
         normalize_obs(p, i, active, cnt, o);
         if (active) p.st.rms_count[i] = cnt;
     }
-    R d = norm3(cpx - s_tab[0], cpy - s_tab[1], cpz - s_tab[2]);
+    const R ex = cpx - s_tab[0], ey = cpy - s_tab[1], ez = cpz - s_tab[2];
+    const R d = FM<R>::sqrt0(ex * ex + ey * ey + ez * ez);
     if (active) {
-        p.st.g0[i] = make_float4((float)c.spawn[0], (float)c.spawn[1], (float)c.spawn[2], (float)d);
-        p.st.g1[i] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
-        p.st.g2[i] = make_float4(0.0f, 0.0f, 0.0f, (float)d);
-        p.st.g3[i] = make_float4(0.0f, 0.0f, 0.0f, pack_meta(0, 0, 0));
-        p.st.g4[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        p.st.g5[i] = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(0));
-        p.st.g6[i] = make_float4((float)cpx, (float)cpy, (float)cpz, 0.0f);
+        b.g0[li] = make_float4((float)c.spawn[0], (float)c.spawn[1], (float)c.spawn[2], (float)d);
+        b.g1[li] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+        b.g2[li] = make_float4(0.0f, 0.0f, 0.0f, (float)d);
+        b.g3[li] = make_float4(0.0f, 0.0f, 0.0f, pack_meta(0, 0, 0));
+        b.g4[li] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        b.g5[li] = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(0));
+        b.g6[li] = make_float4((float)cpx, (float)cpy, (float)cpz, 0.0f);
     }
-    store_obs_tile(s_tile, obs, tile_base, p.n, lane, active, o);
+    store_obs_tile(s_tile, obs + tile_base * DN_OBS_DIM, rows, lane, o);
 }
 
 // =====================================================================================================
@@ -737,6 +926,24 @@ __global__ __launch_bounds__(1024) void dn_compact_kernel(const unsigned long lo
         }
     }
     if (threadIdx.x == 1023) *count = base + incl;
+}
+
+// A1-A3 on their own (dn_preprocess_action): N x PBDroneEnv._preprocessAction + the force/torque lines of
+// BaseAviary._physics, so the float32 chain can be checked bit for bit against the reference's golden vectors.
+__global__ __launch_bounds__(256) void dn_action_chain_kernel(const float4 *__restrict__ actions, long long n, int normalize_actions,
+                                                              float4 *__restrict__ rpm, float4 *__restrict__ forces,
+                                                              float *__restrict__ z_torque)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 A = actions[i];
+    const float a[4] = {A.x, A.y, A.z, A.w};
+    float tq[4], f[4], r[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) f[j] = rotor_force_from_action(a[j], normalize_actions != 0, tq[j], &r[j]);
+    if (rpm) rpm[i] = make_float4(r[0], r[1], r[2], r[3]);
+    if (forces) forces[i] = make_float4(f[0], f[1], f[2], f[3]);
+    if (z_torque) z_torque[i] = z_torque32(tq);
 }
 
 __global__ __launch_bounds__(256) void dn_fill4_kernel(float4 *dst, float4 v, long long n)
@@ -817,6 +1024,15 @@ hipError_t dn_launch_gae(const float *rewards, const float *values, const uint8_
     const unsigned grid = (unsigned)((N + 255) / 256);
     hipLaunchKernelGGL(dn_gae_kernel, dim3(grid), dim3(256), 0, stream, rewards, values, dones, last_values,
                        last_dones, T, N, gamma, gl, adv, ret);
+    return hipGetLastError();
+}
+
+hipError_t dn_launch_action_chain(const float *actions, long long n, int normalize_actions, float *rpm, float *forces,
+                                  float *z_torque, hipStream_t stream)
+{
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(dn_action_chain_kernel, dim3(grid), dim3(256), 0, stream, reinterpret_cast<const float4 *>(actions), n,
+                       normalize_actions, reinterpret_cast<float4 *>(rpm), reinterpret_cast<float4 *>(forces), z_torque);
     return hipGetLastError();
 }
 

@@ -385,6 +385,23 @@ def _numpy_to_states(states, n):
     return arr
 
 
+def preprocess_action(actions, normalize_actions=True):
+    """PBDroneEnv._preprocessAction + the rotor force/torque lines of BaseAviary._physics for a float32 CUDA
+    tensor [N, 4] (dn_preprocess_action).  Returns (rpm [N,4], forces [N,4], z_torque [N]) float32 tensors."""
+    dev = actions.device
+    if dev.type != "cuda" or actions.dtype != torch.float32 or actions.dim() != 2 or actions.shape[1] != ACT_DIM:
+        raise ValueError("actions must be a float32 CUDA tensor [N, 4]; there is no CPU fallback")
+    a = actions.contiguous()
+    n = a.shape[0]
+    rpm, forces = torch.empty_like(a), torch.empty_like(a)
+    zt = torch.empty(n, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _capi.check(_capi.load().dn_preprocess_action(a.data_ptr(), n, int(bool(normalize_actions)), rpm.data_ptr(),
+                                                      forces.data_ptr(), zt.data_ptr(), dev.index,
+                                                      C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    return rpm, forces, zt
+
+
 def gae(rewards, values, dones, last_values, last_dones, gamma=0.99, gae_lambda=0.95):
     """Generalised advantage estimation on the GPU (dn_gae).  Tensors laid out [n_steps, n_envs];
     `dones[t]` is the episode-start flag of step t (cleanRLPPO.py:207-248)."""

@@ -164,6 +164,14 @@ int32_t dn_reset_stats(dn_env *env, void *stream);
 int32_t dn_get_step_count(const dn_env *env, uint64_t *out);
 int32_t dn_set_step_count(dn_env *env, uint64_t value);
 
+/* The float32 action chain on its own: replaces N x PBDroneEnv._preprocessAction (PBDroneEnv.py:872-895, with
+ * rescale_action :949-971 and env_utils.cmd2pwm / pwm2rpm, env_utils.py:8-59) plus the rotor force / torque lines of
+ * BaseAviary._physics (BaseAviary.py:776-780).  dn_step runs exactly this code in-kernel; the entry point exists so
+ * the chain can be checked bit for bit.  actions: device float[N*4]; rpm, forces: device float[N*4] or NULL;
+ * z_torque: device float[N] or NULL (at least one output). */
+int32_t dn_preprocess_action(const float *actions, int64_t num_envs, int32_t normalize_actions, float *rpm,
+                             float *forces, float *z_torque, int32_t device_id, void *stream);
+
 /* Generalised advantage estimation on device buffers laid out [n_steps, n_envs]
  * (the reference's only in-tree statement of the recursion: Sol/Model/Algorithms/cleanRLPPO.py:234-248).
  * dones[t] is the episode-start flag of step t (cleanRL: dones[t] = next_done before step t),

@@ -65,6 +65,8 @@ STATE_F32 = ("pos", "quat", "vel", "ang_v", "prev_vel", "prev_ang_v", "cur_pos",
 
 
 def compare_step(out, ref, tag, obs_atol=1e-5, rew_atol=1e-5):
+    """rew_atol: 1e-5 teacher-forced.  Free-running comparisons (both sides keep their own float32 state) pass 1e-4:
+    a stored distance may differ by one float32 ulp (1.2e-7) and the reward carries 3000 (d_prev - d) / 25 = 120x that."""
     obs, rew, done, info = out
     assert np.array_equal(done.cpu().numpy(), ref["done"]), f"{tag}: done"
     assert np.array_equal(info["truncated"].cpu().numpy(), ref["truncated"]), f"{tag}: TimeLimit.truncated"
@@ -114,8 +116,10 @@ def test_teacher_forced_vs_oracle(track_name, n, T, norm):
         for k in ("idx", "steps", "just_found", "ep_len"):
             assert np.array_equal(st2[k], ora.envs[k]), f"{track_name} t={t}: {k}"
         if norm:
-            np.testing.assert_allclose(st2["rms_mean"], ora.envs["rms_mean"], rtol=1e-12, atol=1e-14)
-            np.testing.assert_allclose(st2["rms_var"], ora.envs["rms_var"], rtol=1e-12, atol=1e-14)
+            # the Welford update is float64 on both sides; its input observation is float32 and may differ from
+            # the oracle's by an ulp or two (float32 inverse trigonometry), which enters the mean divided by the count
+            np.testing.assert_allclose(st2["rms_mean"], ora.envs["rms_mean"], rtol=0, atol=1e-6)
+            np.testing.assert_allclose(st2["rms_var"], ora.envs["rms_var"], rtol=1e-6, atol=1e-6)
     assert n_done > n // 4, "the auto-reset path must be exercised"
     assert n_crash > n // 8 and n_done > n_crash, "both crashes (-10) and truncations must occur"
     print(f"{track_name}: {n_done} episodes, max |state err| = {max_state_err:.3e}")
@@ -200,7 +204,7 @@ def test_ragged_sizes(n):
     dev = torch.device("cuda:0")
     for t in range(170):
         a = actions_mixed(rng, n)
-        compare_step(env.step_tensor(torch.from_numpy(a).to(dev)), ora.step(a), f"n={n} t={t}")
+        compare_step(env.step_tensor(torch.from_numpy(a).to(dev)), ora.step(a), f"n={n} t={t}", rew_atol=1e-4)
     env.close()
 
 
@@ -220,7 +224,8 @@ def test_option_switches(kw):
             a = actions_mixed(rng, n)
         else:   # physical thrusts in newtons
             a = rng.uniform(0.02, 0.16, (n, 4)).astype(np.float32)
-        done_total += compare_step(env.step_tensor(torch.from_numpy(a).to(dev)), ora.step(a), f"{kw} t={t}")
+        done_total += compare_step(env.step_tensor(torch.from_numpy(a).to(dev)), ora.step(a), f"{kw} t={t}",
+                                   rew_atol=1e-4)
     assert done_total > 0
     env.close()
 
@@ -241,7 +246,7 @@ def test_many_waypoints_and_single_waypoint():
             a = (0.0922 + 0.002 * rng.standard_normal((512, 4))).astype(np.float32)
             out = env.step_tensor(torch.from_numpy(a).to(dev))
             ref = ora.step(a)
-            compare_step(out, ref, f"W={len(track.waypoints)} t={t}")
+            compare_step(out, ref, f"W={len(track.waypoints)} t={t}", rew_atol=1e-4)
             found = max(found, int(ref["found_targets"].max()))
         assert found >= 1
         env.close()
@@ -297,7 +302,7 @@ def test_noise_streams_match_oracle():
     dev = torch.device("cuda:0")
     for t in range(60):
         a = (0.0922 + 0.002 * rng.standard_normal((n, 4))).astype(np.float32)
-        compare_step(env.step_tensor(torch.from_numpy(a).to(dev)), ora.step(a), f"noise t={t}")
+        compare_step(env.step_tensor(torch.from_numpy(a).to(dev)), ora.step(a), f"noise t={t}", rew_atol=1e-4)
     env.close()
 
 
@@ -482,3 +487,43 @@ def test_rollout_collector_matches_oracle_replay():
     assert n_trunc > 0, "TimeLimit truncations must occur so the bootstrap is exercised"
     assert col.num_timesteps == 2 * T * n
     env.close()
+
+
+def test_action_chain_bit_exact_vs_reference_golden(golden):
+    """A1-A3 through dn_preprocess_action against the vectors captured from the reference's own Python
+    (rescale_action, _preprocessAction, the forces/torque handed to Bullet): bit-exact, float32."""
+    pkg = _gpu()
+    g = golden("actions")
+    dev = torch.device("cuda:0")
+    acts = np.ascontiguousarray(g["actions"], np.float32)
+    rpm, forces, zt = pkg.preprocess_action(torch.from_numpy(acts).to(dev), normalize_actions=True)
+    assert np.array_equal(rpm.cpu().numpy().view(np.uint32), g["rpm"].view(np.uint32))
+    assert np.array_equal(forces.cpu().numpy().astype(np.float64), g["forces"])
+    assert np.array_equal(zt.cpu().numpy().astype(np.float64), g["z_torque"])
+    # and against the oracle on a dense random + edge sweep, both action modes (incl. out-of-range and huge inputs)
+    rng = np.random.default_rng(12)
+    a = np.concatenate([rng.uniform(-1, 1, (200000, 4)), rng.uniform(0.0899, 0.0972, (200000, 4)),
+                        rng.uniform(0.02, 0.16, (100000, 4)),
+                        np.array([[-1, 1, 0, -0.0], [2, -2, 1e30, -1e30], [3e38, -3e38, 1e-40, 0.0922]])]).astype(np.float32)
+    import ctypes as C
+    FP = C.POINTER(C.c_float)
+    L = O.lib()
+    for norm in (True, False):
+        rpm, forces, zt = pkg.preprocess_action(torch.from_numpy(a).to(dev), normalize_actions=norm)
+        rpm_ref = np.zeros_like(a)
+        f_ref = np.zeros_like(a)
+        z_ref = np.zeros(len(a), np.float32)
+        sel = np.r_[rng.integers(0, len(a) - 3, 20000), np.arange(len(a) - 3, len(a))]
+        for i in sel:
+            src = a[i].copy()
+            if norm:
+                r = np.zeros(4, np.float32)
+                L.orc_rescale_action(src.ctypes.data_as(FP), r.ctypes.data_as(FP))
+                src = r
+            L.orc_preprocess_action(src.ctypes.data_as(FP), rpm_ref[i].ctypes.data_as(FP))
+            z = C.c_float()
+            L.orc_rotor_forces(rpm_ref[i].ctypes.data_as(FP), f_ref[i].ctypes.data_as(FP), C.byref(z))
+            z_ref[i] = z.value
+        assert np.array_equal(rpm.cpu().numpy()[sel].view(np.uint32), rpm_ref[sel].view(np.uint32)), norm
+        assert np.array_equal(forces.cpu().numpy()[sel].view(np.uint32), f_ref[sel].view(np.uint32)), norm
+        assert np.array_equal(zt.cpu().numpy()[sel].view(np.uint32), z_ref[sel].view(np.uint32)), norm
