@@ -153,31 +153,38 @@ def main():
             if rc:
                 pkg._capi.check(rc)
 
-    graph = None
-    if args.mode == "graph":
-        # capture A back-to-back launches once; replay ceil(K/A) times (K is rounded to a multiple of A)
+    def build_graph():
+        """hipGraph of A single-step launches (dn_step x A), captured once: what a policy-in-the-loop step costs on
+        the GPU timeline when the host's per-launch overhead (ctypes + hipLaunchKernel, ~7 us) is taken out."""
         side = torch.cuda.Stream(dev)
         side.wait_stream(stream)
-        with torch.cuda.stream(side):
+        with torch.cuda.stream(side):                      # warm the kernels on the capture stream
             sp = C.c_void_p(side.cuda_stream)
-            pkg._capi.check(lib.dn_step_many(h, A, acts.data_ptr(), o["obs"].data_ptr(), o["reward"].data_ptr(),
-                                             o["done"].data_ptr(), o["trunc"].data_ptr(), o["found"].data_ptr(),
-                                             None, None, None, None, sp))
+            for p_ in ptrs[:2]:
+                pkg._capi.check(lib.dn_step(h, p_[0], p_[1], p_[2], p_[3], p_[4], p_[5], None, None, None, None, sp))
         stream.wait_stream(side)
         torch.cuda.synchronize(dev)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=side):
+        g_ = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g_, stream=side):
             sp = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-            pkg._capi.check(lib.dn_step_many(h, A, acts.data_ptr(), o["obs"].data_ptr(), o["reward"].data_ptr(),
-                                             o["done"].data_ptr(), o["trunc"].data_ptr(), o["found"].data_ptr(),
-                                             None, None, None, None, sp))
+            for p_ in ptrs:
+                pkg._capi.check(lib.dn_step(h, p_[0], p_[1], p_[2], p_[3], p_[4], p_[5], None, None, None, None, sp))
+        return g_
+
+    graph = None
+
+    def run_graph(k):
+        nonlocal graph
+        if graph is None:
+            graph = build_graph()
+        for _ in range((k + A - 1) // A):
+            graph.replay()
+
+    if args.mode == "graph":
         if K % A or W % A:
             raise SystemExit(f"--mode graph needs --steps and --warmup to be multiples of {A}")
-
-        def run_graph(k):
-            for _ in range(k // A):
-                graph.replay()
-    run = {"many": run_many, "single": run_single, "graph": run_graph if graph else None}[args.mode]
+        run_graph(A)
+    run = {"many": run_many, "single": run_single, "graph": run_graph}[args.mode]
 
     def barrier():
         if dist is not None:
@@ -211,16 +218,24 @@ def main():
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
         wall, gpu_ms = float(tw[0]), float(tw[1])
     st = env.stats()
-    # the other launch shape, outside the timed region, for the record: "single" = one dn_step launch per step
-    # (what a policy-in-the-loop VecEnv.step() costs), "many" = the fused K-step kernel
-    other = "single" if args.mode != "single" else "many"
+    # the other launch shapes, outside the timed region, for the record: "single" = one dn_step launch per step from
+    # Python (what a policy-in-the-loop VecEnv.step_tensor() costs incl. host launch overhead), "graph" = the same
+    # launches replayed from a hipGraph (GPU timeline only), "many" = the fused K-step kernel
     k2 = max(A, min(K, 4096) // A * A)
-    other_us = timed({"single": run_single, "many": run_many}[other], k2)
+    others = {}
+    for m_ in ("many", "single", "graph"):
+        if m_ != args.mode and not (world > 1 and m_ == "graph"):
+            fn = {"many": run_many, "single": run_single, "graph": run_graph}[m_]
+            fn(A)
+            us = timed(fn, k2)
+            others[m_] = {"us_per_vector_step": round(us, 4), "value": round(n * world / (us * 1e-6), 1),
+                          "roofline_frac": round(ALGO_BYTES_PER_ENV_STEP * n / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 5)}
+    waves = env.kernel_waves(fused=args.mode == "many")
 
     if rank == 0:
         value = n * world * K / wall
         step_us = gpu_ms * 1e3 / K
-        steps_per_launch = 1 if args.mode == "single" else A
+        steps_per_launch = A if args.mode == "many" else 1
         launch_us = step_us * steps_per_launch
         achieved = ALGO_BYTES_PER_ENV_STEP * n / (step_us * 1e-6) / 1e9
         traffic = None
@@ -229,7 +244,7 @@ def main():
             try:
                 tj = json.load(open(tpath))
                 key = f"{args.track}_{n}_{args.compute_dtype}" + ("_norm" if args.normalize_obs else "") + \
-                    ("_single" if args.mode == "single" else f"_fused{A}")
+                    ("_single" if args.mode in ("single", "graph") else f"_fused{A}") + f"_{waves}w"
                 traffic = tj.get(key, {}).get("bytes_per_launch")
             except Exception:  # noqa: BLE001
                 traffic = None
@@ -245,14 +260,15 @@ def main():
                        "episodes_finished_rank0": st["episodes"]},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
-                         "kernel": "%s<%s>" % ("dn_step_kernel" if args.mode == "single" else "dn_step_many_kernel",
-                                               "double" if args.compute_dtype == "float64" else "float"),
+                         "traffic_frac": (round(traffic / (launch_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 5) if traffic else None),
+                         "kernel": "dn_step_many_%dw_kernel<%s, %s, false, %s>" % (
+                             waves, "double" if args.compute_dtype == "float64" else "float",
+                             "true" if args.normalize_obs else "false", "false" if args.mode == "many" else "true"),
+                         "waves_per_64_drones": waves,
                          "env_steps_per_launch": n * steps_per_launch, "vector_steps_per_launch": steps_per_launch,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n * steps_per_launch,
                          "avg_launch_us": round(launch_us, 4), "us_per_vector_step": round(step_us, 4)},
-            "other_launch_shape": {"mode": other, "us_per_vector_step": round(other_us, 4),
-                                   "value": round(n * world / (other_us * 1e-6), 1),
-                                   "roofline_frac": round(ALGO_BYTES_PER_ENV_STEP * n / (other_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 5)},
+            "other_launch_shapes": others,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(track, n, max_steps, args.cpu_baseline_seconds)

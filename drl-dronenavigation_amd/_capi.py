@@ -72,6 +72,7 @@ PROTOTYPES = {
     "dn_set_state": (_I32, [_VP, _VP, _I64]),
     "dn_get_stats": (_I32, [_VP, C.POINTER(DnStats), _VP]),
     "dn_reset_stats": (_I32, [_VP, _VP]),
+    "dn_get_kernel_waves": (_I32, [_VP, _I32]),
     "dn_get_step_count": (_I32, [_VP, C.POINTER(C.c_uint64)]),
     "dn_set_step_count": (_I32, [_VP, C.c_uint64]),
     "dn_preprocess_action": (_I32, [_VP, _I64, _I32, _VP, _VP, _VP, _I32, _VP]),

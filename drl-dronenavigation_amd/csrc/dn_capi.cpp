@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -35,6 +36,8 @@ int32_t fail(dn_status st, const char *fmt, ...)
 
 inline double norm3d(const double v[3]) { return std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
 
+constexpr long long DN_TWO_WAVE_MAX_TILES = 1024;   // 65536 drones: one tile per SIMD
+
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 }  // namespace
@@ -48,6 +51,8 @@ struct dn_env {
     float *tab32 = nullptr;
     uint64_t step_count = 0;
     long long blocks = 0;
+    int waves_fused = 2;        // kernel shape of dn_step_many (k > 1), see dn_launch_step_many
+    int waves_single = 1;       // kernel shape of dn_step (k == 1)
 };
 
 namespace {
@@ -220,6 +225,16 @@ int32_t dn_create(const dn_config *cfg, dn_env **out)
     e->cfg = *cfg;
     const long long n = cfg->num_envs;
     e->blocks = (n + DN_BLOCK - 1) / DN_BLOCK;
+    // Measured on MI355X (profiles/r01_f_sweep_shapes.txt): the fused K-step kernel is instruction-issue bound, and
+    // two waves per tile win while the tiles alone leave SIMDs idle (<= 1024 tiles = 65536 drones on 1024 SIMDs);
+    // the single-step launch is latency bound (launch + load round trip) and one wave is never slower.
+    // DN_WAVES=1|2 forces one shape for every launch (A/B measurements, the bit-identity test).
+    e->waves_fused = e->blocks <= DN_TWO_WAVE_MAX_TILES ? 2 : 1;
+    e->waves_single = 1;
+    if (const char *w = getenv("DN_WAVES")) {
+        if (w[0] == '1') e->waves_fused = e->waves_single = 1;
+        else if (w[0] == '2') e->waves_fused = e->waves_single = 2;
+    }
     const Layout L = make_layout(n, cfg->normalize_obs);
     hipError_t he = hipMalloc(&e->arena, L.total);
     if (he != hipSuccess) {
@@ -315,7 +330,7 @@ int32_t dn_step(dn_env *env, const float *actions, float *obs, float *reward, ui
     io.found_targets = found_targets; io.terminal_obs = terminal_obs; io.ep_return = ep_return;
     io.ep_length = ep_length; io.done_mask = (unsigned long long *)done_mask;
     env->p.step_count = (unsigned)env->step_count;
-    DN_HIP(dn_launch_step(env->p, io, env->cfg.compute_f32 != 0, (hipStream_t)stream));
+    DN_HIP(dn_launch_step_many(env->p, io, 1, env->cfg.compute_f32 != 0, env->waves_single == 2, (hipStream_t)stream));
     env->step_count += 1;
     return DN_OK;
 }
@@ -342,7 +357,7 @@ int32_t dn_step_many(dn_env *env, int64_t k, const float *actions, float *obs, f
     io.found_targets = found_targets; io.terminal_obs = terminal_obs; io.ep_return = ep_return;
     io.ep_length = ep_length; io.done_mask = (unsigned long long *)done_mask;
     env->p.step_count = (unsigned)env->step_count;
-    DN_HIP(dn_launch_step_many(env->p, io, (int)k, env->cfg.compute_f32 != 0, (hipStream_t)stream));
+    DN_HIP(dn_launch_step_many(env->p, io, (int)k, env->cfg.compute_f32 != 0, env->waves_fused == 2, (hipStream_t)stream));
     env->step_count += (uint64_t)k;
     return DN_OK;
 }
@@ -467,6 +482,8 @@ int32_t dn_reset_stats(dn_env *env, void *stream)
     DN_HIP(hipMemsetAsync(env->p.st.stats, 0, (size_t)env->blocks * sizeof(DnStatSlot), (hipStream_t)stream));
     return DN_OK;
 }
+
+int32_t dn_get_kernel_waves(const dn_env *env, int32_t fused) { return env ? (fused ? env->waves_fused : env->waves_single) : 0; }
 
 int32_t dn_get_step_count(const dn_env *env, uint64_t *out)
 {

@@ -7,9 +7,10 @@
 
 #include "../../include/dronenav.h"
 
-// One wave per workgroup: N = 32768 drones is only 512 waves, and 512 workgroups of one wave spread
-// over all 256 CUs (2 per CU, block b -> XCD b % 8) where 128 workgroups of four would leave half the
-// chip idle.  Every wave-level idiom below (ballot, LDS tile transpose) assumes DN_BLOCK == 64.
+// 64 drones per workgroup: N = 32768 drones is only 512 tiles, and 512 workgroups spread over all 256 CUs
+// (2 per CU, block b -> XCD b % 8) where 128 workgroups of 256 drones would leave half the chip idle.  A
+// workgroup is one wave (all phases) or two (flight wave + report wave over the same 64 drones).  Every
+// wave-level idiom below (ballot, LDS tile transpose) assumes DN_BLOCK == 64.
 #define DN_BLOCK 64
 
 // Layout of one waypoint-table entry (entry k describes waypoint k and the corridor segment that ends
@@ -92,8 +93,7 @@ struct DnParams {
     DnConsts<float> c32;
 };
 
-hipError_t dn_launch_step(const DnParams &p, const DnStepIO &io, bool f32, hipStream_t stream);
-hipError_t dn_launch_step_many(const DnParams &p, const DnStepIO &io, int k, bool f32, hipStream_t stream);
+hipError_t dn_launch_step_many(const DnParams &p, const DnStepIO &io, int k, bool f32, bool two_wave, hipStream_t stream);
 hipError_t dn_launch_reset(const DnParams &p, float *obs, bool f32, hipStream_t stream);
 hipError_t dn_launch_gae(const float *rewards, const float *values, const uint8_t *dones,
                          const float *last_values, const uint8_t *last_dones, long long T, long long N,

@@ -389,14 +389,33 @@ DN_DEV StepOut block_out(const DnStepIO &io, long long tile_base, long long step
     return o;
 }
 
+// LDS written by some lanes of a wave and read by other lanes of the SAME wave: order the accesses without a
+// workgroup barrier (the observation tile belongs to one wave).
+DN_DEV void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0) only: LDS traffic, not the outstanding global stores
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// Workgroup barrier that orders LDS only.  __syncthreads() would also drain the global stores in flight
+// (vmcnt(0)), i.e. stall every step on the HBM round trip of the previous step's outputs.
+DN_DEV void block_lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // Stores the wave's [64,13] observation tile: lanes park their 13 floats in LDS (stride 13 dwords: odd, so
 // conflict-free), then the wave streams the 3328 contiguous bytes out as float4 (ds_read_b128 +
 // global_store_dwordx4), i.e. 4 store instructions instead of 13 strided dword stores per destination.
 DN_DEV void store_obs_tile(float *s_tile, float *gtile, unsigned rows, unsigned lane, const float o[DN_OBS_DIM])
 {
+    wave_lds_sync();                                      // the previous step's tile reads are done
 #pragma unroll
     for (int k = 0; k < DN_OBS_DIM; ++k) s_tile[lane * DN_OBS_DIM + k] = o[k];
-    __syncthreads();
+    wave_lds_sync();
     if (rows == DN_BLOCK) {
         float4 *g4 = reinterpret_cast<float4 *>(gtile);
         const float4 *s4 = reinterpret_cast<const float4 *>(s_tile);
@@ -411,10 +430,9 @@ DN_DEV void store_obs_tile(float *s_tile, float *gtile, unsigned rows, unsigned 
 
 template <typename R>
 DN_DEV void stage_table(const DnParams &p, R *s_tab)
-{
+{   // all threads of the workgroup cooperate; the caller's next block barrier publishes the table
     const R *g = table_ptr<R>(p);
-    for (int j = threadIdx.x; j < p.num_waypoints * DN_T_STRIDE; j += DN_BLOCK) s_tab[j] = g[j];
-    __syncthreads();
+    for (unsigned j = threadIdx.x; j < (unsigned)(p.num_waypoints * DN_T_STRIDE); j += blockDim.x) s_tab[j] = g[j];
 }
 
 // Observation of a body that has just been (re)loaded at the spawn pose (BaseAviary.reset -> _computeObs,
@@ -428,14 +446,29 @@ DN_DEV void reset_obs(const DnParams &p, const DnConsts<R> &c, R d_last, float o
 }
 
 // =====================================================================================================
-// The step kernel.
+// The step, in four phases.
 // =====================================================================================================
-// NORM / NOISE compile the optional per-drone observation normaliser and the Philox noise streams in or out:
-// the reference-default kernels <R, false, false> carry neither their registers nor their code.
+// One control step of one drone (one lane) is cut where its data dependencies allow two wavefronts to work on it
+// at the same time:
 //
-// step_body advances ONE drone (this lane) by one control step.  The persistent state travels as the six
-// float4 groups G0..G5 exactly as they sit in HBM (float32), so the single-step kernel (load, step, store)
-// and the fused multi-step kernel (load, K x step, store) run the same arithmetic on the same roundings.
+//     report wave                                     flight wave
+//     -----------                                     -----------
+//     thrust_phase   A1-A3: action -> rotor forces
+//              \\____ Thrust ________________________  physics_phase  A4: Bullet step -> post-physics state
+//                                       ______ Flight /
+//     observe_phase  A5-A7: Euler, observation,      rules_phase    A8-A9: collision, gate logic, truncation,
+//                    reward candidates                               post-step distance, auto-reset of the body
+//              \\                        ______ Verdict/
+//     report_phase   A7 select, A10-A11: Monitor, terminal observation, reset observation, statistics, outputs
+//
+// The flight wave owns the state the dynamics and the rules feed on (G0-G3, G6); the report wave owns what only
+// the outputs feed on (G4 prev_vel/episode return, G5 prev_ang_v/episode length, normaliser statistics).  At
+// 32 768 drones the chip holds one wave per SIMD on half its SIMDs and the step is instruction-issue bound, so
+// putting the two halves of a step on two SIMDs shortens the step itself; the structs below are what crosses
+// from one wave to the other (through LDS in the two-wave kernels, in registers in the one-wave kernels -- the
+// values are float64 either way, so both kernel shapes produce identical bits).
+//
+// NORM / NOISE compile the optional per-drone observation normaliser and the Philox noise streams in or out.
 //
 // Algebra used to shorten Bullet's free-base step (A4) without changing what it computes beyond float64 rounding:
 //   * linear part: Bullet forms F_b = f_thrust_b + R^T (0,0,-M G) - M v_b (c + c |v_b|) in the body frame and
@@ -443,105 +476,208 @@ DN_DEV void reset_obs(const DnParams &p, const DnConsts<R> &c, R d_last, float o
 //   * the exponential-map quaternion update needs |w| only through (|w| dt / 2)^2 (sinc/cos are even), so no sqrt.
 //   * get_forward_vector (PBDroneEnv.py:588-597) = (cos yaw cos pitch, sin yaw cos pitch, sin pitch) is the first
 //     column of the rotation matrix of the (just normalised) quaternion: (1 - 2(y^2+z^2), 2(xy+wz), -2(xz-wy)).
-template <typename R, bool NORM, bool NOISE>
-DN_DEV void step_body(const DnParams &p, const DnConsts<R> &c, const R *s_tab, float *s_tile, const StepOut &out,
-                      float4 *g6_blk, const unsigned step_count, const long long tile_base, const unsigned li,
-                      const unsigned lane, const unsigned rows, const bool active, const float4 A, float4 &G0,
-                      float4 &G1, float4 &G2, float4 &G3, float4 &G4, float4 &G5)
-{
-#pragma clang fp contract(fast)
-    const long long i = tile_base + li;
-    const unsigned long long gid = (unsigned long long)(p.env_id_offset + i);
+struct Thrust {
+    float f[4];        // rotor forces along body z (newton)
+    float zt;          // yaw torque
+};
+constexpr int DN_NTHRUST = 5;
+template <typename R> struct Flight {
+    R px, py, pz, qx, qy, qz, qw, vx, vy, vz, wx, wy, wz;   // post-physics body state (before any reset)
+    R vex, vey, vez, aex, aey, aez;                          // entry velocities = current_vel / current_ang_v (quirk Q4)
+    R d_e, dprev_e;                                          // entry _distance_to_target / _prev_distance_to_target
+    int idx_e, just_found_e, truncated;                      // entry index / flag; _computeTruncated (entry _steps)
+};
+constexpr int DN_NFLIGHT = 21;                               // R-valued fields of Flight
+template <typename R> struct Verdict {
+    R d_obs;           // the distance the reset observation shows (quirk Q2)
+    int coll1;         // _computeTerminated inside _computeReward (entry index)
+    int terminated;    // _computeTerminated of BaseAviary.step (advanced index, _is_done)
+};
+
+template <bool NOISE>
+DN_DEV Thrust thrust_phase(const DnParams &p, unsigned long long gid, unsigned step_count, const float4 A)
+{   // float32, unfused: bit-exact numpy
     float a[4] = {A.x, A.y, A.z, A.w};
     if (NOISE && p.act_noise_sigma > 0.0f) add_act_noise(p, gid, step_count, a);
-
-    // ---- A1-A3 (float32, unfused) ------------------------------------------------------------------
-    float tq[4], f32[4];
+    Thrust t;
+    float tq[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) f32[j] = rotor_force_from_action(a[j], p.normalize_actions != 0, tq[j]);
-    const float zt32 = z_torque32(tq);                 // BaseAviary.py:780
+    for (int j = 0; j < 4; ++j) t.f[j] = rotor_force_from_action(a[j], p.normalize_actions != 0, tq[j]);
+    t.zt = z_torque32(tq);                             // BaseAviary.py:780
+    return t;
+}
 
-    // ---- unpack the entry state -----------------------------------------------------------------------
+// ---- A4: p.stepSimulation, one free rigid body [3P-recall of Bullet3 btMultiBody] -------------------------
+template <typename R>
+DN_DEV Flight<R> physics_phase(const Thrust &th, const float4 G0, const float4 G1, const float4 G2, const float4 G3,
+                               const int max_steps)
+{
+#pragma clang fp contract(fast)
+    Flight<R> fl;
     R px = G0.x, py = G0.y, pz = G0.z;
-    const R d_e = G0.w;
     R qx = G1.x, qy = G1.y, qz = G1.z, qw = G1.w;
     R vx = G2.x, vy = G2.y, vz = G2.z;
-    const R dprev_e = G2.w;
     R wx = G3.x, wy = G3.y, wz = G3.z;
     const Meta m_e = unpack_meta(G3.w);
-    const R pvx = G4.x, pvy = G4.y, pvz = G4.z;
-    const R epret_e = G4.w;
-    const R pwx = G5.x, pwy = G5.y, pwz = G5.z;
-    const int eplen_e = __float_as_int(G5.w);
-    const R pos_ex = px, pos_ey = py, pos_ez = pz;     // entry position  (= _current_position while steps > 0)
-    const R vel_ex = vx, vel_ey = vy, vel_ez = vz;     // entry velocity  (= current_vel, quirk Q4)
-    const R ang_ex = wx, ang_ey = wy, ang_ez = wz;     //                 (= current_ang_v)
-
-    // ---- A4: p.stepSimulation, one free rigid body [3P-recall of Bullet3 btMultiBody] -------------------
-    R w2;                                              // |w_new|^2, reused by the observation
-    {
-        const R dt = K<R>::DT;
-        // btMatrix3x3::setRotation: s = 2 / |q|^2
-        const R s = R(2.0) * FM<R>::rcp(qx * qx + qy * qy + qz * qz + qw * qw);
-        const R xs = qx * s, ys = qy * s, zs = qz * s;
-        const R wxs = qw * xs, wys = qw * ys, wzs = qw * zs;
-        const R xx = qx * xs, xy = qx * ys, xz = qx * zs;
-        const R yy = qy * ys, yz = qy * zs, zz = qz * zs;
-        const R r00 = R(1.0) - (yy + zz), r01 = xy - wzs, r02 = xz + wys;
-        const R r10 = xy + wzs, r11 = R(1.0) - (xx + zz), r12 = yz - wxs;
-        const R r20 = xz - wys, r21 = yz + wxs, r22 = R(1.0) - (xx + yy);
-        // rotor thrusts along body z at the prop offsets (+,-) (-,-) (-,+) (+,+) * 0.028 (cf2x.urdf:42,54,66,78)
-        const R F0 = f32[0], F1 = f32[1], F2 = f32[2], F3 = f32[3];
-        const R fz = (F0 + F1) + (F2 + F3);
-        const R tx = K<R>::ARM * ((F2 + F3) - (F0 + F1));
-        const R ty = K<R>::ARM * ((F1 + F2) - (F0 + F3));
-        // linear: a = R[:,2] fz/M - (0,0,G) - v (c + c|v|)
-        const R kl = K<R>::LIN_DAMP + K<R>::LIN_DAMP * FM<R>::sqrt0(vx * vx + vy * vy + vz * vz);
-        const R fm = fz * K<R>::INV_M;
-        const R awx = r02 * fm - vx * kl, awy = r12 * fm - vy * kl, awz = (r22 * fm - K<R>::G) - vz * kl;
-        // angular, in the body frame: I dw = tau - w x (I w) - I w (c + c|w|)
-        const R wbx = r00 * wx + r10 * wy + r20 * wz, wby = r01 * wx + r11 * wy + r21 * wz, wbz = r02 * wx + r12 * wy + r22 * wz;
-        const R ka = K<R>::ANG_DAMP + K<R>::ANG_DAMP * FM<R>::sqrt0(wx * wx + wy * wy + wz * wz);
-        const R Iwx = K<R>::IXX * wbx, Iwy = K<R>::IYY * wby, Iwz = K<R>::IZZ * wbz;
-        const R gx = wby * Iwz - wbz * Iwy, gy = wbz * Iwx - wbx * Iwz, gz = wbx * Iwy - wby * Iwx;
-        const R dbx = (tx - gx - Iwx * ka) * K<R>::INV_IXX, dby = (ty - gy - Iwy * ka) * K<R>::INV_IYY,
-                dbz = ((R)zt32 - gz - Iwz * ka) * K<R>::INV_IZZ;
-        const R dwx = r00 * dbx + r01 * dby + r02 * dbz, dwy = r10 * dbx + r11 * dby + r12 * dbz, dwz = r20 * dbx + r21 * dby + r22 * dbz;
-        wx += dwx * dt; wy += dwy * dt; wz += dwz * dt;       // applyDeltaVeeMultiDof
-        vx += awx * dt; vy += awy * dt; vz += awz * dt;
-        // btMultiBody clamps every velocity coordinate at m_maxCoordinateVelocity; no reachable state gets there
-        // (thrust/weight = 5.5, damping), so test once per wave and clamp only then.  NaN stays NaN either way.
-        const R mv = K<R>::MAX_COORD_VEL;
-        const R big = fmax(fmax(fmax(fabs(wx), fabs(wy)), fmax(fabs(wz), fabs(vx))), fmax(fabs(vy), fabs(vz)));
-        if (big > mv) {
-            wx = clipv(wx, -mv, mv); wy = clipv(wy, -mv, mv); wz = clipv(wz, -mv, mv);
-            vx = clipv(vx, -mv, mv); vy = clipv(vy, -mv, mv); vz = clipv(vz, -mv, mv);
-        }
-        px += dt * vx; py += dt * vy; pz += dt * vz;          // stepPositionsMultiDof
-        // exponential map: Bullet clamps the angle rate, fAngle = min(|w|, (pi/4)/dt), and takes
-        // axis = w sin(h)/fAngle with h = fAngle dt/2, i.e. w (dt/2) sinc(h), and cos(h): both are even in h, so only
-        // h^2 = min(|w|^2 dt^2/4, (pi/8)^2) is needed and the sqrt of |w|^2 never is.  (Bullet's |w| < 1e-3 Taylor
-        // branch is the same function to 1e-24.)
-        w2 = wx * wx + wy * wy + wz * wz;
-        R h2 = (R(0.25) * dt * dt) * w2;
-        const R h2max = R(0.015625) * K<R>::PI * K<R>::PI;     // (pi/8)^2
-        h2 = h2 > h2max ? h2max : h2;
-        R sinc, aw;
-        sinc_cos_small<R>(h2, sinc, aw);
-        const R k = (R(0.5) * dt) * sinc;
-        const R ax = wx * k, ay = wy * k, az = wz * k;
-        const R nx = aw * qx + ax * qw + ay * qz - az * qy;
-        const R ny = aw * qy + ay * qw + az * qx - ax * qz;
-        const R nz = aw * qz + az * qw + ax * qy - ay * qx;
-        const R nw_ = aw * qw - ax * qx - ay * qy - az * qz;
-        const R inv = FM<R>::rsq(nx * nx + ny * ny + nz * nz + nw_ * nw_);
-        qx = nx * inv; qy = ny * inv; qz = nz * inv; qw = nw_ * inv;
+    fl.d_e = G0.w; fl.dprev_e = G2.w;
+    fl.idx_e = m_e.idx; fl.just_found_e = m_e.just_found;
+    fl.truncated = max_steps <= m_e.steps;             // PBDroneEnv.py:444-454, evaluated on the un-incremented _steps
+    fl.vex = vx; fl.vey = vy; fl.vez = vz; fl.aex = wx; fl.aey = wy; fl.aez = wz;
+    const R dt = K<R>::DT;
+    // btMatrix3x3::setRotation: s = 2 / |q|^2
+    const R s = R(2.0) * FM<R>::rcp(qx * qx + qy * qy + qz * qz + qw * qw);
+    const R xs = qx * s, ys = qy * s, zs = qz * s;
+    const R wxs = qw * xs, wys = qw * ys, wzs = qw * zs;
+    const R xx = qx * xs, xy = qx * ys, xz = qx * zs;
+    const R yy = qy * ys, yz = qy * zs, zz = qz * zs;
+    const R r00 = R(1.0) - (yy + zz), r01 = xy - wzs, r02 = xz + wys;
+    const R r10 = xy + wzs, r11 = R(1.0) - (xx + zz), r12 = yz - wxs;
+    const R r20 = xz - wys, r21 = yz + wxs, r22 = R(1.0) - (xx + yy);
+    // rotor thrusts along body z at the prop offsets (+,-) (-,-) (-,+) (+,+) * 0.028 (cf2x.urdf:42,54,66,78)
+    const R F0 = th.f[0], F1 = th.f[1], F2 = th.f[2], F3 = th.f[3];
+    const R fz = (F0 + F1) + (F2 + F3);
+    const R tx = K<R>::ARM * ((F2 + F3) - (F0 + F1));
+    const R ty = K<R>::ARM * ((F1 + F2) - (F0 + F3));
+    // linear: a = R[:,2] fz/M - (0,0,G) - v (c + c|v|)
+    const R kl = K<R>::LIN_DAMP + K<R>::LIN_DAMP * FM<R>::sqrt0(vx * vx + vy * vy + vz * vz);
+    const R fm = fz * K<R>::INV_M;
+    const R awx = r02 * fm - vx * kl, awy = r12 * fm - vy * kl, awz = (r22 * fm - K<R>::G) - vz * kl;
+    // angular, in the body frame: I dw = tau - w x (I w) - I w (c + c|w|)
+    const R wbx = r00 * wx + r10 * wy + r20 * wz, wby = r01 * wx + r11 * wy + r21 * wz, wbz = r02 * wx + r12 * wy + r22 * wz;
+    const R ka = K<R>::ANG_DAMP + K<R>::ANG_DAMP * FM<R>::sqrt0(wx * wx + wy * wy + wz * wz);
+    const R Iwx = K<R>::IXX * wbx, Iwy = K<R>::IYY * wby, Iwz = K<R>::IZZ * wbz;
+    const R gx = wby * Iwz - wbz * Iwy, gy = wbz * Iwx - wbx * Iwz, gz = wbx * Iwy - wby * Iwx;
+    const R dbx = (tx - gx - Iwx * ka) * K<R>::INV_IXX, dby = (ty - gy - Iwy * ka) * K<R>::INV_IYY,
+            dbz = ((R)th.zt - gz - Iwz * ka) * K<R>::INV_IZZ;
+    const R dwx = r00 * dbx + r01 * dby + r02 * dbz, dwy = r10 * dbx + r11 * dby + r12 * dbz, dwz = r20 * dbx + r21 * dby + r22 * dbz;
+    wx += dwx * dt; wy += dwy * dt; wz += dwz * dt;       // applyDeltaVeeMultiDof
+    vx += awx * dt; vy += awy * dt; vz += awz * dt;
+    // btMultiBody clamps every velocity coordinate at m_maxCoordinateVelocity; no reachable state gets there
+    // (thrust/weight = 5.5, damping), so test once per wave and clamp only then.  NaN stays NaN either way.
+    const R mv = K<R>::MAX_COORD_VEL;
+    const R big = fmax(fmax(fmax(fabs(wx), fabs(wy)), fmax(fabs(wz), fabs(vx))), fmax(fabs(vy), fabs(vz)));
+    if (big > mv) {
+        wx = clipv(wx, -mv, mv); wy = clipv(wy, -mv, mv); wz = clipv(wz, -mv, mv);
+        vx = clipv(vx, -mv, mv); vy = clipv(vy, -mv, mv); vz = clipv(vz, -mv, mv);
     }
+    px += dt * vx; py += dt * vy; pz += dt * vz;          // stepPositionsMultiDof
+    // exponential map: Bullet clamps the angle rate, fAngle = min(|w|, (pi/4)/dt), and takes
+    // axis = w sin(h)/fAngle with h = fAngle dt/2, i.e. w (dt/2) sinc(h), and cos(h): both are even in h, so only
+    // h^2 = min(|w|^2 dt^2/4, (pi/8)^2) is needed and the sqrt of |w|^2 never is.  (Bullet's |w| < 1e-3 Taylor
+    // branch is the same function to 1e-24.)
+    R h2 = (R(0.25) * dt * dt) * (wx * wx + wy * wy + wz * wz);
+    const R h2max = R(0.015625) * K<R>::PI * K<R>::PI;     // (pi/8)^2
+    h2 = h2 > h2max ? h2max : h2;
+    R sinc, aw;
+    sinc_cos_small<R>(h2, sinc, aw);
+    const R k = (R(0.5) * dt) * sinc;
+    const R ax = wx * k, ay = wy * k, az = wz * k;
+    const R nx = aw * qx + ax * qw + ay * qz - az * qy;
+    const R ny = aw * qy + ay * qw + az * qx - ax * qz;
+    const R nz = aw * qz + az * qw + ax * qy - ay * qx;
+    const R nw_ = aw * qw - ax * qx - ay * qy - az * qz;
+    const R inv = FM<R>::rsq(nx * nx + ny * ny + nz * nz + nw_ * nw_);
+    fl.px = px; fl.py = py; fl.pz = pz;
+    fl.qx = nx * inv; fl.qy = ny * inv; fl.qz = nz * inv; fl.qw = nw_ * inv;
+    fl.vx = vx; fl.vy = vy; fl.vz = vz; fl.wx = wx; fl.wy = wy; fl.wz = wz;
+    return fl;
+}
 
-    // ---- A5: p.getEulerFromQuaternion [3P-recall of pybullet.c] ------------------------------------------
-    // The three angles only feed observation columns 3..5 (float32, bar 1e-5): the quaternion products are formed
-    // in R, the inverse trigonometry runs in float32 (atan2f ~1e-7 rad).  The forward vector feeds a compare and
-    // stays in R.
+// ---- A8 + A9 on the flight wave: _computeTerminated (PBDroneEnv.py:456-473) as evaluated inside _computeReward
+// (:489) and again by BaseAviary.step (BaseAviary.py:448), the gate bookkeeping of _computeReward (:539-552),
+// _update_state_post_step (:201-223, skipped on a terminated step: quirk Q5) and the body/bookkeeping half of the
+// SubprocVecEnv auto-reset -> PBDroneEnv.reset (:609-665; _current_position is NOT reset: quirk Q3).
+// Only the segment corridor depends on the waypoint index, so the common part of the collision test runs once
+// and the segment test once per index that is actually needed.
+template <typename R>
+DN_DEV Verdict<R> rules_phase(const DnParams &p, const DnConsts<R> &c, const R *s_tab, const Flight<R> &fl,
+                              const float4 G0e, const float4 G3e, float4 *g6_blk, const unsigned li, const bool active,
+                              float4 &G0, float4 &G1, float4 &G2, float4 &G3)
+{
+#pragma clang fp contract(fast)
+    const Meta m_e = unpack_meta(G3e.w);
+    const R px = fl.px, py = fl.py, pz = fl.pz;
+    // rotation entry R[2][2] of the new (unit) attitude, for the ground-contact approximation only
+    const R r22n = R(1.0) - R(2.0) * (fl.qx * fl.qx + fl.qy * fl.qy);
+    int idx = m_e.idx, just_found = m_e.just_found;
+    const bool seg_track = p.cylinder && !p.circle;
+    const bool coll1 = collision_common<R>(p, c, px, py, pz, r22n) ||
+                       (seg_track && outside_segment_corridor<R>(c, s_tab, px, py, pz, idx));
+    const bool found_now = fl.d_e <= c.threshold;      // :539
+    const bool last_gate = idx + 1 == p.num_waypoints;
+    R d_prev = fl.dprev_e;
+    bool terminated;
+    if (coll1) terminated = true;                      // :489-490 (entry _is_done is always False here)
+    else if (found_now) {
+        idx += 1;
+        if (last_gate) terminated = true;              // :542-546, _is_done
+        else {
+            just_found = 1;                            // :548-552
+            // second _computeTerminated: the common part is already known to be false
+            terminated = seg_track && outside_segment_corridor<R>(c, s_tab, px, py, pz, idx);
+        }
+        d_prev = fl.d_e;
+    } else { just_found = 0; d_prev = fl.d_e; terminated = false; }
+    const bool done = terminated || fl.truncated != 0;
+
+    int steps = m_e.steps;
+    R d = fl.d_e;
+    if (!terminated) {                                 // _update_state_post_step
+        steps += 1;
+        const R *wp = s_tab + idx * DN_T_STRIDE;
+        const R ex = wp[0] - px, ey = wp[1] - py, ez = wp[2] - pz;
+        d = FM<R>::sqrt0(ex * ex + ey * ey + ez * ez);
+    }
+    Verdict<R> v;
+    v.d_obs = d; v.coll1 = coll1; v.terminated = terminated;
+
+    // the advanced body state as the float32 words that go back to HBM
+    float4 S0 = make_float4((float)px, (float)py, (float)pz, 0.0f);
+    float4 S1 = make_float4((float)fl.qx, (float)fl.qy, (float)fl.qz, (float)fl.qw);
+    float4 S2 = make_float4((float)fl.vx, (float)fl.vy, (float)fl.vz, 0.0f);
+    float4 S3 = make_float4((float)fl.wx, (float)fl.wy, (float)fl.wz, 0.0f);
+    if (__ballot(done) != 0ull) {                      // wave-uniform: most wave-steps of a long flight skip this
+        if (done) {
+            R cpx, cpy, cpz;
+            if (!terminated) { cpx = px; cpy = py; cpz = pz; }            // post-step ran: it is the new position
+            else if (m_e.steps > 0) { cpx = G0e.x; cpy = G0e.y; cpz = G0e.z; }
+            else { const float4 G6 = g6_blk[li]; cpx = G6.x; cpy = G6.y; cpz = G6.z; }
+            if (active && !(terminated && m_e.steps == 0)) g6_blk[li] = make_float4((float)cpx, (float)cpy, (float)cpz, 0.0f);
+            // freshly loaded body at the spawn pose, at rest
+            S0 = make_float4((float)c.spawn[0], (float)c.spawn[1], (float)c.spawn[2], 0.0f);
+            S1 = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+            S2 = S3 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            const R ex = cpx - s_tab[0], ey = cpy - s_tab[1], ez = cpz - s_tab[2];
+            d = FM<R>::sqrt0(ex * ex + ey * ey + ez * ez);                // :651
+            d_prev = d;                                                   // :652
+            idx = 0; steps = 0; just_found = 0;
+        }
+    }
+    S0.w = (float)d; S2.w = (float)d_prev; S3.w = pack_meta(steps, idx, just_found);
+    G0 = S0; G1 = S1; G2 = S2; G3 = S3;
+    return v;
+}
+
+// What the report wave carries from observe_phase to report_phase.
+template <typename R> struct Observed {
+    float o[DN_OBS_DIM];   // step observation, after sensor noise and the normaliser (also terminal_observation)
+    R r_normal;            // _computeReward's ordinary branch, before /25
+    float r_found32;       // gate-pass branch, float32 as the reference accumulates it
+    double rms_count;      // running count of the normaliser (NORM only)
+};
+
+// ---- A5 + A6 + the value side of A7 on the report wave ---------------------------------------------------
+template <typename R, bool NORM, bool NOISE>
+DN_DEV Observed<R> observe_phase(const DnParams &p, const DnConsts<R> &c, const R *s_tab, const Flight<R> &fl,
+                                 const float4 G4, const float4 G5, const unsigned long long gid, const unsigned step_count,
+                                 const long long i, const bool active)
+{
+#pragma clang fp contract(fast)
+    Observed<R> ob;
+    const R qx = fl.qx, qy = fl.qy, qz = fl.qz, qw = fl.qw;
+    // p.getEulerFromQuaternion [3P-recall of pybullet.c].  The three angles only feed observation columns 3..5
+    // (float32, bar 1e-5): the quaternion products are formed in R, the inverse trigonometry runs in float32
+    // (atan2f ~1e-7 rad).  The forward vector feeds a compare and stays in R.
     float roll32, pitch32, yaw32;
     R fwx, fwy, fwz;
     {
@@ -565,115 +701,88 @@ DN_DEV void step_body(const DnParams &p, const DnConsts<R> &c, const R *s_tab, f
             fwx = yc; fwy = ys; fwz = sarg;
         }
     }
-    // rotation entry R[2][2] of the NEW (unit) attitude, for the ground-contact approximation only
-    const R r22n = R(1.0) - R(2.0) * (qx * qx + qy * qy);
-
-    // ---- A6: _computeObs (PBDroneEnv.py:296-336, :338-398), stale distance d_e (quirk Q1) -----------------
-    // The reference clips position / yaw / distance columns to the float32 range before the cast (:326); positions
-    // are bounded by the aviary box plus one step at the velocity cap, so those clips can never bind and are not
-    // evaluated.  clip(v, -3, 3)/3 is monotone, so it equals clip(float32(v/3), -1, 1) exactly.
-    float o[DN_OBS_DIM];
+    // _computeObs (PBDroneEnv.py:296-336, :338-398), stale distance d_e (quirk Q1).  The reference clips position /
+    // yaw / distance columns to the float32 range before the cast (:326); positions are bounded by the aviary box
+    // plus one step at the velocity cap, so those clips can never bind and are not evaluated.  clip(v, -3, 3)/3 is
+    // monotone, so it equals clip(float32(v/3), -1, 1) exactly.
     {
+        float *o = ob.o;
         const float inv_pi32 = (float)K<R>::INV_PI;
-        o[0] = (float)(px * c.inv_dim[0]);
-        o[1] = (float)(py * c.inv_dim[1]);
-        o[2] = (float)(pz * c.inv_dim[2]);
+        o[0] = (float)(fl.px * c.inv_dim[0]);
+        o[1] = (float)(fl.py * c.inv_dim[1]);
+        o[2] = (float)(fl.pz * c.inv_dim[2]);
         o[3] = roll32 * inv_pi32;
         o[4] = pitch32 * inv_pi32;
         o[5] = yaw32 * inv_pi32;
         const float third32 = (float)K<R>::THIRD;
-        o[6] = clipv((float)(vx * K<R>::THIRD), -1.0f, 1.0f);
-        o[7] = clipv((float)(vy * K<R>::THIRD), -1.0f, 1.0f);
-        o[8] = clipv((float)(vz * K<R>::THIRD), -third32, third32);
+        o[6] = clipv((float)(fl.vx * K<R>::THIRD), -1.0f, 1.0f);
+        o[7] = clipv((float)(fl.vy * K<R>::THIRD), -1.0f, 1.0f);
+        o[8] = clipv((float)(fl.vz * K<R>::THIRD), -third32, third32);
+        const R w2 = fl.wx * fl.wx + fl.wy * fl.wy + fl.wz * fl.wz;
         if (w2 != R(0.0)) {                                   // ang_v / |ang_v|, zero stays zero (:383-384)
             const R rw = FM<R>::rsq_f32grade(w2);
-            o[9] = (float)(wx * rw); o[10] = (float)(wy * rw); o[11] = (float)(wz * rw);
-        } else { o[9] = (float)wx; o[10] = (float)wy; o[11] = (float)wz; }
-        o[12] = p.include_distance ? (float)(d_e * c.inv_max_target_dist) : 0.0f;
+            o[9] = (float)(fl.wx * rw); o[10] = (float)(fl.wy * rw); o[11] = (float)(fl.wz * rw);
+        } else { o[9] = (float)fl.wx; o[10] = (float)fl.wy; o[11] = (float)fl.wz; }
+        o[12] = p.include_distance ? (float)(fl.d_e * c.inv_max_target_dist) : 0.0f;
     }
-
-    // ---- A7 + A8: _computeReward (PBDroneEnv.py:475-571), _computeTerminated (:456-473) --------------------
-    // _computeReward evaluates _computeTerminated with the entry index (:489); after a gate pass BaseAviary.step
-    // evaluates it again with the advanced index (BaseAviary.py:448).  Only the segment corridor depends on the
-    // index, so the common part runs once and the segment test once per index that is actually needed; likewise the
-    // orientation term is evaluated once, against the waypoint the taken branch refers to.
-    int idx = m_e.idx, just_found = m_e.just_found, is_done = 0;
-    R d_prev = dprev_e;
-    R reward;
-    const bool seg_track = p.cylinder && !p.circle;
-    const bool coll1 = collision_common<R>(p, c, px, py, pz, r22n) ||
-                       (seg_track && outside_segment_corridor<R>(c, s_tab, px, py, pz, idx));
-    const bool found_now = d_e <= c.threshold;         // :539
-    const bool last_gate = idx + 1 == p.num_waypoints;
-    const int idx_ori = (found_now && !last_gate) ? idx + 1 : idx;
-    const int ori = orientation_reward<R>(fwx, fwy, fwz, px, py, pz, s_tab + idx_ori * DN_T_STRIDE);
-    bool terminated;
-    if (coll1) {                                       // :489-490 (entry _is_done is always False here)
-        reward = R(-10.0);
-        terminated = true;
-    } else if (found_now) {
-        idx += 1;
+    // _computeReward (PBDroneEnv.py:475-571): both value branches; report_phase selects once the verdict is in.
+    // The orientation term is evaluated once, against the waypoint the taken branch refers to.
+    {
+        const bool found_now = fl.d_e <= c.threshold;
+        const bool last_gate = fl.idx_e + 1 == p.num_waypoints;
+        const int idx_ori = (found_now && !last_gate) ? fl.idx_e + 1 : fl.idx_e;
+        const int ori = orientation_reward<R>(fwx, fwy, fwz, fl.px, fl.py, fl.pz, s_tab + idx_ori * DN_T_STRIDE);
         float r32 = 0.0f;
-        if (last_gate) { r32 = r32 + 200.0f; is_done = 1; terminated = true; }    // :542-546
-        else {
-            r32 = r32 + 75.0f;                                                    // :548-552
-            r32 = r32 + (float)(ori * 5);
-            just_found = 1;
-            // second _computeTerminated: the common part is already known to be false
-            terminated = seg_track && outside_segment_corridor<R>(c, s_tab, px, py, pz, idx);
-        }
-        d_prev = d_e;
-        reward = (R)(r32 / 25.0f);
-    } else {
-        R r = R(3.0) * (R)expf((float)(R(-2.0) * d_e));                           // :555 (3/25 e^-2d: float32 exp is 1e-8 here)
-        r = r + (just_found ? R(0.0) : (dprev_e - d_e) * R(3000.0));              // :556
+        if (last_gate) r32 = r32 + 200.0f;                                        // :542-546
+        else { r32 = r32 + 75.0f; r32 = r32 + (float)(ori * 5); }                 // :548-552
+        ob.r_found32 = r32;
+        R r = R(3.0) * (R)expf((float)(R(-2.0) * fl.d_e));                        // :555 (3/25 e^-2d: float32 exp is 1e-8 here)
+        r = r + (fl.just_found_e ? R(0.0) : (fl.dprev_e - fl.d_e) * R(3000.0));   // :556
         r = r + (R)(ori * 3);                                                     // :557
         // smoothness_reward (:599-607) on the stale post-step copies (quirk Q4): -|dv| if |dv| > 0.7, -|dw| if > 0.3
-        const R lx = vel_ex - pvx, ly = vel_ey - pvy, lz = vel_ez - pvz;
-        const R ax_ = ang_ex - pwx, ay_ = ang_ey - pwy, az_ = ang_ez - pwz;
+        const R lx = fl.vex - (R)G4.x, ly = fl.vey - (R)G4.y, lz = fl.vez - (R)G4.z;
+        const R ax_ = fl.aex - (R)G5.x, ay_ = fl.aey - (R)G5.y, az_ = fl.aez - (R)G5.z;
         const R la2 = lx * lx + ly * ly + lz * lz, aa2 = ax_ * ax_ + ay_ * ay_ + az_ * az_;
         if (la2 > R(0.7) * R(0.7)) r = r - FM<R>::sqrt0(la2);                     // needs > 160 m/s^2: rare
         if (aa2 > R(0.3) * R(0.3)) r = r - FM<R>::sqrt0(aa2);
-        just_found = 0;
-        d_prev = d_e;
-        reward = r * K<R>::INV_25;
-        terminated = false;
+        ob.r_normal = r;
     }
-    const bool truncated = p.max_steps <= m_e.steps;   // :444-454, evaluated on the un-incremented _steps
-    const int found = idx;
+    // sensor noise / per-drone normaliser act on the step observation (which is also terminal_observation)
+    ob.rms_count = 0.0;
+    if (NORM) ob.rms_count = p.st.rms_count[i];
+    if (NOISE && p.obs_noise_sigma > 0.0f) add_obs_noise(p, gid, step_count, 1u, ob.o);
+    if (NORM) normalize_obs(p, i, active, ob.rms_count, ob.o);
+    return ob;
+}
+
+// ---- A7 select + A10/A11 on the report wave: Monitor, SubprocVecEnv worker, outputs ---------------------------
+template <typename R, bool NORM, bool NOISE>
+DN_DEV void report_phase(const DnParams &p, const DnConsts<R> &c, float *s_tile, const StepOut &out, const Flight<R> &fl,
+                         const Verdict<R> &v, Observed<R> &ob, const unsigned long long gid, const unsigned step_count,
+                         const long long i, const unsigned li, const unsigned lane, const unsigned rows, const bool active,
+                         float4 &G4, float4 &G5)
+{
+#pragma clang fp contract(fast)
+    const bool coll1 = v.coll1 != 0, terminated = v.terminated != 0, truncated = fl.truncated != 0;
+    const bool found_now = !coll1 && fl.d_e <= c.threshold;
+    const bool is_done = found_now && fl.idx_e + 1 == p.num_waypoints;
+    const int found = fl.idx_e + (found_now ? 1 : 0);
     const bool done = terminated || truncated;
-
-    // ---- A9: _update_state_post_step (:201-223), skipped on a terminated step (quirk Q5) -----------------
-    int steps = m_e.steps;
-    R d = d_e;
-    R npvx = pvx, npvy = pvy, npvz = pvz, npwx = pwx, npwy = pwy, npwz = pwz;
-    if (!terminated) {
-        steps += 1;
-        npvx = vel_ex; npvy = vel_ey; npvz = vel_ez;
-        npwx = ang_ex; npwy = ang_ey; npwz = ang_ez;
-        const R *wp = s_tab + idx * DN_T_STRIDE;
-        const R ex = wp[0] - px, ey = wp[1] - py, ez = wp[2] - pz;
-        d = FM<R>::sqrt0(ex * ex + ey * ey + ez * ez);
-    }
-
-    // ---- A11: Monitor + SubprocVecEnv worker ---------------------------------------------------------------
+    R reward;
+    if (coll1) reward = R(-10.0);                                                 // :489-490
+    else if (found_now) reward = (R)(ob.r_found32 / 25.0f);                       // :568-571
+    else reward = ob.r_normal * K<R>::INV_25;
+    const R epret_e = G4.w;
+    const int eplen_e = __float_as_int(G5.w);
     R ep_ret = epret_e + reward;
     int ep_len = eplen_e + 1;
-
-    // sensor noise / per-drone normaliser act on the step observation (which is also terminal_observation)
-    double rms_count = 0.0;
-    if (NORM) rms_count = p.st.rms_count[i];
-    if (NOISE && p.obs_noise_sigma > 0.0f) add_obs_noise(p, gid, step_count, 1u, o);
-    if (NORM) normalize_obs(p, i, active, rms_count, o);
-
-    // the advanced state as the float32 words that go back to HBM (w slots are filled in below)
-    float4 S0 = make_float4((float)px, (float)py, (float)pz, 0.0f);
-    float4 S1 = make_float4((float)qx, (float)qy, (float)qz, (float)qw);
-    float4 S2 = make_float4((float)vx, (float)vy, (float)vz, 0.0f);
-    float4 S3 = make_float4((float)wx, (float)wy, (float)wz, 0.0f);
-    float4 S4 = make_float4((float)npvx, (float)npvy, (float)npvz, 0.0f);
-    float4 S5 = make_float4((float)npwx, (float)npwy, (float)npwz, 0.0f);
-
+    // prev_vel / prev_ang_v shift in _update_state_post_step (skipped on a terminated step, quirk Q5)
+    float4 S4 = G4, S5 = G5;
+    if (!terminated) {
+        S4 = make_float4((float)fl.vex, (float)fl.vey, (float)fl.vez, 0.0f);
+        S5 = make_float4((float)fl.aex, (float)fl.aey, (float)fl.aez, 0.0f);
+    }
+    float *o = ob.o;
     const unsigned long long done_ballot = __ballot(done && active);
     if (done_ballot != 0ull) {                         // wave-uniform: waves without a finished drone skip all of this
         const long long fix = llrint((double)ep_ret * 1e6);                       // Monitor 'r' in 1e-6 fixed point
@@ -686,23 +795,10 @@ DN_DEV void step_body(const DnParams &p, const DnConsts<R> &c, const R *s_tab, f
                 if (out.ep_return) out.ep_return[li] = (float)ep_ret;
                 if (out.ep_length) out.ep_length[li] = ep_len;
             }
-            // PBDroneEnv.reset (:609-665): _current_position is NOT reset (quirk Q3)
-            R cpx, cpy, cpz;
-            if (!terminated) { cpx = px; cpy = py; cpz = pz; }            // post-step ran: it is the new position
-            else if (m_e.steps > 0) { cpx = pos_ex; cpy = pos_ey; cpz = pos_ez; }
-            else { const float4 G6 = g6_blk[li]; cpx = G6.x; cpy = G6.y; cpz = G6.z; }
-            if (active && !(terminated && m_e.steps == 0)) g6_blk[li] = make_float4((float)cpx, (float)cpy, (float)cpz, 0.0f);
-            reset_obs<R>(p, c, d, o);                                     // BaseAviary.py:318 before :617-658 (Q2)
+            reset_obs<R>(p, c, v.d_obs, o);                               // BaseAviary.py:318 before :617-658 (Q2)
             if (NOISE && p.obs_noise_sigma > 0.0f) add_obs_noise(p, gid, step_count, 5u, o);
-            if (NORM) normalize_obs(p, i, active, rms_count, o);
-            // freshly loaded body at the spawn pose, at rest; selects act on the float32 words that go back to HBM
-            S0 = make_float4((float)c.spawn[0], (float)c.spawn[1], (float)c.spawn[2], 0.0f);
-            S1 = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
-            S2 = S3 = S4 = S5 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            const R ex = cpx - s_tab[0], ey = cpy - s_tab[1], ez = cpz - s_tab[2];
-            d = FM<R>::sqrt0(ex * ex + ey * ey + ez * ez);                // :651
-            d_prev = d;                                                   // :652
-            idx = 0; steps = 0; just_found = 0;
+            if (NORM) normalize_obs(p, i, active, ob.rms_count, o);
+            S4 = S5 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             ep_ret = R(0.0); ep_len = 0;
         }
         // Episode statistics of this wave -> this workgroup's slot (no atomics, deterministic).  Counts are ballots
@@ -727,12 +823,9 @@ DN_DEV void step_body(const DnParams &p, const DnConsts<R> &c, const R *s_tab, f
             p.st.stats[blockIdx.x] = sl;
         }
     }
-    if (NORM && active) p.st.rms_count[i] = rms_count;
-
-    // ---- hand the state back as float32 groups; scalars and the observation tile go straight to HBM -----------
-    S0.w = (float)d; S2.w = (float)d_prev; S3.w = pack_meta(steps, idx, just_found);
+    if (NORM && active) p.st.rms_count[i] = ob.rms_count;
     S4.w = (float)ep_ret; S5.w = __int_as_float(ep_len);
-    G0 = S0; G1 = S1; G2 = S2; G3 = S3; G4 = S4; G5 = S5;
+    G4 = S4; G5 = S5;
     if (active) {
         out.reward[li] = (float)reward;
         out.done[li] = (uint8_t)done;
@@ -743,22 +836,27 @@ DN_DEV void step_body(const DnParams &p, const DnConsts<R> &c, const R *s_tab, f
     store_obs_tile(s_tile, out.obs, rows, lane, o);
 }
 
-// Loads this lane's six state groups + nothing else; the block base is uniform, the lane offset 32-bit.
 struct BlockState {
     float4 *g0, *g1, *g2, *g3, *g4, *g5, *g6;
 };
 DN_DEV BlockState block_state(const DnState &st, long long tile_base)
-{
+{   // uniform block bases (SGPR pairs); a lane adds its 32-bit offset
     BlockState b;
     b.g0 = st.g0 + tile_base; b.g1 = st.g1 + tile_base; b.g2 = st.g2 + tile_base; b.g3 = st.g3 + tile_base;
     b.g4 = st.g4 + tile_base; b.g5 = st.g5 + tile_base; b.g6 = st.g6 + tile_base;
     return b;
 }
 
-// One control step per launch: what VecEnv.step() maps to when a policy sits between steps.
-template <typename R, bool NORM, bool NOISE>
-__global__ __launch_bounds__(DN_BLOCK) void dn_step_kernel(const DnParams p, const DnStepIO io)
+// -----------------------------------------------------------------------------------------------------
+// One-wave kernels: all four phases on one wavefront, messages in registers.  Used where there are enough
+// drones to fill the chip with whole steps (see dn_launch_step) and as the cross-check of the two-wave kernels.
+// -----------------------------------------------------------------------------------------------------
+// ONE = true is the single-step launch (dn_step): k_steps is the constant 1, and the kernel gets its own name in
+// profiles (dn_step_many_*_kernel<..., true> = one control step per launch, <..., false> = k_arg steps per launch).
+template <typename R, bool NORM, bool NOISE, bool ONE>
+__global__ __launch_bounds__(DN_BLOCK) void dn_step_many_1w_kernel(const DnParams p, const DnStepIO io0, const int k_arg)
 {
+    const int k_steps = ONE ? 1 : k_arg;
     __shared__ R s_tab[DN_MAX_WAYPOINTS * DN_T_STRIDE];
     __shared__ __attribute__((aligned(16))) float s_tile[DN_BLOCK * DN_OBS_DIM];
     const unsigned lane = threadIdx.x;
@@ -768,51 +866,153 @@ __global__ __launch_bounds__(DN_BLOCK) void dn_step_kernel(const DnParams p, con
     const bool active = lane < rows;
     const unsigned li = active ? lane : rows - 1;       // inactive lanes shadow the last drone, never store
     __builtin_assume(li < DN_BLOCK);                    // lets the lane offset stay a 32-bit VGPR (saddr addressing)
+    const long long i = tile_base + li;
+    const unsigned long long gid = (unsigned long long)(p.env_id_offset + i);
     const BlockState b = block_state(p.st, tile_base);
-    // issue every load up front (6 x 16 B state + 16 B action per lane), then stage the table
-    const float4 A = (reinterpret_cast<const float4 *>(io.actions) + tile_base)[li];
-    float4 G0 = b.g0[li], G1 = b.g1[li], G2 = b.g2[li], G3 = b.g3[li], G4 = b.g4[li], G5 = b.g5[li];
-    stage_table<R>(p, s_tab);
-    const StepOut out = block_out(io, tile_base, 0, 0);
-    step_body<R, NORM, NOISE>(p, consts<R>(p), s_tab, s_tile, out, b.g6, p.step_count, tile_base, li, lane, rows, active,
-                              A, G0, G1, G2, G3, G4, G5);
-    if (active) {
-        b.g0[li] = G0; b.g1[li] = G1; b.g2[li] = G2; b.g3[li] = G3; b.g4[li] = G4; b.g5[li] = G5;
-    }
-}
-
-// K control steps per launch for open-loop action sequences (dn_step_many): the state is read once, stays in
-// registers for K steps and is written once; per step only the action (16 B) comes in and the outputs (62 B) go
-// out, and the K-1 kernel boundaries disappear.  Buffers are step-major [K, N, ...].
-template <typename R, bool NORM, bool NOISE>
-__global__ __launch_bounds__(DN_BLOCK) void dn_step_many_kernel(const DnParams p, const DnStepIO io0, const int k_steps)
-{
-    __shared__ R s_tab[DN_MAX_WAYPOINTS * DN_T_STRIDE];
-    __shared__ __attribute__((aligned(16))) float s_tile[DN_BLOCK * DN_OBS_DIM];
-    const unsigned lane = threadIdx.x;
-    const long long tile_base = (long long)blockIdx.x * DN_BLOCK;
-    const long long left = p.n - tile_base;
-    const unsigned rows = left < DN_BLOCK ? (unsigned)left : DN_BLOCK;
-    const bool active = lane < rows;
-    const unsigned li = active ? lane : rows - 1;
-    __builtin_assume(li < DN_BLOCK);
-    const BlockState b = block_state(p.st, tile_base);
+    const DnConsts<R> &c = consts<R>(p);
     const float4 *act = reinterpret_cast<const float4 *>(io0.actions) + tile_base;
+    // issue every load up front (6 x 16 B state + 16 B action per lane), then stage the table
     float4 A = act[li];
     float4 G0 = b.g0[li], G1 = b.g1[li], G2 = b.g2[li], G3 = b.g3[li], G4 = b.g4[li], G5 = b.g5[li];
     stage_table<R>(p, s_tab);
+    block_lds_barrier();
     const long long n = p.n, words = (p.n + 63) / 64;
 #pragma clang loop unroll(disable)
     for (int t = 0; t < k_steps; ++t) {
         // prefetch the next step's action while this step computes
         const float4 A_next = (act + (long long)(t + 1 < k_steps ? t + 1 : t) * n)[li];
         const StepOut out = block_out(io0, tile_base, (long long)t * n, (long long)t * words);
-        step_body<R, NORM, NOISE>(p, consts<R>(p), s_tab, s_tile, out, b.g6, p.step_count + (unsigned)t, tile_base, li,
-                                  lane, rows, active, A, G0, G1, G2, G3, G4, G5);
+        const unsigned sc = p.step_count + (unsigned)t;
+        const Thrust th = thrust_phase<NOISE>(p, gid, sc, A);
+        const Flight<R> fl = physics_phase<R>(th, G0, G1, G2, G3, p.max_steps);
+        const float4 G0e = G0, G3e = G3;
+        const Verdict<R> v = rules_phase<R>(p, c, s_tab, fl, G0e, G3e, b.g6, li, active, G0, G1, G2, G3);
+        Observed<R> ob = observe_phase<R, NORM, NOISE>(p, c, s_tab, fl, G4, G5, gid, sc, i, active);
+        report_phase<R, NORM, NOISE>(p, c, s_tile, out, fl, v, ob, gid, sc, i, li, lane, rows, active, G4, G5);
         A = A_next;
     }
     if (active) {
         b.g0[li] = G0; b.g1[li] = G1; b.g2[li] = G2; b.g3[li] = G3; b.g4[li] = G4; b.g5[li] = G5;
+    }
+}
+
+// -----------------------------------------------------------------------------------------------------
+// Two-wave kernels: 128 threads = flight wave (threads 0..63) + report wave (64..127) over the same 64 drones.
+// Per step two LDS-only barriers:
+//
+//   flight:  Thrust(t) <- LDS | physics(t) | Flight(t) -> LDS  ==A==  rules(t) | Verdict(t) -> LDS  ==B==  ...
+//   report:  report(t-1) | thrust(t+1) -> LDS[(t+1)&1]         ==A==  Flight(t) <- LDS | observe(t)  ==B==  Verdict(t) <- LDS ...
+//
+// so the flight wave's physics(t+1) overlaps the report wave's report(t) + thrust(t+2), and rules(t) overlaps
+// observe(t).  Thrust is double-buffered (written one step ahead while the previous one may still be read);
+// Flight and Verdict are single-buffered (each is consumed inside the barrier interval after it was produced).
+// With k_steps == 1 this is the single-step kernel: thrust | physics | rules || observe | report.
+// -----------------------------------------------------------------------------------------------------
+template <typename R> struct Mail {       // LDS, field-major so that consecutive lanes hit consecutive banks
+    R flight[DN_NFLIGHT][DN_BLOCK];
+    int flight_bits[DN_BLOCK];
+    R verdict_d[DN_BLOCK];
+    int verdict_bits[DN_BLOCK];
+    float thrust[2][DN_NTHRUST][DN_BLOCK];
+};
+template <typename R> DN_DEV void post_flight(Mail<R> &m, unsigned lane, const Flight<R> &f)
+{
+    const R v[DN_NFLIGHT] = {f.px, f.py, f.pz, f.qx, f.qy, f.qz, f.qw, f.vx, f.vy, f.vz, f.wx, f.wy, f.wz,
+                             f.vex, f.vey, f.vez, f.aex, f.aey, f.aez, f.d_e, f.dprev_e};
+#pragma unroll
+    for (int k = 0; k < DN_NFLIGHT; ++k) m.flight[k][lane] = v[k];
+    m.flight_bits[lane] = f.idx_e | (f.just_found_e << 8) | (f.truncated << 9);
+}
+template <typename R> DN_DEV Flight<R> take_flight(const Mail<R> &m, unsigned lane)
+{
+    Flight<R> f;
+    R v[DN_NFLIGHT];
+#pragma unroll
+    for (int k = 0; k < DN_NFLIGHT; ++k) v[k] = m.flight[k][lane];
+    f.px = v[0]; f.py = v[1]; f.pz = v[2]; f.qx = v[3]; f.qy = v[4]; f.qz = v[5]; f.qw = v[6];
+    f.vx = v[7]; f.vy = v[8]; f.vz = v[9]; f.wx = v[10]; f.wy = v[11]; f.wz = v[12];
+    f.vex = v[13]; f.vey = v[14]; f.vez = v[15]; f.aex = v[16]; f.aey = v[17]; f.aez = v[18];
+    f.d_e = v[19]; f.dprev_e = v[20];
+    const int bits = m.flight_bits[lane];
+    f.idx_e = bits & 0xFF; f.just_found_e = (bits >> 8) & 1; f.truncated = (bits >> 9) & 1;
+    return f;
+}
+
+template <typename R, bool NORM, bool NOISE, bool ONE>
+__global__ __launch_bounds__(2 * DN_BLOCK) void dn_step_many_2w_kernel(const DnParams p, const DnStepIO io0, const int k_arg)
+{
+    const int k_steps = ONE ? 1 : k_arg;
+    __shared__ R s_tab[DN_MAX_WAYPOINTS * DN_T_STRIDE];
+    __shared__ __attribute__((aligned(16))) float s_tile[DN_BLOCK * DN_OBS_DIM];
+    __shared__ Mail<R> mail;
+    const unsigned lane = threadIdx.x & (DN_BLOCK - 1);
+    const bool report_wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) != 0;    // wave-uniform role
+    const long long tile_base = (long long)blockIdx.x * DN_BLOCK;
+    const long long left = p.n - tile_base;
+    const unsigned rows = left < DN_BLOCK ? (unsigned)left : DN_BLOCK;
+    const bool active = lane < rows;
+    const unsigned li = active ? lane : rows - 1;
+    __builtin_assume(li < DN_BLOCK);
+    const long long i = tile_base + li;
+    const unsigned long long gid = (unsigned long long)(p.env_id_offset + i);
+    const BlockState b = block_state(p.st, tile_base);
+    const DnConsts<R> &c = consts<R>(p);
+    const long long n = p.n, words = (p.n + 63) / 64;
+    stage_table<R>(p, s_tab);
+    if (report_wave) {
+        const float4 *act = reinterpret_cast<const float4 *>(io0.actions) + tile_base;
+        float4 A = act[li];
+        float4 G4 = b.g4[li], G5 = b.g5[li];
+        float4 A_next = (act + (long long)(1 < k_steps ? 1 : 0) * n)[li];
+        {   // thrust(0) for the flight wave
+            const Thrust th = thrust_phase<NOISE>(p, gid, p.step_count, A);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) mail.thrust[0][k][lane] = th.f[k];
+            mail.thrust[0][4][lane] = th.zt;
+        }
+        block_lds_barrier();                                               // P: table + Thrust(0) published
+#pragma clang loop unroll(disable)
+        for (int t = 0; t < k_steps; ++t) {
+            const unsigned sc = p.step_count + (unsigned)t;
+            if (t + 1 < k_steps) {                                         // thrust(t+1), one step ahead
+                A = A_next;
+                A_next = (act + (long long)(t + 2 < k_steps ? t + 2 : t + 1) * n)[li];
+                const Thrust th = thrust_phase<NOISE>(p, gid, sc + 1u, A);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) mail.thrust[(t + 1) & 1][k][lane] = th.f[k];
+                mail.thrust[(t + 1) & 1][4][lane] = th.zt;
+            }
+            block_lds_barrier();                                           // A(t): Flight(t) is in the mail
+            const Flight<R> fl = take_flight<R>(mail, lane);
+            Observed<R> ob = observe_phase<R, NORM, NOISE>(p, c, s_tab, fl, G4, G5, gid, sc, i, active);
+            block_lds_barrier();                                           // B(t): Verdict(t) is in the mail
+            Verdict<R> v;
+            v.d_obs = mail.verdict_d[lane];
+            const int vb = mail.verdict_bits[lane];
+            v.coll1 = vb & 1; v.terminated = (vb >> 1) & 1;
+            const StepOut out = block_out(io0, tile_base, (long long)t * n, (long long)t * words);
+            report_phase<R, NORM, NOISE>(p, c, s_tile, out, fl, v, ob, gid, sc, i, li, lane, rows, active, G4, G5);
+        }
+        if (active) { b.g4[li] = G4; b.g5[li] = G5; }
+    } else {
+        float4 G0 = b.g0[li], G1 = b.g1[li], G2 = b.g2[li], G3 = b.g3[li];
+        block_lds_barrier();                                               // P
+#pragma clang loop unroll(disable)
+        for (int t = 0; t < k_steps; ++t) {
+            Thrust th;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) th.f[k] = mail.thrust[t & 1][k][lane];
+            th.zt = mail.thrust[t & 1][4][lane];
+            const Flight<R> fl = physics_phase<R>(th, G0, G1, G2, G3, p.max_steps);
+            post_flight<R>(mail, lane, fl);
+            block_lds_barrier();                                           // A(t)
+            const float4 G0e = G0, G3e = G3;
+            const Verdict<R> v = rules_phase<R>(p, c, s_tab, fl, G0e, G3e, b.g6, li, active, G0, G1, G2, G3);
+            mail.verdict_d[lane] = v.d_obs;
+            mail.verdict_bits[lane] = v.coll1 | (v.terminated << 1);
+            block_lds_barrier();                                           // B(t)
+        }
+        if (active) { b.g0[li] = G0; b.g1[li] = G1; b.g2[li] = G2; b.g3[li] = G3; }
     }
 }
 
@@ -837,6 +1037,7 @@ __global__ __launch_bounds__(DN_BLOCK) void dn_reset_kernel(const DnParams p, fl
     const BlockState b = block_state(p.st, tile_base);
     const float4 G0 = b.g0[li], G3 = b.g3[li], G6 = b.g6[li];
     stage_table<R>(p, s_tab);
+    block_lds_barrier();
     const Meta m = unpack_meta(G3.w);
     R cpx, cpy, cpz;
     if (m.steps > 0) { cpx = G0.x; cpy = G0.y; cpz = G0.z; } else { cpx = G6.x; cpy = G6.y; cpz = G6.z; }
@@ -973,13 +1174,25 @@ hipError_t dn_launch_filld(double *dst, double v, long long n, hipStream_t strea
     return hipGetLastError();
 }
 
-hipError_t dn_launch_step(const DnParams &p, const DnStepIO &io, bool f32, hipStream_t stream)
+// Kernel shape: two waves per 64 drones where the chip would otherwise idle (the step is issue-bound and the
+// second wave runs on another SIMD), one wave per 64 drones where there are enough drones to fill every SIMD with
+// whole steps.  Both produce identical bits (tests/test_gpu_parity.py::test_kernel_shapes_are_bit_identical).
+hipError_t dn_launch_step_many(const DnParams &p, const DnStepIO &io, int k, bool f32, bool two_wave, hipStream_t stream)
 {
     const unsigned grid = (unsigned)((p.n + DN_BLOCK - 1) / DN_BLOCK);
     const bool norm = p.normalize_obs != 0;
     const bool noise = p.act_noise_sigma > 0.0f || p.obs_noise_sigma > 0.0f;
-#define DN_LAUNCH(R, NORM, NOISE) \
-    hipLaunchKernelGGL((dn_step_kernel<R, NORM, NOISE>), dim3(grid), dim3(DN_BLOCK), 0, stream, p, io)
+#define DN_LAUNCH2(R, NORM, NOISE, ONE)                                                                                 \
+    do {                                                                                                                \
+        if (two_wave)                                                                                                   \
+            hipLaunchKernelGGL((dn_step_many_2w_kernel<R, NORM, NOISE, ONE>), dim3(grid), dim3(2 * DN_BLOCK), 0, stream, p, io, k); \
+        else                                                                                                            \
+            hipLaunchKernelGGL((dn_step_many_1w_kernel<R, NORM, NOISE, ONE>), dim3(grid), dim3(DN_BLOCK), 0, stream, p, io, k);     \
+    } while (0)
+#define DN_LAUNCH(R, NORM, NOISE)                                                                                       \
+    do {                                                                                                                \
+        if (k == 1) DN_LAUNCH2(R, NORM, NOISE, true); else DN_LAUNCH2(R, NORM, NOISE, false);                           \
+    } while (0)
     if (f32) {
         if (norm) { if (noise) DN_LAUNCH(float, true, true); else DN_LAUNCH(float, true, false); }
         else { if (noise) DN_LAUNCH(float, false, true); else DN_LAUNCH(float, false, false); }
@@ -988,24 +1201,7 @@ hipError_t dn_launch_step(const DnParams &p, const DnStepIO &io, bool f32, hipSt
         else { if (noise) DN_LAUNCH(double, false, true); else DN_LAUNCH(double, false, false); }
     }
 #undef DN_LAUNCH
-    return hipGetLastError();
-}
-
-hipError_t dn_launch_step_many(const DnParams &p, const DnStepIO &io, int k, bool f32, hipStream_t stream)
-{
-    const unsigned grid = (unsigned)((p.n + DN_BLOCK - 1) / DN_BLOCK);
-    const bool norm = p.normalize_obs != 0;
-    const bool noise = p.act_noise_sigma > 0.0f || p.obs_noise_sigma > 0.0f;
-#define DN_LAUNCH(R, NORM, NOISE) \
-    hipLaunchKernelGGL((dn_step_many_kernel<R, NORM, NOISE>), dim3(grid), dim3(DN_BLOCK), 0, stream, p, io, k)
-    if (f32) {
-        if (norm) { if (noise) DN_LAUNCH(float, true, true); else DN_LAUNCH(float, true, false); }
-        else { if (noise) DN_LAUNCH(float, false, true); else DN_LAUNCH(float, false, false); }
-    } else {
-        if (norm) { if (noise) DN_LAUNCH(double, true, true); else DN_LAUNCH(double, true, false); }
-        else { if (noise) DN_LAUNCH(double, false, true); else DN_LAUNCH(double, false, false); }
-    }
-#undef DN_LAUNCH
+#undef DN_LAUNCH2
     return hipGetLastError();
 }
 

@@ -353,6 +353,11 @@ class DroneVecEnv(_VecEnvBase):
     def reset_stats(self):
         _capi.check(self._lib.dn_reset_stats(self._handle, self._stream()))
 
+    def kernel_waves(self, fused=False):
+        """Kernel shape of dn_step (fused=False) / dn_step_many (fused=True): 2 = flight wave + report wave per 64
+        drones, 1 = one wave per 64 drones (dn_get_kernel_waves)."""
+        return int(self._lib.dn_get_kernel_waves(self._handle, int(bool(fused))))
+
     @property
     def step_count(self):
         v = C.c_uint64()

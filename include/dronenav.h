@@ -160,6 +160,12 @@ int32_t dn_set_state(dn_env *env, const dn_env_state *states, int64_t count);
 int32_t dn_get_stats(dn_env *env, dn_stats *out, void *stream);
 int32_t dn_reset_stats(dn_env *env, void *stream);
 
+/* Kernel shape chosen for this environment's launches (fused != 0: dn_step_many with k > 1; fused == 0: dn_step):
+ * 2 = a flight wave + a report wave per 64 drones (small fleets, fused launches: the step is instruction-issue bound
+ * and the second wave runs on an otherwise idle SIMD), 1 = one wave per 64 drones.  Both shapes produce identical
+ * bits.  Environment variable DN_WAVES=1|2 forces one shape for every launch. */
+int32_t dn_get_kernel_waves(const dn_env *env, int32_t fused);
+
 /* Vector-step counter used as the Philox counter word of the noise streams. */
 int32_t dn_get_step_count(const dn_env *env, uint64_t *out);
 int32_t dn_set_step_count(dn_env *env, uint64_t value);

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Turn the rocprofv3 (ROCm 7.2, rocpd sqlite) outputs written by scratch/prof.sh into a small text summary
+"""Turn the rocprofv3 (ROCm 7.2, rocpd sqlite) outputs written by profiles/prof.sh into a small text summary
 that can be committed:  python profiles/summarize.py gpurun_out/prof_<tag> > profiles/<name>.txt
 
 Reads  <dir>/stats/stats_results.db   (--kernel-trace --stats)
@@ -49,7 +49,7 @@ def main(d):
                                  "and kernel_name like '%dn_%' group by kernel_name"):
             out.append(f"  {avg:14.2f} KB  x{n:6d}  {name}")
             vals[(ctr, name)] = avg
-    steps = [k[1] for k in vals if "dn_step_kernel" in k[1] or "dn_step_many_kernel" in k[1]]
+    steps = [k[1] for k in vals if "dn_step_" in k[1]]
     for name in sorted(set(steps)):
         f, w = vals.get(("FETCH_SIZE", name)), vals.get(("WRITE_SIZE", name))
         if f is not None and w is not None:
@@ -58,6 +58,8 @@ def main(d):
             out.append(f"  read  = 2 x FETCH_SIZE = {2 * f * 1024 / 1e6:.3f} MB   (gfx950 wide-load correction x2)")
             out.append(f"  write =     WRITE_SIZE = {w * 1024 / 1e6:.3f} MB")
             out.append(f"  total = {hbm / 1e6:.3f} MB per launch")
+    out.append("\n(dn_step_many_Nw_kernel<R, NORM, NOISE, ONE>: N = waves per 64 drones; ONE = true is the single-step launch "
+               "dn_step, ONE = false the fused K-step launch dn_step_many)")
     print("\n".join(out))
 
 

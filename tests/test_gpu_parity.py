@@ -527,3 +527,44 @@ def test_action_chain_bit_exact_vs_reference_golden(golden):
         assert np.array_equal(rpm.cpu().numpy()[sel].view(np.uint32), rpm_ref[sel].view(np.uint32)), norm
         assert np.array_equal(forces.cpu().numpy()[sel].view(np.uint32), f_ref[sel].view(np.uint32)), norm
         assert np.array_equal(zt.cpu().numpy()[sel].view(np.uint32), z_ref[sel].view(np.uint32)), norm
+
+
+@pytest.mark.parametrize("norm,noise", [(False, 0.0), (True, 0.01)])
+def test_kernel_shapes_are_bit_identical(norm, noise, monkeypatch):
+    """The two-wave kernels (flight wave + report wave, messages through LDS) and the one-wave kernels (same
+    phases, messages in registers) must agree bit for bit: state, outputs, statistics; single steps and fused."""
+    pkg = _gpu()
+    track = _tracks().reaching()
+    n, K = 1000, 70                       # ragged last tile on purpose
+    kw = dict(normalize_obs=norm, max_steps=30, obs_noise_sigma=noise, act_noise_sigma=noise / 10, seed=5)
+    envs = {}
+    for shape in ("1", "2"):
+        monkeypatch.setenv("DN_WAVES", shape)
+        envs[shape] = pkg.DroneVecEnv(track, n, device="cuda:0", **kw)
+        envs[shape].reset()
+    monkeypatch.delenv("DN_WAVES")
+    rng = np.random.default_rng(21)
+    dev = torch.device("cuda:0")
+    acts = torch.from_numpy(np.stack([actions_mixed(rng, n) for _ in range(K)])).to(dev)
+    outs = {}
+    for shape, env in envs.items():
+        first = [env.step_tensor(acts[t]) for t in range(6)]       # single-step launches ...
+        first = [(o.clone(), r.clone(), d.clone(), {k: v.clone() for k, v in i.items()}) for o, r, d, i in first[-1:]]
+        rest = env.rollout_tensor(acts[6:].contiguous(), want_terminal=True)   # ... then one fused launch (n % 4 == 0)
+        outs[shape] = (first, rest, env.get_state(), env.stats())
+    (f1, r1, s1, st1), (f2, r2, s2, st2) = outs["1"], outs["2"]
+    for a, b in zip(f1, f2):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+        for k in a[3]:
+            assert torch.equal(a[3][k], b[3][k]), k
+    for k in r1:
+        if k in ("terminal_obs", "ep_return", "ep_length"):
+            d = r1["done"].bool()
+            assert torch.equal(r1[k][d], r2[k][d]), k
+        else:
+            assert torch.equal(r1[k], r2[k]), k
+    for k in s1.dtype.names:
+        assert np.ascontiguousarray(s1[k]).tobytes() == np.ascontiguousarray(s2[k]).tobytes(), k
+    assert st1 == st2 and st1["episodes"] > n
+    for env in envs.values():
+        env.close()
