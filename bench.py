@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--action-batches", type=int, default=64, help="distinct resident action batches cycled")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ppo-rollout", action="store_true", help="skip the policy-in-the-loop rollout measurement")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the RCCL process group even for one rank (exercises the N > 1 code path on a 1-GPU box)")
     return ap.parse_args()
 
 
@@ -94,6 +97,37 @@ def cpu_baseline(track, num_envs, max_steps, seconds):
             "thread_ladder": {str(t): round(v, 1) for t, v in probe.items()}}
 
 
+def ppo_rollout(pkg, track, n, max_steps, dev, rank):
+    """BASELINE configs[2] as the learner sees it: SB3-PPO-shaped rollout collection with the policy in the loop --
+    n_steps x (MLP 13-512-512-256 actor + critic, Gaussian sample, clip, dn_step, truncation bootstrap) + GAE, every
+    buffer on the GPU, the rollout replayed from a hipGraph.  Reported beside the headline, never as `value`."""
+    import torch
+    from drl_dronenavigation_amd.collector import RolloutCollector
+    n_steps = 32                                   # re-parameterised from 4096 (SURVEY section 7: 4096 x 32768 does not fit)
+    torch.manual_seed(1 + rank)
+    net = pkg.MlpActorCritic().to(dev)
+    res = {}
+    for label, use_graph in (("eager", False), ("graph", True)):
+        env = pkg.DroneVecEnv(track, n, max_steps=max_steps, normalize_obs=True, env_id_offset=rank * n, device=dev)
+        col = RolloutCollector(env, net, n_steps, value_fn=net.predict_values, use_graph=use_graph)
+        for _ in range(3):
+            col.collect()
+        torch.cuda.synchronize(dev)
+        reps = 5
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            col.collect()
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        res[label] = n * n_steps * reps / dt
+        env.close()
+    return {"value": round(res["graph"], 1), "unit": "env-steps/s", "eager_value": round(res["eager"], 1),
+            "n_steps": n_steps, "num_envs": n,
+            "what": "policy-in-the-loop rollout: torch MLP 13-512-512-256 (pi, vf; Tanh; fp32, rocBLAS) + Gaussian sample + "
+                    "dn_step + V(terminal_obs) bootstrap per step, dn_gae per rollout, per-drone obs normaliser on, "
+                    "hipGraph replay"}
+
+
 def main():
     args = parse()
     import torch
@@ -107,9 +141,10 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import drl_dronenavigation_amd as pkg
@@ -270,6 +305,8 @@ def main():
                          "avg_launch_us": round(launch_us, 4), "us_per_vector_step": round(step_us, 4)},
             "other_launch_shapes": others,
         }
+        if world == 1 and not args.no_ppo_rollout:
+            line["ppo_rollout"] = ppo_rollout(pkg, track, n, max_steps, dev, rank)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(track, n, max_steps, args.cpu_baseline_seconds)
         print(json.dumps(line), flush=True)

@@ -11,7 +11,7 @@ from ._capi import DroneNavError, DroneNavLibraryError  # noqa: F401
 from .tracks import Track  # noqa: F401
 
 __all__ = ["DroneVecEnv", "Track", "tracks", "gae", "DroneNavError", "DroneNavLibraryError", "make_config",
-           "RolloutCollector", "ShardPlan", "all_gather_rollout", "preprocess_action"]
+           "RolloutCollector", "ShardPlan", "all_gather_rollout", "preprocess_action", "MlpActorCritic"]
 
 
 def __getattr__(name):
@@ -23,4 +23,7 @@ def __getattr__(name):
     if name in ("collector", "RolloutCollector", "ShardPlan", "all_gather_rollout"):
         collector = importlib.import_module(__name__ + ".collector")
         return collector if name == "collector" else getattr(collector, name)
+    if name in ("policy", "MlpActorCritic"):
+        policy = importlib.import_module(__name__ + ".policy")
+        return policy if name == "policy" else getattr(policy, name)
     raise AttributeError(name)

@@ -78,37 +78,49 @@ class RolloutCollector:
     policy(obs[N,13] f32) -> (actions[N,4] f32, values[N] f32, log_probs[N] f32), all on the env's device;
     value_fn(obs) -> values[N] (defaults to the policy's second output).  Actions are clipped to the action
     space before the step, as SB3 does.  `bootstrap_truncated` adds gamma * V(terminal_observation) to the reward
-    of drones whose episode hit the time limit (SB3's TimeLimit handling)."""
+    of drones whose episode hit the time limit (SB3's TimeLimit handling).
+
+    `use_graph`: the whole rollout -- n_steps x (policy kernels, clip, dn_step, bootstrap, buffer writes) and the
+    GAE kernel -- is captured into one hipGraph on the second call to collect() (the first call runs eagerly and
+    doubles as the warm-up) and replayed afterwards: the loop is launch-bound (a 13->512->512->256 MLP step is a
+    dozen small kernels), and a graph replay takes the host out of it.  Every tensor the loop touches is a static
+    buffer; the environment's vector-step counter lives on the device, so noise streams keep advancing under replay.
+    The policy must be capture-safe (no host synchronisation, no data-dependent shapes)."""
 
     def __init__(self, env, policy, n_steps, *, value_fn=None, gamma=0.99, gae_lambda=0.95, bootstrap_truncated=True,
-                 gather=False, group=None):
+                 gather=False, group=None, use_graph=False):
         from .vec_env import ACT_DIM, DroneVecEnv
         if not isinstance(env, DroneVecEnv):
             raise TypeError("RolloutCollector drives a DroneVecEnv (HIP); there is no CPU path")
         self.env, self.policy, self.value_fn = env, policy, value_fn
         self.n_steps, self.gamma, self.gae_lambda = int(n_steps), float(gamma), float(gae_lambda)
         self.bootstrap_truncated, self.gather, self.group = bool(bootstrap_truncated), bool(gather), group
+        self.use_graph = bool(use_graph)
         n, T, dev, f32 = env.num_envs, self.n_steps, env.device, torch.float32
         self.buf = dict(
             obs=torch.empty((T, n, env.obs_dim), dtype=f32, device=dev),
             actions=torch.empty((T, n, ACT_DIM), dtype=f32, device=dev),
             values=torch.empty((T, n), dtype=f32, device=dev), log_probs=torch.empty((T, n), dtype=f32, device=dev),
             rewards=torch.empty((T, n), dtype=f32, device=dev),
-            episode_starts=torch.empty((T, n), dtype=torch.uint8, device=dev))
+            episode_starts=torch.empty((T, n), dtype=torch.uint8, device=dev),
+            advantages=torch.empty((T, n), dtype=f32, device=dev), returns=torch.empty((T, n), dtype=f32, device=dev),
+            last_values=torch.empty(n, dtype=f32, device=dev), last_dones=torch.empty(n, dtype=torch.uint8, device=dev))
+        self._clipped = torch.empty((n, ACT_DIM), dtype=f32, device=dev)
         self._last_obs = env.reset_tensor().clone()
         self._last_done = torch.ones(n, dtype=torch.uint8, device=dev)       # SB3: _last_episode_starts = True
         self.num_timesteps = 0
+        self._graph = None
+        self._calls = 0
 
     def _values(self, obs):
         if self.value_fn is not None:
             return self.value_fn(obs).reshape(-1)
         return self.policy(obs)[1].reshape(-1)
 
-    @torch.no_grad()
-    def collect(self):
-        """One rollout.  Returns the buffer dict plus `advantages`, `returns` ([n_steps, N_local]) and, with
-        `gather`, `advantages_global` / `returns_global` ([n_steps, N_global])."""
-        from .vec_env import gae
+    def _rollout(self):
+        """One rollout on the current stream, in place in the static buffers (eager or under graph capture)."""
+        from . import _capi
+        import ctypes as C
         env, b = self.env, self.buf
         obs, done = self._last_obs, self._last_done
         for t in range(self.n_steps):
@@ -118,19 +130,42 @@ class RolloutCollector:
             b["values"][t].copy_(values.reshape(-1))
             b["log_probs"][t].copy_(log_probs.reshape(-1))
             b["actions"][t].copy_(actions)
-            clipped = b["actions"][t].clamp(-1.0, 1.0)
-            next_obs, reward, next_done, info = env.step_tensor(clipped, want_terminal=self.bootstrap_truncated)
+            torch.clamp(b["actions"][t], -1.0, 1.0, out=self._clipped)
+            next_obs, reward, next_done, info = env.step_tensor(self._clipped, want_terminal=self.bootstrap_truncated)
             if self.bootstrap_truncated:
                 # rows of terminal_obs are valid only where done; `truncated` is zero elsewhere
                 tv = self._values(torch.where(next_done.bool()[:, None], info["terminal_obs"], next_obs))
                 reward = reward + self.gamma * tv * info["truncated"].to(reward.dtype)
             b["rewards"][t].copy_(reward)
-            obs, done = next_obs.clone(), next_done.clone()
-        self._last_obs, self._last_done = obs, done
+            obs.copy_(next_obs)
+            done.copy_(next_done)
+        b["last_values"].copy_(self._values(obs))
+        b["last_dones"].copy_(done)
+        dev = env.device
+        _capi.check(_capi.load().dn_gae(
+            b["rewards"].data_ptr(), b["values"].data_ptr(), b["episode_starts"].data_ptr(), b["last_values"].data_ptr(),
+            b["last_dones"].data_ptr(), self.n_steps, env.num_envs, self.gamma, self.gae_lambda,
+            b["advantages"].data_ptr(), b["returns"].data_ptr(), dev.index,
+            C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+
+    @torch.no_grad()
+    def collect(self):
+        """One rollout.  Returns the buffer dict (static tensors, overwritten by the next call) with `advantages`,
+        `returns` ([n_steps, N_local]) and, with `gather`, `advantages_global` / `returns_global` ([n_steps, N_global])."""
+        env = self.env
+        with torch.cuda.device(env.device):
+            if self.use_graph and self._calls >= 1:
+                if self._graph is None:
+                    torch.cuda.synchronize(env.device)
+                    self._graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(self._graph):
+                        self._rollout()
+                self._graph.replay()
+            else:
+                self._rollout()
+        self._calls += 1
         self.num_timesteps += self.n_steps * env.num_envs
-        last_values = self._values(obs)
-        adv, ret = gae(b["rewards"], b["values"], b["episode_starts"], last_values, done, self.gamma, self.gae_lambda)
-        out = dict(b, advantages=adv, returns=ret, last_values=last_values, last_dones=done)
+        out = dict(self.buf)
         if self.gather:
-            out["advantages_global"], out["returns_global"] = all_gather_rollout(adv, ret, self.group)
+            out["advantages_global"], out["returns_global"] = all_gather_rollout(out["advantages"], out["returns"], self.group)
         return out

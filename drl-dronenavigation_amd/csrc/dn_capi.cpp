@@ -49,7 +49,6 @@ struct dn_env {
     size_t arena_bytes = 0;
     double *tab64 = nullptr;
     float *tab32 = nullptr;
-    uint64_t step_count = 0;
     long long blocks = 0;
     int waves_fused = 2;        // kernel shape of dn_step_many (k > 1), see dn_launch_step_many
     int waves_single = 1;       // kernel shape of dn_step (k == 1)
@@ -311,7 +310,6 @@ int32_t dn_reset(dn_env *env, float *obs, void *stream)
 {
     if (!env) return fail(DN_ERR_INVALID_ARGUMENT, "env is NULL");
     if (!obs) return fail(DN_ERR_INVALID_ARGUMENT, "obs is NULL");
-    env->p.step_count = (unsigned)env->step_count;
     DN_HIP(dn_launch_reset(env->p, obs, env->cfg.compute_f32 != 0, (hipStream_t)stream));
     return DN_OK;
 }
@@ -329,9 +327,7 @@ int32_t dn_step(dn_env *env, const float *actions, float *obs, float *reward, ui
     io.actions = actions; io.obs = obs; io.reward = reward; io.done = done; io.truncated = truncated;
     io.found_targets = found_targets; io.terminal_obs = terminal_obs; io.ep_return = ep_return;
     io.ep_length = ep_length; io.done_mask = (unsigned long long *)done_mask;
-    env->p.step_count = (unsigned)env->step_count;
     DN_HIP(dn_launch_step_many(env->p, io, 1, env->cfg.compute_f32 != 0, env->waves_single == 2, (hipStream_t)stream));
-    env->step_count += 1;
     return DN_OK;
 }
 
@@ -356,9 +352,7 @@ int32_t dn_step_many(dn_env *env, int64_t k, const float *actions, float *obs, f
     io.actions = actions; io.obs = obs; io.reward = reward; io.done = done; io.truncated = truncated;
     io.found_targets = found_targets; io.terminal_obs = terminal_obs; io.ep_return = ep_return;
     io.ep_length = ep_length; io.done_mask = (unsigned long long *)done_mask;
-    env->p.step_count = (unsigned)env->step_count;
     DN_HIP(dn_launch_step_many(env->p, io, (int)k, env->cfg.compute_f32 != 0, env->waves_fused == 2, (hipStream_t)stream));
-    env->step_count += (uint64_t)k;
     return DN_OK;
 }
 
@@ -472,14 +466,19 @@ int32_t dn_get_stats(dn_env *env, dn_stats *out, void *stream)
         out->sum_ep_len += s.sum_len; out->sum_found_targets += s.sum_found; fix += s.sum_ret_fix;
     }
     out->sum_ep_return = (double)fix * 1e-6;
-    out->env_steps = (int64_t)env->step_count * env->cfg.num_envs;
+    out->env_steps = (int64_t)slots[0].step_count * env->cfg.num_envs;
     return DN_OK;
 }
 
 int32_t dn_reset_stats(dn_env *env, void *stream)
 {
     if (!env) return fail(DN_ERR_INVALID_ARGUMENT, "env is NULL");
+    // the slots also hold the vector-step counter, which a statistics reset must not rewind
+    uint64_t steps = 0;
+    int32_t rc = dn_get_step_count(env, &steps);
+    if (rc != DN_OK) return rc;
     DN_HIP(hipMemsetAsync(env->p.st.stats, 0, (size_t)env->blocks * sizeof(DnStatSlot), (hipStream_t)stream));
+    DN_HIP(dn_launch_set_step_count(env->p.st.stats, env->blocks, steps, (hipStream_t)stream));
     return DN_OK;
 }
 
@@ -488,14 +487,22 @@ int32_t dn_get_kernel_waves(const dn_env *env, int32_t fused) { return env ? (fu
 int32_t dn_get_step_count(const dn_env *env, uint64_t *out)
 {
     if (!env || !out) return fail(DN_ERR_INVALID_ARGUMENT, "env and out are required");
-    *out = env->step_count;
+    // the counter lives on the device (it advances under hipGraph replay too); every tile carries the same value
+    DN_HIP(hipSetDevice(env->cfg.device_id));
+    DN_HIP(hipDeviceSynchronize());
+    unsigned long long v = 0;
+    DN_HIP(hipMemcpy(&v, &env->p.st.stats[0].step_count, sizeof v, hipMemcpyDeviceToHost));
+    *out = v;
     return DN_OK;
 }
 
 int32_t dn_set_step_count(dn_env *env, uint64_t value)
 {
     if (!env) return fail(DN_ERR_INVALID_ARGUMENT, "env is NULL");
-    env->step_count = value;
+    DN_HIP(hipSetDevice(env->cfg.device_id));
+    DN_HIP(hipDeviceSynchronize());
+    DN_HIP(dn_launch_set_step_count(env->p.st.stats, env->blocks, value, nullptr));
+    DN_HIP(hipStreamSynchronize(nullptr));
     return DN_OK;
 }
 

@@ -28,8 +28,12 @@ enum {
 
 // Per-workgroup episode statistics slot (workgroup b always owns drones [64b, 64b+64), so its lane 0
 // read-modify-writes the slot without atomics: deterministic, no contended counter).
+// The slot also carries the tile's vector-step counter (the Philox counter word of the noise streams and the
+// source of dn_stats.env_steps): it advances on the device, so launches replayed from a hipGraph keep counting.
 struct DnStatSlot {
     long long episodes, truncated, completed, sum_len, sum_found, sum_ret_fix;
+    unsigned long long step_count;
+    long long pad_;
 };
 
 // Persistent state in HBM: "SoA of float4 groups" -- each group is an array of N float4, lane i reads
@@ -86,7 +90,6 @@ struct DnParams {
     float act_noise_sigma, obs_noise_sigma;
     unsigned long long seed;
     long long env_id_offset;
-    unsigned int step_count;
     const double *tab64;   // [W][DN_T_STRIDE] float64 table
     const float *tab32;    // same, float32
     DnConsts<double> c64;
@@ -102,6 +105,7 @@ hipError_t dn_launch_action_chain(const float *actions, long long n, int normali
                                   float *z_torque, hipStream_t stream);
 hipError_t dn_launch_fill4(float4 *dst, float4 v, long long n, hipStream_t stream);
 hipError_t dn_launch_filld(double *dst, double v, long long n, hipStream_t stream);
+hipError_t dn_launch_set_step_count(DnStatSlot *slots, long long blocks, unsigned long long value, hipStream_t stream);
 hipError_t dn_launch_compact(const unsigned long long *mask, long long n, int32_t *indices, int32_t *count,
                              hipStream_t stream);
 

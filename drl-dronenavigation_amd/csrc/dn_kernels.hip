@@ -877,12 +877,13 @@ __global__ __launch_bounds__(DN_BLOCK) void dn_step_many_1w_kernel(const DnParam
     stage_table<R>(p, s_tab);
     block_lds_barrier();
     const long long n = p.n, words = (p.n + 63) / 64;
+    const unsigned long long sc0 = p.st.stats[blockIdx.x].step_count;      // this tile's vector-step counter
 #pragma clang loop unroll(disable)
     for (int t = 0; t < k_steps; ++t) {
         // prefetch the next step's action while this step computes
         const float4 A_next = (act + (long long)(t + 1 < k_steps ? t + 1 : t) * n)[li];
         const StepOut out = block_out(io0, tile_base, (long long)t * n, (long long)t * words);
-        const unsigned sc = p.step_count + (unsigned)t;
+        const unsigned sc = (unsigned)sc0 + (unsigned)t;
         const Thrust th = thrust_phase<NOISE>(p, gid, sc, A);
         const Flight<R> fl = physics_phase<R>(th, G0, G1, G2, G3, p.max_steps);
         const float4 G0e = G0, G3e = G3;
@@ -891,6 +892,7 @@ __global__ __launch_bounds__(DN_BLOCK) void dn_step_many_1w_kernel(const DnParam
         report_phase<R, NORM, NOISE>(p, c, s_tile, out, fl, v, ob, gid, sc, i, li, lane, rows, active, G4, G5);
         A = A_next;
     }
+    if (lane == 0) p.st.stats[blockIdx.x].step_count = sc0 + (unsigned long long)k_steps;
     if (active) {
         b.g0[li] = G0; b.g1[li] = G1; b.g2[li] = G2; b.g3[li] = G3; b.g4[li] = G4; b.g5[li] = G5;
     }
@@ -960,12 +962,13 @@ __global__ __launch_bounds__(2 * DN_BLOCK) void dn_step_many_2w_kernel(const DnP
     const long long n = p.n, words = (p.n + 63) / 64;
     stage_table<R>(p, s_tab);
     if (report_wave) {
+        const unsigned long long sc0 = p.st.stats[blockIdx.x].step_count;  // this tile's vector-step counter
         const float4 *act = reinterpret_cast<const float4 *>(io0.actions) + tile_base;
         float4 A = act[li];
         float4 G4 = b.g4[li], G5 = b.g5[li];
         float4 A_next = (act + (long long)(1 < k_steps ? 1 : 0) * n)[li];
         {   // thrust(0) for the flight wave
-            const Thrust th = thrust_phase<NOISE>(p, gid, p.step_count, A);
+            const Thrust th = thrust_phase<NOISE>(p, gid, (unsigned)sc0, A);
 #pragma unroll
             for (int k = 0; k < 4; ++k) mail.thrust[0][k][lane] = th.f[k];
             mail.thrust[0][4][lane] = th.zt;
@@ -973,7 +976,7 @@ __global__ __launch_bounds__(2 * DN_BLOCK) void dn_step_many_2w_kernel(const DnP
         block_lds_barrier();                                               // P: table + Thrust(0) published
 #pragma clang loop unroll(disable)
         for (int t = 0; t < k_steps; ++t) {
-            const unsigned sc = p.step_count + (unsigned)t;
+            const unsigned sc = (unsigned)sc0 + (unsigned)t;
             if (t + 1 < k_steps) {                                         // thrust(t+1), one step ahead
                 A = A_next;
                 A_next = (act + (long long)(t + 2 < k_steps ? t + 2 : t + 1) * n)[li];
@@ -993,6 +996,7 @@ __global__ __launch_bounds__(2 * DN_BLOCK) void dn_step_many_2w_kernel(const DnP
             const StepOut out = block_out(io0, tile_base, (long long)t * n, (long long)t * words);
             report_phase<R, NORM, NOISE>(p, c, s_tile, out, fl, v, ob, gid, sc, i, li, lane, rows, active, G4, G5);
         }
+        if (lane == 0) p.st.stats[blockIdx.x].step_count = sc0 + (unsigned long long)k_steps;
         if (active) { b.g4[li] = G4; b.g5[li] = G5; }
     } else {
         float4 G0 = b.g0[li], G1 = b.g1[li], G2 = b.g2[li], G3 = b.g3[li];
@@ -1044,7 +1048,7 @@ __global__ __launch_bounds__(DN_BLOCK) void dn_reset_kernel(const DnParams p, fl
     float o[DN_OBS_DIM];
     reset_obs<R>(p, c, (R)G0.w, o);
     const unsigned long long gid = (unsigned long long)(p.env_id_offset + i);
-    if (p.obs_noise_sigma > 0.0f) add_obs_noise(p, gid, p.step_count, 5u, o);
+    if (p.obs_noise_sigma > 0.0f) add_obs_noise(p, gid, (unsigned)p.st.stats[blockIdx.x].step_count, 5u, o);
     if (p.normalize_obs) {
         double cnt = p.st.rms_count[i];
         normalize_obs(p, i, active, cnt, o);
@@ -1147,6 +1151,12 @@ __global__ __launch_bounds__(256) void dn_action_chain_kernel(const float4 *__re
     if (z_torque) z_torque[i] = z_torque32(tq);
 }
 
+__global__ __launch_bounds__(256) void dn_set_step_count_kernel(DnStatSlot *slots, long long blocks, unsigned long long value)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < blocks; i += (long long)gridDim.x * blockDim.x)
+        slots[i].step_count = value;
+}
+
 __global__ __launch_bounds__(256) void dn_fill4_kernel(float4 *dst, float4 v, long long n)
 {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) dst[i] = v;
@@ -1229,6 +1239,13 @@ hipError_t dn_launch_action_chain(const float *actions, long long n, int normali
     const unsigned grid = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(dn_action_chain_kernel, dim3(grid), dim3(256), 0, stream, reinterpret_cast<const float4 *>(actions), n,
                        normalize_actions, reinterpret_cast<float4 *>(rpm), reinterpret_cast<float4 *>(forces), z_torque);
+    return hipGetLastError();
+}
+
+hipError_t dn_launch_set_step_count(DnStatSlot *slots, long long blocks, unsigned long long value, hipStream_t stream)
+{
+    const unsigned grid = (unsigned)((blocks + 255) / 256 < 1024 ? (blocks + 255) / 256 : 1024);
+    hipLaunchKernelGGL(dn_set_step_count_kernel, dim3(grid), dim3(256), 0, stream, slots, blocks, value);
     return hipGetLastError();
 }
 

@@ -1,0 +1,59 @@
+"""The policy/value network the reference trains, as a plain torch module for the rollout collector and benches.
+
+Reference: PBDroneSimulator.setup_agent builds SB3 `PPO(ActorCriticPolicy, policy_kwargs=dict(activation_fn=Tanh,
+net_arch=dict(pi=[512, 512, 256], vf=[512, 512, 256])))` (Sol/Model/PBDroneSimulator.py:251-286): separate
+actor and critic MLPs over the 13-float observation, a linear action head with a state-independent log-std
+(diagonal Gaussian, log_std_init = 0) and a linear value head; SB3 initialises orthogonally (gain sqrt(2) for the
+trunk, 0.01 for the action head, 1 for the value head) [3P-recall].  The GEMMs go to rocBLAS/hipBLASLt through
+torch (plain library GEMMs); this module is host-side plumbing around the step kernel, not part of its roofline.
+"""
+import math
+
+import torch
+from torch import nn
+
+
+def _mlp(sizes, act):
+    layers = []
+    for a, b in zip(sizes[:-1], sizes[1:]):
+        layers += [nn.Linear(a, b), act()]
+    return nn.Sequential(*layers)
+
+
+class MlpActorCritic(nn.Module):
+    def __init__(self, obs_dim=13, act_dim=4, pi=(512, 512, 256), vf=(512, 512, 256), log_std_init=0.0,
+                 ortho_init=True):
+        super().__init__()
+        self.pi = _mlp((obs_dim,) + tuple(pi), nn.Tanh)
+        self.vf = _mlp((obs_dim,) + tuple(vf), nn.Tanh)
+        self.action_net = nn.Linear(pi[-1], act_dim)
+        self.value_net = nn.Linear(vf[-1], 1)
+        self.log_std = nn.Parameter(torch.full((act_dim,), float(log_std_init)))
+        if ortho_init:
+            for mod, gain in ((self.pi, math.sqrt(2)), (self.vf, math.sqrt(2)), (self.action_net, 0.01), (self.value_net, 1.0)):
+                for m in mod.modules():
+                    if isinstance(m, nn.Linear):
+                        nn.init.orthogonal_(m.weight, gain=gain)
+                        nn.init.zeros_(m.bias)
+
+    def _dist(self, obs):
+        return self.action_net(self.pi(obs)), self.log_std.expand(obs.shape[0], -1)
+
+    @staticmethod
+    def _log_prob(actions, mean, log_std):
+        z = (actions - mean) * torch.exp(-log_std)
+        return (-0.5 * z * z - log_std - 0.5 * math.log(2 * math.pi)).sum(-1)
+
+    def forward(self, obs, deterministic=False):
+        """obs [N, obs_dim] -> (actions [N, act_dim] (unclipped, as SB3 stores them), values [N], log_prob [N])."""
+        mean, log_std = self._dist(obs)
+        actions = mean if deterministic else mean + torch.exp(log_std) * torch.randn_like(mean)
+        return actions, self.value_net(self.vf(obs)).squeeze(-1), self._log_prob(actions, mean, log_std)
+
+    def predict_values(self, obs):
+        return self.value_net(self.vf(obs)).squeeze(-1)
+
+    def evaluate_actions(self, obs, actions):
+        mean, log_std = self._dist(obs)
+        entropy = (0.5 + 0.5 * math.log(2 * math.pi) + log_std).sum(-1)
+        return self.predict_values(obs), self._log_prob(actions, mean, log_std), entropy

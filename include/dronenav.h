@@ -166,7 +166,9 @@ int32_t dn_reset_stats(dn_env *env, void *stream);
  * bits.  Environment variable DN_WAVES=1|2 forces one shape for every launch. */
 int32_t dn_get_kernel_waves(const dn_env *env, int32_t fused);
 
-/* Vector-step counter used as the Philox counter word of the noise streams. */
+/* Vector-step counter: the Philox counter word of the noise streams and the source of dn_stats.env_steps.  It
+ * lives on the device and is advanced by the step kernels themselves, so dn_step / dn_step_many launches captured
+ * into a hipGraph keep counting when the graph is replayed.  Both calls synchronise the device. */
 int32_t dn_get_step_count(const dn_env *env, uint64_t *out);
 int32_t dn_set_step_count(dn_env *env, uint64_t value);
 

@@ -568,3 +568,45 @@ def test_kernel_shapes_are_bit_identical(norm, noise, monkeypatch):
     assert st1 == st2 and st1["episodes"] > n
     for env in envs.values():
         env.close()
+
+
+def test_graph_replayed_rollouts_equal_eager_rollouts():
+    """RolloutCollector(use_graph=True) replays the captured rollout (policy kernels + dn_step + GAE) from a
+    hipGraph; with a deterministic policy it must reproduce the eager collector bit for bit, rollout after rollout
+    -- including the Philox noise streams, whose step counter lives on the device and keeps advancing under replay."""
+    pkg = _gpu()
+    from drl_dronenavigation_amd.collector import RolloutCollector
+    track = _tracks().reaching()
+    n, T = 2048, 16
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    net = pkg.MlpActorCritic().to(dev)
+    with torch.no_grad():
+        net.action_net.bias.fill_(0.0922)          # hover, so that flights last and gates get passed
+
+    def policy(obs):
+        a, v, lp = net(obs, deterministic=True)
+        return a, v, lp
+
+    outs = []
+    for use_graph in (False, True):
+        env = pkg.DroneVecEnv(track, n, normalize_obs=True, max_steps=40, act_noise_sigma=0.003, obs_noise_sigma=0.01,
+                              seed=9, device=dev)
+        col = RolloutCollector(env, policy, T, value_fn=net.predict_values, use_graph=use_graph)
+        runs = []
+        for it in range(4):
+            out = col.collect()
+            torch.cuda.synchronize()
+            runs.append({k: v.clone() for k, v in out.items()})
+        assert (col._graph is not None) == use_graph
+        assert env.step_count == 4 * T
+        outs.append((runs, env.get_state(), env.stats()))
+        env.close()
+    (r_e, s_e, st_e), (r_g, s_g, st_g) = outs
+    for it in range(4):
+        for k in r_e[it]:
+            assert torch.equal(r_e[it][k], r_g[it][k]), (it, k)
+    for k in s_e.dtype.names:
+        assert np.ascontiguousarray(s_e[k]).tobytes() == np.ascontiguousarray(s_g[k]).tobytes(), k
+    assert st_e == st_g and st_e["episodes"] > 0 and st_e["env_steps"] == 4 * T * n
+    assert float(r_e[3]["rewards"].abs().sum()) > 0
