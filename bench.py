@@ -107,7 +107,8 @@ def ppo_rollout(pkg, track, n, max_steps, dev, rank):
     torch.manual_seed(1 + rank)
     net = pkg.MlpActorCritic().to(dev)
     res = {}
-    for label, use_graph in (("eager", False), ("graph", True)):
+    for label, use_graph, trunk in (("eager", False, None), ("graph", True, None), ("graph_bf16", True, torch.bfloat16)):
+        net.trunk_dtype = trunk
         env = pkg.DroneVecEnv(track, n, max_steps=max_steps, normalize_obs=True, env_id_offset=rank * n, device=dev)
         col = RolloutCollector(env, net, n_steps, value_fn=net.predict_values, use_graph=use_graph)
         for _ in range(3):
@@ -122,6 +123,7 @@ def ppo_rollout(pkg, track, n, max_steps, dev, rank):
         res[label] = n * n_steps * reps / dt
         env.close()
     return {"value": round(res["graph"], 1), "unit": "env-steps/s", "eager_value": round(res["eager"], 1),
+            "bf16_trunk_value": round(res["graph_bf16"], 1),
             "n_steps": n_steps, "num_envs": n,
             "what": "policy-in-the-loop rollout: torch MLP 13-512-512-256 (pi, vf; Tanh; fp32, rocBLAS) + Gaussian sample + "
                     "dn_step + V(terminal_obs) bootstrap per step, dn_gae per rollout, per-drone obs normaliser on, "

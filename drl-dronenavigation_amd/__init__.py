@@ -23,6 +23,8 @@ def __getattr__(name):
     if name in ("collector", "RolloutCollector", "ShardPlan", "all_gather_rollout"):
         collector = importlib.import_module(__name__ + ".collector")
         return collector if name == "collector" else getattr(collector, name)
+    if name == "metrics":
+        return importlib.import_module(__name__ + ".metrics")
     if name in ("policy", "MlpActorCritic"):
         policy = importlib.import_module(__name__ + ".policy")
         return policy if name == "policy" else getattr(policy, name)

@@ -400,15 +400,35 @@ def gen_gae(out):
                       advantages=ns["advantages"].numpy(), returns=ns["returns"].numpy())
 
 
+def gen_rollout_dump(out):
+    """N3: the reference's rollout text dump (PBDroneEnv.collect_rollout, PBDroneEnv.py:811-821): its own method,
+    called on a minimal stand-in for `self`, over observation/reward pairs incl. awkward float32 values."""
+    import tempfile
+    import threading
+    import types
+    rng = np.random.default_rng(7)
+    obs = rng.uniform(-1, 1, (40, 13)).astype(np.float32)
+    obs[0] = np.float32([0, -0.0, 1, -1, 0.5, 1e-7, -1e-7, 1e-20, 3.4e38, 0.1, 1 / 3, 2 / 3, 1e-45])
+    obs[1, :4] = np.float32([0.0899400, 0.3535533845424652, 123456.789, 1e10])
+    rewards = [np.float64(x) for x in rng.uniform(-10, 8, 38)] + [-10.0, 8.0]     # np.float64 and Python floats
+    rewards[2] = np.float64(np.float32(-0.11290731))                              # a float32-valued reward
+    with tempfile.TemporaryDirectory() as d:
+        stub = types.SimpleNamespace(rollout_path=os.path.join(d, "rollouts.txt"), lock=threading.Lock())
+        for o, r in zip(obs, rewards):
+            PBDroneEnv.collect_rollout(stub, o, r)
+        text = open(stub.rollout_path, "rb").read()
+    out["rollout_dump"] = dict(obs=obs, rewards=np.array([float(r) for r in rewards], dtype=np.float64),
+                               text=np.frombuffer(text, dtype=np.uint8))
+
+
 def main():
     out = {}
-    gen_constants_and_actions(out)
-    gen_tracks(out)
-    gen_obs_pack(out)
-    gen_closed_loop(out)
-    gen_scripted(out)
-    gen_normalize(out)
-    gen_gae(out)
+    only = set(sys.argv[1:])
+    gens = dict(actions=gen_constants_and_actions, tracks=gen_tracks, obs_pack=gen_obs_pack, closed_loop=gen_closed_loop,
+                scripted=gen_scripted, normalize=gen_normalize, gae=gen_gae, rollout_dump=gen_rollout_dump)
+    for key, fn in gens.items():          # `python gen_golden.py rollout_dump` regenerates only that group
+        if not only or key in only:
+            fn(out)
     for name, d in out.items():
         path = os.path.join(HERE, name + ".npz")
         np.savez_compressed(path, **d)
