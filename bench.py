@@ -31,6 +31,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 ALGO_BYTES_PER_ENV_STEP = 288          # state R+W 104, bookkeeping R+W 106, action 16, outputs 62
+ALGO_BYTES_NORMALISER = 432            # per-drone NormalizeObservation statistics, 27 float64 R+W
 HBM_PEAK_GBPS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -269,12 +270,15 @@ def main():
                           "roofline_frac": round(ALGO_BYTES_PER_ENV_STEP * n / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 5)}
     waves = env.kernel_waves(fused=args.mode == "many")
 
+    algo = ALGO_BYTES_PER_ENV_STEP + (ALGO_BYTES_NORMALISER if args.normalize_obs else 0)
+    for o_ in others.values():
+        o_["roofline_frac"] = round(algo * n / (o_["us_per_vector_step"] * 1e-6) / 1e9 / HBM_PEAK_GBPS, 5)
     if rank == 0:
         value = n * world * K / wall
         step_us = gpu_ms * 1e3 / K
         steps_per_launch = A if args.mode == "many" else 1
         launch_us = step_us * steps_per_launch
-        achieved = ALGO_BYTES_PER_ENV_STEP * n / (step_us * 1e-6) / 1e9
+        achieved = algo * n / (step_us * 1e-6) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):                          # per-launch HBM bytes from the committed rocprofv3 --pmc passes
@@ -303,7 +307,7 @@ def main():
                              "true" if args.normalize_obs else "false", "false" if args.mode == "many" else "true"),
                          "waves_per_64_drones": waves,
                          "env_steps_per_launch": n * steps_per_launch, "vector_steps_per_launch": steps_per_launch,
-                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n * steps_per_launch,
+                         "algorithmic_bytes_per_launch": algo * n * steps_per_launch, "algorithmic_bytes_per_env_step": algo,
                          "avg_launch_us": round(launch_us, 4), "us_per_vector_step": round(step_us, 4)},
             "other_launch_shapes": others,
         }

@@ -178,26 +178,63 @@ DN_DEV void add_obs_noise(const DnParams &p, unsigned long long gid, unsigned st
 }
 
 // ---- A10: normalize.NormalizeObservation with a batch of one (normalize.py:34-47, :94-97) ---------
-DN_DEV void normalize_obs(const DnParams &p, long long i, bool active, double &count, float o[DN_OBS_DIM])
+// The statistics of one drone (13 means, 13 variances, the count) live in registers for the whole launch: loaded
+// once, updated by every observation the drone emits (step observations and reset observations, in that order),
+// stored once.  The reference's update, with batch_count = 1 and batch_var = 0,
+//     tot = count + 1;  new_mean = mean + delta / tot;  M2 = var count + delta^2 count / tot;  new_var = M2 / tot
+// is evaluated as  new_mean = mean + delta r,  new_var = (var + delta^2 r) (count r)  with r = 1/tot from
+// v_rcp_f64 + two Newton steps (shared by the 13 columns), and the normalised value uses v_rsq_f64 + one Newton step
+// (it leaves as float32): 16 instructions per column instead of ~90 for three IEEE divides and a sqrt, equal to the
+// literal form to 1e-16.
+struct Rms {
+    double mean[DN_OBS_DIM], var[DN_OBS_DIM], count;
+};
+DN_DEV void load_rms(const DnParams &p, long long i, Rms &r)
 {
-    double tot = count + 1.0;
 #pragma unroll
     for (int k = 0; k < DN_OBS_DIM; ++k) {
-        double mean = p.st.rms_mean[(long long)k * p.n + i];
-        double var = p.st.rms_var[(long long)k * p.n + i];
-        double x = (double)o[k];
-        double delta = x - mean;
-        double new_mean = mean + delta * 1.0 / tot;
-        double m_a = var * count;
-        double M2 = m_a + 0.0 + delta * delta * count * 1.0 / tot;
-        double new_var = M2 / tot;
-        if (active) {
-            p.st.rms_mean[(long long)k * p.n + i] = new_mean;
-            p.st.rms_var[(long long)k * p.n + i] = new_var;
-        }
-        o[k] = (float)((x - new_mean) / sqrt(new_var + 1e-8));
+        r.mean[k] = p.st.rms_mean[(long long)k * p.n + i];
+        r.var[k] = p.st.rms_var[(long long)k * p.n + i];
     }
-    count = tot;
+    r.count = p.st.rms_count[i];
+}
+DN_DEV void store_rms(const DnParams &p, long long i, const Rms &r)
+{
+#pragma unroll
+    for (int k = 0; k < DN_OBS_DIM; ++k) {
+        p.st.rms_mean[(long long)k * p.n + i] = r.mean[k];
+        p.st.rms_var[(long long)k * p.n + i] = r.var[k];
+    }
+    p.st.rms_count[i] = r.count;
+}
+DN_DEV double rcp_f64(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-x, r, 1.0);
+    return __builtin_fma(r, e, r);
+}
+DN_DEV void normalize_obs(Rms &r, float o[DN_OBS_DIM])
+{
+#pragma clang fp contract(fast)
+    const double tot = r.count + 1.0;
+    const double inv = rcp_f64(tot);
+    const double cw = r.count * inv;
+#pragma unroll
+    for (int k = 0; k < DN_OBS_DIM; ++k) {
+        const double x = (double)o[k];
+        const double delta = x - r.mean[k];
+        const double new_mean = r.mean[k] + delta * inv;
+        const double new_var = (r.var[k] + delta * delta * inv) * cw;
+        r.mean[k] = new_mean;
+        r.var[k] = new_var;
+        const double s = new_var + 1e-8;
+        double y = __builtin_amdgcn_rsq(s);
+        y = __builtin_fma(y, __builtin_fma(-(0.5 * s * y), y, 0.5), y);
+        o[k] = (float)((x - new_mean) * y);
+    }
+    r.count = tot;
 }
 
 // ---- waypoint/corridor table in LDS ------------------------------------------------------------
@@ -660,14 +697,13 @@ template <typename R> struct Observed {
     float o[DN_OBS_DIM];   // step observation, after sensor noise and the normaliser (also terminal_observation)
     R r_normal;            // _computeReward's ordinary branch, before /25
     float r_found32;       // gate-pass branch, float32 as the reference accumulates it
-    double rms_count;      // running count of the normaliser (NORM only)
 };
 
 // ---- A5 + A6 + the value side of A7 on the report wave ---------------------------------------------------
 template <typename R, bool NORM, bool NOISE>
 DN_DEV Observed<R> observe_phase(const DnParams &p, const DnConsts<R> &c, const R *s_tab, const Flight<R> &fl,
                                  const float4 G4, const float4 G5, const unsigned long long gid, const unsigned step_count,
-                                 const long long i, const bool active)
+                                 Rms &rms)
 {
 #pragma clang fp contract(fast)
     Observed<R> ob;
@@ -745,10 +781,8 @@ DN_DEV Observed<R> observe_phase(const DnParams &p, const DnConsts<R> &c, const 
         ob.r_normal = r;
     }
     // sensor noise / per-drone normaliser act on the step observation (which is also terminal_observation)
-    ob.rms_count = 0.0;
-    if (NORM) ob.rms_count = p.st.rms_count[i];
     if (NOISE && p.obs_noise_sigma > 0.0f) add_obs_noise(p, gid, step_count, 1u, ob.o);
-    if (NORM) normalize_obs(p, i, active, ob.rms_count, ob.o);
+    if (NORM) normalize_obs(rms, ob.o);
     return ob;
 }
 
@@ -773,8 +807,8 @@ DN_DEV void flush_stats(const DnParams &p, const StatAcc &a, unsigned long long 
 template <typename R, bool NORM, bool NOISE>
 DN_DEV void report_phase(const DnParams &p, const DnConsts<R> &c, float *s_tile, const StepOut &out, const Flight<R> &fl,
                          const Verdict<R> &v, Observed<R> &ob, const unsigned long long gid, const unsigned step_count,
-                         const long long i, const unsigned li, const unsigned lane, const unsigned rows, const bool active,
-                         float4 &G4, float4 &G5, StatAcc &acc)
+                         const unsigned li, const unsigned lane, const unsigned rows, const bool active,
+                         float4 &G4, float4 &G5, StatAcc &acc, Rms &rms)
 {
 #pragma clang fp contract(fast)
     const bool coll1 = v.coll1 != 0, terminated = v.terminated != 0, truncated = fl.truncated != 0;
@@ -811,7 +845,7 @@ DN_DEV void report_phase(const DnParams &p, const DnConsts<R> &c, float *s_tile,
             }
             reset_obs<R>(p, c, v.d_obs, o);                               // BaseAviary.py:318 before :617-658 (Q2)
             if (NOISE && p.obs_noise_sigma > 0.0f) add_obs_noise(p, gid, step_count, 5u, o);
-            if (NORM) normalize_obs(p, i, active, ob.rms_count, o);
+            if (NORM) normalize_obs(rms, o);
             S4 = S5 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             ep_ret = R(0.0); ep_len = 0;
         }
@@ -833,7 +867,6 @@ DN_DEV void report_phase(const DnParams &p, const DnConsts<R> &c, float *s_tile,
         acc.episodes += __popcll(done_ballot); acc.truncated += n_trunc; acc.completed += n_compl;
         acc.sum_len += s_len; acc.sum_found += s_fd; acc.sum_ret_fix += s_ret;
     }
-    if (NORM && active) p.st.rms_count[i] = ob.rms_count;
     S4.w = (float)ep_ret; S5.w = __int_as_float(ep_len);
     G4 = S4; G5 = S5;
     if (active) {
@@ -889,6 +922,8 @@ __global__ __launch_bounds__(DN_BLOCK) void dn_step_many_1w_kernel(const DnParam
     const long long n = p.n, words = (p.n + 63) / 64;
     const unsigned long long sc0 = p.st.stats[blockIdx.x].step_count;      // this tile's vector-step counter
     StatAcc acc;
+    Rms rms;
+    if (NORM) load_rms(p, i, rms);
 #pragma clang loop unroll(disable)
     for (int t = 0; t < k_steps; ++t) {
         // prefetch the next step's action while this step computes
@@ -899,11 +934,12 @@ __global__ __launch_bounds__(DN_BLOCK) void dn_step_many_1w_kernel(const DnParam
         const Flight<R> fl = physics_phase<R>(th, G0, G1, G2, G3, p.max_steps);
         const float4 G0e = G0, G3e = G3;
         const Verdict<R> v = rules_phase<R>(p, c, s_tab, fl, G0e, G3e, b.g6, li, active, G0, G1, G2, G3);
-        Observed<R> ob = observe_phase<R, NORM, NOISE>(p, c, s_tab, fl, G4, G5, gid, sc, i, active);
-        report_phase<R, NORM, NOISE>(p, c, s_tile, out, fl, v, ob, gid, sc, i, li, lane, rows, active, G4, G5, acc);
+        Observed<R> ob = observe_phase<R, NORM, NOISE>(p, c, s_tab, fl, G4, G5, gid, sc, rms);
+        report_phase<R, NORM, NOISE>(p, c, s_tile, out, fl, v, ob, gid, sc, li, lane, rows, active, G4, G5, acc, rms);
         A = A_next;
     }
     flush_stats(p, acc, sc0 + (unsigned long long)k_steps, lane);
+    if (NORM && active) store_rms(p, i, rms);
     if (active) {
         b.g0[li] = G0; b.g1[li] = G1; b.g2[li] = G2; b.g3[li] = G3; b.g4[li] = G4; b.g5[li] = G5;
     }
@@ -982,6 +1018,8 @@ __global__ __launch_bounds__(2 * DN_BLOCK) void dn_step_many_2w_kernel(const DnP
     if (report_wave) {
         float4 G4 = b.g4[li], G5 = b.g5[li];
         StatAcc acc;
+        Rms rms;
+        if (NORM) load_rms(p, i, rms);
         block_lds_barrier();                                               // P: table published
 #pragma clang loop unroll(disable)
         for (int t = 0; t <= k_steps; ++t) {
@@ -991,13 +1029,14 @@ __global__ __launch_bounds__(2 * DN_BLOCK) void dn_step_many_2w_kernel(const DnP
                 Flight<R> fl;
                 Verdict<R> v;
                 take_mail<R>(mail[u & 1], lane, fl, v);
-                Observed<R> ob = observe_phase<R, NORM, NOISE>(p, c, s_tab, fl, G4, G5, gid, sc, i, active);
+                Observed<R> ob = observe_phase<R, NORM, NOISE>(p, c, s_tab, fl, G4, G5, gid, sc, rms);
                 const StepOut out = block_out(io0, tile_base, (long long)u * n, (long long)u * words);
-                report_phase<R, NORM, NOISE>(p, c, s_tile, out, fl, v, ob, gid, sc, i, li, lane, rows, active, G4, G5, acc);
+                report_phase<R, NORM, NOISE>(p, c, s_tile, out, fl, v, ob, gid, sc, li, lane, rows, active, G4, G5, acc, rms);
             }
             if (t < k_steps) block_lds_barrier();                          // barrier t
         }
         flush_stats(p, acc, sc0 + (unsigned long long)k_steps, lane);
+        if (NORM && active) store_rms(p, i, rms);
         if (active) { b.g4[li] = G4; b.g5[li] = G5; }
     } else {
         const float4 *act = reinterpret_cast<const float4 *>(io0.actions) + tile_base;
@@ -1050,9 +1089,10 @@ __global__ __launch_bounds__(DN_BLOCK) void dn_reset_kernel(const DnParams p, fl
     const unsigned long long gid = (unsigned long long)(p.env_id_offset + i);
     if (p.obs_noise_sigma > 0.0f) add_obs_noise(p, gid, (unsigned)p.st.stats[blockIdx.x].step_count, 5u, o);
     if (p.normalize_obs) {
-        double cnt = p.st.rms_count[i];
-        normalize_obs(p, i, active, cnt, o);
-        if (active) p.st.rms_count[i] = cnt;
+        Rms rms;
+        load_rms(p, i, rms);
+        normalize_obs(rms, o);
+        if (active) store_rms(p, i, rms);
     }
     const R ex = cpx - s_tab[0], ey = cpy - s_tab[1], ez = cpz - s_tab[2];
     const R d = FM<R>::sqrt0(ex * ex + ey * ey + ez * ez);
