@@ -108,10 +108,15 @@ def ppo_rollout(pkg, track, n, max_steps, dev, rank):
     torch.manual_seed(1 + rank)
     net = pkg.MlpActorCritic().to(dev)
     res = {}
-    for label, use_graph, trunk in (("eager", False, None), ("graph", True, None), ("graph_bf16", True, torch.bfloat16)):
-        net.trunk_dtype = trunk
+    fused = pkg.FusedMlpPolicy(net, n, dev)
+    for label, use_graph, trunk in (("eager", False, None), ("graph", True, None), ("graph_bf16", True, torch.bfloat16),
+                                    ("graph_mfma", True, "mfma"), ("eager_mfma", False, "mfma")):
+        net.trunk_dtype = trunk if trunk != "mfma" else None
         env = pkg.DroneVecEnv(track, n, max_steps=max_steps, normalize_obs=True, env_id_offset=rank * n, device=dev)
-        col = RolloutCollector(env, net, n_steps, value_fn=net.predict_values, use_graph=use_graph)
+        if trunk == "mfma":
+            col = RolloutCollector(env, fused, n_steps, value_fn=fused.predict_values, use_graph=use_graph)
+        else:
+            col = RolloutCollector(env, net, n_steps, value_fn=net.predict_values, use_graph=use_graph)
         for _ in range(3):
             col.collect()
         torch.cuda.synchronize(dev)
@@ -123,12 +128,14 @@ def ppo_rollout(pkg, track, n, max_steps, dev, rank):
         dt = time.perf_counter() - t0
         res[label] = n * n_steps * reps / dt
         env.close()
-    return {"value": round(res["graph"], 1), "unit": "env-steps/s", "eager_value": round(res["eager"], 1),
-            "bf16_trunk_value": round(res["graph_bf16"], 1),
+    return {"value": round(res["graph_mfma"], 1), "unit": "env-steps/s", "policy": "fused MFMA MLP (dn_mlp_forward, bf16 "
+            "weights/activations, float32 accumulate), hipGraph replay",
+            "variants": {"torch fp32 eager": round(res["eager"], 1), "torch fp32 hipGraph": round(res["graph"], 1),
+                         "torch bf16 trunks hipGraph": round(res["graph_bf16"], 1),
+                         "fused MFMA eager": round(res["eager_mfma"], 1), "fused MFMA hipGraph": round(res["graph_mfma"], 1)},
             "n_steps": n_steps, "num_envs": n,
-            "what": "policy-in-the-loop rollout: torch MLP 13-512-512-256 (pi, vf; Tanh; fp32, rocBLAS) + Gaussian sample + "
-                    "dn_step + V(terminal_obs) bootstrap per step, dn_gae per rollout, per-drone obs normaliser on, "
-                    "hipGraph replay"}
+            "what": "policy-in-the-loop rollout: MLP 13-512-512-256 (pi, vf; Tanh) + Gaussian sample + dn_step + "
+                    "V(terminal_obs) bootstrap per step, dn_gae per rollout, per-drone obs normaliser on"}
 
 
 def main():

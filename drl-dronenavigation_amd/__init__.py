@@ -23,6 +23,9 @@ def __getattr__(name):
     if name in ("collector", "RolloutCollector", "ShardPlan", "all_gather_rollout"):
         collector = importlib.import_module(__name__ + ".collector")
         return collector if name == "collector" else getattr(collector, name)
+    if name in ("policy_mfma", "FusedMlpPolicy"):
+        pm = importlib.import_module(__name__ + ".policy_mfma")
+        return pm if name == "policy_mfma" else getattr(pm, name)
     if name == "metrics":
         return importlib.import_module(__name__ + ".metrics")
     if name in ("policy", "MlpActorCritic"):

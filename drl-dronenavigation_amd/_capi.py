@@ -49,6 +49,12 @@ class DnEnvState(C.Structure):
     ]
 
 
+class DnMlpNet(C.Structure):
+    _fields_ = [("w1", C.c_void_p), ("w2", C.c_void_p), ("w3", C.c_void_p), ("wh", C.c_void_p),
+                ("b1", C.c_void_p), ("b2", C.c_void_p), ("b3", C.c_void_p), ("bh", C.c_void_p),
+                ("out", C.c_void_p), ("out_dim", C.c_int32)]
+
+
 class DnStats(C.Structure):
     _fields_ = [("env_steps", C.c_int64), ("episodes", C.c_int64), ("truncated", C.c_int64), ("completed", C.c_int64),
                 ("sum_ep_len", C.c_int64), ("sum_found_targets", C.c_int64), ("sum_ep_return", C.c_double)]
@@ -76,6 +82,7 @@ PROTOTYPES = {
     "dn_get_step_count": (_I32, [_VP, C.POINTER(C.c_uint64)]),
     "dn_set_step_count": (_I32, [_VP, C.c_uint64]),
     "dn_preprocess_action": (_I32, [_VP, _I64, _I32, _VP, _VP, _VP, _I32, _VP]),
+    "dn_mlp_forward": (_I32, [_VP, _I32, _VP, _VP, _I64, _I32, _I32, _VP]),
     "dn_gae": (_I32, [_VP] * 5 + [_I64, _I64, C.c_double, C.c_double, _VP, _VP, _I32, _VP]),
     "dn_state_bytes": (_I64, [_I64, _I32]),
 }

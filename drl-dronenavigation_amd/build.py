@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libdronenav.so")
-SOURCES = ["dn_kernels.hip", "dn_capi.cpp"]
+SOURCES = ["dn_kernels.hip", "dn_mlp.hip", "dn_capi.cpp"]
 HEADERS = ["dn_internal.h", os.path.join("..", "..", "include", "dronenav.h")]
 # -ffp-contract=off: the reference (numpy, Bullet) rounds every operation, so no fused multiply-add.
 # Correctly rounded float32 divide/sqrt is hipcc's default; stated explicitly because parity relies on it.

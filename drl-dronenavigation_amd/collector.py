@@ -96,6 +96,11 @@ class RolloutCollector:
         self.n_steps, self.gamma, self.gae_lambda = int(n_steps), float(gamma), float(gae_lambda)
         self.bootstrap_truncated, self.gather, self.group = bool(bootstrap_truncated), bool(gather), group
         self.use_graph = bool(use_graph)
+        import inspect
+        try:        # a value function that can skip unflagged tiles (FusedMlpPolicy.predict_values) gets the truncation mask
+            self._value_fn_takes_mask = value_fn is not None and "row_mask" in inspect.signature(value_fn).parameters
+        except (TypeError, ValueError):
+            self._value_fn_takes_mask = False
         n, T, dev, f32 = env.num_envs, self.n_steps, env.device, torch.float32
         self.buf = dict(
             obs=torch.empty((T, n, env.obs_dim), dtype=f32, device=dev),
@@ -112,8 +117,10 @@ class RolloutCollector:
         self._graph = None
         self._calls = 0
 
-    def _values(self, obs):
+    def _values(self, obs, row_mask=None):
         if self.value_fn is not None:
+            if row_mask is not None and self._value_fn_takes_mask:
+                return self.value_fn(obs, row_mask=row_mask).reshape(-1)
             return self.value_fn(obs).reshape(-1)
         return self.policy(obs)[1].reshape(-1)
 
@@ -134,7 +141,8 @@ class RolloutCollector:
             next_obs, reward, next_done, info = env.step_tensor(self._clipped, want_terminal=self.bootstrap_truncated)
             if self.bootstrap_truncated:
                 # rows of terminal_obs are valid only where done; `truncated` is zero elsewhere
-                tv = self._values(torch.where(next_done.bool()[:, None], info["terminal_obs"], next_obs))
+                tv = self._values(torch.where(next_done.bool()[:, None], info["terminal_obs"], next_obs),
+                                  row_mask=info["truncated"])
                 reward = reward + self.gamma * tv * info["truncated"].to(reward.dtype)
             b["rewards"][t].copy_(reward)
             obs.copy_(next_obs)

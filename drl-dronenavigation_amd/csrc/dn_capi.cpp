@@ -518,6 +518,26 @@ int32_t dn_preprocess_action(const float *actions, int64_t num_envs, int32_t nor
     return DN_OK;
 }
 
+int32_t dn_mlp_forward(const dn_mlp_net *nets, int32_t num_nets, const float *obs, const uint8_t *row_mask, int64_t num_envs,
+                       int32_t obs_dim, int32_t device_id, void *stream)
+{
+    if (!nets || !obs) return fail(DN_ERR_INVALID_ARGUMENT, "nets and obs are required");
+    if (num_nets < 1 || num_nets > 2) return fail(DN_ERR_INVALID_ARGUMENT, "num_nets must be 1 or 2 (got %d)", num_nets);
+    if (num_envs < 1) return fail(DN_ERR_INVALID_ARGUMENT, "num_envs must be >= 1");
+    if (obs_dim < 1 || obs_dim > 16) return fail(DN_ERR_INVALID_ARGUMENT, "obs_dim must be in 1..16 (got %d)", obs_dim);
+    for (int k = 0; k < num_nets; ++k) {
+        const dn_mlp_net &n = nets[k];
+        if (!n.w1 || !n.w2 || !n.w3 || !n.wh || !n.b1 || !n.b2 || !n.b3 || !n.bh || !n.out)
+            return fail(DN_ERR_INVALID_ARGUMENT, "net %d: every weight, bias and output pointer is required", k);
+        if (n.out_dim < 1 || n.out_dim > 32) return fail(DN_ERR_INVALID_ARGUMENT, "net %d: out_dim must be in 1..32", k);
+        if (((uintptr_t)n.w1 | (uintptr_t)n.w2 | (uintptr_t)n.w3 | (uintptr_t)n.wh) & 15u)
+            return fail(DN_ERR_INVALID_ARGUMENT, "net %d: packed weights must be 16-byte aligned", k);
+    }
+    DN_HIP(hipSetDevice(device_id));
+    DN_HIP(dn_launch_mlp(nets, num_nets, obs, row_mask, num_envs, obs_dim, (hipStream_t)stream));
+    return DN_OK;
+}
+
 int32_t dn_gae(const float *rewards, const float *values, const uint8_t *dones, const float *last_values,
                const uint8_t *last_dones, int64_t n_steps, int64_t n_envs, double gamma, double gae_lambda,
                float *advantages, float *returns, int32_t device_id, void *stream)

@@ -106,6 +106,8 @@ hipError_t dn_launch_action_chain(const float *actions, long long n, int normali
 hipError_t dn_launch_fill4(float4 *dst, float4 v, long long n, hipStream_t stream);
 hipError_t dn_launch_filld(double *dst, double v, long long n, hipStream_t stream);
 hipError_t dn_launch_set_step_count(DnStatSlot *slots, long long blocks, unsigned long long value, hipStream_t stream);
+hipError_t dn_launch_mlp(const dn_mlp_net *nets, int num_nets, const float *obs, const uint8_t *row_mask, long long n, int obs_dim,
+                         hipStream_t stream);
 hipError_t dn_launch_compact(const unsigned long long *mask, long long n, int32_t *indices, int32_t *count,
                              hipStream_t stream);
 

@@ -1,0 +1,126 @@
+"""The reference's policy/value networks on the fused MFMA kernel (csrc/dn_mlp.hip, dn_mlp_forward).
+
+`pack_mlp` turns the float32 [out, in] matrices of one 13-512-512-256-out network into the bfloat16 fragment order
+the kernel loads (see dn_mlp.hip for why the K index of every layer but the first is permuted), `FusedMlpPolicy`
+wraps an `MlpActorCritic` so that the rollout collector's policy(obs) -> (actions, values, log_probs) runs both
+trunks and both heads in ONE kernel launch; the Gaussian sample and its log-probability (a few element-wise ops on
+[N, 4]) stay in torch, float32.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _capi
+
+HIDDEN = (512, 512, 256)
+
+
+def _k_order(in_features, first):
+    """Input-feature index read by (K-step kk, lane group g, slot s) -> [KS, 2, 8]."""
+    if first:
+        ks = 1
+        f = 16 * np.arange(ks)[:, None, None] + 8 * np.arange(2)[None, :, None] + np.arange(8)[None, None, :]
+        return np.where(f < in_features, f, -1)
+    ks = in_features // 16
+    kk = np.arange(ks)[:, None, None]
+    g = np.arange(2)[None, :, None]
+    r = 8 * (kk & 1) + np.arange(8)[None, None, :]
+    return 32 * (kk >> 1) + 4 * g + (r & 3) + 8 * (r >> 2)
+
+
+def pack_layer(weight, bias, first):
+    """weight [out, in] float32, bias [out] -> (packed bf16 [MT, KS, 64, 8] as a torch tensor, bias padded to 32*MT)."""
+    w = np.asarray(weight.detach().cpu().float().numpy() if hasattr(weight, "detach") else weight, dtype=np.float32)
+    b = np.asarray(bias.detach().cpu().float().numpy() if hasattr(bias, "detach") else bias, dtype=np.float32)
+    out_f, in_f = w.shape
+    if not first and in_f % 32:
+        raise ValueError("hidden widths must be multiples of 32")
+    mt = (out_f + 31) // 32
+    korder = _k_order(in_f, first)                               # [KS, 2, 8]
+    ks = korder.shape[0]
+    wp = np.zeros((mt * 32, in_f + 1), np.float32)               # extra zero column for the -1 (padding) index
+    wp[:out_f, :in_f] = w
+    rows = (32 * np.arange(mt)[:, None] + np.arange(32)[None, :])            # [MT, 32]
+    lane_row = np.concatenate([rows, rows], axis=1)                          # lane l -> row 32 mo + (l & 31)   [MT, 64]
+    lane_g = np.repeat(np.arange(2), 32)                                     # lane l -> group l >> 5           [64]
+    cols = korder[:, lane_g, :]                                              # [KS, 64, 8]
+    packed = wp[lane_row[:, None, :, None], cols[None, :, :, :]]             # [MT, KS, 64, 8]
+    bp = np.zeros(mt * 32, np.float32)
+    bp[:out_f] = b
+    return torch.from_numpy(packed).to(torch.bfloat16).contiguous(), torch.from_numpy(bp)
+
+
+def pack_mlp(layers, device):
+    """layers: [(W1, b1), (W2, b2), (W3, b3), (Wh, bh)] of one network -> dict of device tensors for dn_mlp_net."""
+    if [tuple(w.shape) for w, _ in layers[1:3]] != [(HIDDEN[1], HIDDEN[0]), (HIDDEN[2], HIDDEN[1])] or \
+            layers[0][0].shape[0] != HIDDEN[0] or layers[3][0].shape[1] != HIDDEN[2]:
+        raise ValueError("the fused kernel is built for obs -> 512 -> 512 -> 256 -> out (PBDroneSimulator.py:251-258)")
+    out = {}
+    for name, (w, b), first in zip(("1", "2", "3", "h"), layers, (True, False, False, False)):
+        pw, pb = pack_layer(w, b, first)
+        out["w" + name], out["b" + name] = pw.to(device), pb.to(device)
+    out["out_dim"] = int(layers[3][0].shape[0])
+    out["obs_dim"] = int(layers[0][0].shape[1])
+    return out
+
+
+def _net_struct(pk, out_tensor):
+    n = _capi.DnMlpNet()
+    for k in ("w1", "w2", "w3", "wh", "b1", "b2", "b3", "bh"):
+        setattr(n, k, pk[k].data_ptr())
+    n.out, n.out_dim = out_tensor.data_ptr(), pk["out_dim"]
+    return n
+
+
+def mlp_forward(packs, obs, outs=None, row_mask=None):
+    """Run one or two packed networks over obs [N, obs_dim] (float32, CUDA) in one launch; returns the list of
+    float32 outputs [N, out_dim].  row_mask (uint8 [N], optional): 32-drone tiles without a flagged drone are skipped
+    and their outputs zeroed."""
+    if obs.device.type != "cuda" or obs.dtype != torch.float32 or obs.dim() != 2:
+        raise ValueError("obs must be a float32 CUDA tensor [N, obs_dim]; there is no CPU fallback")
+    obs = obs.contiguous()
+    n, dev = obs.shape[0], obs.device
+    if outs is None:
+        outs = [torch.empty((n, p["out_dim"]), dtype=torch.float32, device=dev) for p in packs]
+    arr = (_capi.DnMlpNet * len(packs))(*[_net_struct(p, o) for p, o in zip(packs, outs)])
+    with torch.cuda.device(dev):
+        _capi.check(_capi.load().dn_mlp_forward(C.cast(arr, C.c_void_p), len(packs), obs.data_ptr(),
+                                                row_mask.data_ptr() if row_mask is not None else None, n, obs.shape[1],
+                                                dev.index, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    return outs
+
+
+class FusedMlpPolicy:
+    """policy(obs) -> (actions, values, log_probs) for RolloutCollector on the fused kernel, from an MlpActorCritic's
+    weights (re-pack with `refresh()` after every optimiser step).  Static output buffers: hipGraph-capture safe."""
+
+    def __init__(self, module, num_envs, device):
+        self.module, self.device = module, torch.device(device)
+        self._mean = torch.empty((num_envs, module.action_net.out_features), dtype=torch.float32, device=self.device)
+        self._value = torch.empty((num_envs, 1), dtype=torch.float32, device=self.device)
+        self.refresh()
+
+    def refresh(self):
+        m = self.module
+        lin = lambda seq: [l for l in seq if isinstance(l, torch.nn.Linear)]           # noqa: E731
+        pi = [(l.weight, l.bias) for l in lin(m.pi)] + [(m.action_net.weight, m.action_net.bias)]
+        vf = [(l.weight, l.bias) for l in lin(m.vf)] + [(m.value_net.weight, m.value_net.bias)]
+        self.pi, self.vf = pack_mlp(pi, self.device), pack_mlp(vf, self.device)
+        self.log_std = m.log_std.detach().to(self.device).float()
+
+    def __call__(self, obs, deterministic=False):
+        mlp_forward([self.pi, self.vf], obs, [self._mean, self._value])
+        mean = self._mean
+        std = torch.exp(self.log_std)
+        actions = mean if deterministic else mean + std * torch.randn_like(mean)
+        z = (actions - mean) / std
+        log_prob = (-0.5 * z * z - self.log_std - 0.5 * math.log(2 * math.pi)).sum(-1)
+        return actions, self._value.squeeze(-1), log_prob
+
+    def predict_values(self, obs, out=None, row_mask=None):
+        """V(obs); with row_mask (uint8 [N]) only tiles that contain a flagged drone are evaluated, the rest read 0."""
+        out = self._value if out is None else out
+        mlp_forward([self.vf], obs, [out], row_mask=row_mask)
+        return out.squeeze(-1)

@@ -189,6 +189,25 @@ int32_t dn_gae(const float *rewards, const float *values, const uint8_t *dones,
                double gamma, double gae_lambda, float *advantages, float *returns,
                int32_t device_id, void *stream);
 
+/* One actor or critic network of the reference's policy (SB3 ActorCriticPolicy with net_arch pi = vf = [512, 512,
+ * 256], Tanh, built at Sol/Model/PBDroneSimulator.py:251-286): obs -> 512 -> 512 -> 256 -> out_dim.  Weights are
+ * bfloat16 in the fragment order of the kernel (drl-dronenavigation_amd/policy_mfma.py::pack_mlp produces it from
+ * the [out, in] float32 matrices), biases float32 padded to 512 / 512 / 256 / 32.  All pointers are device pointers. */
+typedef struct dn_mlp_net {
+    const void *w1, *w2, *w3, *wh;              /* packed bf16 weights of the three hidden layers and the head */
+    const float *b1, *b2, *b3, *bh;             /* biases */
+    float *out;                                 /* float[num_envs * out_dim] */
+    int32_t out_dim;                            /* 1..32 (4 action means / 1 value) */
+} dn_mlp_net;
+
+/* Forward pass of one or two such networks over the same observations in one launch (replaces the mlp_extractor +
+ * action_net / value_net part of SB3's ActorCriticPolicy.forward / predict_values): a fused MFMA kernel, one wavefront
+ * per 32 drones, activations resident in registers.  obs: device float[num_envs * obs_dim], obs_dim <= 16.
+ * row_mask: device uint8[num_envs] or NULL; with a mask, a 32-drone tile without a flagged drone writes zeros and
+ * skips the network (V(terminal_observation) is needed only where an episode hit the time limit). */
+int32_t dn_mlp_forward(const dn_mlp_net *nets, int32_t num_nets, const float *obs, const uint8_t *row_mask,
+                       int64_t num_envs, int32_t obs_dim, int32_t device_id, void *stream);
+
 /* Bytes of HBM the persistent state of `num_envs` drones occupies (capacity planning). */
 int64_t dn_state_bytes(int64_t num_envs, int32_t normalize_obs);
 

@@ -610,3 +610,57 @@ def test_graph_replayed_rollouts_equal_eager_rollouts():
         assert np.ascontiguousarray(s_e[k]).tobytes() == np.ascontiguousarray(s_g[k]).tobytes(), k
     assert st_e == st_g and st_e["episodes"] > 0 and st_e["env_steps"] == 4 * T * n
     assert float(r_e[3]["rewards"].abs().sum()) > 0
+
+
+def _mlp_reference(layers, x):
+    """The fused kernel's arithmetic spelled out in torch: bf16 weights and activations, float32 accumulation and bias,
+    tanh in float32, float32 head output."""
+    h = x.to(torch.bfloat16).float()
+    for k, (w, b) in enumerate(layers):
+        h = h @ w.to(torch.bfloat16).float().t() + b.float()
+        if k < len(layers) - 1:
+            h = torch.tanh(h).to(torch.bfloat16).float()
+    return h
+
+
+@pytest.mark.parametrize("n", [32, 1000, 32768])
+def test_fused_mfma_mlp_matches_torch(n):
+    """dn_mlp_forward (one wavefront per 32 drones, activations in registers, K-permuted bf16 weight fragments) against
+    the same network in torch: asymmetric random weights catch any row/column/K-order slip; tolerance is bf16-level."""
+    pkg = _gpu()
+    from drl_dronenavigation_amd import policy_mfma as pm
+    dev = torch.device("cuda:0")
+    torch.manual_seed(n)
+    net = pkg.MlpActorCritic().to(dev)
+    with torch.no_grad():
+        for p_ in net.parameters():
+            p_.add_(0.05 * torch.randn_like(p_))          # non-zero biases, not-quite-orthogonal weights
+    obs = (torch.rand(n, 13, device=dev) * 2 - 1)
+    lin = lambda seq: [l for l in seq if isinstance(l, torch.nn.Linear)]      # noqa: E731
+    pi = [(l.weight.detach(), l.bias.detach()) for l in lin(net.pi)] + [(net.action_net.weight.detach(), net.action_net.bias.detach())]
+    vf = [(l.weight.detach(), l.bias.detach()) for l in lin(net.vf)] + [(net.value_net.weight.detach(), net.value_net.bias.detach())]
+    pol = pm.FusedMlpPolicy(net, n, dev)
+    mean, value = pm.mlp_forward([pol.pi, pol.vf], obs)
+    torch.cuda.synchronize()
+    ref_m, ref_v = _mlp_reference(pi, obs), _mlp_reference(vf, obs)
+    # the emulation differs only in summation order and the 1e-7 tanh; where that flips the bf16 rounding of a hidden
+    # activation the outputs move by a bf16 ulp of a weight-activation product: 1e-2 worst case, 3e-4 on average
+    for got, ref in ((mean, ref_m), (value, ref_v)):
+        err = (got - ref).abs()
+        assert float(err.max()) < 1e-2 and float(err.mean()) < 3e-4, (float(err.max()), float(err.mean()))
+    # and stays at bf16 distance from the float32 network SB3 would run
+    with torch.no_grad():
+        f32_m = net.action_net(net.pi(obs))
+    assert float((mean - f32_m).abs().max()) < 5e-2
+    a, v, lp = pol(obs, deterministic=True)
+    assert torch.equal(a, mean) and v.shape == (n,) and lp.shape == (n,)
+    # single-network launch (predict_values) gives the same values; a masked launch evaluates exactly the tiles that
+    # hold a flagged drone and zeroes the others
+    assert torch.equal(pol.predict_values(obs).clone(), value.squeeze(-1))
+    mask = torch.zeros(n, dtype=torch.uint8, device=dev)
+    mask[::97] = 1
+    mv = pol.predict_values(obs, row_mask=mask).clone()
+    tile_has = torch.zeros((n + 31) // 32 * 32, dtype=torch.bool, device=dev)
+    tile_has[:n] = mask.bool()
+    tile_has = tile_has.view(-1, 32).any(1).repeat_interleave(32)[:n]
+    assert torch.equal(mv[tile_has], value.squeeze(-1)[tile_has]) and float(mv[~tile_has].abs().sum()) == 0.0
