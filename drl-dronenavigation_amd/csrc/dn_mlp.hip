@@ -21,6 +21,8 @@
 // v_exp_f32 / v_rcp_f32 (absolute error ~1e-7, far inside bf16), float32 output of the head.
 #include "dn_internal.h"
 
+#include <cstdlib>
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -46,13 +48,32 @@ struct MlpArgs {
 };
 
 MLP_DEV float tanh_fast(float x)
-{
-    const float e = __expf(2.0f * x);
-    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+{   // 1 - 2 / (1 + 2^(x * 2 log2 e)): v_mul, v_exp_f32, v_add, v_rcp_f32, v_fma
+    const float e = __builtin_amdgcn_exp2f(x * 2.885390081777927f);
+    return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
 }
 
 // Row (output feature) of accumulator register r in lane group g of M-tile m: the C/D map of the 32x32 MFMA.
 MLP_DEV int acc_row(int m, int g, int r) { return 32 * m + 4 * g + (r & 3) + 8 * (r >> 2); }
+
+// The epilogue of an M-tile (16 accumulator values per lane: bias already in, tanh, bf16) costs ~700 VALU cycles, two
+// thirds of the tile's 32 MFMAs (1024 cycles on the matrix pipe).  Issued after the MFMAs it would idle the matrix pipe;
+// issued one element every second MFMA of the NEXT tile it runs entirely in their shadow (the VALU and the matrix pipe
+// are separate; an MFMA only occupies the issue slot once).
+MLP_DEV void epilogue_elem(const f32x16 &acc, const int e, bf16x8 &lo, bf16x8 &hi)
+{
+    const __bf16 v = (__bf16)tanh_fast(acc[e]);
+    if (e < 8) lo[e] = v; else hi[e - 8] = v;
+}
+
+MLP_DEV void epilogue(const f32x16 &acc, const bool tanh_on, bf16x8 &lo, bf16x8 &hi)
+{
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        lo[s] = (__bf16)(tanh_on ? tanh_fast(acc[s]) : acc[s]);
+        hi[s] = (__bf16)(tanh_on ? tanh_fast(acc[8 + s]) : acc[8 + s]);
+    }
+}
 
 // One Linear(+Tanh) layer for this wave's 32 drones.  KS = K-steps of 16 input features, MT = M-tiles of 32 output
 // features.  in[kk] is the B operand of K-step kk; out[2m], out[2m+1] become K-steps 2m, 2m+1 of the next layer.
@@ -70,6 +91,7 @@ MLP_DEV void layer(const uint4 *__restrict__ w, const float *__restrict__ bias, 
     uint4 ring[P];
 #pragma unroll
     for (int t = 0; t < P; ++t) ring[t] = wl[t * 64];
+    f32x16 prev;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         f32x16 acc;
@@ -81,17 +103,11 @@ MLP_DEV void layer(const uint4 *__restrict__ w, const float *__restrict__ bias, 
             const uint4 a = ring[t % P];
             if (t + P < T) ring[t % P] = wl[(t + P) * 64];
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), in[kk], acc, 0, 0, 0);
+            // the previous tile's epilogue, one element every second MFMA (KS = 32), in the MFMAs' shadow
+            if (TANH && KS == 32 && m > 0 && (kk & 1)) epilogue_elem(prev, kk >> 1, out[2 * (m - 1)], out[2 * (m - 1) + 1]);
         }
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            bf16x8 o;
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                const float v = acc[8 * h + s];
-                o[s] = (__bf16)(TANH ? tanh_fast(v) : v);
-            }
-            out[2 * m + h] = o;
-        }
+        if (TANH && KS == 32 && m + 1 < MT) prev = acc;
+        else epilogue(acc, TANH, out[2 * m], out[2 * m + 1]);
     }
 }
 
@@ -150,6 +166,176 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     }
 }
 
+// -----------------------------------------------------------------------------------------------------
+// Shared-weights shape: 4 wavefronts (128 drones) per workgroup stream every weight fragment through LDS ONCE.
+//
+// In the one-wave shape each of the four waves of a CU pulls every 1 KB fragment through the CU's vector memory path
+// (64 B/clk): 4 KB per 32-cycle MFMA step is 128 B/clk, twice what the path delivers, and the kernel runs at a
+// quarter of the MFMA rate however deep the loads are pipelined (measured: 41 us per network at 32768 drones with 2
+// or with 10 fragments in flight).  Here a fragment crosses that path once per workgroup -- an LDS-DMA
+// (global_load_lds_dwordx4: 64 lanes x 16 B land lane-linear, which IS the fragment layout) issued by one of the
+// four waves -- and the four waves read it from LDS (ds_read_b128, 128 B/clk).  Weights move in chunks of up to 32
+// fragments (one M-tile of a 512-wide layer), double-buffered: the DMA of chunk c+1 is in flight while chunk c is
+// multiplied; one `s_waitcnt vmcnt(0)` + `s_barrier` per chunk.
+// -----------------------------------------------------------------------------------------------------
+constexpr int CHUNK = 32;                                  // fragments (KB) per LDS buffer
+constexpr int WAVES = 4;
+constexpr int LDS_RING = 8;
+
+MLP_DEV void dma_chunk(const uint4 *__restrict__ src, uint4 *lds, const int nfrag, const int wave, const int lane)
+{   // wave w brings in fragments [w*nfrag/4, (w+1)*nfrag/4) of the chunk.
+    // The LDS-DMA is issued from inline asm on purpose: hipcc drains a builtin LDS-DMA (s_waitcnt vmcnt(0)) before the
+    // next ds_read because it cannot tell the two LDS buffers apart, which would expose the whole HBM/L2 round trip at
+    // the start of every chunk.  An asm load is invisible to its counters; chunk_barrier() waits for it explicitly.
+    // A wave's pieces are contiguous both in global memory and in LDS (1 KB apart), and the instruction's immediate
+    // offset applies to both addresses, so four pieces share one M0 / one address register: offset:0 .. offset:3072.
+    const int per = nfrag / WAVES;                          // 8 (32-fragment chunk) or 4 (16-fragment chunk)
+#pragma unroll
+    for (int j0 = 0; j0 < CHUNK / WAVES; j0 += 4) {
+        if (j0 < per) {
+            const int f = wave * per + j0;
+            const uint4 *gsrc = src + f * 64 + lane;
+            const unsigned lds_dst = (unsigned)(uintptr_t)(lds + f * 64);    // wave-uniform LDS byte address -> M0
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                         "global_load_lds_dwordx4 %1, off\n\t"
+                         "global_load_lds_dwordx4 %1, off offset:1024\n\t"
+                         "global_load_lds_dwordx4 %1, off offset:2048\n\t"
+                         "global_load_lds_dwordx4 %1, off offset:3072\n\t"
+                         "s_mov_b32 m0, %0"
+                         : "=&s"(keep)
+                         : "v"(gsrc), "s"(lds_dst)
+                         : "memory");
+        }
+    }
+}
+MLP_DEV void chunk_barrier()
+{
+    __builtin_amdgcn_s_waitcnt(0x0070);                    // vmcnt(0) & lgkmcnt(0): my DMA pieces landed, my LDS reads done
+    __builtin_amdgcn_s_barrier();
+}
+
+// A 512-input layer, weights through LDS: one chunk = the 32 fragments of one M-tile.  PAR = parity of the LDS buffer
+// that holds this layer's chunk 0 (requested by the previous layer, landed before its last barrier); `next` = the
+// following layer's weights, whose first NEXT_FR fragments are requested during this layer's last chunk.
+template <int MT, int PAR, int NEXT_FR>
+MLP_DEV void layer_lds(const uint4 *__restrict__ w, const float *__restrict__ bias, const uint4 *__restrict__ next,
+                       const bf16x8 (&in)[CHUNK], bf16x8 (&out)[2 * MT], uint4 *lds, const int wave, const int lane)
+{
+    const int g = lane >> 5;
+    // biases one M-tile ahead, requested BEFORE the chunk's DMA: memory returns in order, so a bias load queued behind
+    // eight DMA pieces would hold the first MFMA of the chunk until they have all landed
+    f32x16 bnext, prev;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bnext[r] = bias[acc_row(0, g, r)];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        uint4 *cur = lds + ((PAR + m) & 1) * (CHUNK * 64);
+        uint4 *nxt = lds + ((PAR + m + 1) & 1) * (CHUNK * 64);
+        f32x16 acc = bnext;
+        if (m + 1 < MT) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bnext[r] = bias[acc_row(m + 1, g, r)];
+            dma_chunk(w + (size_t)(m + 1) * CHUNK * 64, nxt, CHUNK, wave, lane);
+        } else dma_chunk(next, nxt, NEXT_FR, wave, lane);
+        // LDS -> register ring LDS_RING fragments ahead of the MFMA that consumes them (an LDS round trip is ~64-128 cycles,
+        // an MFMA 32): without it every MFMA waits for its own ds_read
+        uint4 ring[LDS_RING];
+#pragma unroll
+        for (int kk = 0; kk < LDS_RING; ++kk) ring[kk] = cur[kk * 64 + lane];
+#pragma unroll
+        for (int kk = 0; kk < CHUNK; ++kk) {
+            const uint4 a = ring[kk % LDS_RING];
+            if (kk + LDS_RING < CHUNK) ring[kk % LDS_RING] = cur[(kk + LDS_RING) * 64 + lane];
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), in[kk], acc, 0, 0, 0);
+            // the previous tile's epilogue, one element every second MFMA, in the MFMAs' shadow
+            if (m > 0 && (kk & 1)) epilogue_elem(prev, kk >> 1, out[2 * (m - 1)], out[2 * (m - 1) + 1]);
+        }
+        if (m + 1 < MT) prev = acc;
+        else epilogue(acc, true, out[2 * m], out[2 * m + 1]);
+        chunk_barrier();                                    // everyone is done with `cur`; the next chunk has landed in `nxt`
+    }
+}
+
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(1, 1))) void dn_mlp_lds_kernel(const MlpArgs a)
+{
+    // ONE __shared__ object (a second one makes hipcc drain the LDS-DMA before every first ds_read of a chunk):
+    // 64 KB = two chunks, plus one uint4 for the masked-forward vote
+    __shared__ __attribute__((aligned(16))) uint4 lds[2 * CHUNK * 64 + 1];
+    int *s_any = reinterpret_cast<int *>(lds + 2 * CHUNK * 64);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 5, col = lane & 31;
+    const MlpNetDev &net = a.net[blockIdx.y];
+    const long long row0 = ((long long)blockIdx.x * WAVES + wave) * TILE;
+    const bool live = row0 + col < a.n;
+    const long long row = live ? row0 + col : a.n - 1;      // ragged tail: shadow the last drone, never store
+    bool tile_wanted = true;
+    if (a.row_mask) {
+        // masked forward: the four waves vote; a workgroup none of whose 128 drones is flagged writes zeros and leaves;
+        // inside a workgroup that stays, a wave whose own 32 drones are all unflagged still computes (it shares the
+        // barriers and the DMA duty) but stores zeros
+        const bool wanted = live && a.row_mask[row0 + col] != 0;
+        tile_wanted = __ballot(wanted) != 0ull;
+        if (lane == 0) s_any[wave] = tile_wanted;
+        __syncthreads();
+        if ((s_any[0] | s_any[1] | s_any[2] | s_any[3]) == 0) {
+            if (g == 0 && live)
+                for (int j = 0; j < net.out_dim; ++j) net.out[(row0 + col) * net.out_dim + j] = 0.0f;
+            return;
+        }
+    }
+    dma_chunk(net.w1, lds, H1 / 32, wave, lane);            // layer 1 = one chunk of 16 fragments, into buffer 0
+    bf16x8 x0[1];
+    {
+        const float *o = a.obs + row * a.obs_dim;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int k = 8 * g + s;
+            x0[0][s] = (__bf16)(k < a.obs_dim ? o[k] : 0.0f);
+        }
+    }
+    chunk_barrier();
+    // LDS buffer parities: layer 1 (one chunk of 16 fragments) in buffer 0; layer 2's 16 chunks start in buffer 1;
+    // layer 3's 8 chunks start at 1 + 16 -> buffer 1; the head (one chunk of 16 fragments) at 17 + 8 -> buffer 1
+    bf16x8 h1[H1 / 16];
+    {
+        dma_chunk(net.w2, lds + CHUNK * 64, CHUNK, wave, lane);          // layer 2, chunk 0 -> buffer 1
+#pragma unroll
+        for (int m = 0; m < H1 / 32; ++m) {                              // K = 16: one fragment per M-tile
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = net.b1[acc_row(m, g, r)];
+            const uint4 w = lds[m * 64 + lane];
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), x0[0], acc, 0, 0, 0);
+            epilogue(acc, true, h1[2 * m], h1[2 * m + 1]);
+        }
+        chunk_barrier();
+    }
+    bf16x8 h2[H2 / 16];
+    layer_lds<H2 / 32, 1, CHUNK>(net.w2, net.b2, net.w3, h1, h2, lds, wave, lane);
+    bf16x8 h3[H3 / 16];
+    layer_lds<H3 / 32, 1, H3 / 16>(net.w3, net.b3, net.wh, h2, h3, lds, wave, lane);
+    // head: one M-tile of H3/16 = 16 fragments; float32 result straight from the accumulator
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = net.bh[acc_row(0, g, r)];
+    const uint4 *cur = lds + 1 * (CHUNK * 64);
+#pragma unroll
+    for (int kk = 0; kk < H3 / 16; ++kk) {
+        const uint4 w = cur[kk * 64 + lane];
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), h3[kk], acc, 0, 0, 0);
+    }
+    if (live) {
+        float *o = net.out + (row0 + col) * net.out_dim;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = acc_row(0, g, r);
+            if (j < net.out_dim) o[j] = tile_wanted ? acc[r] : 0.0f;
+        }
+    }
+}
+
 }  // namespace
 
 hipError_t dn_launch_mlp(const dn_mlp_net *nets, int num_nets, const float *obs, const uint8_t *row_mask, long long n, int obs_dim,
@@ -165,6 +351,8 @@ hipError_t dn_launch_mlp(const dn_mlp_net *nets, int num_nets, const float *obs,
     }
     a.obs = obs; a.row_mask = row_mask; a.n = n; a.obs_dim = obs_dim;
     const unsigned tiles = (unsigned)((n + TILE - 1) / TILE);
-    hipLaunchKernelGGL(dn_mlp_kernel, dim3(tiles, num_nets), dim3(64), 0, stream, a);
+    static const int shape = [] { const char *e = getenv("DN_MLP_SHAPE"); return e ? atoi(e) : 4; }();   // 1 | 4 waves per workgroup
+    if (shape == 1) hipLaunchKernelGGL(dn_mlp_kernel, dim3(tiles, num_nets), dim3(64), 0, stream, a);
+    else hipLaunchKernelGGL(dn_mlp_lds_kernel, dim3((tiles + WAVES - 1) / WAVES, num_nets), dim3(64 * WAVES), 0, stream, a);
     return hipGetLastError();
 }
