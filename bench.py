@@ -276,6 +276,20 @@ def main():
             others[m_] = {"us_per_vector_step": round(us, 4), "value": round(n * world / (us * 1e-6), 1),
                           "roofline_frac": round(ALGO_BYTES_PER_ENV_STEP * n / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 5)}
     waves = env.kernel_waves(fused=args.mode == "many")
+    # the SB3 NumPy surface (PCIe-inclusive: H2D actions, D2H obs/reward/done/found, N info dicts built in Python);
+    # host bound, reported for the record only
+    if world == 1:
+        import numpy as np
+        a_np = acts[0].cpu().numpy()
+        for mode_ in ("full", "sparse"):
+            env.info_mode = mode_
+            env.step(a_np)
+            t0_ = time.perf_counter()
+            reps_ = 5
+            for _ in range(reps_):
+                env.step(a_np)
+            us = (time.perf_counter() - t0_) * 1e6 / reps_
+            others["sb3_numpy_step_infos_" + mode_] = {"us_per_vector_step": round(us, 1), "value": round(n / (us * 1e-6), 1)}
 
     algo = ALGO_BYTES_PER_ENV_STEP + (ALGO_BYTES_NORMALISER if args.normalize_obs else 0)
     for o_ in others.values():

@@ -177,3 +177,74 @@ class RolloutCollector:
         if self.gather:
             out["advantages_global"], out["returns_global"] = all_gather_rollout(out["advantages"], out["returns"], self.group)
         return out
+
+
+class ReplayBuffer:
+    """Device-resident ring buffer with the layout and semantics of SB3's `ReplayBuffer` as the reference's SAC/DDPG
+    agents use it (PBDroneSimulator.py:297-338; `SaveReplayBufferCallback`, Sol/Utilities/Callbacks.py:13-39)
+    [3P-recall]: per slot and drone `obs`, `next_obs` (the TERMINAL observation where the episode ended, not the reset
+    one), `action`, `reward`, `done` (with `handle_timeout_termination`: a TimeLimit truncation is stored as not done)
+    and `timeout`.  Step-major [buffer_size, N, ...]; `add` is a handful of in-place copies, `sample` a gather."""
+
+    def __init__(self, buffer_size, num_envs, obs_dim, act_dim, device):
+        f32, dev = torch.float32, torch.device(device)
+        self.buffer_size, self.num_envs = int(buffer_size), int(num_envs)
+        self.obs = torch.empty((self.buffer_size, num_envs, obs_dim), dtype=f32, device=dev)
+        self.next_obs = torch.empty_like(self.obs)
+        self.actions = torch.empty((self.buffer_size, num_envs, act_dim), dtype=f32, device=dev)
+        self.rewards = torch.empty((self.buffer_size, num_envs), dtype=f32, device=dev)
+        self.dones = torch.empty((self.buffer_size, num_envs), dtype=f32, device=dev)
+        self.timeouts = torch.empty((self.buffer_size, num_envs), dtype=f32, device=dev)
+        self.pos, self.full = 0, False
+
+    def add(self, obs, next_obs, action, reward, done, timeout):
+        p = self.pos
+        self.obs[p].copy_(obs)
+        self.next_obs[p].copy_(next_obs)
+        self.actions[p].copy_(action)
+        self.rewards[p].copy_(reward)
+        self.dones[p].copy_(done)
+        self.timeouts[p].copy_(timeout)
+        self.pos = (p + 1) % self.buffer_size
+        self.full = self.full or self.pos == 0
+
+    def __len__(self):
+        return (self.buffer_size if self.full else self.pos) * self.num_envs
+
+    def sample(self, batch_size, generator=None):
+        upper = self.buffer_size if self.full else self.pos
+        if upper == 0:
+            raise RuntimeError("the replay buffer is empty")
+        dev = self.obs.device
+        t = torch.randint(0, upper, (batch_size,), device=dev, generator=generator)
+        e = torch.randint(0, self.num_envs, (batch_size,), device=dev, generator=generator)
+        return dict(obs=self.obs[t, e], next_obs=self.next_obs[t, e], actions=self.actions[t, e], rewards=self.rewards[t, e],
+                    dones=self.dones[t, e] * (1.0 - self.timeouts[t, e]))
+
+
+class OffPolicyCollector:
+    """BASELINE config 5's collection loop (SAC: one environment step per policy step, every transition into the
+    replay buffer): actor(obs) -> actions in [-1, 1] -> dn_step -> ReplayBuffer.add with SB3's terminal-observation
+    handling.  Sharded like the on-policy collector: a rank's drones feed the rank's buffer, no collective."""
+
+    def __init__(self, env, actor, buffer_size):
+        from .vec_env import ACT_DIM, DroneVecEnv
+        if not isinstance(env, DroneVecEnv):
+            raise TypeError("OffPolicyCollector drives a DroneVecEnv (HIP); there is no CPU path")
+        self.env, self.actor = env, actor
+        self.buffer = ReplayBuffer(buffer_size, env.num_envs, env.obs_dim, ACT_DIM, env.device)
+        self._obs = env.reset_tensor().clone()
+        self.num_timesteps = 0
+
+    @torch.no_grad()
+    def collect(self, n_steps=1):
+        env = self.env
+        for _ in range(int(n_steps)):
+            actions = self.actor(self._obs).clamp(-1.0, 1.0)
+            next_obs, reward, done, info = env.step_tensor(actions, want_terminal=True)
+            d = done.bool()[:, None]
+            self.buffer.add(self._obs, torch.where(d, info["terminal_obs"], next_obs), actions, reward, done.float(),
+                            info["truncated"].float())
+            self._obs.copy_(next_obs)
+            self.num_timesteps += env.num_envs
+        return self.buffer

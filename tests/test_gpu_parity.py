@@ -664,3 +664,46 @@ def test_fused_mfma_mlp_matches_torch(n):
     tile_has[:n] = mask.bool()
     tile_has = tile_has.view(-1, 32).any(1).repeat_interleave(32)[:n]
     assert torch.equal(mv[tile_has], value.squeeze(-1)[tile_has]) and float(mv[~tile_has].abs().sum()) == 0.0
+
+
+def test_off_policy_collector_fills_replay_buffer_like_sb3():
+    """BASELINE config 5: SAC-style collection with Philox action/observation noise on; every stored transition is
+    checked against an oracle replay of the actions taken: next_obs is the terminal observation where the episode
+    ended, a TimeLimit truncation is stored as done with the timeout flag (sampled as not done)."""
+    pkg = _gpu()
+    from drl_dronenavigation_amd.collector import OffPolicyCollector
+    track = _tracks().reaching()
+    n, T = 512, 230
+    kw = dict(max_steps=100, normalize_obs=False, act_noise_sigma=0.001, obs_noise_sigma=0.01, seed=4, env_id_offset=7 * 1024)
+    env, ora = make_pair(track, n, f32_state=True, **kw)
+    dev = env.device
+    g = torch.Generator(device="cpu").manual_seed(5)
+    w = (torch.randn(13, 4, generator=g) * 0.02).to(dev)
+    pattern = torch.sign(torch.randn(n, 4, generator=g)).to(dev)       # a fixed bang-bang pattern per drone
+
+    def actor(obs):
+        hover = (torch.arange(n, device=dev) % 2 == 1)[:, None]
+        return torch.where(hover, torch.full((n, 4), 0.0922, device=dev) + obs @ w * 0.001, pattern * (1.3 + obs[:, :1] * 0.0))
+
+    col = OffPolicyCollector(env, actor, buffer_size=T)
+    obs_ref = ora.reset()
+    buf = col.collect(T)
+    assert len(buf) == T * n and buf.full
+    n_timeouts = n_term = 0
+    for t in range(T):
+        np.testing.assert_allclose(buf.obs[t].cpu().numpy(), obs_ref, rtol=0, atol=1e-5)
+        ref = ora.step(buf.actions[t].cpu().numpy())
+        dn = ref["done"].astype(bool)
+        want_next = np.where(dn[:, None], ref["terminal_obs"], ref["obs"])
+        np.testing.assert_allclose(buf.next_obs[t].cpu().numpy(), want_next, rtol=0, atol=1e-5)
+        np.testing.assert_allclose(buf.rewards[t].cpu().numpy(), ref["reward"], rtol=1e-5, atol=1e-4)
+        assert np.array_equal(buf.dones[t].cpu().numpy().astype(bool), dn)
+        assert np.array_equal(buf.timeouts[t].cpu().numpy().astype(bool), ref["truncated"].astype(bool))
+        n_timeouts += int(ref["truncated"].sum())
+        n_term += int((dn & ~ref["truncated"].astype(bool)).sum())
+        obs_ref = ref["obs"]
+    assert n_timeouts > 0 and n_term > 0, (n_timeouts, n_term)
+    batch = buf.sample(4096, generator=torch.Generator(device=dev).manual_seed(1))
+    assert batch["obs"].shape == (4096, 13) and batch["actions"].shape == (4096, 4)
+    assert float(batch["dones"].max()) <= 1.0 and float((buf.dones * buf.timeouts).sum()) == n_timeouts
+    env.close()
