@@ -707,3 +707,59 @@ def test_off_policy_collector_fills_replay_buffer_like_sb3():
     assert batch["obs"].shape == (4096, 13) and batch["actions"].shape == (4096, 4)
     assert float(batch["dones"].max()) <= 1.0 and float((buf.dones * buf.timeouts).sum()) == n_timeouts
     env.close()
+
+
+@pytest.mark.parametrize("dist", ["uniform", "hover"])
+def test_baseline_config2_teacher_forced_1024_steps(dist):
+    """BASELINE configs[1] as SURVEY 8(d) C2 spells it out: 4096 drones, 4-gate circle track, T = 1024 steps, actions
+    U(-1,1)^4 float32 from numpy Generator(PCG64(seed=1)) drawn as one (T, N, 4) tensor (second distribution:
+    0.0922 + 0.003 N(0,1), hover +- noise, for long flights and gate passes); observation normaliser off; GPU vs the
+    float64 oracle teacher-forced every step: state 1e-5, done / truncated / waypoint index exact."""
+    track = _tracks().circle(1, 4, 1)
+    n, T = 4096, 1024
+    env, ora = make_pair(track, n, f32_state=False, max_steps=4096 if dist == "uniform" else 300, normalize_obs=False)
+    env.reset_tensor()
+    ora.reset()
+    rng = np.random.Generator(np.random.PCG64(seed=1))
+    if dist == "uniform":
+        acts = rng.uniform(-1, 1, (T, n, 4)).astype(np.float32)
+    else:
+        acts = (0.0922 + 0.003 * rng.standard_normal((T, n, 4))).astype(np.float32)
+    dev = torch.device("cuda:0")
+    a_dev = torch.from_numpy(acts).to(dev)
+    n_done = n_gates = 0
+    worst = 0.0
+    for t in range(T):
+        st = env.get_state()
+        gpu_state_to_oracle(st, ora.envs, t)
+        out = env.step_tensor(a_dev[t])
+        ref = ora.step(acts[t])
+        n_done += compare_step(out, ref, f"C2 {dist} t={t}")
+        n_gates = max(n_gates, int(ref["found_targets"].max()))
+        if t % 16 == 0:
+            st2 = env.get_state()
+            for k in STATE_F32:
+                err = float(np.abs(st2[k].astype(np.float64) - ora.envs[k]).max())
+                worst = max(worst, err)
+                assert err <= 1e-5, (dist, t, k, err)
+    assert n_done > n            # uniform: crashes within tens of steps; hover: time-limit truncations and drift-outs
+    print(f"C2 {dist}: {n_done} episodes, deepest waypoint index {n_gates}, max |state err| {worst:.2e}")
+    env.close()
+
+
+def test_baseline_full_size_matches_oracle_free_running():
+    """BASELINE configs[2] size (32768 drones, race track) against the oracle itself, not only through properties: 64
+    free-running steps of the mixed action stream (the oracle keeps float32 state like HBM does), every drone, every
+    output."""
+    track = _tracks().reaching()
+    n, T = 32768, 64
+    env, ora = make_pair(track, n, f32_state=True, max_steps=40, normalize_obs=False)
+    np.testing.assert_allclose(env.reset_tensor().cpu().numpy(), ora.reset(), rtol=0, atol=1e-6)
+    rng = np.random.default_rng(32768)
+    dev = torch.device("cuda:0")
+    n_done = 0
+    for t in range(T):
+        a = actions_mixed(rng, n)
+        n_done += compare_step(env.step_tensor(torch.from_numpy(a).to(dev)), ora.step(a), f"full-size t={t}", rew_atol=1e-4)
+    assert n_done >= n // 2
+    env.close()
