@@ -103,17 +103,20 @@ def ppo_rollout(pkg, track, n, max_steps, dev, rank):
     n_steps x (MLP 13-512-512-256 actor + critic, Gaussian sample, clip, dn_step, truncation bootstrap) + GAE, every
     buffer on the GPU, the rollout replayed from a hipGraph.  Reported beside the headline, never as `value`."""
     import torch
-    from drl_dronenavigation_amd.collector import RolloutCollector
+    from drl_dronenavigation_amd.collector import FusedRolloutCollector, RolloutCollector
     n_steps = 32                                   # re-parameterised from 4096 (SURVEY section 7: 4096 x 32768 does not fit)
     torch.manual_seed(1 + rank)
     net = pkg.MlpActorCritic().to(dev)
     res = {}
     fused = pkg.FusedMlpPolicy(net, n, dev)
     for label, use_graph, trunk in (("eager", False, None), ("graph", True, None), ("graph_bf16", True, torch.bfloat16),
-                                    ("graph_mfma", True, "mfma"), ("eager_mfma", False, "mfma")):
-        net.trunk_dtype = trunk if trunk != "mfma" else None
+                                    ("graph_mfma", True, "mfma"), ("eager_mfma", False, "mfma"),
+                                    ("fused_eager", False, "fused"), ("fused_graph", True, "fused")):
+        net.trunk_dtype = trunk if trunk not in ("mfma", "fused") else None
         env = pkg.DroneVecEnv(track, n, max_steps=max_steps, normalize_obs=True, env_id_offset=rank * n, device=dev)
-        if trunk == "mfma":
+        if trunk == "fused":
+            col = FusedRolloutCollector(env, fused, n_steps, use_graph=use_graph, seed=1 + rank)
+        elif trunk == "mfma":
             col = RolloutCollector(env, fused, n_steps, value_fn=fused.predict_values, use_graph=use_graph)
         else:
             col = RolloutCollector(env, net, n_steps, value_fn=net.predict_values, use_graph=use_graph)
@@ -128,11 +131,15 @@ def ppo_rollout(pkg, track, n, max_steps, dev, rank):
         dt = time.perf_counter() - t0
         res[label] = n * n_steps * reps / dt
         env.close()
-    return {"value": round(res["graph_mfma"], 1), "unit": "env-steps/s", "policy": "fused MFMA MLP (dn_mlp_forward, bf16 "
-            "weights/activations, float32 accumulate), hipGraph replay",
+    return {"value": round(res["fused_graph"], 1), "unit": "env-steps/s",
+            "policy": "fused MFMA MLP (dn_mlp_forward, bf16 weights/activations, float32 accumulate) + dn_policy_sample + "
+                      "dn_step + masked bootstrap: five launches per step, hipGraph replay",
             "variants": {"torch fp32 eager": round(res["eager"], 1), "torch fp32 hipGraph": round(res["graph"], 1),
                          "torch bf16 trunks hipGraph": round(res["graph_bf16"], 1),
-                         "fused MFMA eager": round(res["eager_mfma"], 1), "fused MFMA hipGraph": round(res["graph_mfma"], 1)},
+                         "fused MFMA policy, torch glue, eager": round(res["eager_mfma"], 1),
+                         "fused MFMA policy, torch glue, hipGraph": round(res["graph_mfma"], 1),
+                         "fused collector eager": round(res["fused_eager"], 1),
+                         "fused collector hipGraph": round(res["fused_graph"], 1)},
             "n_steps": n_steps, "num_envs": n,
             "what": "policy-in-the-loop rollout: MLP 13-512-512-256 (pi, vf; Tanh) + Gaussian sample + dn_step + "
                     "V(terminal_obs) bootstrap per step, dn_gae per rollout, per-drone obs normaliser on"}

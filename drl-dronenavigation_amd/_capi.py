@@ -82,6 +82,8 @@ PROTOTYPES = {
     "dn_get_step_count": (_I32, [_VP, C.POINTER(C.c_uint64)]),
     "dn_set_step_count": (_I32, [_VP, C.c_uint64]),
     "dn_preprocess_action": (_I32, [_VP, _I64, _I32, _VP, _VP, _VP, _I32, _VP]),
+    "dn_policy_sample": (_I32, [_VP, _VP, C.POINTER(C.c_float), C.c_uint64, _I32, _VP, _VP, _VP, _VP]),
+    "dn_add_bootstrap": (_I32, [_VP, _VP, _VP, C.c_double, _I64, _I32, _VP]),
     "dn_mlp_forward": (_I32, [_VP, _I32, _VP, _VP, _I64, _I32, _I32, _VP]),
     "dn_gae": (_I32, [_VP] * 5 + [_I64, _I64, C.c_double, C.c_double, _VP, _VP, _I32, _VP]),
     "dn_state_bytes": (_I64, [_I64, _I32]),

@@ -248,3 +248,104 @@ class OffPolicyCollector:
             self._obs.copy_(next_obs)
             self.num_timesteps += env.num_envs
         return self.buffer
+
+
+class FusedRolloutCollector:
+    """The on-policy rollout with every per-step operation on a purpose-built kernel and no intermediate copies:
+
+        dn_mlp_forward (actor + critic, one launch; the value lands in the rollout buffer)
+        dn_policy_sample (Gaussian sample from the environment's Philox streams, clip, log-probability -> buffer)
+        dn_step (writes the next observation, the reward and the episode-start flag straight into the buffer slots)
+        dn_mlp_forward masked by `truncated` on the terminal observations + dn_add_bootstrap (SB3's TimeLimit bootstrap)
+
+    five launches per step instead of ~25 small torch kernels, then dn_gae; the whole rollout is captured into one
+    hipGraph on the second call (`use_graph`).  Same results contract as RolloutCollector (SB3 collect_rollouts
+    semantics); the action noise comes from Philox (seed, global drone id, step counter), so a rollout is reproducible
+    and independent of how the drones are sharded.  Call `policy.refresh()` after optimiser steps and `recapture()`
+    if log_std changed (it is baked into the captured launches)."""
+
+    def __init__(self, env, policy, n_steps, *, gamma=0.99, gae_lambda=0.95, bootstrap_truncated=True, gather=False,
+                 group=None, use_graph=True, seed=0):
+        from .policy_mfma import FusedMlpPolicy
+        from .vec_env import ACT_DIM, OBS_DIM, DroneVecEnv
+        if not isinstance(env, DroneVecEnv) or not isinstance(policy, FusedMlpPolicy):
+            raise TypeError("FusedRolloutCollector needs a DroneVecEnv and a FusedMlpPolicy (HIP); there is no CPU path")
+        if env.num_envs % 4 or env.obs_dim != OBS_DIM:
+            raise ValueError("num_envs must be a multiple of 4 and the observation the full 13 columns")
+        self.env, self.policy = env, policy
+        self.n_steps, self.gamma, self.gae_lambda = int(n_steps), float(gamma), float(gae_lambda)
+        self.bootstrap_truncated, self.gather, self.group, self.use_graph = bool(bootstrap_truncated), bool(gather), group, bool(use_graph)
+        self.seed = int(seed)
+        n, T, dev, f32, u8 = env.num_envs, self.n_steps, env.device, torch.float32, torch.uint8
+        self.buf = dict(
+            obs=torch.empty((T + 1, n, OBS_DIM), dtype=f32, device=dev),
+            actions=torch.empty((T, n, ACT_DIM), dtype=f32, device=dev),
+            values=torch.empty((T, n), dtype=f32, device=dev), log_probs=torch.empty((T, n), dtype=f32, device=dev),
+            rewards=torch.empty((T, n), dtype=f32, device=dev),
+            episode_starts=torch.ones((T + 1, n), dtype=u8, device=dev),          # SB3: _last_episode_starts = True
+            advantages=torch.empty((T, n), dtype=f32, device=dev), returns=torch.empty((T, n), dtype=f32, device=dev),
+            last_values=torch.empty((n, 1), dtype=f32, device=dev))
+        self._mean = torch.empty((n, ACT_DIM), dtype=f32, device=dev)
+        self._clipped = torch.empty((n, ACT_DIM), dtype=f32, device=dev)
+        self._trunc = torch.zeros(n, dtype=u8, device=dev)
+        self._found = torch.zeros(n, dtype=torch.int32, device=dev)
+        self._term_obs = torch.zeros((n, OBS_DIM), dtype=f32, device=dev)
+        self._tv = torch.zeros((n, 1), dtype=f32, device=dev)
+        self.buf["obs"][0].copy_(env.reset_tensor())
+        self.num_timesteps = 0
+        self._graph, self._calls = None, 0
+
+    def recapture(self):
+        self._graph = None
+
+    def _rollout(self):
+        import ctypes as C
+        from . import _capi
+        from .policy_mfma import mlp_forward
+        env, pol, b, T = self.env, self.policy, self.buf, self.n_steps
+        lib, h, n, dev = _capi.load(), env._handle, env.num_envs, env.device
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        log_std = (C.c_float * 4)(*[float(x) for x in pol.log_std_host])
+        for t in range(T):
+            obs_t = b["obs"][t]
+            mlp_forward([pol.pi, pol.vf], obs_t, [self._mean, b["values"][t].view(n, 1)])
+            _capi.check(lib.dn_policy_sample(h, self._mean.data_ptr(), log_std, self.seed, 0, b["actions"][t].data_ptr(),
+                                             self._clipped.data_ptr(), b["log_probs"][t].data_ptr(), stream))
+            _capi.check(lib.dn_step(h, self._clipped.data_ptr(), b["obs"][t + 1].data_ptr(), b["rewards"][t].data_ptr(),
+                                    b["episode_starts"][t + 1].data_ptr(), self._trunc.data_ptr(), self._found.data_ptr(),
+                                    self._term_obs.data_ptr() if self.bootstrap_truncated else None, None, None, None, stream))
+            if self.bootstrap_truncated:
+                mlp_forward([pol.vf], self._term_obs, [self._tv], row_mask=self._trunc)
+                _capi.check(lib.dn_add_bootstrap(b["rewards"][t].data_ptr(), self._tv.data_ptr(), self._trunc.data_ptr(),
+                                                 self.gamma, n, dev.index, stream))
+        mlp_forward([pol.vf], b["obs"][T], [b["last_values"]])
+        _capi.check(lib.dn_gae(b["rewards"].data_ptr(), b["values"].data_ptr(), b["episode_starts"].data_ptr(),
+                               b["last_values"].data_ptr(), b["episode_starts"][T].data_ptr(), T, n, self.gamma,
+                               self.gae_lambda, b["advantages"].data_ptr(), b["returns"].data_ptr(), dev.index, stream))
+
+    @torch.no_grad()
+    def collect(self):
+        """One rollout; returns views of the static buffers (obs / episode_starts hold n_steps + 1 slots: the last one is
+        the observation / start flag the next rollout begins with)."""
+        env, b, T = self.env, self.buf, self.n_steps
+        with torch.cuda.device(env.device):
+            if self._calls > 0:                            # carry the last observation / start flags over
+                b["obs"][0].copy_(b["obs"][T])
+                b["episode_starts"][0].copy_(b["episode_starts"][T])
+            if self.use_graph and self._calls >= 1:
+                if self._graph is None:
+                    torch.cuda.synchronize(env.device)
+                    self._graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(self._graph):
+                        self._rollout()
+                self._graph.replay()
+            else:
+                self._rollout()
+        self._calls += 1
+        self.num_timesteps += T * env.num_envs
+        out = dict(obs=b["obs"][:T], actions=b["actions"], values=b["values"], log_probs=b["log_probs"], rewards=b["rewards"],
+                   episode_starts=b["episode_starts"][:T], advantages=b["advantages"], returns=b["returns"],
+                   last_values=b["last_values"].view(-1), last_dones=b["episode_starts"][T], next_obs=b["obs"][T])
+        if self.gather:
+            out["advantages_global"], out["returns_global"] = all_gather_rollout(out["advantages"], out["returns"], self.group)
+        return out

@@ -518,6 +518,27 @@ int32_t dn_preprocess_action(const float *actions, int64_t num_envs, int32_t nor
     return DN_OK;
 }
 
+int32_t dn_policy_sample(dn_env *env, const float *mean, const float *log_std, uint64_t seed, int32_t deterministic, float *actions,
+                         float *clipped, float *log_prob, void *stream)
+{
+    if (!env || !mean || !log_std || !actions || !clipped || !log_prob)
+        return fail(DN_ERR_INVALID_ARGUMENT, "env, mean, log_std, actions, clipped and log_prob are required");
+    if (((uintptr_t)mean | (uintptr_t)actions | (uintptr_t)clipped) & 15u)
+        return fail(DN_ERR_INVALID_ARGUMENT, "mean, actions and clipped must be 16-byte aligned");
+    DN_HIP(dn_launch_policy_sample(env->p, mean, log_std, seed, deterministic, actions, clipped, log_prob, (hipStream_t)stream));
+    return DN_OK;
+}
+
+int32_t dn_add_bootstrap(float *reward, const float *terminal_value, const uint8_t *truncated, double gamma, int64_t num_envs,
+                         int32_t device_id, void *stream)
+{
+    if (!reward || !terminal_value || !truncated || num_envs < 1)
+        return fail(DN_ERR_INVALID_ARGUMENT, "reward, terminal_value, truncated are required and num_envs >= 1");
+    DN_HIP(hipSetDevice(device_id));
+    DN_HIP(dn_launch_add_bootstrap(reward, terminal_value, truncated, (float)gamma, num_envs, (hipStream_t)stream));
+    return DN_OK;
+}
+
 int32_t dn_mlp_forward(const dn_mlp_net *nets, int32_t num_nets, const float *obs, const uint8_t *row_mask, int64_t num_envs,
                        int32_t obs_dim, int32_t device_id, void *stream)
 {

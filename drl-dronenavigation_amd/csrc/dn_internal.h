@@ -105,6 +105,10 @@ hipError_t dn_launch_action_chain(const float *actions, long long n, int normali
                                   float *z_torque, hipStream_t stream);
 hipError_t dn_launch_fill4(float4 *dst, float4 v, long long n, hipStream_t stream);
 hipError_t dn_launch_filld(double *dst, double v, long long n, hipStream_t stream);
+hipError_t dn_launch_policy_sample(const DnParams &p, const float *mean, const float *log_std4, unsigned long long seed, int deterministic,
+                                   float *actions, float *clipped, float *log_prob, hipStream_t stream);
+hipError_t dn_launch_add_bootstrap(float *reward, const float *terminal_value, const uint8_t *truncated, float gamma, long long n,
+                                   hipStream_t stream);
 hipError_t dn_launch_set_step_count(DnStatSlot *slots, long long blocks, unsigned long long value, hipStream_t stream);
 hipError_t dn_launch_mlp(const dn_mlp_net *nets, int num_nets, const float *obs, const uint8_t *row_mask, long long n, int obs_dim,
                          hipStream_t stream);

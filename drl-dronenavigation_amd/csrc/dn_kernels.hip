@@ -1191,6 +1191,45 @@ __global__ __launch_bounds__(256) void dn_action_chain_kernel(const float4 *__re
     if (z_torque) z_torque[i] = z_torque32(tq);
 }
 
+// Rollout-step glue around the policy network (the host loop's small element-wise kernels, fused):
+//   dn_policy_sample_kernel  -- SB3 DiagGaussianDistribution.sample / log_prob and the np.clip of collect_rollouts
+//                               [3P-recall]: actions = mean + exp(log_std) z, z ~ N(0,1) from the environment's Philox
+//                               stream (seed, global drone id, the tile's vector-step counter, stream 9), the clipped copy
+//                               that goes to dn_step, and log N(actions; mean, std) summed over the four action dims.
+//   dn_add_bootstrap_kernel  -- reward += gamma * V(terminal_observation) where TimeLimit.truncated (SB3's
+//                               collect_rollouts bootstrap) [3P-recall].
+__global__ __launch_bounds__(256) void dn_policy_sample_kernel(const DnParams p, const float4 *__restrict__ mean,
+                                                               const float4 log_std, const unsigned long long seed,
+                                                               const int deterministic, float4 *__restrict__ actions,
+                                                               float4 *__restrict__ clipped, float *__restrict__ log_prob)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.n) return;
+    const float4 m = mean[i];
+    const float mu[4] = {m.x, m.y, m.z, m.w};
+    const float ls[4] = {log_std.x, log_std.y, log_std.z, log_std.w};
+    float z[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (!deterministic)
+        noise4(seed, (unsigned long long)(p.env_id_offset + i), (unsigned)p.st.stats[i / DN_BLOCK].step_count, 9u, z);
+    float a[4], lp = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        a[j] = mu[j] + expf(ls[j]) * z[j];
+        // log N(a; mu, sigma) with (a - mu)/sigma = z
+        lp += -0.5f * z[j] * z[j] - ls[j] - 0.91893853320467274178f;
+    }
+    actions[i] = make_float4(a[0], a[1], a[2], a[3]);
+    clipped[i] = make_float4(clipv(a[0], -1.0f, 1.0f), clipv(a[1], -1.0f, 1.0f), clipv(a[2], -1.0f, 1.0f), clipv(a[3], -1.0f, 1.0f));
+    log_prob[i] = lp;
+}
+
+__global__ __launch_bounds__(256) void dn_add_bootstrap_kernel(float *__restrict__ reward, const float *__restrict__ terminal_value,
+                                                               const uint8_t *__restrict__ truncated, float gamma, long long n)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && truncated[i]) reward[i] = reward[i] + gamma * terminal_value[i];
+}
+
 __global__ __launch_bounds__(256) void dn_set_step_count_kernel(DnStatSlot *slots, long long blocks, unsigned long long value)
 {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < blocks; i += (long long)gridDim.x * blockDim.x)
@@ -1279,6 +1318,24 @@ hipError_t dn_launch_action_chain(const float *actions, long long n, int normali
     const unsigned grid = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(dn_action_chain_kernel, dim3(grid), dim3(256), 0, stream, reinterpret_cast<const float4 *>(actions), n,
                        normalize_actions, reinterpret_cast<float4 *>(rpm), reinterpret_cast<float4 *>(forces), z_torque);
+    return hipGetLastError();
+}
+
+hipError_t dn_launch_policy_sample(const DnParams &p, const float *mean, const float *log_std4, unsigned long long seed, int deterministic,
+                                   float *actions, float *clipped, float *log_prob, hipStream_t stream)
+{
+    const unsigned grid = (unsigned)((p.n + 255) / 256);
+    hipLaunchKernelGGL(dn_policy_sample_kernel, dim3(grid), dim3(256), 0, stream, p, reinterpret_cast<const float4 *>(mean),
+                       make_float4(log_std4[0], log_std4[1], log_std4[2], log_std4[3]), seed, deterministic,
+                       reinterpret_cast<float4 *>(actions), reinterpret_cast<float4 *>(clipped), log_prob);
+    return hipGetLastError();
+}
+
+hipError_t dn_launch_add_bootstrap(float *reward, const float *terminal_value, const uint8_t *truncated, float gamma, long long n,
+                                   hipStream_t stream)
+{
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(dn_add_bootstrap_kernel, dim3(grid), dim3(256), 0, stream, reward, terminal_value, truncated, gamma, n);
     return hipGetLastError();
 }
 

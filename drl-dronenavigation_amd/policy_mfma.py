@@ -109,6 +109,7 @@ class FusedMlpPolicy:
         vf = [(l.weight, l.bias) for l in lin(m.vf)] + [(m.value_net.weight, m.value_net.bias)]
         self.pi, self.vf = pack_mlp(pi, self.device), pack_mlp(vf, self.device)
         self.log_std = m.log_std.detach().to(self.device).float()
+        self.log_std_host = [float(x) for x in m.log_std.detach().cpu().float()]     # dn_policy_sample takes it by value
 
     def __call__(self, obs, deterministic=False):
         mlp_forward([self.pi, self.vf], obs, [self._mean, self._value])

@@ -208,6 +208,19 @@ typedef struct dn_mlp_net {
 int32_t dn_mlp_forward(const dn_mlp_net *nets, int32_t num_nets, const float *obs, const uint8_t *row_mask,
                        int64_t num_envs, int32_t obs_dim, int32_t device_id, void *stream);
 
+/* The small element-wise steps of SB3's OnPolicyAlgorithm.collect_rollouts around the policy network, as kernels
+ * [3P-recall of SB3]:
+ *   dn_policy_sample  DiagGaussianDistribution.sample + log_prob and the np.clip(actions, -1, 1) handed to env.step:
+ *                     actions = mean + exp(log_std) z with z ~ N(0,1) from the environment's Philox streams (seed, global
+ *                     drone id, the vector-step counter; reproducible under hipGraph replay), `clipped` = the copy that goes
+ *                     to dn_step, log_prob = sum over the 4 action dims.  mean/actions/clipped: device float[N*4];
+ *                     log_std: HOST float[4]; log_prob: device float[N].
+ *   dn_add_bootstrap  reward[i] += gamma * terminal_value[i] where truncated[i] (TimeLimit bootstrap). */
+int32_t dn_policy_sample(dn_env *env, const float *mean, const float *log_std, uint64_t seed, int32_t deterministic,
+                         float *actions, float *clipped, float *log_prob, void *stream);
+int32_t dn_add_bootstrap(float *reward, const float *terminal_value, const uint8_t *truncated, double gamma,
+                         int64_t num_envs, int32_t device_id, void *stream);
+
 /* Bytes of HBM the persistent state of `num_envs` drones occupies (capacity planning). */
 int64_t dn_state_bytes(int64_t num_envs, int32_t normalize_obs);
 

@@ -763,3 +763,69 @@ def test_baseline_full_size_matches_oracle_free_running():
         n_done += compare_step(env.step_tensor(torch.from_numpy(a).to(dev)), ora.step(a), f"full-size t={t}", rew_atol=1e-4)
     assert n_done >= n // 2
     env.close()
+
+
+def test_fused_rollout_collector_against_oracle_and_graph_replay():
+    """FusedRolloutCollector (dn_mlp_forward -> dn_policy_sample -> dn_step -> masked bootstrap, five launches per step,
+    no copies): the sampled actions are mean + std * z with z from the environment's Philox stream 9 (checked against
+    the oracle's generator), rewards / start flags / bootstrap / advantages against an oracle replay, and the hipGraph
+    replay must reproduce the eager rollouts bit for bit."""
+    pkg = _gpu()
+    import ctypes as C
+    from drl_dronenavigation_amd.collector import FusedRolloutCollector
+    track = _tracks().circle(1, 4, 1)
+    n, T, gamma, lam, seed = 1024, 24, 0.99, 0.95, 31
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    net = pkg.MlpActorCritic(log_std_init=-5.5).to(dev)           # sigma = 0.004: actions stay around the hover band
+    with torch.no_grad():
+        net.action_net.bias.fill_(0.0922)
+    runs = []
+    for use_graph in (False, True):
+        env, ora = make_pair(track, n, f32_state=True, max_steps=20, normalize_obs=False, env_id_offset=5000)
+        pol = pkg.FusedMlpPolicy(net, n, dev)
+        col = FusedRolloutCollector(env, pol, T, gamma=gamma, gae_lambda=lam, use_graph=use_graph, seed=seed)
+        ora.reset()
+        outs = []
+        for it in range(3):
+            out = col.collect()
+            torch.cuda.synchronize()
+            outs.append({k: v.clone() for k, v in out.items()})
+        runs.append(outs)
+        if use_graph:
+            assert col._graph is not None
+            break
+        # eager run: check against the oracle
+        L = O.lib()
+        last_done = np.ones(n, np.uint8)
+        step = 0
+        n_trunc = 0
+        for it in range(3):
+            o = outs[it]
+            mean, value = pkg.policy_mfma.mlp_forward([pol.pi, pol.vf], o["obs"].reshape(-1, 13).contiguous())
+            mean = mean.view(T, n, 4).cpu().numpy()
+            np.testing.assert_allclose(o["values"].cpu().numpy(), value.view(T, n).cpu().numpy(), rtol=0, atol=1e-6)
+            acts, logp = o["actions"].cpu().numpy(), o["log_probs"].cpu().numpy()
+            rew = np.zeros((T, n), np.float32)
+            for t in range(T):
+                z = np.zeros((n, 4), np.float32)
+                for i in range(0, n, 37):                     # the Philox draw of a sample of drones
+                    L.orc_noise4(seed, 5000 + i, step, 9, z[i].ctypes.data_as(C.POINTER(C.c_float)))
+                    np.testing.assert_allclose(acts[t, i], mean[t, i] + np.exp(np.float32(-5.5)) * z[i], rtol=0, atol=2e-6)
+                    assert abs(logp[t, i] - float((-0.5 * z[i].astype(np.float64) ** 2 + 5.5 - 0.9189385332046727).sum())) < 1e-4
+                assert np.array_equal(o["episode_starts"][t].cpu().numpy(), last_done), (it, t)
+                ref = ora.step(np.clip(acts[t], -1, 1))
+                tv = pol.predict_values(torch.from_numpy(ref["terminal_obs"]).to(dev)).cpu().numpy()
+                rew[t] = ref["reward"] + (gamma * tv * ref["truncated"]).astype(np.float32)
+                n_trunc += int(ref["truncated"].sum())
+                last_done = ref["done"]
+                step += 1
+            np.testing.assert_allclose(o["rewards"].cpu().numpy(), rew, rtol=1e-5, atol=2e-4)
+            a_ref, r_ref = O.gae(o["rewards"].cpu().numpy(), o["values"].cpu().numpy(), o["episode_starts"].cpu().numpy(),
+                                 o["last_values"].cpu().numpy(), o["last_dones"].cpu().numpy(), gamma, lam)
+            assert np.array_equal(o["advantages"].cpu().numpy().view(np.uint32), a_ref.view(np.uint32))
+        assert n_trunc > 0
+        env.close()
+    for it in range(3):
+        for k in runs[0][it]:
+            assert torch.equal(runs[0][it][k], runs[1][it][k]), (it, k)
