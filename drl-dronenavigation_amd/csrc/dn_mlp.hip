@@ -27,6 +27,8 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));     // a B operand as the four dwords it occupies
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 #define MLP_DEV __device__ __forceinline__
 
@@ -58,20 +60,27 @@ MLP_DEV int acc_row(int m, int g, int r) { return 32 * m + 4 * g + (r & 3) + 8 *
 
 // The epilogue of an M-tile (16 accumulator values per lane: bias already in, tanh, bf16) costs ~700 VALU cycles, two
 // thirds of the tile's 32 MFMAs (1024 cycles on the matrix pipe).  Issued after the MFMAs it would idle the matrix pipe;
-// issued one element every second MFMA of the NEXT tile it runs entirely in their shadow (the VALU and the matrix pipe
-// are separate; an MFMA only occupies the issue slot once).
-MLP_DEV void epilogue_elem(const f32x16 &acc, const int e, bf16x8 &lo, bf16x8 &hi)
+// it is spread over the NEXT tile's MFMA stream, one pair of elements every fourth MFMA, so that the matrix pipe is
+// never left without a queued MFMA while the wave grinds through 100 VALU instructions.
+MLP_DEV unsigned pack2(float a, float b)
 {
-    const __bf16 v = (__bf16)tanh_fast(acc[e]);
-    if (e < 8) lo[e] = v; else hi[e - 8] = v;
+    bf16x2 pk;
+    pk[0] = (__bf16)a;
+    pk[1] = (__bf16)b;
+    return __builtin_bit_cast(unsigned, pk);                 // one v_cvt_pk_bf16_f32
+}
+MLP_DEV void epilogue_pair(const f32x16 &acc, const int q, u32x4 &lo, u32x4 &hi)
+{   // accumulator elements 2q, 2q+1 -> one dword of the packed B operand
+    const unsigned u = pack2(tanh_fast(acc[2 * q]), tanh_fast(acc[2 * q + 1]));
+    if (q < 4) lo[q] = u; else hi[q - 4] = u;
 }
 
-MLP_DEV void epilogue(const f32x16 &acc, const bool tanh_on, bf16x8 &lo, bf16x8 &hi)
+MLP_DEV void epilogue(const f32x16 &acc, const bool tanh_on, u32x4 &lo, u32x4 &hi)
 {
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-        lo[s] = (__bf16)(tanh_on ? tanh_fast(acc[s]) : acc[s]);
-        hi[s] = (__bf16)(tanh_on ? tanh_fast(acc[8 + s]) : acc[8 + s]);
+    for (int q = 0; q < 4; ++q) {
+        lo[q] = tanh_on ? pack2(tanh_fast(acc[2 * q]), tanh_fast(acc[2 * q + 1])) : pack2(acc[2 * q], acc[2 * q + 1]);
+        hi[q] = tanh_on ? pack2(tanh_fast(acc[8 + 2 * q]), tanh_fast(acc[9 + 2 * q])) : pack2(acc[8 + 2 * q], acc[9 + 2 * q]);
     }
 }
 
@@ -81,7 +90,7 @@ MLP_DEV void epilogue(const f32x16 &acc, const bool tanh_on, bf16x8 &lo, bf16x8 
 // is kept in flight ahead of the MFMA that uses them, because one fragment is one L2 round trip (~200+ cycles) and an
 // MFMA only 32: without the ring the wave waits on every load.
 template <int KS, int MT, bool TANH, int RING>
-MLP_DEV void layer(const uint4 *__restrict__ w, const float *__restrict__ bias, const bf16x8 (&in)[KS], bf16x8 (&out)[2 * MT],
+MLP_DEV void layer(const uint4 *__restrict__ w, const float *__restrict__ bias, const u32x4 (&in)[KS], u32x4 (&out)[2 * MT],
                    const int lane)
 {
     const int g = lane >> 5;
@@ -102,9 +111,9 @@ MLP_DEV void layer(const uint4 *__restrict__ w, const float *__restrict__ bias, 
             const int t = m * KS + kk;
             const uint4 a = ring[t % P];
             if (t + P < T) ring[t % P] = wl[(t + P) * 64];
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), in[kk], acc, 0, 0, 0);
-            // the previous tile's epilogue, one element every second MFMA (KS = 32), in the MFMAs' shadow
-            if (TANH && KS == 32 && m > 0 && (kk & 1)) epilogue_elem(prev, kk >> 1, out[2 * (m - 1)], out[2 * (m - 1) + 1]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, in[kk]), acc, 0, 0, 0);
+            // the previous tile's epilogue, one pair of elements every fourth MFMA (KS = 32)
+            if (TANH && KS == 32 && m > 0 && (kk & 3) == 3) epilogue_pair(prev, kk >> 2, out[2 * (m - 1)], out[2 * (m - 1) + 1]);
         }
         if (TANH && KS == 32 && m + 1 < MT) prev = acc;
         else epilogue(acc, TANH, out[2 * m], out[2 * m + 1]);
@@ -131,20 +140,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     }
 
     // layer-1 B operand: this drone's observation, K = 16 (obs_dim <= 16, zero padded), lane group g holds k = 8g..8g+7
-    bf16x8 x0[1];
+    u32x4 x0[1];
     {
         const float *o = a.obs + row * a.obs_dim;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const int k = 8 * g + s;
-            x0[0][s] = (__bf16)(k < a.obs_dim ? o[k] : 0.0f);
+        for (int q = 0; q < 4; ++q) {
+            const int k = 8 * g + 2 * q;
+            x0[0][q] = pack2(k < a.obs_dim ? o[k] : 0.0f, k + 1 < a.obs_dim ? o[k + 1] : 0.0f);
         }
     }
-    bf16x8 h1[H1 / 16];
+    u32x4 h1[H1 / 16];
     layer<1, H1 / 32, true, 16>(net.w1, net.b1, x0, h1, lane);
-    bf16x8 h2[H2 / 16];
+    u32x4 h2[H2 / 16];
     layer<H1 / 16, H2 / 32, true, 16>(net.w2, net.b2, h1, h2, lane);
-    bf16x8 h3[H3 / 16];
+    u32x4 h3[H3 / 16];
     layer<H2 / 16, H3 / 32, true, 16>(net.w3, net.b3, h2, h3, lane);
 
     // head: one M-tile (out_dim <= 32 rows, zero-padded weights), float32 result straight from the accumulator
@@ -154,7 +163,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #pragma unroll
     for (int kk = 0; kk < H3 / 16; ++kk) {
         const uint4 w = net.wh[kk * 64 + lane];
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), h3[kk], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, h3[kk]), acc, 0, 0, 0);
     }
     if (row0 + col < a.n) {
         float *o = net.out + (row0 + col) * net.out_dim;
@@ -220,7 +229,7 @@ MLP_DEV void chunk_barrier()
 // following layer's weights, whose first NEXT_FR fragments are requested during this layer's last chunk.
 template <int MT, int PAR, int NEXT_FR>
 MLP_DEV void layer_lds(const uint4 *__restrict__ w, const float *__restrict__ bias, const uint4 *__restrict__ next,
-                       const bf16x8 (&in)[CHUNK], bf16x8 (&out)[2 * MT], uint4 *lds, const int wave, const int lane)
+                       const u32x4 (&in)[CHUNK], u32x4 (&out)[2 * MT], uint4 *lds, const int wave, const int lane)
 {
     const int g = lane >> 5;
     // biases one M-tile ahead, requested BEFORE the chunk's DMA: memory returns in order, so a bias load queued behind
@@ -247,9 +256,9 @@ MLP_DEV void layer_lds(const uint4 *__restrict__ w, const float *__restrict__ bi
         for (int kk = 0; kk < CHUNK; ++kk) {
             const uint4 a = ring[kk % LDS_RING];
             if (kk + LDS_RING < CHUNK) ring[kk % LDS_RING] = cur[(kk + LDS_RING) * 64 + lane];
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), in[kk], acc, 0, 0, 0);
-            // the previous tile's epilogue, one element every second MFMA, in the MFMAs' shadow
-            if (m > 0 && (kk & 1)) epilogue_elem(prev, kk >> 1, out[2 * (m - 1)], out[2 * (m - 1) + 1]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, in[kk]), acc, 0, 0, 0);
+            // the previous tile's epilogue, one pair of elements every fourth MFMA
+            if (m > 0 && (kk & 3) == 3) epilogue_pair(prev, kk >> 2, out[2 * (m - 1)], out[2 * (m - 1) + 1]);
         }
         if (m + 1 < MT) prev = acc;
         else epilogue(acc, true, out[2 * m], out[2 * m + 1]);
@@ -286,19 +295,19 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(1, 1
         }
     }
     dma_chunk(net.w1, lds, H1 / 32, wave, lane);            // layer 1 = one chunk of 16 fragments, into buffer 0
-    bf16x8 x0[1];
+    u32x4 x0[1];
     {
         const float *o = a.obs + row * a.obs_dim;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const int k = 8 * g + s;
-            x0[0][s] = (__bf16)(k < a.obs_dim ? o[k] : 0.0f);
+        for (int q = 0; q < 4; ++q) {
+            const int k = 8 * g + 2 * q;
+            x0[0][q] = pack2(k < a.obs_dim ? o[k] : 0.0f, k + 1 < a.obs_dim ? o[k + 1] : 0.0f);
         }
     }
     chunk_barrier();
     // LDS buffer parities: layer 1 (one chunk of 16 fragments) in buffer 0; layer 2's 16 chunks start in buffer 1;
     // layer 3's 8 chunks start at 1 + 16 -> buffer 1; the head (one chunk of 16 fragments) at 17 + 8 -> buffer 1
-    bf16x8 h1[H1 / 16];
+    u32x4 h1[H1 / 16];
     {
         dma_chunk(net.w2, lds + CHUNK * 64, CHUNK, wave, lane);          // layer 2, chunk 0 -> buffer 1
 #pragma unroll
@@ -307,14 +316,14 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(1, 1
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = net.b1[acc_row(m, g, r)];
             const uint4 w = lds[m * 64 + lane];
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), x0[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x0[0]), acc, 0, 0, 0);
             epilogue(acc, true, h1[2 * m], h1[2 * m + 1]);
         }
         chunk_barrier();
     }
-    bf16x8 h2[H2 / 16];
+    u32x4 h2[H2 / 16];
     layer_lds<H2 / 32, 1, CHUNK>(net.w2, net.b2, net.w3, h1, h2, lds, wave, lane);
-    bf16x8 h3[H3 / 16];
+    u32x4 h3[H3 / 16];
     layer_lds<H3 / 32, 1, H3 / 16>(net.w3, net.b3, net.wh, h2, h3, lds, wave, lane);
     // head: one M-tile of H3/16 = 16 fragments; float32 result straight from the accumulator
     f32x16 acc;
@@ -324,7 +333,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(1, 1
 #pragma unroll
     for (int kk = 0; kk < H3 / 16; ++kk) {
         const uint4 w = cur[kk * 64 + lane];
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), h3[kk], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, h3[kk]), acc, 0, 0, 0);
     }
     if (live) {
         float *o = net.out + (row0 + col) * net.out_dim;
