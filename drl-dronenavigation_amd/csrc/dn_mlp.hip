@@ -18,7 +18,8 @@
 // No LDS, no barriers, no inter-wave traffic; the weights (0.8 MB per network in bf16) stream from L2.
 //
 // Arithmetic: bf16 inputs/weights, float32 accumulation, float32 bias, tanh(x) = 1 - 2 / (1 + e^{2x}) on
-// v_exp_f32 / v_rcp_f32 (absolute error ~1e-7, far inside bf16), float32 output of the head.
+// v_exp_f32 / v_rcp_f32 (absolute error ~1e-7, far inside bf16; the 2 log2(e) of the exponent is pre-multiplied into
+// the hidden layers' packed weights and biases), float32 output of the head.
 #include "dn_internal.h"
 
 #include <cstdlib>
@@ -49,9 +50,12 @@ struct MlpArgs {
     int obs_dim;
 };
 
+// tanh(h) = 1 - 2 / (1 + 2^(2 log2(e) h)).  The factor 2 log2(e) is folded into the hidden layers' weights and biases
+// when they are packed (policy_mfma.pack_layer), so the accumulator already holds x = 2 log2(e) h and the activation is
+// v_exp_f32, v_add, v_rcp_f32, v_fma.
 MLP_DEV float tanh_fast(float x)
-{   // 1 - 2 / (1 + 2^(x * 2 log2 e)): v_mul, v_exp_f32, v_add, v_rcp_f32, v_fma
-    const float e = __builtin_amdgcn_exp2f(x * 2.885390081777927f);
+{
+    const float e = __builtin_amdgcn_exp2f(x);
     return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
 }
 
@@ -345,6 +349,209 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(1, 1
     }
 }
 
+// -----------------------------------------------------------------------------------------------------
+// Pair shape: 8 wavefronts per workgroup, TWO per SIMD, each pair sharing one tile of 32 drones by splitting K.
+//
+// Measured on MI355X (scratch micro-benchmark): a chain of v_mfma_f32_32x32x16_bf16 issues every 32.3 cycles, but with
+// five VALU instructions per MFMA in the same wave it takes 50-63 -- inside ONE wave the VALU work is not hidden behind
+// the matrix pipe.  The four-wave shape above issues ~9 non-MFMA instructions per MFMA (ds_read, accumulator reads,
+// tanh, packing) and runs at ~95 cycles per MFMA.  Two waves on a SIMD do overlap (one's MFMAs run while the other
+// issues VALU), so here waves w and w + 4 (same SIMD) work on the same 32 drones:
+//   * each holds HALF of a layer's input activations (64 registers instead of 128: that is what makes two waves fit
+//     in the register file) and multiplies its half of K for every M-tile (16 MFMAs instead of 32);
+//   * per M-tile one of the two is the owner (tiles of the lower half of the layer's outputs belong to wave-half 0,
+//     the rest to wave-half 1 = exactly the K-half each needs for the NEXT layer): the other one parks its partial
+//     accumulator in LDS (4 KB), the owner adds it after the chunk barrier, applies bias + tanh and packs the result
+//     into its own next-layer operands.  No activation ever needs to be re-distributed.
+//   * weights stream through LDS exactly as in the four-wave shape (each fragment now read by four waves, one per
+//     pair), biases are staged in LDS once, and the only global traffic inside the loop is the LDS-DMA.
+// -----------------------------------------------------------------------------------------------------
+constexpr int PWAVES = 8;
+constexpr int DN_MLP_DEFAULT_SHAPE = 8;       // measured: 68.9 us (pair) vs 77.9 us (4 waves) vs 79 us (1 wave) for pi+vf at 32768 drones
+constexpr int NBIAS = H1 + H2 + H3 + 32;                      // float32 biases of the four layers, staged in LDS
+constexpr int XB_U4 = 4 * 2 * 4 * 64;                         // exchange: 4 pairs x 2 parities x (16 f32 per lane = 4 uint4) x 64 lanes
+constexpr int LDS_PAIR_U4 = 2 * CHUNK * 64 + XB_U4 + (NBIAS + 3) / 4 + 1;
+
+template <int NF>
+MLP_DEV void dma_pair(const uint4 *__restrict__ src, uint4 *lds, const int wave, const int lane)
+{   // NF fragments shared by 8 waves: 4 (NF = 32) or 2 (NF = 16) consecutive fragments each
+    constexpr int per = NF / PWAVES;
+    const int f = wave * per;
+    const uint4 *gsrc = src + f * 64 + lane;
+    const unsigned lds_dst = (unsigned)(uintptr_t)(lds + f * 64);
+    unsigned keep;
+    if (per == 4)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, off\n\t"
+                     "global_load_lds_dwordx4 %1, off offset:1024\n\t"
+                     "global_load_lds_dwordx4 %1, off offset:2048\n\t"
+                     "global_load_lds_dwordx4 %1, off offset:3072\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, off\n\t"
+                     "global_load_lds_dwordx4 %1, off offset:1024\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+MLP_DEV void park_partial(float4 *xb, const int parity, const int lane, const f32x16 &acc)
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xb[(parity * 4 + j) * 64 + lane] = make_float4(acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]);
+}
+// owner: own partial + partner's partial + bias (from LDS), in place
+MLP_DEV void merge_partial(const float4 *xb, const int parity, const int lane, const float *lbias, const int m, const int g, f32x16 &acc)
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float4 p = xb[(parity * 4 + j) * 64 + lane];
+        const float4 b = *reinterpret_cast<const float4 *>(lbias + 32 * m + 4 * g + 8 * j);     // rows acc_row(m, g, 4j..4j+3)
+        acc[4 * j] += p.x + b.x; acc[4 * j + 1] += p.y + b.y; acc[4 * j + 2] += p.z + b.z; acc[4 * j + 3] += p.w + b.w;
+    }
+}
+
+// A 512-input layer for wave-half HALF: K-steps [16 HALF, 16 HALF + 16) of every M-tile, owner of tiles
+// [HALF MT/2, (HALF + 1) MT/2).  inh = this half's 16 B operands; outh = the owned tiles' outputs = this half's B
+// operands of the next layer.
+template <int HALF, int MT, int PAR, int NEXT_FR>
+MLP_DEV void layer_pair(const uint4 *__restrict__ w, const float *lbias, const uint4 *__restrict__ next, const u32x4 (&inh)[16],
+                        u32x4 (&outh)[MT], uint4 *wbuf, float4 *xb, const int wave, const int lane)
+{
+    const int g = lane >> 5;
+    f32x16 prev;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        uint4 *cur = wbuf + ((PAR + m) & 1) * (CHUNK * 64);
+        uint4 *nxt = wbuf + ((PAR + m + 1) & 1) * (CHUNK * 64);
+        if (m + 1 < MT) dma_pair<CHUNK>(w + (size_t)(m + 1) * CHUNK * 64, nxt, wave, lane);
+        else dma_pair<NEXT_FR>(next, nxt, wave, lane);
+        const bool fin = m > 0 && (((m - 1) >= MT / 2) == (HALF == 1));      // I own tile m-1: finish it under this tile's MFMAs
+        if (fin) merge_partial(xb, (m - 1) & 1, lane, lbias, m - 1, g, prev);
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        uint4 ring[LDS_RING];
+#pragma unroll
+        for (int kk = 0; kk < LDS_RING; ++kk) ring[kk] = cur[(HALF * 16 + kk) * 64 + lane];
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const uint4 a = ring[kk % LDS_RING];
+            if (kk + LDS_RING < 16) ring[kk % LDS_RING] = cur[(HALF * 16 + kk + LDS_RING) * 64 + lane];
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, inh[kk]), acc, 0, 0, 0);
+            if (fin && (kk & 1)) {
+                constexpr int unused = 0; (void)unused;
+                const int ml = (m - 1) - HALF * (MT / 2);
+                epilogue_pair(prev, kk >> 1, outh[2 * ml], outh[2 * ml + 1]);
+            }
+        }
+        if ((m >= MT / 2) == (HALF == 1)) prev = acc;                         // mine: keep, finish next round
+        else park_partial(xb, m & 1, lane, acc);                             // partner's: hand over through LDS
+        chunk_barrier();
+    }
+    if (HALF == 1) {                                                         // the last tile belongs to half 1
+        merge_partial(xb, (MT - 1) & 1, lane, lbias, MT - 1, g, prev);
+        epilogue(prev, true, outh[MT - 2], outh[MT - 1]);
+    }
+}
+
+template <int HALF>
+MLP_DEV void mlp_pair_body(const MlpArgs &a, const MlpNetDev &net, uint4 *wbuf, float4 *xb, const float *lbias, const int wave,
+                           const int lane, const long long row0, const bool live, const long long row, const bool tile_wanted)
+{
+    const int g = lane >> 5, col = lane & 31;
+    u32x4 x0;
+    {
+        const float *o = a.obs + row * a.obs_dim;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = 8 * g + 2 * q;
+            x0[q] = pack2(k < a.obs_dim ? o[k] : 0.0f, k + 1 < a.obs_dim ? o[k + 1] : 0.0f);
+        }
+    }
+    // layer 1 (K = 16: one K-step, no split): this half computes its own 8 tiles outright.  Its 16 fragments are in buffer 0.
+    u32x4 h1[16];
+    dma_pair<CHUNK>(net.w2, wbuf + CHUNK * 64, wave, lane);                  // layer 2, chunk 0 -> buffer 1
+#pragma unroll
+    for (int ml = 0; ml < 8; ++ml) {
+        const int m = HALF * 8 + ml;
+        f32x16 acc;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float4 b = *reinterpret_cast<const float4 *>(lbias + 32 * m + 4 * g + 8 * j);
+            acc[4 * j] = b.x; acc[4 * j + 1] = b.y; acc[4 * j + 2] = b.z; acc[4 * j + 3] = b.w;
+        }
+        const uint4 w = wbuf[m * 64 + lane];
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x0), acc, 0, 0, 0);
+        epilogue(acc, true, h1[2 * ml], h1[2 * ml + 1]);
+    }
+    chunk_barrier();
+    u32x4 h2[16];
+    layer_pair<HALF, H2 / 32, 1, CHUNK>(net.w2, lbias + H1, net.w3, h1, h2, wbuf, xb, wave, lane);
+    u32x4 h3[8];
+    layer_pair<HALF, H3 / 32, 1, H3 / 16>(net.w3, lbias + H1 + H2, net.wh, h2, h3, wbuf, xb, wave, lane);
+    // head: one tile, K = 256 = 16 K-steps, 8 per half; fragments in buffer 1 (parity 1 + 16 + 8 -> 1)
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    const uint4 *cur = wbuf + CHUNK * 64;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+        const uint4 w = cur[(HALF * 8 + kk) * 64 + lane];
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, h3[kk]), acc, 0, 0, 0);
+    }
+    if (HALF == 1) park_partial(xb, 0, lane, acc);
+    chunk_barrier();
+    if (HALF == 0) {
+        merge_partial(xb, 0, lane, lbias + H1 + H2 + H3, 0, g, acc);
+        if (live) {
+            float *o = net.out + (row0 + col) * net.out_dim;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = acc_row(0, g, r);
+                if (j < net.out_dim) o[j] = tile_wanted ? acc[r] : 0.0f;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(64 * PWAVES) void dn_mlp_pair_kernel(const MlpArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint4 lds[LDS_PAIR_U4];         // ONE __shared__ object (see dn_mlp_lds_kernel)
+    uint4 *wbuf = lds;
+    float *lbias = reinterpret_cast<float *>(lds + 2 * CHUNK * 64 + XB_U4);
+    int *s_any = reinterpret_cast<int *>(lds + LDS_PAIR_U4 - 1);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pair = wave & 3, half = wave >> 2;                              // waves w and w + 4 share a SIMD
+    float4 *xb = reinterpret_cast<float4 *>(lds + 2 * CHUNK * 64) + pair * (2 * 4 * 64);
+    const int col = lane & 31;
+    const MlpNetDev &net = a.net[blockIdx.y];
+    const long long row0 = ((long long)blockIdx.x * 4 + pair) * TILE;
+    const bool live = row0 + col < a.n;
+    const long long row = live ? row0 + col : a.n - 1;
+    bool tile_wanted = true;
+    if (a.row_mask) {
+        const bool wanted = live && a.row_mask[row0 + col] != 0;
+        tile_wanted = __ballot(wanted) != 0ull;
+        if (lane == 0 && half == 0) s_any[pair] = tile_wanted;
+        __syncthreads();
+        if ((s_any[0] | s_any[1] | s_any[2] | s_any[3]) == 0) {
+            if (half == 0 && (lane >> 5) == 0 && live)
+                for (int j = 0; j < net.out_dim; ++j) net.out[(row0 + col) * net.out_dim + j] = 0.0f;
+            return;
+        }
+    }
+    // biases -> LDS (once), layer-1 fragments -> buffer 0
+    for (int i = threadIdx.x; i < NBIAS; i += 64 * PWAVES)
+        lbias[i] = i < H1 ? net.b1[i] : i < H1 + H2 ? net.b2[i - H1] : i < H1 + H2 + H3 ? net.b3[i - H1 - H2] : net.bh[i - H1 - H2 - H3];
+    dma_pair<H1 / 32>(net.w1, wbuf, wave, lane);
+    chunk_barrier();
+    if (half == 0) mlp_pair_body<0>(a, net, wbuf, xb, lbias, wave, lane, row0, live, row, tile_wanted);
+    else mlp_pair_body<1>(a, net, wbuf, xb, lbias, wave, lane, row0, live, row, tile_wanted);
+}
+
 }  // namespace
 
 hipError_t dn_launch_mlp(const dn_mlp_net *nets, int num_nets, const float *obs, const uint8_t *row_mask, long long n, int obs_dim,
@@ -360,8 +567,10 @@ hipError_t dn_launch_mlp(const dn_mlp_net *nets, int num_nets, const float *obs,
     }
     a.obs = obs; a.row_mask = row_mask; a.n = n; a.obs_dim = obs_dim;
     const unsigned tiles = (unsigned)((n + TILE - 1) / TILE);
-    static const int shape = [] { const char *e = getenv("DN_MLP_SHAPE"); return e ? atoi(e) : 4; }();   // 1 | 4 waves per workgroup
+    const char *e = getenv("DN_MLP_SHAPE");                  // 1 | 4 | 8 waves per workgroup (A/B measurements, tests)
+    const int shape = e ? atoi(e) : DN_MLP_DEFAULT_SHAPE;
     if (shape == 1) hipLaunchKernelGGL(dn_mlp_kernel, dim3(tiles, num_nets), dim3(64), 0, stream, a);
+    else if (shape == 8) hipLaunchKernelGGL(dn_mlp_pair_kernel, dim3((tiles + 3) / 4, num_nets), dim3(64 * PWAVES), 0, stream, a);
     else hipLaunchKernelGGL(dn_mlp_lds_kernel, dim3((tiles + WAVES - 1) / WAVES, num_nets), dim3(64 * WAVES), 0, stream, a);
     return hipGetLastError();
 }

@@ -30,10 +30,15 @@ def _k_order(in_features, first):
     return 32 * (kk >> 1) + 4 * g + (r & 3) + 8 * (r >> 2)
 
 
-def pack_layer(weight, bias, first):
-    """weight [out, in] float32, bias [out] -> (packed bf16 [MT, KS, 64, 8] as a torch tensor, bias padded to 32*MT)."""
+TANH_PRESCALE = 2.0 / math.log(2.0)          # 2 log2(e): the kernel's tanh is 1 - 2 / (1 + 2^x) on pre-scaled x
+
+
+def pack_layer(weight, bias, first, scale=1.0):
+    """weight [out, in] float32, bias [out] -> (packed bf16 [MT, KS, 64, 8] as a torch tensor, bias padded to 32*MT).
+    `scale` multiplies both before the bf16 rounding (TANH_PRESCALE for the layers that feed a tanh)."""
     w = np.asarray(weight.detach().cpu().float().numpy() if hasattr(weight, "detach") else weight, dtype=np.float32)
     b = np.asarray(bias.detach().cpu().float().numpy() if hasattr(bias, "detach") else bias, dtype=np.float32)
+    w, b = (w * np.float32(scale)).astype(np.float32), (b * np.float32(scale)).astype(np.float32)
     out_f, in_f = w.shape
     if not first and in_f % 32:
         raise ValueError("hidden widths must be multiples of 32")
@@ -59,7 +64,7 @@ def pack_mlp(layers, device):
         raise ValueError("the fused kernel is built for obs -> 512 -> 512 -> 256 -> out (PBDroneSimulator.py:251-258)")
     out = {}
     for name, (w, b), first in zip(("1", "2", "3", "h"), layers, (True, False, False, False)):
-        pw, pb = pack_layer(w, b, first)
+        pw, pb = pack_layer(w, b, first, scale=1.0 if name == "h" else TANH_PRESCALE)
         out["w" + name], out["b" + name] = pw.to(device), pb.to(device)
     out["out_dim"] = int(layers[3][0].shape[0])
     out["obs_dim"] = int(layers[0][0].shape[1])

@@ -615,20 +615,25 @@ def test_graph_replayed_rollouts_equal_eager_rollouts():
 def _mlp_reference(layers, x):
     """The fused kernel's arithmetic spelled out in torch: bf16 weights and activations, float32 accumulation and bias,
     tanh in float32, float32 head output."""
+    from drl_dronenavigation_amd.policy_mfma import TANH_PRESCALE as c      # folded into the hidden layers before bf16
     h = x.to(torch.bfloat16).float()
     for k, (w, b) in enumerate(layers):
-        h = h @ w.to(torch.bfloat16).float().t() + b.float()
         if k < len(layers) - 1:
-            h = torch.tanh(h).to(torch.bfloat16).float()
+            z = h @ (w.float() * c).to(torch.bfloat16).float().t() + b.float() * c
+            h = torch.tanh(z / c).to(torch.bfloat16).float()
+        else:
+            h = h @ w.to(torch.bfloat16).float().t() + b.float()
     return h
 
 
+@pytest.mark.parametrize("shape", ["1", "4", "8"])
 @pytest.mark.parametrize("n", [32, 1000, 32768])
-def test_fused_mfma_mlp_matches_torch(n):
+def test_fused_mfma_mlp_matches_torch(n, shape, monkeypatch):
     """dn_mlp_forward (one wavefront per 32 drones, activations in registers, K-permuted bf16 weight fragments) against
     the same network in torch: asymmetric random weights catch any row/column/K-order slip; tolerance is bf16-level."""
     pkg = _gpu()
     from drl_dronenavigation_amd import policy_mfma as pm
+    monkeypatch.setenv("DN_MLP_SHAPE", shape)     # 1: weights from L2 per wave; 4: through LDS; 8: split-K wave pairs
     dev = torch.device("cuda:0")
     torch.manual_seed(n)
     net = pkg.MlpActorCritic().to(dev)
