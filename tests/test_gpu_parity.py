@@ -834,3 +834,28 @@ def test_fused_rollout_collector_against_oracle_and_graph_replay():
     for it in range(3):
         for k in runs[0][it]:
             assert torch.equal(runs[0][it][k], runs[1][it][k]), (it, k)
+
+
+@pytest.mark.parametrize("max_steps,threshold", [(0, 0.3), (1, 0.3), (7, 5.0), (5, 0.0)])
+def test_degenerate_limits_match_oracle(max_steps, threshold):
+    """Edge cases of the episode logic: a time limit of 0 or 1 (truncation on the first / second call, evaluated on
+    the un-incremented counter), a gate radius that swallows the whole track (every step scores a gate, the +200
+    branch every W steps) and a zero radius (no gate can ever be scored)."""
+    track = _tracks().circle(1, 4, 1)
+    n = 192
+    env, ora = make_pair(track, n, f32_state=True, max_steps=max_steps, normalize_obs=True, threshold=threshold)
+    np.testing.assert_allclose(env.reset(), ora.reset(), rtol=0, atol=1e-6)
+    rng = np.random.default_rng(max_steps + 17)
+    dev = torch.device("cuda:0")
+    n_done = completed = 0
+    for t in range(40):
+        a = actions_mixed(rng, n)
+        out = env.step_tensor(torch.from_numpy(a).to(dev))
+        ref = ora.step(a)
+        n_done += compare_step(out, ref, f"max_steps={max_steps} thr={threshold} t={t}", rew_atol=1e-4)
+        completed += int((ref["reward"] == np.float32(8.0)).sum())
+    assert n_done >= (n * 40) // (max_steps + 2) - n
+    if threshold == 5.0:
+        assert completed > 0, "the all-gates-passed branch (+200/25) must occur"
+    assert env.stats()["episodes"] == n_done
+    env.close()
