@@ -11,7 +11,7 @@ from . import build as _build
 MAX_WAYPOINTS = 64
 OBS_DIM = 13
 ACT_DIM = 4
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 DN_OK = 0
 STATUS_NAMES = {0: "DN_OK", -1: "DN_ERR_INVALID_ARGUMENT", -2: "DN_ERR_HIP", -3: "DN_ERR_OUT_OF_MEMORY",
@@ -36,6 +36,7 @@ class DnConfig(C.Structure):
         ("include_distance", C.c_int32), ("normalize_actions", C.c_int32), ("normalize_obs", C.c_int32),
         ("ground_contact", C.c_int32), ("compute_f32", C.c_int32), ("act_noise_sigma", C.c_float),
         ("obs_noise_sigma", C.c_float), ("seed", C.c_uint64), ("env_id_offset", C.c_int64),
+        ("clip_rew", C.c_int32), ("norm_rew", C.c_int32),
     ]
 
 
@@ -46,6 +47,7 @@ class DnEnvState(C.Structure):
         ("d", C.c_float), ("d_prev", C.c_float), ("idx", C.c_int32), ("steps", C.c_int32), ("just_found", C.c_int32),
         ("ep_ret", C.c_float), ("ep_len", C.c_int32),
         ("rms_mean", C.c_double * OBS_DIM), ("rms_var", C.c_double * OBS_DIM), ("rms_count", C.c_double),
+        ("rr_returns", C.c_double), ("rr_mean", C.c_double), ("rr_var", C.c_double), ("rr_count", C.c_double),
     ]
 
 

@@ -58,10 +58,10 @@ namespace {
 
 // Device arena: seven float4 groups, optional normaliser statistics, statistics slots, tables.
 struct Layout {
-    size_t off_g[7], off_mean, off_var, off_count, off_stats, off_tab64, off_tab32, total;
+    size_t off_g[7], off_mean, off_var, off_count, off_rr, off_stats, off_tab64, off_tab32, total;
 };
 
-Layout make_layout(long long n, int normalize_obs)
+Layout make_layout(long long n, int normalize_obs, int norm_rew = 0)
 {
     Layout L;
     size_t o = 0;
@@ -69,6 +69,7 @@ Layout make_layout(long long n, int normalize_obs)
     L.off_mean = o;  o = align_up(o + (normalize_obs ? (size_t)n * DN_OBS_DIM * sizeof(double) : 0), 256);
     L.off_var = o;   o = align_up(o + (normalize_obs ? (size_t)n * DN_OBS_DIM * sizeof(double) : 0), 256);
     L.off_count = o; o = align_up(o + (normalize_obs ? (size_t)n * sizeof(double) : 0), 256);
+    L.off_rr = o;    o = align_up(o + (norm_rew ? (size_t)n * 4 * sizeof(double) : 0), 256);
     L.off_stats = o; o = align_up(o + (size_t)((n + DN_BLOCK - 1) / DN_BLOCK) * sizeof(DnStatSlot), 256);
     L.off_tab64 = o; o = align_up(o + DN_MAX_WAYPOINTS * DN_T_STRIDE * sizeof(double), 256);
     L.off_tab32 = o; o = align_up(o + DN_MAX_WAYPOINTS * DN_T_STRIDE * sizeof(float), 256);
@@ -166,6 +167,11 @@ int32_t init_state(dn_env *e, hipStream_t s)
         DN_HIP(dn_launch_filld(e->p.st.rms_var, 1.0, n * DN_OBS_DIM, s));
         DN_HIP(dn_launch_filld(e->p.st.rms_count, 1e-4, n, s));
     }
+    if (c.norm_rew) {                              // NormalizeReward.__init__, normalize.py:124-128
+        DN_HIP(dn_launch_filld(e->p.st.rr, 0.0, 2 * n, s));            // returns, return_rms.mean
+        DN_HIP(dn_launch_filld(e->p.st.rr + 2 * n, 1.0, n, s));        // .var
+        DN_HIP(dn_launch_filld(e->p.st.rr + 3 * n, 1e-4, n, s));       // .count
+    }
     DN_HIP(hipMemsetAsync(e->p.st.stats, 0, (size_t)e->blocks * sizeof(DnStatSlot), s));
     return DN_OK;
 }
@@ -234,7 +240,7 @@ int32_t dn_create(const dn_config *cfg, dn_env **out)
         if (w[0] == '1') e->waves_fused = e->waves_single = 1;
         else if (w[0] == '2') e->waves_fused = e->waves_single = 2;
     }
-    const Layout L = make_layout(n, cfg->normalize_obs);
+    const Layout L = make_layout(n, cfg->normalize_obs, cfg->norm_rew);
     hipError_t he = hipMalloc(&e->arena, L.total);
     if (he != hipSuccess) {
         delete e;
@@ -251,6 +257,7 @@ int32_t dn_create(const dn_config *cfg, dn_env **out)
     p.st.rms_mean = (double *)(base + L.off_mean);
     p.st.rms_var = (double *)(base + L.off_var);
     p.st.rms_count = (double *)(base + L.off_count);
+    p.st.rr = (double *)(base + L.off_rr);
     p.st.stats = (DnStatSlot *)(base + L.off_stats);
     e->tab64 = (double *)(base + L.off_tab64);
     e->tab32 = (float *)(base + L.off_tab32);
@@ -262,6 +269,7 @@ int32_t dn_create(const dn_config *cfg, dn_env **out)
     p.circle = cfg->circle != 0; p.cylinder = cfg->cylinder != 0; p.include_distance = cfg->include_distance != 0;
     p.normalize_actions = cfg->normalize_actions != 0; p.normalize_obs = cfg->normalize_obs != 0;
     p.ground_contact = cfg->ground_contact != 0;
+    p.clip_rew = cfg->clip_rew != 0; p.norm_rew = cfg->norm_rew != 0;
     p.act_noise_sigma = cfg->act_noise_sigma; p.obs_noise_sigma = cfg->obs_noise_sigma;
     p.seed = cfg->seed; p.env_id_offset = cfg->env_id_offset;
     build_consts<double>(*cfg, p.c64);
@@ -386,9 +394,15 @@ int32_t dn_get_state(dn_env *env, dn_env_state *states, int64_t count)
         DN_HIP(hipMemcpy(var.data(), env->p.st.rms_var, var.size() * sizeof(double), hipMemcpyDeviceToHost));
         DN_HIP(hipMemcpy(cnt.data(), env->p.st.rms_count, cnt.size() * sizeof(double), hipMemcpyDeviceToHost));
     }
+    std::vector<double> rr;
+    if (env->cfg.norm_rew) {
+        rr.resize((size_t)n * 4);
+        DN_HIP(hipMemcpy(rr.data(), env->p.st.rr, rr.size() * sizeof(double), hipMemcpyDeviceToHost));
+    }
     for (long long i = 0; i < n; ++i) {
         dn_env_state &s = states[i];
         memset(&s, 0, sizeof s);
+        if (env->cfg.norm_rew) { s.rr_returns = rr[(size_t)i]; s.rr_mean = rr[(size_t)n + i]; s.rr_var = rr[(size_t)2 * n + i]; s.rr_count = rr[(size_t)3 * n + i]; }
         s.pos[0] = g[0][i].x; s.pos[1] = g[0][i].y; s.pos[2] = g[0][i].z; s.d = g[0][i].w;
         s.quat[0] = g[1][i].x; s.quat[1] = g[1][i].y; s.quat[2] = g[1][i].z; s.quat[3] = g[1][i].w;
         s.vel[0] = g[2][i].x; s.vel[1] = g[2][i].y; s.vel[2] = g[2][i].z; s.d_prev = g[2][i].w;
@@ -419,8 +433,11 @@ int32_t dn_set_state(dn_env *env, const dn_env_state *states, int64_t count)
     for (int k = 0; k < 7; ++k) g[k].resize((size_t)n);
     std::vector<double> mean, var, cnt;
     if (env->cfg.normalize_obs) { mean.resize((size_t)n * DN_OBS_DIM); var.resize((size_t)n * DN_OBS_DIM); cnt.resize((size_t)n); }
+    std::vector<double> rr;
+    if (env->cfg.norm_rew) rr.resize((size_t)n * 4);
     for (long long i = 0; i < n; ++i) {
         const dn_env_state &s = states[i];
+        if (env->cfg.norm_rew) { rr[(size_t)i] = s.rr_returns; rr[(size_t)n + i] = s.rr_mean; rr[(size_t)2 * n + i] = s.rr_var; rr[(size_t)3 * n + i] = s.rr_count; }
         if (s.idx < 0 || s.idx >= env->cfg.num_waypoints || s.steps < 0 || s.steps > (1 << 24) - 1)
             return fail(DN_ERR_INVALID_ARGUMENT, "state %lld: idx/steps out of range", i);
         if (s.steps > 0 && (s.cur_pos[0] != s.pos[0] || s.cur_pos[1] != s.pos[1] || s.cur_pos[2] != s.pos[2]))
@@ -450,6 +467,7 @@ int32_t dn_set_state(dn_env *env, const dn_env_state *states, int64_t count)
         DN_HIP(hipMemcpy(env->p.st.rms_var, var.data(), var.size() * sizeof(double), hipMemcpyHostToDevice));
         DN_HIP(hipMemcpy(env->p.st.rms_count, cnt.data(), cnt.size() * sizeof(double), hipMemcpyHostToDevice));
     }
+    if (env->cfg.norm_rew) DN_HIP(hipMemcpy(env->p.st.rr, rr.data(), rr.size() * sizeof(double), hipMemcpyHostToDevice));
     return DN_OK;
 }
 

@@ -51,6 +51,7 @@ struct DnState {
     double *rms_mean;   // [13][N]  normalize.RunningMeanStd.mean
     double *rms_var;    // [13][N]
     double *rms_count;  // [N]
+    double *rr;         // [4][N]  NormalizeReward: returns, return_rms.mean, .var, .count (norm_rew only)
     DnStatSlot *stats;  // [ceil(N/64)]
 };
 
@@ -86,7 +87,7 @@ struct DnParams {
     long long n;
     int num_waypoints;
     int max_steps;
-    int circle, cylinder, include_distance, normalize_actions, normalize_obs, ground_contact;
+    int circle, cylinder, include_distance, normalize_actions, normalize_obs, ground_contact, clip_rew, norm_rew;
     float act_noise_sigma, obs_noise_sigma;
     unsigned long long seed;
     long long env_id_offset;

@@ -786,6 +786,43 @@ DN_DEV Observed<R> observe_phase(const DnParams &p, const DnConsts<R> &c, const 
     return ob;
 }
 
+// make_env's optional reward wrappers, inside Monitor (PBDroneSimulator.py:191-194): TransformReward(clip(-10, 10))
+// then NormalizeReward (normalize.py:100-147; batch of one, so batch_var = 0): the discounted return and its running
+// mean / variance / count are four float64 per drone, resident in registers for the launch like the observation
+// statistics.  Same reciprocal / rsq treatment as normalize_obs (equal to the literal form to 1e-16).
+struct RewNorm {
+    double returns, mean, var, count;
+};
+DN_DEV void load_rewnorm(const DnParams &p, long long i, RewNorm &r)
+{
+    r.returns = p.st.rr[i]; r.mean = p.st.rr[p.n + i]; r.var = p.st.rr[2 * p.n + i]; r.count = p.st.rr[3 * p.n + i];
+}
+DN_DEV void store_rewnorm(const DnParams &p, long long i, const RewNorm &r)
+{
+    p.st.rr[i] = r.returns; p.st.rr[p.n + i] = r.mean; p.st.rr[2 * p.n + i] = r.var; p.st.rr[3 * p.n + i] = r.count;
+}
+DN_DEV double reward_wrappers(const DnParams &p, RewNorm &rn, double r, bool done)
+{
+#pragma clang fp contract(fast)
+    if (p.clip_rew) r = clipv(r, -10.0, 10.0);
+    if (p.norm_rew) {
+        rn.returns = rn.returns * 0.99 + r;
+        const double tot = rn.count + 1.0;
+        const double inv = rcp_f64(tot);
+        const double delta = rn.returns - rn.mean;
+        rn.mean = rn.mean + delta * inv;
+        rn.var = (rn.var + delta * delta * inv) * (rn.count * inv);
+        rn.count = tot;
+        const double s = rn.var + 1e-8;
+        double y = __builtin_amdgcn_rsq(s);
+        y = __builtin_fma(y, __builtin_fma(-(0.5 * s * y), y, 0.5), y);
+        y = __builtin_fma(y, __builtin_fma(-(0.5 * s * y), y, 0.5), y);
+        r = r * y;
+        if (done) rn.returns = 0.0;
+    }
+    return r;
+}
+
 // Episode statistics of one tile, accumulated in (wave-uniform) registers over all the steps of a launch and added
 // to the tile's slot in HBM once, at the end: the slot read-modify-write would otherwise put an HBM/L2 round trip
 // on the report wave's critical path in every step that finishes an episode.
@@ -804,11 +841,11 @@ DN_DEV void flush_stats(const DnParams &p, const StatAcc &a, unsigned long long 
 }
 
 // ---- A7 select + A10/A11 on the report wave: Monitor, SubprocVecEnv worker, outputs ---------------------------
-template <typename R, bool NORM, bool NOISE>
+template <typename R, bool NORM, bool NOISE, bool REW>
 DN_DEV void report_phase(const DnParams &p, const DnConsts<R> &c, float *s_tile, const StepOut &out, const Flight<R> &fl,
                          const Verdict<R> &v, Observed<R> &ob, const unsigned long long gid, const unsigned step_count,
                          const unsigned li, const unsigned lane, const unsigned rows, const bool active,
-                         float4 &G4, float4 &G5, StatAcc &acc, Rms &rms)
+                         float4 &G4, float4 &G5, StatAcc &acc, Rms &rms, RewNorm &rn)
 {
 #pragma clang fp contract(fast)
     const bool coll1 = v.coll1 != 0, terminated = v.terminated != 0, truncated = fl.truncated != 0;
@@ -820,6 +857,7 @@ DN_DEV void report_phase(const DnParams &p, const DnConsts<R> &c, float *s_tile,
     if (coll1) reward = R(-10.0);                                                 // :489-490
     else if (found_now) reward = (R)(ob.r_found32 / 25.0f);                       // :568-571
     else reward = ob.r_normal * K<R>::INV_25;
+    if (REW) reward = (R)reward_wrappers(p, rn, (double)reward, done);       // --clip_rew / --norm_rew (compiled out otherwise)
     const R epret_e = G4.w;
     const int eplen_e = __float_as_int(G5.w);
     R ep_ret = epret_e + reward;
@@ -896,7 +934,7 @@ DN_DEV BlockState block_state(const DnState &st, long long tile_base)
 // -----------------------------------------------------------------------------------------------------
 // ONE = true is the single-step launch (dn_step): k_steps is the constant 1, and the kernel gets its own name in
 // profiles (dn_step_many_*_kernel<..., true> = one control step per launch, <..., false> = k_arg steps per launch).
-template <typename R, bool NORM, bool NOISE, bool ONE>
+template <typename R, bool NORM, bool NOISE, bool ONE, bool REW>
 __global__ __launch_bounds__(DN_BLOCK) void dn_step_many_1w_kernel(const DnParams p, const DnStepIO io0, const int k_arg)
 {
     const int k_steps = ONE ? 1 : k_arg;
@@ -924,6 +962,8 @@ __global__ __launch_bounds__(DN_BLOCK) void dn_step_many_1w_kernel(const DnParam
     StatAcc acc;
     Rms rms;
     if (NORM) load_rms(p, i, rms);
+    RewNorm rn = {0.0, 0.0, 1.0, 1e-4};
+    if (REW && p.norm_rew) load_rewnorm(p, i, rn);
 #pragma clang loop unroll(disable)
     for (int t = 0; t < k_steps; ++t) {
         // prefetch the next step's action while this step computes
@@ -935,11 +975,12 @@ __global__ __launch_bounds__(DN_BLOCK) void dn_step_many_1w_kernel(const DnParam
         const float4 G0e = G0, G3e = G3;
         const Verdict<R> v = rules_phase<R>(p, c, s_tab, fl, G0e, G3e, b.g6, li, active, G0, G1, G2, G3);
         Observed<R> ob = observe_phase<R, NORM, NOISE>(p, c, s_tab, fl, G4, G5, gid, sc, rms);
-        report_phase<R, NORM, NOISE>(p, c, s_tile, out, fl, v, ob, gid, sc, li, lane, rows, active, G4, G5, acc, rms);
+        report_phase<R, NORM, NOISE, REW>(p, c, s_tile, out, fl, v, ob, gid, sc, li, lane, rows, active, G4, G5, acc, rms, rn);
         A = A_next;
     }
     flush_stats(p, acc, sc0 + (unsigned long long)k_steps, lane);
     if (NORM && active) store_rms(p, i, rms);
+    if (REW && p.norm_rew && active) store_rewnorm(p, i, rn);
     if (active) {
         b.g0[li] = G0; b.g1[li] = G1; b.g2[li] = G2; b.g3[li] = G3; b.g4[li] = G4; b.g5[li] = G5;
     }
@@ -993,7 +1034,7 @@ template <typename R> DN_DEV void take_mail(const Mail<R> &m, unsigned lane, Fli
     v.coll1 = vb & 1; v.terminated = (vb >> 1) & 1;
 }
 
-template <typename R, bool NORM, bool NOISE, bool ONE>
+template <typename R, bool NORM, bool NOISE, bool ONE, bool REW>
 __global__ __launch_bounds__(2 * DN_BLOCK) void dn_step_many_2w_kernel(const DnParams p, const DnStepIO io0, const int k_arg)
 {
     const int k_steps = ONE ? 1 : k_arg;
@@ -1020,6 +1061,8 @@ __global__ __launch_bounds__(2 * DN_BLOCK) void dn_step_many_2w_kernel(const DnP
         StatAcc acc;
         Rms rms;
         if (NORM) load_rms(p, i, rms);
+        RewNorm rn = {0.0, 0.0, 1.0, 1e-4};
+        if (REW && p.norm_rew) load_rewnorm(p, i, rn);
         block_lds_barrier();                                               // P: table published
 #pragma clang loop unroll(disable)
         for (int t = 0; t <= k_steps; ++t) {
@@ -1031,12 +1074,13 @@ __global__ __launch_bounds__(2 * DN_BLOCK) void dn_step_many_2w_kernel(const DnP
                 take_mail<R>(mail[u & 1], lane, fl, v);
                 Observed<R> ob = observe_phase<R, NORM, NOISE>(p, c, s_tab, fl, G4, G5, gid, sc, rms);
                 const StepOut out = block_out(io0, tile_base, (long long)u * n, (long long)u * words);
-                report_phase<R, NORM, NOISE>(p, c, s_tile, out, fl, v, ob, gid, sc, li, lane, rows, active, G4, G5, acc, rms);
+                report_phase<R, NORM, NOISE, REW>(p, c, s_tile, out, fl, v, ob, gid, sc, li, lane, rows, active, G4, G5, acc, rms, rn);
             }
             if (t < k_steps) block_lds_barrier();                          // barrier t
         }
         flush_stats(p, acc, sc0 + (unsigned long long)k_steps, lane);
         if (NORM && active) store_rms(p, i, rms);
+        if (REW && p.norm_rew && active) store_rewnorm(p, i, rn);
         if (active) { b.g4[li] = G4; b.g5[li] = G5; }
     } else {
         const float4 *act = reinterpret_cast<const float4 *>(io0.actions) + tile_base;
@@ -1271,17 +1315,22 @@ hipError_t dn_launch_step_many(const DnParams &p, const DnStepIO &io, int k, boo
     const unsigned grid = (unsigned)((p.n + DN_BLOCK - 1) / DN_BLOCK);
     const bool norm = p.normalize_obs != 0;
     const bool noise = p.act_noise_sigma > 0.0f || p.obs_noise_sigma > 0.0f;
-#define DN_LAUNCH2(R, NORM, NOISE, ONE)                                                                                 \
+#define DN_LAUNCH3(R, NORM, NOISE, ONE, REW)                                                                            \
     do {                                                                                                                \
         if (two_wave)                                                                                                   \
-            hipLaunchKernelGGL((dn_step_many_2w_kernel<R, NORM, NOISE, ONE>), dim3(grid), dim3(2 * DN_BLOCK), 0, stream, p, io, k); \
+            hipLaunchKernelGGL((dn_step_many_2w_kernel<R, NORM, NOISE, ONE, REW>), dim3(grid), dim3(2 * DN_BLOCK), 0, stream, p, io, k); \
         else                                                                                                            \
-            hipLaunchKernelGGL((dn_step_many_1w_kernel<R, NORM, NOISE, ONE>), dim3(grid), dim3(DN_BLOCK), 0, stream, p, io, k);     \
+            hipLaunchKernelGGL((dn_step_many_1w_kernel<R, NORM, NOISE, ONE, REW>), dim3(grid), dim3(DN_BLOCK), 0, stream, p, io, k);     \
+    } while (0)
+#define DN_LAUNCH2(R, NORM, NOISE, ONE)                                                                                 \
+    do {                                                                                                                \
+        if (rew) DN_LAUNCH3(R, NORM, NOISE, ONE, true); else DN_LAUNCH3(R, NORM, NOISE, ONE, false);                    \
     } while (0)
 #define DN_LAUNCH(R, NORM, NOISE)                                                                                       \
     do {                                                                                                                \
         if (k == 1) DN_LAUNCH2(R, NORM, NOISE, true); else DN_LAUNCH2(R, NORM, NOISE, false);                           \
     } while (0)
+    const bool rew = p.clip_rew != 0 || p.norm_rew != 0;
     if (f32) {
         if (norm) { if (noise) DN_LAUNCH(float, true, true); else DN_LAUNCH(float, true, false); }
         else { if (noise) DN_LAUNCH(float, false, true); else DN_LAUNCH(float, false, false); }
@@ -1291,6 +1340,7 @@ hipError_t dn_launch_step_many(const DnParams &p, const DnStepIO &io, int k, boo
     }
 #undef DN_LAUNCH
 #undef DN_LAUNCH2
+#undef DN_LAUNCH3
     return hipGetLastError();
 }
 

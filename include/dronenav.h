@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define DN_ABI_VERSION 1
+#define DN_ABI_VERSION 2
 #define DN_MAX_WAYPOINTS 64
 #define DN_OBS_DIM 13      /* 12 kinematic + distance, PBDroneEnv._computeObs, PBDroneEnv.py:296-336 */
 #define DN_ACT_DIM 4       /* four rotor thrust commands, PBDroneEnv._actionSpace, PBDroneEnv.py:225-243 */
@@ -72,6 +72,9 @@ typedef struct dn_config {
     float obs_noise_sigma;                      /* sim-to-real: Gaussian observation noise (0 = reference) */
     uint64_t seed;                              /* Philox key for the noise streams */
     int64_t env_id_offset;                      /* global id of drone 0 (rank * num_envs when sharded) */
+    int32_t clip_rew;                           /* --clip_rew: TransformReward(clip(r, -10, 10)), PBDroneSimulator.py:191-192 */
+    int32_t norm_rew;                           /* --norm_rew: NormalizeReward(gamma .99, eps 1e-8), PBDroneSimulator.py:193-194
+                                                   (normalize.py:100-147); both sit inside Monitor, clip first */
 } dn_config;
 
 /* One drone's persistent state, host-side AoS view used by dn_get_state/dn_set_state (tests,
@@ -89,6 +92,8 @@ typedef struct dn_env_state {
     double rms_mean[DN_OBS_DIM];                /* normalize.RunningMeanStd.mean  (normalize_obs only) */
     double rms_var[DN_OBS_DIM];                 /*                         .var                       */
     double rms_count;                           /*                         .count                     */
+    double rr_returns;                          /* NormalizeReward.returns (discounted return, norm_rew only)  */
+    double rr_mean, rr_var, rr_count;           /* NormalizeReward.return_rms                                  */
 } dn_env_state;
 
 /* Wave-reduced episode statistics accumulated on the device since dn_create / dn_reset_stats. */

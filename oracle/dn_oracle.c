@@ -590,11 +590,39 @@ static void round_state_f32(orc_env *e)
 #undef RF
 }
 
+/* make_env's optional reward wrappers (PBDroneSimulator.py:191-194), applied inside Monitor:                  */
+/*   TransformReward(lambda r: np.clip(r, -10, 10))                        if --clip_rew                       */
+/*   NormalizeReward(gamma=0.99, epsilon=1e-8), normalize.py:132-147       if --norm_rew                       */
+/*     returns = returns*gamma + rew; return_rms.update(returns) (batch of one: batch_var = 0);                */
+/*     rew = rew / sqrt(return_rms.var + epsilon); returns[dones] = 0                                          */
+double orc_reward_wrappers(const orc_config *c, orc_env *e, double reward, int32_t done)
+{
+    double r = reward;
+    if (c->clip_rew) r = r < -10.0 ? -10.0 : (r > 10.0 ? 10.0 : r);
+    if (c->norm_rew) {
+        e->rr_returns = e->rr_returns * 0.99 + r;                         /* :134 */
+        /* update_mean_var_count_from_moments, normalize.py:34-47, batch_mean = returns, batch_var = 0, batch_count = 1 */
+        double delta = e->rr_returns - e->rr_mean;
+        double tot = e->rr_count + 1.0;
+        double new_mean = e->rr_mean + delta * 1.0 / tot;
+        double m_a = e->rr_var * e->rr_count;
+        double m_b = 0.0 * 1.0;
+        double M2 = m_a + m_b + delta * delta * e->rr_count * 1.0 / tot;
+        e->rr_mean = new_mean;
+        e->rr_var = M2 / tot;
+        e->rr_count = tot;
+        r = r / sqrt(e->rr_var + 1e-8);                                   /* :147 */
+        if (done) e->rr_returns = 0.0;                                    /* :138 */
+    }
+    return r;
+}
+
 void orc_vec_create(const orc_config *c, orc_env *envs, int64_t n)
 {
     for (int64_t i = 0; i < n; ++i) {
         float obs[ORC_OBS_DIM];
         orc_env_construct(c, &envs[i]);
+        envs[i].rr_returns = 0.0; envs[i].rr_mean = 0.0; envs[i].rr_var = 1.0; envs[i].rr_count = 1e-4;   /* normalize.py:14-18, :127-128 */
         orc_env_reset(c, &envs[i], obs);         /* make_env: env.reset(seed=seed+rank) before wrapping, PBDroneSimulator.py:173 */
         if (c->f32_state) round_state_f32(&envs[i]);
     }
@@ -650,9 +678,10 @@ void orc_vec_step(const orc_config *c, orc_env *envs, int64_t n, const float *ac
         float *o = &obs[i * ORC_OBS_DIM];
         memcpy(o, so.obs, sizeof so.obs);
         finish_obs(c, e, gid, 1u, o);
+        int dn = so.terminated || so.truncated;
+        so.reward = orc_reward_wrappers(c, e, so.reward, dn);
         e->ep_ret += so.reward;                   /* Monitor.step */
         e->ep_len += 1;
-        int dn = so.terminated || so.truncated;
         reward[i] = (float)so.reward;
         done[i] = (uint8_t)dn;
         truncated[i] = (uint8_t)(so.truncated && !so.terminated);

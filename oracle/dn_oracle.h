@@ -59,6 +59,10 @@ typedef struct orc_config {
     float obs_noise_sigma;
     uint64_t seed;
     int64_t env_id_offset;                      /* global id of env 0 (rank sharding) */
+    /* optional reward wrappers of make_env (PBDroneSimulator.py:191-194), inside Monitor:
+     * TransformReward(clip(-10, 10)) if --clip_rew, then gym NormalizeReward() if --norm_rew */
+    int32_t clip_rew;
+    int32_t norm_rew;
 } orc_config;
 
 /* Every per-env variable the reference keeps, under the reference's names. */
@@ -82,6 +86,8 @@ typedef struct orc_env {
     double rms_mean[ORC_OBS_DIM], rms_var[ORC_OBS_DIM], rms_count;
     /* noise counter */
     uint32_t step_count;
+    /* NormalizeReward (normalize.py:100-147): discounted return and its RunningMeanStd(shape=()) */
+    double rr_returns, rr_mean, rr_var, rr_count;
 } orc_env;
 
 /* Result of one gym-level env.step (PBDroneEnv.step), before vectorisation. */
@@ -115,6 +121,8 @@ int32_t orc_compute_truncated(const orc_config *cfg, const orc_env *e);
 int32_t orc_has_collision(const orc_config *cfg, const orc_env *e);
 void orc_post_step(const orc_config *cfg, orc_env *e);
 void orc_normalize_obs(orc_env *e, const float obs_in[ORC_OBS_DIM], double obs_out[ORC_OBS_DIM]);
+/* TransformReward(clip) + NormalizeReward.step for one env (normalize.py:132-147); returns the reward Monitor sees */
+double orc_reward_wrappers(const orc_config *cfg, orc_env *e, double reward, int32_t done);
 
 /* ---- A10/A11: vectorised (SubprocVecEnv + Monitor + NormalizeObservation) --- */
 void orc_vec_create(const orc_config *cfg, orc_env *envs, int64_t n);

@@ -35,6 +35,8 @@ class OrcConfig(C.Structure):
         ("obs_noise_sigma", C.c_float),
         ("seed", C.c_uint64),
         ("env_id_offset", C.c_int64),
+        ("clip_rew", C.c_int32),
+        ("norm_rew", C.c_int32),
     ]
 
 
@@ -50,6 +52,7 @@ class OrcEnv(C.Structure):
         ("ep_ret", C.c_double), ("ep_len", C.c_int32),
         ("rms_mean", C.c_double * OBS_DIM), ("rms_var", C.c_double * OBS_DIM), ("rms_count", C.c_double),
         ("step_count", C.c_uint32),
+        ("rr_returns", C.c_double), ("rr_mean", C.c_double), ("rr_var", C.c_double), ("rr_count", C.c_double),
     ]
 
 
@@ -67,6 +70,7 @@ ENV_DTYPE = np.dtype([
     ("ep_ret", "f8"), ("ep_len", "i4"),
     ("rms_mean", "f8", OBS_DIM), ("rms_var", "f8", OBS_DIM), ("rms_count", "f8"),
     ("step_count", "u4"),
+    ("rr_returns", "f8"), ("rr_mean", "f8"), ("rr_var", "f8"), ("rr_count", "f8"),
 ], align=True)
 
 
@@ -110,6 +114,8 @@ def lib():
         getattr(L, name).restype = C.c_int32
     L.orc_post_step.argtypes = [cfgp, envp]
     L.orc_normalize_obs.argtypes = [envp, fp, dp]
+    L.orc_reward_wrappers.argtypes = [cfgp, envp, C.c_double, C.c_int32]
+    L.orc_reward_wrappers.restype = C.c_double
     L.orc_vec_create.argtypes = [cfgp, C.c_void_p, C.c_int64]
     L.orc_vec_reset.argtypes = [cfgp, C.c_void_p, C.c_int64, C.c_void_p, C.c_int]
     L.orc_vec_step.argtypes = [cfgp, C.c_void_p, C.c_int64] + [C.c_void_p] * 10 + [C.c_int]
@@ -127,7 +133,8 @@ def lib():
 
 def make_config(waypoints, spawn, dim, *, threshold=0.3, max_steps=4096, circle=False, cylinder=True,
                 include_distance=True, normalize_actions=True, normalize_obs=False, ground_contact=True,
-                f32_state=False, act_noise_sigma=0.0, obs_noise_sigma=0.0, seed=0, env_id_offset=0):
+                f32_state=False, act_noise_sigma=0.0, obs_noise_sigma=0.0, seed=0, env_id_offset=0, clip_rew=False,
+                norm_rew=False):
     wp = np.asarray(waypoints, dtype=np.float64).reshape(-1, 3)
     assert 1 <= len(wp) <= MAX_WAYPOINTS
     cfg = OrcConfig()
@@ -145,6 +152,7 @@ def make_config(waypoints, spawn, dim, *, threshold=0.3, max_steps=4096, circle=
     cfg.normalize_obs, cfg.ground_contact, cfg.f32_state = int(normalize_obs), int(ground_contact), int(f32_state)
     cfg.act_noise_sigma, cfg.obs_noise_sigma = float(act_noise_sigma), float(obs_noise_sigma)
     cfg.seed, cfg.env_id_offset = int(seed), int(env_id_offset)
+    cfg.clip_rew, cfg.norm_rew = int(clip_rew), int(norm_rew)
     return cfg
 
 

@@ -367,6 +367,38 @@ def gen_normalize(out):
     out["normalize"] = dict(x=x, y=y, mean=w.obs_rms.mean, var=w.obs_rms.var, count=np.float64(w.obs_rms.count))
 
 
+def gen_reward_wrappers(out):
+    """N4: make_env's optional reward wrappers (PBDroneSimulator.py:191-194): the reference's NormalizeReward (its
+    normalize.py copy of gym's) around a scripted env, with and without the clip lambda in front of it."""
+    rng = np.random.default_rng(41)
+    T = 400
+    rews = np.where(rng.random(T) < 0.1, rng.choice([-10.0, 8.0, 3.0, 40.0, -25.0], T), rng.normal(0.05, 0.4, T))
+    dones = rng.random(T) < 0.04
+
+    class _E:
+        def __init__(self):
+            self.t = 0
+
+        def step(self, action):
+            r, d = float(rews[self.t]), bool(dones[self.t])
+            self.t += 1
+            return None, r, d, False, {}
+
+    clip = lambda r: np.clip(r, -10, 10)                     # noqa: E731  (the lambda of PBDroneSimulator.py:192)
+    res = {}
+    for tag, do_clip in (("norm", False), ("clip_norm", True)):
+        env = _E()
+        if do_clip:
+            inner = env.step
+            env.step = lambda a, inner=inner: (lambda o, r, d, tr, i: (o, clip(r), d, tr, i))(*inner(a))
+        w = ref_normalize.NormalizeReward(env)
+        ys = np.array([float(w.step(None)[1]) for _ in range(T)])
+        res[tag] = ys
+        res[tag + "_mean"], res[tag + "_var"] = np.float64(w.return_rms.mean), np.float64(w.return_rms.var)
+        res[tag + "_count"], res[tag + "_returns"] = np.float64(w.return_rms.count), np.float64(w.returns[0])
+    out["reward_wrappers"] = dict(rewards=rews, dones=dones.astype(np.uint8), **res)
+
+
 def gen_gae(out):
     """N1: execute the reference's GAE lines (cleanRLPPO.py:234-248) on random buffers."""
     import torch
@@ -425,7 +457,8 @@ def main():
     out = {}
     only = set(sys.argv[1:])
     gens = dict(actions=gen_constants_and_actions, tracks=gen_tracks, obs_pack=gen_obs_pack, closed_loop=gen_closed_loop,
-                scripted=gen_scripted, normalize=gen_normalize, gae=gen_gae, rollout_dump=gen_rollout_dump)
+                scripted=gen_scripted, normalize=gen_normalize, gae=gen_gae, rollout_dump=gen_rollout_dump,
+                reward_wrappers=gen_reward_wrappers)
     for key, fn in gens.items():          # `python gen_golden.py rollout_dump` regenerates only that group
         if not only or key in only:
             fn(out)

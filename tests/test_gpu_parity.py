@@ -31,7 +31,7 @@ def make_pair(track, n, *, f32_state, max_steps=4096, **kw):
     env = pkg.DroneVecEnv(track, n, max_steps=max_steps, device="cuda:0", **kw)
     okw = {k: v for k, v in kw.items() if k in ("normalize_obs", "include_distance", "normalize_actions",
                                                 "act_noise_sigma", "obs_noise_sigma", "seed", "env_id_offset",
-                                                "ground_contact", "threshold", "cylinder")}
+                                                "ground_contact", "threshold", "cylinder", "clip_rew", "norm_rew")}
     okw.setdefault("normalize_obs", True)
     cfg = O.make_config(track.targets(), track.initial_xyzs, track.aviary_dim, circle=track.is_circle,
                         max_steps=max_steps, f32_state=f32_state, **okw)
@@ -41,7 +41,8 @@ def make_pair(track, n, *, f32_state, max_steps=4096, **kw):
 def gpu_state_to_oracle(st, envs, step_count):
     """Teacher forcing: load the GPU's float32 state into the oracle's float64 variables."""
     for k in ("pos", "quat", "vel", "ang_v", "prev_vel", "prev_ang_v", "cur_pos", "d", "d_prev", "idx", "steps",
-              "just_found", "ep_ret", "ep_len", "rms_mean", "rms_var", "rms_count"):
+              "just_found", "ep_ret", "ep_len", "rms_mean", "rms_var", "rms_count", "rr_returns", "rr_mean", "rr_var",
+              "rr_count"):
         envs[k] = st[k]
     envs["cur_vel"] = st["vel"]
     envs["cur_ang_v"] = st["ang_v"]
@@ -858,4 +859,33 @@ def test_degenerate_limits_match_oracle(max_steps, threshold):
     if threshold == 5.0:
         assert completed > 0, "the all-gates-passed branch (+200/25) must occur"
     assert env.stats()["episodes"] == n_done
+    env.close()
+
+
+@pytest.mark.parametrize("clip,norm", [(True, False), (False, True), (True, True)])
+def test_reward_wrappers_match_oracle(clip, norm):
+    """make_env's optional reward wrappers (--clip_rew / --norm_rew, PBDroneSimulator.py:191-194) fused into the step:
+    rewards, Monitor returns and the NormalizeReward statistics against the oracle (which is pinned to the reference's
+    own NormalizeReward), free-running and then teacher-forced through get_state / set_state."""
+    track = _tracks().circle(1, 4, 1)
+    n = 640
+    env, ora = make_pair(track, n, f32_state=True, max_steps=45, normalize_obs=False, clip_rew=clip, norm_rew=norm)
+    env.reset()
+    ora.reset()
+    rng = np.random.default_rng(77)
+    dev = torch.device("cuda:0")
+    n_done = 0
+    for t in range(120):
+        a = actions_mixed(rng, n)
+        n_done += compare_step(env.step_tensor(torch.from_numpy(a).to(dev)), ora.step(a), f"rew clip={clip} norm={norm} t={t}",
+                               rew_atol=2e-4)
+    assert n_done > n
+    st = env.get_state()
+    if norm:
+        for k in ("rr_mean", "rr_var", "rr_returns"):
+            np.testing.assert_allclose(st[k], ora.envs[k], rtol=1e-5, atol=1e-5, err_msg=k)
+        assert np.array_equal(st["rr_count"], ora.envs["rr_count"]) and float(np.abs(st["rr_var"] - 1.0).min()) > 1e-3
+        env.set_state(st)                                   # round trip through the host representation
+        st2 = env.get_state()
+        assert np.array_equal(st2["rr_mean"], st["rr_mean"]) and np.array_equal(st2["rr_returns"], st["rr_returns"])
     env.close()

@@ -206,3 +206,20 @@ def test_gae(golden):
                      float(g["gamma"]), float(g["gae_lambda"]))
     assert np.array_equal(adv.view(np.uint32), g["advantages"].view(np.uint32))
     assert np.array_equal(ret.view(np.uint32), g["returns"].view(np.uint32))
+
+
+def test_reward_wrappers_match_reference(golden):
+    """make_env's optional reward wrappers (--clip_rew, --norm_rew; PBDroneSimulator.py:191-194): the oracle against the
+    reference's own NormalizeReward (normalize.py:100-147) driven over a scripted reward / done stream."""
+    g = golden("reward_wrappers")
+    L = O.lib()
+    for tag, clip in (("norm", False), ("clip_norm", True)):
+        cfg = O.make_config(np.zeros((1, 3)), np.zeros(3), np.array([-1, -1, 0, 1, 1, 1.0]), clip_rew=clip, norm_rew=True)
+        env = O.OracleVecEnv(cfg, 1)
+        e = env.envs.ctypes.data_as(C.POINTER(O.OrcEnv))
+        ys = np.array([L.orc_reward_wrappers(C.byref(cfg), e, float(r), int(d)) for r, d in zip(g["rewards"], g["dones"])])
+        np.testing.assert_allclose(ys, g[tag], rtol=1e-12, atol=1e-14)
+        assert abs(env.envs["rr_mean"][0] - float(g[tag + "_mean"])) < 1e-12
+        assert abs(env.envs["rr_var"][0] - float(g[tag + "_var"])) <= 1e-12 * float(g[tag + "_var"])
+        assert env.envs["rr_count"][0] == float(g[tag + "_count"])
+        assert abs(env.envs["rr_returns"][0] - float(g[tag + "_returns"])) < 1e-12
