@@ -50,6 +50,10 @@ def parse():
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ppo-rollout", action="store_true", help="skip the policy-in-the-loop rollout measurement")
+    ap.add_argument("--ppo-sharded", action="store_true",
+                    help="BASELINE configs[3]: also time the policy-in-the-loop rollout on every rank with the per-rollout RCCL "
+                         "all-gather of advantages/returns (opt-in: a collective inside the bench line is not worth risking "
+                         "the scaling run for)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the RCCL process group even for one rank (exercises the N > 1 code path on a 1-GPU box)")
     return ap.parse_args()
@@ -143,6 +147,37 @@ def ppo_rollout(pkg, track, n, max_steps, dev, rank):
             "n_steps": n_steps, "num_envs": n,
             "what": "policy-in-the-loop rollout: MLP 13-512-512-256 (pi, vf; Tanh) + Gaussian sample + dn_step + "
                     "V(terminal_obs) bootstrap per step, dn_gae per rollout, per-drone obs normaliser on"}
+
+
+def ppo_rollout_sharded(pkg, track, n, max_steps, dev, rank, world, dist):
+    """BASELINE configs[3] (131072 drones over 4 GPUs): FusedRolloutCollector per rank on its shard + one all-gather of
+    the packed advantages/returns per rollout over RCCL; aggregate env-steps/s with the collective inside the timed
+    region (MAX over ranks)."""
+    import torch
+    from drl_dronenavigation_amd.collector import FusedRolloutCollector
+    n_steps = 32
+    torch.manual_seed(1)                                   # same weights on every rank
+    net = pkg.MlpActorCritic().to(dev)
+    fused = pkg.FusedMlpPolicy(net, n, dev)
+    env = pkg.DroneVecEnv(track, n, max_steps=max_steps, normalize_obs=True, env_id_offset=rank * n, device=dev)
+    col = FusedRolloutCollector(env, fused, n_steps, gather=True, seed=1)
+    for _ in range(3):
+        out = col.collect()
+    torch.cuda.synchronize(dev)
+    dist.barrier(device_ids=[dev.index])
+    reps = 5
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = col.collect()
+    torch.cuda.synchronize(dev)
+    tw = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+    assert out["advantages_global"].shape == (n_steps, n * world)
+    env.close()
+    return {"value": round(n * world * n_steps * reps / float(tw[0]), 1), "unit": "env-steps/s", "n_steps": n_steps,
+            "global_num_envs": n * world, "all_gather_bytes_sent_per_rank_per_rollout": 2 * n_steps * n * 4,
+            "what": "FusedRolloutCollector(gather=True) on every rank: policy in the loop + one RCCL all-gather of the packed "
+                    "advantages/returns per rollout"}
 
 
 def main():
@@ -298,6 +333,9 @@ def main():
             us = (time.perf_counter() - t0_) * 1e6 / reps_
             others["sb3_numpy_step_infos_" + mode_] = {"us_per_vector_step": round(us, 1), "value": round(n / (us * 1e-6), 1)}
 
+    sharded = None
+    if args.ppo_sharded and dist is not None:
+        sharded = ppo_rollout_sharded(pkg, track, n, max_steps, dev, rank, world, dist)
     algo = ALGO_BYTES_PER_ENV_STEP + (ALGO_BYTES_NORMALISER if args.normalize_obs else 0)
     for o_ in others.values():
         o_["roofline_frac"] = round(algo * n / (o_["us_per_vector_step"] * 1e-6) / 1e9 / HBM_PEAK_GBPS, 5)
@@ -339,6 +377,8 @@ def main():
                          "avg_launch_us": round(launch_us, 4), "us_per_vector_step": round(step_us, 4)},
             "other_launch_shapes": others,
         }
+        if sharded is not None:
+            line["ppo_rollout_sharded"] = sharded
         if world == 1 and not args.no_ppo_rollout:
             line["ppo_rollout"] = ppo_rollout(pkg, track, n, max_steps, dev, rank)
         if world == 1 and not args.no_cpu_baseline:

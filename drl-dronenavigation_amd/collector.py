@@ -57,11 +57,12 @@ class ShardPlan:
 def all_gather_rollout(advantages, returns, group=None):
     """All-gather the per-rank [n_steps, N_local] advantages and returns into [n_steps, N_global] tensors whose
     columns are in global drone order.  One collective for both arrays (packed [2, T, N_local] send buffer ->
-    [R*2, T, N_local] receive buffer), none at all for a single-rank job."""
+    [R*2, T, N_local] receive buffer), none at all without a process group (a one-rank group still goes through the
+    collective, which keeps that code path testable on one GPU)."""
     import torch.distributed as dist
     if advantages.shape != returns.shape or advantages.dim() != 2:
         raise ValueError("advantages and returns must both be [n_steps, N_local]")
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return advantages, returns
     world = dist.get_world_size(group)
     T, n = advantages.shape
