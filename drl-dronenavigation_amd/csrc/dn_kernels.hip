@@ -302,6 +302,32 @@ template <> struct FM<float> {                  // speed option (compute_f32): h
     static DN_DEV float fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 };
 
+// atan2 in float32 for the Euler angles (observation columns 3..5 only, bar 1e-5 on angle/pi): the Cephes atanf scheme
+// -- two range reductions at tan(pi/8) and tan(3pi/8), a degree-4 polynomial in z^2 (|error| < 2e-7 rad) -- on the
+// hardware reciprocal, ~25 instructions against ~52 for the library atan2f with its special-case handling.  Inputs
+// here are finite and not both zero except at exactly zero attitude, which returns 0 like atan2(0, 1).
+DN_DEV float atan_pos32(float t)                       // t >= 0 (may be +inf)
+{
+    const bool big = t > 2.414213562373095f, mid = t > 0.4142135623730950f;
+    const float y0 = big ? 1.5707963267948966f : (mid ? 0.7853981633974483f : 0.0f);
+    const float num = big ? -1.0f : (mid ? t - 1.0f : t);
+    const float den = big ? t : (mid ? t + 1.0f : 1.0f);
+    const float x = num * __builtin_amdgcn_rcpf(den);
+    const float z = x * x;
+    float pz = __builtin_fmaf(8.05374449538e-2f, z, -1.38776856032e-1f);
+    pz = __builtin_fmaf(pz, z, 1.99777106478e-1f);
+    pz = __builtin_fmaf(pz, z, -3.33329491539e-1f);
+    return y0 + __builtin_fmaf(pz * z, x, x);
+}
+DN_DEV float atan2_fast32(float y, float x)
+{
+    const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
+    float r = atan_pos32(ay * __builtin_amdgcn_rcpf(ax));       // ax = 0 -> +inf -> pi/2
+    r = (ax == 0.0f && ay == 0.0f) ? 0.0f : r;
+    r = x < 0.0f ? 3.14159265358979323846f - r : r;
+    return __builtin_copysignf(r, y);
+}
+
 // ---- A8: _has_collision_occurred (PBDroneEnv.py:678-707) + is_out_of_cylinder_bounds (:718-786) ----
 // The reference compares distances, norm(.) > radius; here the squared distance is compared with the squared
 // radius (no sqrt).  The two predicates differ only when the squared distance is within an ulp of the squared
@@ -573,12 +599,13 @@ DN_DEV Flight<R> physics_phase(const Thrust &th, const float4 G0, const float4 G
     const R tx = K<R>::ARM * ((F2 + F3) - (F0 + F1));
     const R ty = K<R>::ARM * ((F1 + F2) - (F0 + F3));
     // linear: a = R[:,2] fz/M - (0,0,G) - v (c + c|v|)
-    const R kl = K<R>::LIN_DAMP + K<R>::LIN_DAMP * FM<R>::sqrt0(vx * vx + vy * vy + vz * vz);
+    // the damping norms enter the velocity update at dt * 0.04: a float32 root moves it by 1e-12 relative
+    const R kl = K<R>::LIN_DAMP + K<R>::LIN_DAMP * (R)__builtin_amdgcn_sqrtf((float)(vx * vx + vy * vy + vz * vz));
     const R fm = fz * K<R>::INV_M;
     const R awx = r02 * fm - vx * kl, awy = r12 * fm - vy * kl, awz = (r22 * fm - K<R>::G) - vz * kl;
     // angular, in the body frame: I dw = tau - w x (I w) - I w (c + c|w|)
     const R wbx = r00 * wx + r10 * wy + r20 * wz, wby = r01 * wx + r11 * wy + r21 * wz, wbz = r02 * wx + r12 * wy + r22 * wz;
-    const R ka = K<R>::ANG_DAMP + K<R>::ANG_DAMP * FM<R>::sqrt0(wx * wx + wy * wy + wz * wz);
+    const R ka = K<R>::ANG_DAMP + K<R>::ANG_DAMP * (R)__builtin_amdgcn_sqrtf((float)(wx * wx + wy * wy + wz * wz));
     const R Iwx = K<R>::IXX * wbx, Iwy = K<R>::IYY * wby, Iwz = K<R>::IZZ * wbz;
     const R gx = wby * Iwz - wbz * Iwy, gy = wbz * Iwx - wbx * Iwz, gz = wbx * Iwy - wby * Iwx;
     const R dbx = (tx - gx - Iwx * ka) * K<R>::INV_IXX, dby = (ty - gy - Iwy * ka) * K<R>::INV_IYY,
@@ -726,8 +753,8 @@ DN_DEV Observed<R> observe_phase(const DnParams &p, const DnConsts<R> &c, const 
             fwx = cos(yaw) * cpit; fwy = sin(yaw) * cpit; fwz = sin(pitch);
             pitch32 = (float)pitch; yaw32 = (float)yaw;
         } else {
-            roll32 = atan2f((float)(R(2.0) * (qy * qz + qw * qx)), (float)(squ - sqx - sqy + sqz));
-            yaw32 = atan2f((float)ys, (float)yc);
+            roll32 = atan2_fast32((float)(R(2.0) * (qy * qz + qw * qx)), (float)(squ - sqx - sqy + sqz));
+            yaw32 = atan2_fast32((float)ys, (float)yc);
             // asin is ill-conditioned towards +-1: beyond 0.95 (pitch > 72 deg, rare) take the R-precision routine
             if (fabs(sarg) > R(0.95)) pitch32 = (float)asin(sarg);
             else pitch32 = asinf((float)sarg);
@@ -769,15 +796,16 @@ DN_DEV Observed<R> observe_phase(const DnParams &p, const DnConsts<R> &c, const 
         if (last_gate) r32 = r32 + 200.0f;                                        // :542-546
         else { r32 = r32 + 75.0f; r32 = r32 + (float)(ori * 5); }                 // :548-552
         ob.r_found32 = r32;
-        R r = R(3.0) * (R)expf((float)(R(-2.0) * fl.d_e));                        // :555 (3/25 e^-2d: float32 exp is 1e-8 here)
+        R r = R(3.0) * (R)__builtin_amdgcn_exp2f((float)(R(-2.0 * 1.4426950408889634) * fl.d_e));   // :555 3 e^{-2d} (v_exp_f32: 1e-7 rel, 1e-8 in the reward)
         r = r + (fl.just_found_e ? R(0.0) : (fl.dprev_e - fl.d_e) * R(3000.0));   // :556
         r = r + (R)(ori * 3);                                                     // :557
         // smoothness_reward (:599-607) on the stale post-step copies (quirk Q4): -|dv| if |dv| > 0.7, -|dw| if > 0.3
         const R lx = fl.vex - (R)G4.x, ly = fl.vey - (R)G4.y, lz = fl.vez - (R)G4.z;
         const R ax_ = fl.aex - (R)G5.x, ay_ = fl.aey - (R)G5.y, az_ = fl.aez - (R)G5.z;
         const R la2 = lx * lx + ly * ly + lz * lz, aa2 = ax_ * ax_ + ay_ * ay_ + az_ * az_;
-        if (la2 > R(0.7) * R(0.7)) r = r - FM<R>::sqrt0(la2);                     // needs > 160 m/s^2: rare
-        if (aa2 > R(0.3) * R(0.3)) r = r - FM<R>::sqrt0(aa2);
+        // the penalties enter the reward at 1/25: a float32 root (1e-7 relative) is far inside the reward's 1e-5 bar
+        if (la2 > R(0.7) * R(0.7)) r = r - (R)__builtin_amdgcn_sqrtf((float)la2);     // needs > 160 m/s^2: rare
+        if (aa2 > R(0.3) * R(0.3)) r = r - (R)__builtin_amdgcn_sqrtf((float)aa2);
         ob.r_normal = r;
     }
     // sensor noise / per-drone normaliser act on the step observation (which is also terminal_observation)
