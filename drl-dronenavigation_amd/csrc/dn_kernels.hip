@@ -542,12 +542,14 @@ struct Thrust {
     float zt;          // yaw torque
 };
 template <typename R> struct Flight {
-    R px, py, pz, qx, qy, qz, qw, vx, vy, vz, wx, wy, wz;   // post-physics body state (before any reset)
-    R vex, vey, vez, aex, aey, aez;                          // entry velocities = current_vel / current_ang_v (quirk Q4)
-    R d_e, dprev_e;                                          // entry _distance_to_target / _prev_distance_to_target
+    R px, py, pz, qx, qy, qz, qw;                            // post-physics pose (before any reset): feeds compares, stays R
+    float vx, vy, vz, wx, wy, wz;                            // post-physics velocities as they go back to HBM (float32):
+                                                             // the report wave only turns them into observation columns
+    float vex, vey, vez, aex, aey, aez;                      // entry velocities = current_vel / current_ang_v (quirk Q4), float32 state
+    float d_e, dprev_e;                                      // entry _distance_to_target / _prev_distance_to_target, float32 state
     int idx_e, just_found_e, truncated;                      // entry index / flag; _computeTruncated (entry _steps)
 };
-constexpr int DN_NFLIGHT = 21;                               // R-valued fields of Flight
+constexpr int DN_NFLIGHT64 = 7;                              // R-valued fields of Flight (the rest travel as float32)
 template <typename R> struct Verdict {
     R d_obs;           // the distance the reset observation shows (quirk Q2)
     int coll1;         // _computeTerminated inside _computeReward (entry index)
@@ -582,7 +584,7 @@ DN_DEV Flight<R> physics_phase(const Thrust &th, const float4 G0, const float4 G
     fl.d_e = G0.w; fl.dprev_e = G2.w;
     fl.idx_e = m_e.idx; fl.just_found_e = m_e.just_found;
     fl.truncated = max_steps <= m_e.steps;             // PBDroneEnv.py:444-454, evaluated on the un-incremented _steps
-    fl.vex = vx; fl.vey = vy; fl.vez = vz; fl.aex = wx; fl.aey = wy; fl.aez = wz;
+    fl.vex = G2.x; fl.vey = G2.y; fl.vez = G2.z; fl.aex = G3.x; fl.aey = G3.y; fl.aez = G3.z;
     const R dt = K<R>::DT;
     // btMatrix3x3::setRotation: s = 2 / |q|^2
     const R s = R(2.0) * FM<R>::rcp(qx * qx + qy * qy + qz * qz + qw * qw);
@@ -640,7 +642,7 @@ DN_DEV Flight<R> physics_phase(const Thrust &th, const float4 G0, const float4 G
     const R inv = FM<R>::rsq(nx * nx + ny * ny + nz * nz + nw_ * nw_);
     fl.px = px; fl.py = py; fl.pz = pz;
     fl.qx = nx * inv; fl.qy = ny * inv; fl.qz = nz * inv; fl.qw = nw_ * inv;
-    fl.vx = vx; fl.vy = vy; fl.vz = vz; fl.wx = wx; fl.wy = wy; fl.wz = wz;
+    fl.vx = (float)vx; fl.vy = (float)vy; fl.vz = (float)vz; fl.wx = (float)wx; fl.wy = (float)wy; fl.wz = (float)wz;
     return fl;
 }
 
@@ -664,9 +666,9 @@ DN_DEV Verdict<R> rules_phase(const DnParams &p, const DnConsts<R> &c, const R *
     const bool seg_track = p.cylinder && !p.circle;
     const bool coll1 = collision_common<R>(p, c, px, py, pz, r22n) ||
                        (seg_track && outside_segment_corridor<R>(c, s_tab, px, py, pz, idx));
-    const bool found_now = fl.d_e <= c.threshold;      // :539
+    const bool found_now = (R)fl.d_e <= c.threshold;   // :539
     const bool last_gate = idx + 1 == p.num_waypoints;
-    R d_prev = fl.dprev_e;
+    R d_prev = (R)fl.dprev_e;
     bool terminated;
     if (coll1) terminated = true;                      // :489-490 (entry _is_done is always False here)
     else if (found_now) {
@@ -677,12 +679,12 @@ DN_DEV Verdict<R> rules_phase(const DnParams &p, const DnConsts<R> &c, const R *
             // second _computeTerminated: the common part is already known to be false
             terminated = seg_track && outside_segment_corridor<R>(c, s_tab, px, py, pz, idx);
         }
-        d_prev = fl.d_e;
-    } else { just_found = 0; d_prev = fl.d_e; terminated = false; }
+        d_prev = (R)fl.d_e;
+    } else { just_found = 0; d_prev = (R)fl.d_e; terminated = false; }
     const bool done = terminated || fl.truncated != 0;
 
     int steps = m_e.steps;
-    R d = fl.d_e;
+    R d = (R)fl.d_e;
     if (!terminated) {                                 // _update_state_post_step
         steps += 1;
         const R *wp = s_tab + idx * DN_T_STRIDE;
@@ -695,8 +697,8 @@ DN_DEV Verdict<R> rules_phase(const DnParams &p, const DnConsts<R> &c, const R *
     // the advanced body state as the float32 words that go back to HBM
     float4 S0 = make_float4((float)px, (float)py, (float)pz, 0.0f);
     float4 S1 = make_float4((float)fl.qx, (float)fl.qy, (float)fl.qz, (float)fl.qw);
-    float4 S2 = make_float4((float)fl.vx, (float)fl.vy, (float)fl.vz, 0.0f);
-    float4 S3 = make_float4((float)fl.wx, (float)fl.wy, (float)fl.wz, 0.0f);
+    float4 S2 = make_float4(fl.vx, fl.vy, fl.vz, 0.0f);
+    float4 S3 = make_float4(fl.wx, fl.wy, fl.wz, 0.0f);
     if (__ballot(done) != 0ull) {                      // wave-uniform: most wave-steps of a long flight skip this
         if (done) {
             R cpx, cpy, cpz;
@@ -775,20 +777,20 @@ DN_DEV Observed<R> observe_phase(const DnParams &p, const DnConsts<R> &c, const 
         o[4] = pitch32 * inv_pi32;
         o[5] = yaw32 * inv_pi32;
         const float third32 = (float)K<R>::THIRD;
-        o[6] = clipv((float)(fl.vx * K<R>::THIRD), -1.0f, 1.0f);
-        o[7] = clipv((float)(fl.vy * K<R>::THIRD), -1.0f, 1.0f);
-        o[8] = clipv((float)(fl.vz * K<R>::THIRD), -third32, third32);
-        const R w2 = fl.wx * fl.wx + fl.wy * fl.wy + fl.wz * fl.wz;
+        o[6] = clipv((float)((R)fl.vx * K<R>::THIRD), -1.0f, 1.0f);
+        o[7] = clipv((float)((R)fl.vy * K<R>::THIRD), -1.0f, 1.0f);
+        o[8] = clipv((float)((R)fl.vz * K<R>::THIRD), -third32, third32);
+        const R w2 = (R)fl.wx * (R)fl.wx + (R)fl.wy * (R)fl.wy + (R)fl.wz * (R)fl.wz;
         if (w2 != R(0.0)) {                                   // ang_v / |ang_v|, zero stays zero (:383-384)
             const R rw = FM<R>::rsq_f32grade(w2);
-            o[9] = (float)(fl.wx * rw); o[10] = (float)(fl.wy * rw); o[11] = (float)(fl.wz * rw);
-        } else { o[9] = (float)fl.wx; o[10] = (float)fl.wy; o[11] = (float)fl.wz; }
-        o[12] = p.include_distance ? (float)(fl.d_e * c.inv_max_target_dist) : 0.0f;
+            o[9] = (float)((R)fl.wx * rw); o[10] = (float)((R)fl.wy * rw); o[11] = (float)((R)fl.wz * rw);
+        } else { o[9] = fl.wx; o[10] = fl.wy; o[11] = fl.wz; }
+        o[12] = p.include_distance ? (float)((R)fl.d_e * c.inv_max_target_dist) : 0.0f;
     }
     // _computeReward (PBDroneEnv.py:475-571): both value branches; report_phase selects once the verdict is in.
     // The orientation term is evaluated once, against the waypoint the taken branch refers to.
     {
-        const bool found_now = fl.d_e <= c.threshold;
+        const bool found_now = (R)fl.d_e <= c.threshold;
         const bool last_gate = fl.idx_e + 1 == p.num_waypoints;
         const int idx_ori = (found_now && !last_gate) ? fl.idx_e + 1 : fl.idx_e;
         const int ori = orientation_reward<R>(fwx, fwy, fwz, fl.px, fl.py, fl.pz, s_tab + idx_ori * DN_T_STRIDE);
@@ -796,12 +798,12 @@ DN_DEV Observed<R> observe_phase(const DnParams &p, const DnConsts<R> &c, const 
         if (last_gate) r32 = r32 + 200.0f;                                        // :542-546
         else { r32 = r32 + 75.0f; r32 = r32 + (float)(ori * 5); }                 // :548-552
         ob.r_found32 = r32;
-        R r = R(3.0) * (R)__builtin_amdgcn_exp2f((float)(R(-2.0 * 1.4426950408889634) * fl.d_e));   // :555 3 e^{-2d} (v_exp_f32: 1e-7 rel, 1e-8 in the reward)
-        r = r + (fl.just_found_e ? R(0.0) : (fl.dprev_e - fl.d_e) * R(3000.0));   // :556
+        R r = R(3.0) * (R)__builtin_amdgcn_exp2f((float)(R(-2.0 * 1.4426950408889634) * (R)fl.d_e));   // :555 3 e^{-2d} (v_exp_f32: 1e-7 rel, 1e-8 in the reward)
+        r = r + (fl.just_found_e ? R(0.0) : ((R)fl.dprev_e - (R)fl.d_e) * R(3000.0));   // :556
         r = r + (R)(ori * 3);                                                     // :557
         // smoothness_reward (:599-607) on the stale post-step copies (quirk Q4): -|dv| if |dv| > 0.7, -|dw| if > 0.3
-        const R lx = fl.vex - (R)G4.x, ly = fl.vey - (R)G4.y, lz = fl.vez - (R)G4.z;
-        const R ax_ = fl.aex - (R)G5.x, ay_ = fl.aey - (R)G5.y, az_ = fl.aez - (R)G5.z;
+        const R lx = (R)fl.vex - (R)G4.x, ly = (R)fl.vey - (R)G4.y, lz = (R)fl.vez - (R)G4.z;
+        const R ax_ = (R)fl.aex - (R)G5.x, ay_ = (R)fl.aey - (R)G5.y, az_ = (R)fl.aez - (R)G5.z;
         const R la2 = lx * lx + ly * ly + lz * lz, aa2 = ax_ * ax_ + ay_ * ay_ + az_ * az_;
         // the penalties enter the reward at 1/25: a float32 root (1e-7 relative) is far inside the reward's 1e-5 bar
         if (la2 > R(0.7) * R(0.7)) r = r - (R)__builtin_amdgcn_sqrtf((float)la2);     // needs > 160 m/s^2: rare
@@ -877,7 +879,7 @@ DN_DEV void report_phase(const DnParams &p, const DnConsts<R> &c, float *s_tile,
 {
 #pragma clang fp contract(fast)
     const bool coll1 = v.coll1 != 0, terminated = v.terminated != 0, truncated = fl.truncated != 0;
-    const bool found_now = !coll1 && fl.d_e <= c.threshold;
+    const bool found_now = !coll1 && (R)fl.d_e <= c.threshold;
     const bool is_done = found_now && fl.idx_e + 1 == p.num_waypoints;
     const int found = fl.idx_e + (found_now ? 1 : 0);
     const bool done = terminated || truncated;
@@ -893,8 +895,8 @@ DN_DEV void report_phase(const DnParams &p, const DnConsts<R> &c, float *s_tile,
     // prev_vel / prev_ang_v shift in _update_state_post_step (skipped on a terminated step, quirk Q5)
     float4 S4 = G4, S5 = G5;
     if (!terminated) {
-        S4 = make_float4((float)fl.vex, (float)fl.vey, (float)fl.vez, 0.0f);
-        S5 = make_float4((float)fl.aex, (float)fl.aey, (float)fl.aez, 0.0f);
+        S4 = make_float4(fl.vex, fl.vey, fl.vez, 0.0f);
+        S5 = make_float4(fl.aex, fl.aey, fl.aez, 0.0f);
     }
     float *o = ob.o;
     const unsigned long long done_ballot = __ballot(done && active);
@@ -1031,34 +1033,32 @@ __global__ __launch_bounds__(DN_BLOCK) void dn_step_many_1w_kernel(const DnParam
 // wave was busy 5610 cycles per step and the flight wave idle for 3040 of its 6410.)
 // -----------------------------------------------------------------------------------------------------
 template <typename R> struct Mail {       // LDS, field-major so that consecutive lanes hit consecutive banks
-    R flight[DN_NFLIGHT][DN_BLOCK];
-    R verdict_d[DN_BLOCK];
-    int flight_bits[DN_BLOCK];
-    int verdict_bits[DN_BLOCK];
+    R f64[DN_NFLIGHT64 + 1][DN_BLOCK];    // pose (7) + Verdict.d_obs
+    float4 f32[4][DN_BLOCK];              // 14 float32 fields + the two flag words: four 16-byte stores per lane
 };
 template <typename R> DN_DEV void post_mail(Mail<R> &m, unsigned lane, const Flight<R> &f, const Verdict<R> &v)
 {
-    const R x[DN_NFLIGHT] = {f.px, f.py, f.pz, f.qx, f.qy, f.qz, f.qw, f.vx, f.vy, f.vz, f.wx, f.wy, f.wz,
-                             f.vex, f.vey, f.vez, f.aex, f.aey, f.aez, f.d_e, f.dprev_e};
+    const R x[DN_NFLIGHT64 + 1] = {f.px, f.py, f.pz, f.qx, f.qy, f.qz, f.qw, v.d_obs};
 #pragma unroll
-    for (int k = 0; k < DN_NFLIGHT; ++k) m.flight[k][lane] = x[k];
-    m.flight_bits[lane] = f.idx_e | (f.just_found_e << 8) | (f.truncated << 9);
-    m.verdict_d[lane] = v.d_obs;
-    m.verdict_bits[lane] = v.coll1 | (v.terminated << 1);
+    for (int k = 0; k < DN_NFLIGHT64 + 1; ++k) m.f64[k][lane] = x[k];
+    const int fb = f.idx_e | (f.just_found_e << 8) | (f.truncated << 9), vb = v.coll1 | (v.terminated << 1);
+    m.f32[0][lane] = make_float4(f.vx, f.vy, f.vz, f.wx);
+    m.f32[1][lane] = make_float4(f.wy, f.wz, f.vex, f.vey);
+    m.f32[2][lane] = make_float4(f.vez, f.aex, f.aey, f.aez);
+    m.f32[3][lane] = make_float4(f.d_e, f.dprev_e, __int_as_float(fb), __int_as_float(vb));
 }
 template <typename R> DN_DEV void take_mail(const Mail<R> &m, unsigned lane, Flight<R> &f, Verdict<R> &v)
 {
-    R x[DN_NFLIGHT];
+    R x[DN_NFLIGHT64 + 1];
 #pragma unroll
-    for (int k = 0; k < DN_NFLIGHT; ++k) x[k] = m.flight[k][lane];
+    for (int k = 0; k < DN_NFLIGHT64 + 1; ++k) x[k] = m.f64[k][lane];
     f.px = x[0]; f.py = x[1]; f.pz = x[2]; f.qx = x[3]; f.qy = x[4]; f.qz = x[5]; f.qw = x[6];
-    f.vx = x[7]; f.vy = x[8]; f.vz = x[9]; f.wx = x[10]; f.wy = x[11]; f.wz = x[12];
-    f.vex = x[13]; f.vey = x[14]; f.vez = x[15]; f.aex = x[16]; f.aey = x[17]; f.aez = x[18];
-    f.d_e = x[19]; f.dprev_e = x[20];
-    const int bits = m.flight_bits[lane];
+    v.d_obs = x[7];
+    const float4 a = m.f32[0][lane], b = m.f32[1][lane], c = m.f32[2][lane], d = m.f32[3][lane];
+    f.vx = a.x; f.vy = a.y; f.vz = a.z; f.wx = a.w; f.wy = b.x; f.wz = b.y; f.vex = b.z; f.vey = b.w;
+    f.vez = c.x; f.aex = c.y; f.aey = c.z; f.aez = c.w; f.d_e = d.x; f.dprev_e = d.y;
+    const int bits = __float_as_int(d.z), vb = __float_as_int(d.w);
     f.idx_e = bits & 0xFF; f.just_found_e = (bits >> 8) & 1; f.truncated = (bits >> 9) & 1;
-    v.d_obs = m.verdict_d[lane];
-    const int vb = m.verdict_bits[lane];
     v.coll1 = vb & 1; v.terminated = (vb >> 1) & 1;
 }
 
