@@ -470,25 +470,50 @@ DN_DEV void block_lds_barrier()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-// Stores the wave's [64,13] observation tile: lanes park their 13 floats in LDS (stride 13 dwords: odd, so
+// The wave's [64,13] observation tile goes out through LDS: lanes park their 13 floats (stride 13 dwords: odd, so
 // conflict-free), then the wave streams the 3328 contiguous bytes out as float4 (ds_read_b128 +
 // global_store_dwordx4), i.e. 4 store instructions instead of 13 strided dword stores per destination.
-DN_DEV void store_obs_tile(float *s_tile, float *gtile, unsigned rows, unsigned lane, const float o[DN_OBS_DIM])
+// Split in two so that the fused two-wave kernel can park step t's tile at the end of report(t) and stream it out
+// at the start of report(t+1), with the LDS round trip hidden behind a whole step of other work; LDS operations of
+// one wave execute in order, so the later reads see the earlier writes without a wait in between.
+DN_DEV void tile_park(float *s_tile, unsigned lane, const float o[DN_OBS_DIM])
 {
-    wave_lds_sync();                                      // the previous step's tile reads are done
+    asm volatile("" ::: "memory");                        // compiler-level ordering only: no s_waitcnt
 #pragma unroll
     for (int k = 0; k < DN_OBS_DIM; ++k) s_tile[lane * DN_OBS_DIM + k] = o[k];
-    wave_lds_sync();
+    asm volatile("" ::: "memory");
+}
+struct TileRegs {
+    float4 r[4];
+};
+DN_DEV TileRegs tile_fetch(const float *s_tile, unsigned lane)
+{
+    asm volatile("" ::: "memory");
+    const float4 *s4 = reinterpret_cast<const float4 *>(s_tile);
+    TileRegs t;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) t.r[r] = s4[r * 64 + lane];
+    t.r[3] = s4[192 + (lane < (DN_BLOCK * DN_OBS_DIM / 4 - 192) ? lane : 0)];
+    asm volatile("" ::: "memory");
+    return t;
+}
+DN_DEV void tile_stream(const TileRegs &t, const float *s_tile, float *gtile, unsigned rows, unsigned lane)
+{
     if (rows == DN_BLOCK) {
         float4 *g4 = reinterpret_cast<float4 *>(gtile);
-        const float4 *s4 = reinterpret_cast<const float4 *>(s_tile);
 #pragma unroll
-        for (int r = 0; r < 3; ++r) g4[r * 64 + lane] = s4[r * 64 + lane];
-        if (lane < (DN_BLOCK * DN_OBS_DIM / 4 - 192)) g4[192 + lane] = s4[192 + lane];
+        for (int r = 0; r < 3; ++r) g4[r * 64 + lane] = t.r[r];
+        if (lane < (DN_BLOCK * DN_OBS_DIM / 4 - 192)) g4[192 + lane] = t.r[3];
     } else {
         const unsigned rem = rows * DN_OBS_DIM;            // ragged last tile
         for (unsigned e = lane; e < rem; e += DN_BLOCK) gtile[e] = s_tile[e];
     }
+}
+DN_DEV void store_obs_tile(float *s_tile, float *gtile, unsigned rows, unsigned lane, const float o[DN_OBS_DIM])
+{   // park + stream back to back (single-step launches, the one-wave kernels, reset)
+    tile_park(s_tile, lane, o);
+    const TileRegs t = tile_fetch(s_tile, lane);
+    tile_stream(t, s_tile, gtile, rows, lane);
 }
 
 template <typename R>
@@ -871,7 +896,7 @@ DN_DEV void flush_stats(const DnParams &p, const StatAcc &a, unsigned long long 
 }
 
 // ---- A7 select + A10/A11 on the report wave: Monitor, SubprocVecEnv worker, outputs ---------------------------
-template <typename R, bool NORM, bool NOISE, bool REW>
+template <typename R, bool NORM, bool NOISE, bool REW, bool DEFER_TILE = false>
 DN_DEV void report_phase(const DnParams &p, const DnConsts<R> &c, float *s_tile, const StepOut &out, const Flight<R> &fl,
                          const Verdict<R> &v, Observed<R> &ob, const unsigned long long gid, const unsigned step_count,
                          const unsigned li, const unsigned lane, const unsigned rows, const bool active,
@@ -944,7 +969,8 @@ DN_DEV void report_phase(const DnParams &p, const DnConsts<R> &c, float *s_tile,
         out.found[li] = found;
     }
     if (out.done_word && lane == 0) *out.done_word = done_ballot;
-    store_obs_tile(s_tile, out.obs, rows, lane, o);
+    if (DEFER_TILE) tile_park(s_tile, lane, o);            // streamed out by the caller one step later
+    else store_obs_tile(s_tile, out.obs, rows, lane, o);
 }
 
 struct BlockState {
@@ -1097,14 +1123,23 @@ __global__ __launch_bounds__(2 * DN_BLOCK) void dn_step_many_2w_kernel(const DnP
             if (t > 0) {                                                   // the step the flight wave finished last iteration
                 const int u = t - 1;
                 const unsigned sc = (unsigned)sc0 + (unsigned)u;
+                // step u-1's observation tile was parked in LDS at the end of the previous iteration: fetch it now,
+                // stream it to HBM after observe(u) -- its LDS round trip hides behind that phase
+                TileRegs tile;
+                if (u > 0) tile = tile_fetch(s_tile, lane);
                 Flight<R> fl;
                 Verdict<R> v;
                 take_mail<R>(mail[u & 1], lane, fl, v);
                 Observed<R> ob = observe_phase<R, NORM, NOISE>(p, c, s_tab, fl, G4, G5, gid, sc, rms);
+                if (u > 0) tile_stream(tile, s_tile, io0.obs + ((long long)(u - 1) * n + tile_base) * DN_OBS_DIM, rows, lane);
                 const StepOut out = block_out(io0, tile_base, (long long)u * n, (long long)u * words);
-                report_phase<R, NORM, NOISE, REW>(p, c, s_tile, out, fl, v, ob, gid, sc, li, lane, rows, active, G4, G5, acc, rms, rn);
+                report_phase<R, NORM, NOISE, REW, true>(p, c, s_tile, out, fl, v, ob, gid, sc, li, lane, rows, active, G4, G5, acc, rms, rn);
             }
             if (t < k_steps) block_lds_barrier();                          // barrier t
+        }
+        {   // the last step's tile
+            const TileRegs tile = tile_fetch(s_tile, lane);
+            tile_stream(tile, s_tile, io0.obs + ((long long)(k_steps - 1) * n + tile_base) * DN_OBS_DIM, rows, lane);
         }
         flush_stats(p, acc, sc0 + (unsigned long long)k_steps, lane);
         if (NORM && active) store_rms(p, i, rms);
