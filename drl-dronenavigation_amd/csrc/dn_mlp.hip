@@ -401,14 +401,21 @@ MLP_DEV void park_partial(float4 *xb, const int parity, const int lane, const f3
 #pragma unroll
     for (int j = 0; j < 4; ++j) xb[(parity * 4 + j) * 64 + lane] = make_float4(acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]);
 }
-// owner: own partial + partner's partial + bias (from LDS), in place
-MLP_DEV void merge_partial(const float4 *xb, const int parity, const int lane, const float *lbias, const int m, const int g, f32x16 &acc)
+// owner: accumulator of an owned tile starts from the bias (staged in LDS), so that merging costs one add per value
+MLP_DEV void bias_init(const float *lbias, const int m, const int g, f32x16 &acc)
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float4 b = *reinterpret_cast<const float4 *>(lbias + 32 * m + 4 * g + 8 * j);     // rows acc_row(m, g, 4j..4j+3)
+        acc[4 * j] = b.x; acc[4 * j + 1] = b.y; acc[4 * j + 2] = b.z; acc[4 * j + 3] = b.w;
+    }
+}
+MLP_DEV void merge_partial(const float4 *xb, const int parity, const int lane, f32x16 &acc)
 {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const float4 p = xb[(parity * 4 + j) * 64 + lane];
-        const float4 b = *reinterpret_cast<const float4 *>(lbias + 32 * m + 4 * g + 8 * j);     // rows acc_row(m, g, 4j..4j+3)
-        acc[4 * j] += p.x + b.x; acc[4 * j + 1] += p.y + b.y; acc[4 * j + 2] += p.z + b.z; acc[4 * j + 3] += p.w + b.w;
+        acc[4 * j] += p.x; acc[4 * j + 1] += p.y; acc[4 * j + 2] += p.z; acc[4 * j + 3] += p.w;
     }
 }
 
@@ -428,10 +435,13 @@ MLP_DEV void layer_pair(const uint4 *__restrict__ w, const float *lbias, const u
         if (m + 1 < MT) dma_pair<CHUNK>(w + (size_t)(m + 1) * CHUNK * 64, nxt, wave, lane);
         else dma_pair<NEXT_FR>(next, nxt, wave, lane);
         const bool fin = m > 0 && (((m - 1) >= MT / 2) == (HALF == 1));      // I own tile m-1: finish it under this tile's MFMAs
-        if (fin) merge_partial(xb, (m - 1) & 1, lane, lbias, m - 1, g, prev);
+        if (fin) merge_partial(xb, (m - 1) & 1, lane, prev);
         f32x16 acc;
+        if ((m >= MT / 2) == (HALF == 1)) bias_init(lbias, m, g, acc);       // mine: start from the bias
+        else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        }
         uint4 ring[LDS_RING];
 #pragma unroll
         for (int kk = 0; kk < LDS_RING; ++kk) ring[kk] = cur[(HALF * 16 + kk) * 64 + lane];
@@ -441,7 +451,6 @@ MLP_DEV void layer_pair(const uint4 *__restrict__ w, const float *lbias, const u
             if (kk + LDS_RING < 16) ring[kk % LDS_RING] = cur[(HALF * 16 + kk + LDS_RING) * 64 + lane];
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, inh[kk]), acc, 0, 0, 0);
             if (fin && (kk & 1)) {
-                constexpr int unused = 0; (void)unused;
                 const int ml = (m - 1) - HALF * (MT / 2);
                 epilogue_pair(prev, kk >> 1, outh[2 * ml], outh[2 * ml + 1]);
             }
@@ -451,7 +460,7 @@ MLP_DEV void layer_pair(const uint4 *__restrict__ w, const float *lbias, const u
         chunk_barrier();
     }
     if (HALF == 1) {                                                         // the last tile belongs to half 1
-        merge_partial(xb, (MT - 1) & 1, lane, lbias, MT - 1, g, prev);
+        merge_partial(xb, (MT - 1) & 1, lane, prev);
         epilogue(prev, true, outh[MT - 2], outh[MT - 1]);
     }
 }
@@ -477,11 +486,7 @@ MLP_DEV void mlp_pair_body(const MlpArgs &a, const MlpNetDev &net, uint4 *wbuf, 
     for (int ml = 0; ml < 8; ++ml) {
         const int m = HALF * 8 + ml;
         f32x16 acc;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float4 b = *reinterpret_cast<const float4 *>(lbias + 32 * m + 4 * g + 8 * j);
-            acc[4 * j] = b.x; acc[4 * j + 1] = b.y; acc[4 * j + 2] = b.z; acc[4 * j + 3] = b.w;
-        }
+        bias_init(lbias, m, g, acc);
         const uint4 w = wbuf[m * 64 + lane];
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x0), acc, 0, 0, 0);
         epilogue(acc, true, h1[2 * ml], h1[2 * ml + 1]);
@@ -493,8 +498,11 @@ MLP_DEV void mlp_pair_body(const MlpArgs &a, const MlpNetDev &net, uint4 *wbuf, 
     layer_pair<HALF, H3 / 32, 1, H3 / 16>(net.w3, lbias + H1 + H2, net.wh, h2, h3, wbuf, xb, wave, lane);
     // head: one tile, K = 256 = 16 K-steps, 8 per half; fragments in buffer 1 (parity 1 + 16 + 8 -> 1)
     f32x16 acc;
+    if (HALF == 0) bias_init(lbias + H1 + H2 + H3, 0, g, acc);
+    else {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    }
     const uint4 *cur = wbuf + CHUNK * 64;
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) {
@@ -504,7 +512,7 @@ MLP_DEV void mlp_pair_body(const MlpArgs &a, const MlpNetDev &net, uint4 *wbuf, 
     if (HALF == 1) park_partial(xb, 0, lane, acc);
     chunk_barrier();
     if (HALF == 0) {
-        merge_partial(xb, 0, lane, lbias + H1 + H2 + H3, 0, g, acc);
+        merge_partial(xb, 0, lane, acc);
         if (live) {
             float *o = net.out + (row0 + col) * net.out_dim;
 #pragma unroll
