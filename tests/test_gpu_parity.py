@@ -195,9 +195,10 @@ def test_golden_fixtures_teacher_forced(golden, name):
     env.close()
 
 
-@pytest.mark.parametrize("n", [1, 63, 64, 65, 200])
+@pytest.mark.parametrize("n", [1, 12, 63, 64, 65, 200])
 def test_ragged_sizes(n):
-    """Ragged last tile (N not a multiple of the 64-lane wave) and the single-drone case."""
+    """Ragged last tile (N not a multiple of the 64-lane wave), the single-drone case and BASELINE configs[0]'s
+    num_envs = 12 on the 4-waypoint circle through the SB3 NumPy surface."""
     track = _tracks().circle(1, 4, 1)
     env, ora = make_pair(track, n, f32_state=True, max_steps=120, normalize_obs=True)
     np.testing.assert_allclose(env.reset(), ora.reset(), rtol=0, atol=1e-6)
