@@ -11,7 +11,7 @@ from . import build as _build
 MAX_WAYPOINTS = 64
 OBS_DIM = 13
 ACT_DIM = 4
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 DN_OK = 0
 STATUS_NAMES = {0: "DN_OK", -1: "DN_ERR_INVALID_ARGUMENT", -2: "DN_ERR_HIP", -3: "DN_ERR_OUT_OF_MEMORY",
@@ -36,7 +36,7 @@ class DnConfig(C.Structure):
         ("include_distance", C.c_int32), ("normalize_actions", C.c_int32), ("normalize_obs", C.c_int32),
         ("ground_contact", C.c_int32), ("compute_f32", C.c_int32), ("act_noise_sigma", C.c_float),
         ("obs_noise_sigma", C.c_float), ("seed", C.c_uint64), ("env_id_offset", C.c_int64),
-        ("clip_rew", C.c_int32), ("norm_rew", C.c_int32),
+        ("clip_rew", C.c_int32), ("norm_rew", C.c_int32), ("physics", C.c_int32), ("action_type", C.c_int32),
     ]
 
 
@@ -48,6 +48,7 @@ class DnEnvState(C.Structure):
         ("ep_ret", C.c_float), ("ep_len", C.c_int32),
         ("rms_mean", C.c_double * OBS_DIM), ("rms_var", C.c_double * OBS_DIM), ("rms_count", C.c_double),
         ("rr_returns", C.c_double), ("rr_mean", C.c_double), ("rr_var", C.c_double), ("rr_count", C.c_double),
+        ("last_rpm", C.c_float * 4),
     ]
 
 

@@ -58,10 +58,10 @@ namespace {
 
 // Device arena: seven float4 groups, optional normaliser statistics, statistics slots, tables.
 struct Layout {
-    size_t off_g[7], off_mean, off_var, off_count, off_rr, off_stats, off_tab64, off_tab32, total;
+    size_t off_g[7], off_g7, off_mean, off_var, off_count, off_rr, off_stats, off_tab64, off_tab32, total;
 };
 
-Layout make_layout(long long n, int normalize_obs, int norm_rew = 0)
+Layout make_layout(long long n, int normalize_obs, int norm_rew = 0, int drag = 0)
 {
     Layout L;
     size_t o = 0;
@@ -70,6 +70,7 @@ Layout make_layout(long long n, int normalize_obs, int norm_rew = 0)
     L.off_var = o;   o = align_up(o + (normalize_obs ? (size_t)n * DN_OBS_DIM * sizeof(double) : 0), 256);
     L.off_count = o; o = align_up(o + (normalize_obs ? (size_t)n * sizeof(double) : 0), 256);
     L.off_rr = o;    o = align_up(o + (norm_rew ? (size_t)n * 4 * sizeof(double) : 0), 256);
+    L.off_g7 = o;    o = align_up(o + (drag ? (size_t)n * sizeof(float4) : 0), 256);
     L.off_stats = o; o = align_up(o + (size_t)((n + DN_BLOCK - 1) / DN_BLOCK) * sizeof(DnStatSlot), 256);
     L.off_tab64 = o; o = align_up(o + DN_MAX_WAYPOINTS * DN_T_STRIDE * sizeof(double), 256);
     L.off_tab32 = o; o = align_up(o + DN_MAX_WAYPOINTS * DN_T_STRIDE * sizeof(float), 256);
@@ -142,6 +143,8 @@ int32_t validate(const dn_config *c)
     for (int j = 0; j < 3; ++j)
         if (!(c->aviary_dim[3 + j] != 0.0)) return fail(DN_ERR_INVALID_ARGUMENT, "aviary_dim high bounds must be non-zero");
     if (c->act_noise_sigma < 0.0f || c->obs_noise_sigma < 0.0f) return fail(DN_ERR_INVALID_ARGUMENT, "noise sigma must be >= 0");
+    if (c->physics < 0 || c->physics > 4) return fail(DN_ERR_INVALID_ARGUMENT, "physics must be 0..4 (PYB, PYB_GND, PYB_DRAG, PYB_DW, PYB_GND_DRAG_DW; got %d)", c->physics);
+    if (c->action_type < 0 || c->action_type > 1) return fail(DN_ERR_INVALID_ARGUMENT, "action_type must be 0 (THRUST) or 1 (RPM) (got %d)", c->action_type);
     for (int j = 0; j < c->num_waypoints * 3; ++j)
         if (!std::isfinite(c->waypoints[j])) return fail(DN_ERR_INVALID_ARGUMENT, "waypoint %d is not finite", j / 3);
     return DN_OK;
@@ -172,6 +175,7 @@ int32_t init_state(dn_env *e, hipStream_t s)
         DN_HIP(dn_launch_filld(e->p.st.rr + 2 * n, 1.0, n, s));        // .var
         DN_HIP(dn_launch_filld(e->p.st.rr + 3 * n, 1e-4, n, s));       // .count
     }
+    if (e->p.drag) DN_HIP(dn_launch_fill4(e->p.st.g7, make_float4(0.f, 0.f, 0.f, 0.f), n, s));   // BaseAviary.py:545
     DN_HIP(hipMemsetAsync(e->p.st.stats, 0, (size_t)e->blocks * sizeof(DnStatSlot), s));
     return DN_OK;
 }
@@ -240,7 +244,8 @@ int32_t dn_create(const dn_config *cfg, dn_env **out)
         if (w[0] == '1') e->waves_fused = e->waves_single = 1;
         else if (w[0] == '2') e->waves_fused = e->waves_single = 2;
     }
-    const Layout L = make_layout(n, cfg->normalize_obs, cfg->norm_rew);
+    const int drag = cfg->physics == 2 || cfg->physics == 4;
+    const Layout L = make_layout(n, cfg->normalize_obs, cfg->norm_rew, drag);
     hipError_t he = hipMalloc(&e->arena, L.total);
     if (he != hipSuccess) {
         delete e;
@@ -254,6 +259,7 @@ int32_t dn_create(const dn_config *cfg, dn_env **out)
     p.st.g2 = (float4 *)(base + L.off_g[2]); p.st.g3 = (float4 *)(base + L.off_g[3]);
     p.st.g4 = (float4 *)(base + L.off_g[4]); p.st.g5 = (float4 *)(base + L.off_g[5]);
     p.st.g6 = (float4 *)(base + L.off_g[6]);
+    p.st.g7 = drag ? (float4 *)(base + L.off_g7) : nullptr;
     p.st.rms_mean = (double *)(base + L.off_mean);
     p.st.rms_var = (double *)(base + L.off_var);
     p.st.rms_count = (double *)(base + L.off_count);
@@ -270,6 +276,7 @@ int32_t dn_create(const dn_config *cfg, dn_env **out)
     p.normalize_actions = cfg->normalize_actions != 0; p.normalize_obs = cfg->normalize_obs != 0;
     p.ground_contact = cfg->ground_contact != 0;
     p.clip_rew = cfg->clip_rew != 0; p.norm_rew = cfg->norm_rew != 0;
+    p.gnd = cfg->physics == 1 || cfg->physics == 4; p.drag = drag; p.rpm_actions = cfg->action_type == 1;
     p.act_noise_sigma = cfg->act_noise_sigma; p.obs_noise_sigma = cfg->obs_noise_sigma;
     p.seed = cfg->seed; p.env_id_offset = cfg->env_id_offset;
     build_consts<double>(*cfg, p.c64);
@@ -399,9 +406,15 @@ int32_t dn_get_state(dn_env *env, dn_env_state *states, int64_t count)
         rr.resize((size_t)n * 4);
         DN_HIP(hipMemcpy(rr.data(), env->p.st.rr, rr.size() * sizeof(double), hipMemcpyDeviceToHost));
     }
+    std::vector<float4> g7;
+    if (env->p.drag) {
+        g7.resize((size_t)n);
+        DN_HIP(hipMemcpy(g7.data(), env->p.st.g7, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost));
+    }
     for (long long i = 0; i < n; ++i) {
         dn_env_state &s = states[i];
         memset(&s, 0, sizeof s);
+        if (env->p.drag) { s.last_rpm[0] = g7[(size_t)i].x; s.last_rpm[1] = g7[(size_t)i].y; s.last_rpm[2] = g7[(size_t)i].z; s.last_rpm[3] = g7[(size_t)i].w; }
         if (env->cfg.norm_rew) { s.rr_returns = rr[(size_t)i]; s.rr_mean = rr[(size_t)n + i]; s.rr_var = rr[(size_t)2 * n + i]; s.rr_count = rr[(size_t)3 * n + i]; }
         s.pos[0] = g[0][i].x; s.pos[1] = g[0][i].y; s.pos[2] = g[0][i].z; s.d = g[0][i].w;
         s.quat[0] = g[1][i].x; s.quat[1] = g[1][i].y; s.quat[2] = g[1][i].z; s.quat[3] = g[1][i].w;
@@ -435,8 +448,11 @@ int32_t dn_set_state(dn_env *env, const dn_env_state *states, int64_t count)
     if (env->cfg.normalize_obs) { mean.resize((size_t)n * DN_OBS_DIM); var.resize((size_t)n * DN_OBS_DIM); cnt.resize((size_t)n); }
     std::vector<double> rr;
     if (env->cfg.norm_rew) rr.resize((size_t)n * 4);
+    std::vector<float4> g7;
+    if (env->p.drag) g7.resize((size_t)n);
     for (long long i = 0; i < n; ++i) {
         const dn_env_state &s = states[i];
+        if (env->p.drag) g7[(size_t)i] = make_float4(s.last_rpm[0], s.last_rpm[1], s.last_rpm[2], s.last_rpm[3]);
         if (env->cfg.norm_rew) { rr[(size_t)i] = s.rr_returns; rr[(size_t)n + i] = s.rr_mean; rr[(size_t)2 * n + i] = s.rr_var; rr[(size_t)3 * n + i] = s.rr_count; }
         if (s.idx < 0 || s.idx >= env->cfg.num_waypoints || s.steps < 0 || s.steps > (1 << 24) - 1)
             return fail(DN_ERR_INVALID_ARGUMENT, "state %lld: idx/steps out of range", i);
@@ -468,6 +484,7 @@ int32_t dn_set_state(dn_env *env, const dn_env_state *states, int64_t count)
         DN_HIP(hipMemcpy(env->p.st.rms_count, cnt.data(), cnt.size() * sizeof(double), hipMemcpyHostToDevice));
     }
     if (env->cfg.norm_rew) DN_HIP(hipMemcpy(env->p.st.rr, rr.data(), rr.size() * sizeof(double), hipMemcpyHostToDevice));
+    if (env->p.drag) DN_HIP(hipMemcpy(env->p.st.g7, g7.data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice));
     return DN_OK;
 }
 

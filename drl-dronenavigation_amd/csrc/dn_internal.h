@@ -48,6 +48,7 @@ struct DnState {
     float4 *g4;  // prev_vel.xyz, ep_ret (Monitor)
     float4 *g5;  // prev_ang_v.xyz, ep_len bits (Monitor)
     float4 *g6;  // _current_position.xyz (valid while steps == 0; otherwise it equals pos), pad
+    float4 *g7;  // BaseAviary.last_clipped_action (previous step's rpm); allocated with Physics.PYB_DRAG only, else NULL
     double *rms_mean;   // [13][N]  normalize.RunningMeanStd.mean
     double *rms_var;    // [13][N]
     double *rms_count;  // [N]
@@ -88,6 +89,7 @@ struct DnParams {
     int num_waypoints;
     int max_steps;
     int circle, cylinder, include_distance, normalize_actions, normalize_obs, ground_contact, clip_rew, norm_rew;
+    int gnd, drag, rpm_actions;     // N4: Physics.PYB_GND / PYB_DRAG force terms, ActionType.RPM
     float act_noise_sigma, obs_noise_sigma;
     unsigned long long seed;
     long long env_id_offset;

@@ -86,17 +86,19 @@ DN_DEV float sqrt_rn32(float x)
     out = rp > 0.0f ? sp : out;
     return out;
 }
+DN_DEV float rescale_action32(float a)
+{   // PBDroneEnv.rescale_action, PBDroneEnv.py:949-971
+    const float ac = __builtin_amdgcn_fmed3f(a, -2.0f, 2.0f);   // beyond +-2 the result is saturated anyway
+    const float num = ac - A_LOW32;
+    const float q = div_const32(num, DEN32, INV_DEN32);
+    const float m = 2.0f * q;                // (high - low) = 1 - (-1)
+    const float r = -1.0f + m;
+    return __builtin_amdgcn_fmed3f(r, -1.0f, 1.0f);
+}
 DN_DEV float rotor_force_from_action(float a, bool normalize_actions, float &torque, float *rpm_out = nullptr)
 {
     float cmd = a;
-    if (normalize_actions) {                     // PBDroneEnv.rescale_action, PBDroneEnv.py:949-971
-        const float ac = __builtin_amdgcn_fmed3f(a, -2.0f, 2.0f);   // beyond +-2 the result is saturated anyway
-        const float num = ac - A_LOW32;
-        const float q = div_const32(num, DEN32, INV_DEN32);
-        const float m = 2.0f * q;                // (high - low) = 1 - (-1)
-        const float r = -1.0f + m;
-        cmd = __builtin_amdgcn_fmed3f(r, -1.0f, 1.0f);
-    }
+    if (normalize_actions) cmd = rescale_action32(a);
     // PBDroneEnv._preprocessAction, PBDroneEnv.py:889.  The clip makes thrust >= a_low > 0, so cmd2pwm's
     // maximum(thrust, 0) (env_utils.py:29) is the identity.
     const float thrust = __builtin_amdgcn_fmed3f(cmd, A_LOW32, A_HIGH32);
@@ -120,6 +122,53 @@ DN_DEV float z_torque32(const float tq[4])
     z = z - tq[2];
     z = z + tq[3];
     return z;
+}
+
+// ---- N4: options that are present but unreachable in the reference (BaseAviary.step pins Physics.PYB,
+// BaseAviary.py:411; PBDroneEnv overrides _preprocessAction).  Compiled only into the XOPT kernels.  These helpers
+// stay outside every `fp contract(fast)` region: their float32 halves follow numpy's operation order unfused.
+constexpr double GND_EFF_COEFF = 11.36859, PROP_RADIUS = 2.31348e-2, DRAG_XY = 9.1785e-7, DRAG_Z = 10.311e-7;   // cf2x.urdf:5
+constexpr double HOVER_RPM = 14468.429183500699;         // sqrt(GRAVITY / (4 KF)), BaseAviary.py:164
+constexpr double GND_EFF_H_CLIP = 0.03776371349209501;   // BaseAviary.py:175-176
+struct Extras {
+    int gnd, drag, rpm_f32;     // Physics.PYB_GND / PYB_DRAG terms on; the rpm array is float32 (ActionType.THRUST chain)
+    double rpm[4];              // this step's clipped_action (rpm)
+    float4 last;                // BaseAviary.last_clipped_action: the previous step's rpm, zeros after a reset
+};
+DN_DEV double gnd_effect_rotor(double rpm, bool rpm_f32)
+{   // np.array(rpm**2) * KF * GND_EFF_COEFF, BaseAviary.py:822 -- float32 while the rpm array is
+    if (rpm_f32) {
+        const float r = (float)rpm;
+        float t = r * r;
+        t = t * KF32;
+        t = t * (float)GND_EFF_COEFF;
+        return (double)t;
+    }
+    double t = rpm * rpm;
+    t = t * 3.16e-10;
+    return t * GND_EFF_COEFF;
+}
+DN_DEV double drag_omega_sum(const float4 last, bool rpm_f32)
+{   // np.sum(np.array(2*np.pi*rpm/60)), BaseAviary.py:852 (left-to-right reduce)
+    const float r[4] = {last.x, last.y, last.z, last.w};
+    if (rpm_f32) {
+        float w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float m = (float)(2.0 * 3.14159265358979323846) * r[j];
+            w[j] = m / 60.0f;
+        }
+        float sum = w[0] + w[1];
+        sum = sum + w[2];
+        sum = sum + w[3];
+        return (double)sum;
+    }
+    double w[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[j] = (2.0 * 3.14159265358979323846) * (double)r[j] / 60.0;
+    double sum = w[0] + w[1];
+    sum = sum + w[2];
+    return sum + w[3];
 }
 
 // ---- noise (BASELINE config 5; sigma = 0 is the reference): Philox4x32-10 + float64 Box-Muller ------
@@ -581,6 +630,46 @@ template <typename R> struct Verdict {
     int terminated;    // _computeTerminated of BaseAviary.step (advanced index, _is_done)
 };
 
+struct ThrustX {       // XOPT kernels: float64 carriers (ActionType.RPM works in float64) + the rpm for the extra terms
+    double f[4];
+    double zt;
+};
+template <bool NOISE>
+DN_DEV ThrustX thrust_phase_x(const DnParams &p, unsigned long long gid, unsigned step_count, const float4 A, Extras &x)
+{
+    float a[4] = {A.x, A.y, A.z, A.w};
+    if (NOISE && p.act_noise_sigma > 0.0f) add_act_noise(p, gid, step_count, a);
+    ThrustX t;
+    x.gnd = p.gnd; x.drag = p.drag; x.rpm_f32 = !p.rpm_actions;
+    if (p.rpm_actions) {   // BaseSingleAgentAviary._preprocessAction, ActionType.RPM (BaseSingleAgentAviary.py:176-179)
+        double tq[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float cmd = p.normalize_actions ? rescale_action32(a[j]) : a[j];   // PBDroneEnv.step, :173-176
+            const float s = 0.05f * cmd;
+            const float u = 1.0f + s;
+            const double rpm = HOVER_RPM * (double)u;       // np.float64 scalar (x) float32 array
+            const double sq = rpm * rpm;                    // BaseAviary._physics, BaseAviary.py:776-777
+            x.rpm[j] = rpm;
+            t.f[j] = sq * 3.16e-10;
+            tq[j] = sq * 7.94e-12;
+        }
+        double z = -tq[0];
+        z = z + tq[1];
+        z = z - tq[2];
+        t.zt = z + tq[3];
+    } else {
+        float tq[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float rpm;
+            t.f[j] = (double)rotor_force_from_action(a[j], p.normalize_actions != 0, tq[j], &rpm);
+            x.rpm[j] = (double)rpm;
+        }
+        t.zt = (double)z_torque32(tq);
+    }
+    return t;
+}
 template <bool NOISE>
 DN_DEV Thrust thrust_phase(const DnParams &p, unsigned long long gid, unsigned step_count, const float4 A)
 {   // float32, unfused: bit-exact numpy
@@ -595,9 +684,9 @@ DN_DEV Thrust thrust_phase(const DnParams &p, unsigned long long gid, unsigned s
 }
 
 // ---- A4: p.stepSimulation, one free rigid body [3P-recall of Bullet3 btMultiBody] -------------------------
-template <typename R>
-DN_DEV Flight<R> physics_phase(const Thrust &th, const float4 G0, const float4 G1, const float4 G2, const float4 G3,
-                               const int max_steps)
+template <typename R, typename TH = Thrust, bool XOPT = false>
+DN_DEV Flight<R> physics_phase(const TH &th, const float4 G0, const float4 G1, const float4 G2, const float4 G3,
+                               const int max_steps, const Extras *x = nullptr)
 {
 #pragma clang fp contract(fast)
     Flight<R> fl;
@@ -621,7 +710,35 @@ DN_DEV Flight<R> physics_phase(const Thrust &th, const float4 G0, const float4 G
     const R r10 = xy + wzs, r11 = R(1.0) - (xx + zz), r12 = yz - wxs;
     const R r20 = xz - wys, r21 = yz + wxs, r22 = R(1.0) - (xx + yy);
     // rotor thrusts along body z at the prop offsets (+,-) (-,-) (-,+) (+,+) * 0.028 (cf2x.urdf:42,54,66,78)
-    const R F0 = th.f[0], F1 = th.f[1], F2 = th.f[2], F3 = th.f[3];
+    R F0 = th.f[0], F1 = th.f[1], F2 = th.f[2], F3 = th.f[3];
+    R dax = R(0.0), day = R(0.0), daz = R(0.0);
+    if (XOPT) {
+        if (x->gnd) {   // BaseAviary._groundEffect (BaseAviary.py:800-832): a second +z force on each prop link
+            // |roll| < pi/2 and |pitch| < pi/2 on the cached rpy (getEulerFromQuaternion [3P-recall]): roll =
+            // atan2(., w^2-x^2-y^2+z^2) is inside (-pi/2, pi/2) iff its second argument = r22 |q|^2 is positive;
+            // pitch = asin(s), s = -r20, is +-pi/2 exactly in the gimbal branch |s| >= 0.99999
+            const bool ok = fabs(r20) < R(0.99999) && r22 > R(0.0);
+            const R X[4] = {K<R>::ARM, -K<R>::ARM, -K<R>::ARM, K<R>::ARM}, Y[4] = {-K<R>::ARM, -K<R>::ARM, K<R>::ARM, K<R>::ARM};
+            R g[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                R h = pz + (r20 * X[j] + r21 * Y[j]);          // world z of prop link j (p.getLinkStates)
+                h = h < R(GND_EFF_H_CLIP) ? R(GND_EFF_H_CLIP) : h;
+                const R q = R(PROP_RADIUS) / (R(4.0) * h);
+                g[j] = ok ? (R)gnd_effect_rotor(x->rpm[j], x->rpm_f32 != 0) * (q * q) : R(0.0);
+            }
+            F0 += g[0]; F1 += g[1]; F2 += g[2]; F3 += g[3];
+        }
+        if (x->drag) {  // BaseAviary._drag (:836-862): base_rot . (-DRAG_COEFF sum(omega) * vel) as a LINK_FRAME force on link 4
+            const R sum = (R)drag_omega_sum(x->last, x->rpm_f32 != 0);
+            const R kxy = R(-DRAG_XY) * sum, kz = R(-DRAG_Z) * sum;
+            const R ux = kxy * vx, uy = kxy * vy, uz = kz * vz;
+            const R bx = r00 * ux + r01 * uy + r02 * uz, by = r10 * ux + r11 * uy + r12 * uz, bz = r20 * ux + r21 * uy + r22 * uz;
+            dax = (r00 * bx + r01 * by + r02 * bz) * K<R>::INV_M;
+            day = (r10 * bx + r11 * by + r12 * bz) * K<R>::INV_M;
+            daz = (r20 * bx + r21 * by + r22 * bz) * K<R>::INV_M;
+        }
+    }
     const R fz = (F0 + F1) + (F2 + F3);
     const R tx = K<R>::ARM * ((F2 + F3) - (F0 + F1));
     const R ty = K<R>::ARM * ((F1 + F2) - (F0 + F3));
@@ -629,7 +746,8 @@ DN_DEV Flight<R> physics_phase(const Thrust &th, const float4 G0, const float4 G
     // the damping norms enter the velocity update at dt * 0.04: a float32 root moves it by 1e-12 relative
     const R kl = K<R>::LIN_DAMP + K<R>::LIN_DAMP * (R)__builtin_amdgcn_sqrtf((float)(vx * vx + vy * vy + vz * vz));
     const R fm = fz * K<R>::INV_M;
-    const R awx = r02 * fm - vx * kl, awy = r12 * fm - vy * kl, awz = (r22 * fm - K<R>::G) - vz * kl;
+    R awx = r02 * fm - vx * kl, awy = r12 * fm - vy * kl, awz = (r22 * fm - K<R>::G) - vz * kl;
+    if (XOPT) { awx += dax; awy += day; awz += daz; }
     // angular, in the body frame: I dw = tau - w x (I w) - I w (c + c|w|)
     const R wbx = r00 * wx + r10 * wy + r20 * wz, wby = r01 * wx + r11 * wy + r21 * wz, wbz = r02 * wx + r12 * wy + r22 * wz;
     const R ka = K<R>::ANG_DAMP + K<R>::ANG_DAMP * (R)__builtin_amdgcn_sqrtf((float)(wx * wx + wy * wy + wz * wz));
@@ -974,14 +1092,31 @@ DN_DEV void report_phase(const DnParams &p, const DnConsts<R> &c, float *s_tile,
 }
 
 struct BlockState {
-    float4 *g0, *g1, *g2, *g3, *g4, *g5, *g6;
+    float4 *g0, *g1, *g2, *g3, *g4, *g5, *g6, *g7;
 };
 DN_DEV BlockState block_state(const DnState &st, long long tile_base)
 {   // uniform block bases (SGPR pairs); a lane adds its 32-bit offset
     BlockState b;
     b.g0 = st.g0 + tile_base; b.g1 = st.g1 + tile_base; b.g2 = st.g2 + tile_base; b.g3 = st.g3 + tile_base;
     b.g4 = st.g4 + tile_base; b.g5 = st.g5 + tile_base; b.g6 = st.g6 + tile_base;
+    b.g7 = st.g7 + tile_base;      // allocated with Physics.PYB_DRAG only; never touched otherwise
     return b;
+}
+
+// thrust + physics of one step; the XOPT kernels take the float64 carriers and the optional force terms (N4)
+template <typename R, bool NOISE, bool XOPT>
+DN_DEV Flight<R> fly(const DnParams &p, unsigned long long gid, unsigned sc, const float4 A, const float4 G0, const float4 G1,
+                     const float4 G2, const float4 G3, const float4 G7, float4 &rpm_now)
+{
+    if (XOPT) {
+        Extras x;
+        x.last = G7;
+        const ThrustX th = thrust_phase_x<NOISE>(p, gid, sc, A, x);
+        rpm_now = make_float4((float)x.rpm[0], (float)x.rpm[1], (float)x.rpm[2], (float)x.rpm[3]);
+        return physics_phase<R, ThrustX, true>(th, G0, G1, G2, G3, p.max_steps, &x);
+    }
+    const Thrust th = thrust_phase<NOISE>(p, gid, sc, A);
+    return physics_phase<R>(th, G0, G1, G2, G3, p.max_steps);
 }
 
 // -----------------------------------------------------------------------------------------------------
@@ -990,7 +1125,7 @@ DN_DEV BlockState block_state(const DnState &st, long long tile_base)
 // -----------------------------------------------------------------------------------------------------
 // ONE = true is the single-step launch (dn_step): k_steps is the constant 1, and the kernel gets its own name in
 // profiles (dn_step_many_*_kernel<..., true> = one control step per launch, <..., false> = k_arg steps per launch).
-template <typename R, bool NORM, bool NOISE, bool ONE, bool REW>
+template <typename R, bool NORM, bool NOISE, bool ONE, bool XOPT>
 __global__ __launch_bounds__(DN_BLOCK) void dn_step_many_1w_kernel(const DnParams p, const DnStepIO io0, const int k_arg)
 {
     const int k_steps = ONE ? 1 : k_arg;
@@ -1011,6 +1146,8 @@ __global__ __launch_bounds__(DN_BLOCK) void dn_step_many_1w_kernel(const DnParam
     // issue every load up front (6 x 16 B state + 16 B action per lane), then stage the table
     float4 A = act[li];
     float4 G0 = b.g0[li], G1 = b.g1[li], G2 = b.g2[li], G3 = b.g3[li], G4 = b.g4[li], G5 = b.g5[li];
+    float4 G7 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (XOPT && p.drag) G7 = b.g7[li];
     stage_table<R>(p, s_tab);
     block_lds_barrier();
     const long long n = p.n, words = (p.n + 63) / 64;
@@ -1019,26 +1156,28 @@ __global__ __launch_bounds__(DN_BLOCK) void dn_step_many_1w_kernel(const DnParam
     Rms rms;
     if (NORM) load_rms(p, i, rms);
     RewNorm rn = {0.0, 0.0, 1.0, 1e-4};
-    if (REW && p.norm_rew) load_rewnorm(p, i, rn);
+    if (XOPT && p.norm_rew) load_rewnorm(p, i, rn);
 #pragma clang loop unroll(disable)
     for (int t = 0; t < k_steps; ++t) {
         // prefetch the next step's action while this step computes
         const float4 A_next = (act + (long long)(t + 1 < k_steps ? t + 1 : t) * n)[li];
         const StepOut out = block_out(io0, tile_base, (long long)t * n, (long long)t * words);
         const unsigned sc = (unsigned)sc0 + (unsigned)t;
-        const Thrust th = thrust_phase<NOISE>(p, gid, sc, A);
-        const Flight<R> fl = physics_phase<R>(th, G0, G1, G2, G3, p.max_steps);
+        float4 rpm_now;
+        const Flight<R> fl = fly<R, NOISE, XOPT>(p, gid, sc, A, G0, G1, G2, G3, G7, rpm_now);
         const float4 G0e = G0, G3e = G3;
         const Verdict<R> v = rules_phase<R>(p, c, s_tab, fl, G0e, G3e, b.g6, li, active, G0, G1, G2, G3);
+        if (XOPT && p.drag) G7 = (v.terminated || fl.truncated) ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : rpm_now;   // BaseAviary.py:442,545
         Observed<R> ob = observe_phase<R, NORM, NOISE>(p, c, s_tab, fl, G4, G5, gid, sc, rms);
-        report_phase<R, NORM, NOISE, REW>(p, c, s_tile, out, fl, v, ob, gid, sc, li, lane, rows, active, G4, G5, acc, rms, rn);
+        report_phase<R, NORM, NOISE, XOPT>(p, c, s_tile, out, fl, v, ob, gid, sc, li, lane, rows, active, G4, G5, acc, rms, rn);
         A = A_next;
     }
     flush_stats(p, acc, sc0 + (unsigned long long)k_steps, lane);
     if (NORM && active) store_rms(p, i, rms);
-    if (REW && p.norm_rew && active) store_rewnorm(p, i, rn);
+    if (XOPT && p.norm_rew && active) store_rewnorm(p, i, rn);
     if (active) {
         b.g0[li] = G0; b.g1[li] = G1; b.g2[li] = G2; b.g3[li] = G3; b.g4[li] = G4; b.g5[li] = G5;
+        if (XOPT && p.drag) b.g7[li] = G7;
     }
 }
 
@@ -1088,7 +1227,7 @@ template <typename R> DN_DEV void take_mail(const Mail<R> &m, unsigned lane, Fli
     v.coll1 = vb & 1; v.terminated = (vb >> 1) & 1;
 }
 
-template <typename R, bool NORM, bool NOISE, bool ONE, bool REW>
+template <typename R, bool NORM, bool NOISE, bool ONE, bool XOPT>
 __global__ __launch_bounds__(2 * DN_BLOCK) void dn_step_many_2w_kernel(const DnParams p, const DnStepIO io0, const int k_arg)
 {
     const int k_steps = ONE ? 1 : k_arg;
@@ -1116,7 +1255,7 @@ __global__ __launch_bounds__(2 * DN_BLOCK) void dn_step_many_2w_kernel(const DnP
         Rms rms;
         if (NORM) load_rms(p, i, rms);
         RewNorm rn = {0.0, 0.0, 1.0, 1e-4};
-        if (REW && p.norm_rew) load_rewnorm(p, i, rn);
+        if (XOPT && p.norm_rew) load_rewnorm(p, i, rn);
         block_lds_barrier();                                               // P: table published
 #pragma clang loop unroll(disable)
         for (int t = 0; t <= k_steps; ++t) {
@@ -1133,7 +1272,7 @@ __global__ __launch_bounds__(2 * DN_BLOCK) void dn_step_many_2w_kernel(const DnP
                 Observed<R> ob = observe_phase<R, NORM, NOISE>(p, c, s_tab, fl, G4, G5, gid, sc, rms);
                 if (u > 0) tile_stream(tile, s_tile, io0.obs + ((long long)(u - 1) * n + tile_base) * DN_OBS_DIM, rows, lane);
                 const StepOut out = block_out(io0, tile_base, (long long)u * n, (long long)u * words);
-                report_phase<R, NORM, NOISE, REW, true>(p, c, s_tile, out, fl, v, ob, gid, sc, li, lane, rows, active, G4, G5, acc, rms, rn);
+                report_phase<R, NORM, NOISE, XOPT, true>(p, c, s_tile, out, fl, v, ob, gid, sc, li, lane, rows, active, G4, G5, acc, rms, rn);
             }
             if (t < k_steps) block_lds_barrier();                          // barrier t
         }
@@ -1143,26 +1282,30 @@ __global__ __launch_bounds__(2 * DN_BLOCK) void dn_step_many_2w_kernel(const DnP
         }
         flush_stats(p, acc, sc0 + (unsigned long long)k_steps, lane);
         if (NORM && active) store_rms(p, i, rms);
-        if (REW && p.norm_rew && active) store_rewnorm(p, i, rn);
+        if (XOPT && p.norm_rew && active) store_rewnorm(p, i, rn);
         if (active) { b.g4[li] = G4; b.g5[li] = G5; }
     } else {
         const float4 *act = reinterpret_cast<const float4 *>(io0.actions) + tile_base;
         float4 A = act[li];
         float4 G0 = b.g0[li], G1 = b.g1[li], G2 = b.g2[li], G3 = b.g3[li];
+        float4 G7 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (XOPT && p.drag) G7 = b.g7[li];
         block_lds_barrier();                                               // P
 #pragma clang loop unroll(disable)
         for (int t = 0; t < k_steps; ++t) {
             // prefetch the next step's action while this step computes
             const float4 A_next = (act + (long long)(t + 1 < k_steps ? t + 1 : t) * n)[li];
-            const Thrust th = thrust_phase<NOISE>(p, gid, (unsigned)sc0 + (unsigned)t, A);
-            const Flight<R> fl = physics_phase<R>(th, G0, G1, G2, G3, p.max_steps);
+            float4 rpm_now;
+            const Flight<R> fl = fly<R, NOISE, XOPT>(p, gid, (unsigned)sc0 + (unsigned)t, A, G0, G1, G2, G3, G7, rpm_now);
             const float4 G0e = G0, G3e = G3;
             const Verdict<R> v = rules_phase<R>(p, c, s_tab, fl, G0e, G3e, b.g6, li, active, G0, G1, G2, G3);
+            if (XOPT && p.drag) G7 = (v.terminated || fl.truncated) ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : rpm_now;
             post_mail<R>(mail[t & 1], lane, fl, v);
             block_lds_barrier();                                           // barrier t
             A = A_next;
         }
         if (active) { b.g0[li] = G0; b.g1[li] = G1; b.g2[li] = G2; b.g3[li] = G3; }
+        if (XOPT && p.drag && active) b.g7[li] = G7;
     }
 }
 
@@ -1211,6 +1354,7 @@ __global__ __launch_bounds__(DN_BLOCK) void dn_reset_kernel(const DnParams p, fl
         b.g4[li] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         b.g5[li] = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(0));
         b.g6[li] = make_float4((float)cpx, (float)cpy, (float)cpz, 0.0f);
+        if (p.drag) b.g7[li] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);      // last_clipped_action, BaseAviary.py:545
     }
     store_obs_tile(s_tile, obs + tile_base * DN_OBS_DIM, rows, lane, o);
 }
@@ -1378,12 +1522,12 @@ hipError_t dn_launch_step_many(const DnParams &p, const DnStepIO &io, int k, boo
     const unsigned grid = (unsigned)((p.n + DN_BLOCK - 1) / DN_BLOCK);
     const bool norm = p.normalize_obs != 0;
     const bool noise = p.act_noise_sigma > 0.0f || p.obs_noise_sigma > 0.0f;
-#define DN_LAUNCH3(R, NORM, NOISE, ONE, REW)                                                                            \
+#define DN_LAUNCH3(R, NORM, NOISE, ONE, XOPT)                                                                           \
     do {                                                                                                                \
         if (two_wave)                                                                                                   \
-            hipLaunchKernelGGL((dn_step_many_2w_kernel<R, NORM, NOISE, ONE, REW>), dim3(grid), dim3(2 * DN_BLOCK), 0, stream, p, io, k); \
+            hipLaunchKernelGGL((dn_step_many_2w_kernel<R, NORM, NOISE, ONE, XOPT>), dim3(grid), dim3(2 * DN_BLOCK), 0, stream, p, io, k); \
         else                                                                                                            \
-            hipLaunchKernelGGL((dn_step_many_1w_kernel<R, NORM, NOISE, ONE, REW>), dim3(grid), dim3(DN_BLOCK), 0, stream, p, io, k);     \
+            hipLaunchKernelGGL((dn_step_many_1w_kernel<R, NORM, NOISE, ONE, XOPT>), dim3(grid), dim3(DN_BLOCK), 0, stream, p, io, k);     \
     } while (0)
 #define DN_LAUNCH2(R, NORM, NOISE, ONE)                                                                                 \
     do {                                                                                                                \
@@ -1393,7 +1537,8 @@ hipError_t dn_launch_step_many(const DnParams &p, const DnStepIO &io, int k, boo
     do {                                                                                                                \
         if (k == 1) DN_LAUNCH2(R, NORM, NOISE, true); else DN_LAUNCH2(R, NORM, NOISE, false);                           \
     } while (0)
-    const bool rew = p.clip_rew != 0 || p.norm_rew != 0;
+    // the rarely used options share one set of instantiations (runtime switches inside): reward wrappers, N4 physics terms
+    const bool rew = p.clip_rew != 0 || p.norm_rew != 0 || p.gnd != 0 || p.drag != 0 || p.rpm_actions != 0;
     if (f32) {
         if (norm) { if (noise) DN_LAUNCH(float, true, true); else DN_LAUNCH(float, true, false); }
         else { if (noise) DN_LAUNCH(float, false, true); else DN_LAUNCH(float, false, false); }

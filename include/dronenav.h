@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define DN_ABI_VERSION 2
+#define DN_ABI_VERSION 3
 #define DN_MAX_WAYPOINTS 64
 #define DN_OBS_DIM 13      /* 12 kinematic + distance, PBDroneEnv._computeObs, PBDroneEnv.py:296-336 */
 #define DN_ACT_DIM 4       /* four rotor thrust commands, PBDroneEnv._actionSpace, PBDroneEnv.py:225-243 */
@@ -75,6 +75,12 @@ typedef struct dn_config {
     int32_t clip_rew;                           /* --clip_rew: TransformReward(clip(r, -10, 10)), PBDroneSimulator.py:191-192 */
     int32_t norm_rew;                           /* --norm_rew: NormalizeReward(gamma .99, eps 1e-8), PBDroneSimulator.py:193-194
                                                    (normalize.py:100-147); both sit inside Monitor, clip first */
+    int32_t physics;                            /* enums.Physics (enums.py:12-21) as dispatched by BaseAviary.step (BaseAviary.py:412-437):
+                                                   0 PYB (what the reference always runs: :411 pins it) | 1 PYB_GND (_groundEffect, :800-832)
+                                                   | 2 PYB_DRAG (_drag, :836-862) | 3 PYB_DW (_downwash: other drones of the same world,
+                                                   none here -> as PYB) | 4 PYB_GND_DRAG_DW */
+    int32_t action_type;                        /* 0 ActionType.THRUST (PBDroneEnv._preprocessAction, PBDroneEnv.py:872-895)
+                                                   | 1 ActionType.RPM (BaseSingleAgentAviary.py:176-179: rpm = HOVER_RPM (1 + 0.05 a)) */
 } dn_config;
 
 /* One drone's persistent state, host-side AoS view used by dn_get_state/dn_set_state (tests,
@@ -94,6 +100,7 @@ typedef struct dn_env_state {
     double rms_count;                           /*                         .count                     */
     double rr_returns;                          /* NormalizeReward.returns (discounted return, norm_rew only)  */
     double rr_mean, rr_var, rr_count;           /* NormalizeReward.return_rms                                  */
+    float last_rpm[4];                          /* BaseAviary.last_clipped_action (physics with drag only; zeros otherwise) */
 } dn_env_state;
 
 /* Wave-reduced episode statistics accumulated on the device since dn_create / dn_reset_stats. */

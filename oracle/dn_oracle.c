@@ -193,6 +193,13 @@ static inline double norm3(const double v[3])
 void orc_bullet_step(double pos[3], double quat[4], double vel[3], double ang_v[3],
                      const double forces[4], double z_torque)
 {
+    const double none[3] = {0.0, 0.0, 0.0};
+    orc_bullet_step_ex(pos, quat, vel, ang_v, forces, z_torque, none);
+}
+
+void orc_bullet_step_ex(double pos[3], double quat[4], double vel[3], double ang_v[3],
+                        const double forces[4], double z_torque, const double body_force[3])
+{
     const double dt = ORC_DT;
     double R[9];
     quat_to_mat(quat, R);                       /* base -> world */
@@ -215,9 +222,10 @@ void orc_bullet_step(double pos[3], double quat[4], double vel[3], double ang_v[
     double nv = norm3(vb), nw = norm3(wb);
     double kl = ORC_LIN_DAMP + ORC_LIN_DAMP * nv;
     double ka = ORC_ANG_DAMP + ORC_ANG_DAMP * nw;
-    double Fb[3] = { gb[0] - ORC_M * vb[0] * kl,
-                     gb[1] - ORC_M * vb[1] * kl,
-                     fz + gb[2] - ORC_M * vb[2] * kl };
+    /* body_force: LINK_FRAME force on link 4, whose frame coincides with the base frame (cf2x.urdf:88-98) */
+    double Fb[3] = { body_force[0] + gb[0] - ORC_M * vb[0] * kl,
+                     body_force[1] + gb[1] - ORC_M * vb[1] * kl,
+                     body_force[2] + fz + gb[2] - ORC_M * vb[2] * kl };
     const double I[3] = {ORC_IXX, ORC_IYY, ORC_IZZ};
     double Iw[3] = {I[0] * wb[0], I[1] * wb[1], I[2] * wb[2]};
     double gyro[3] = { wb[1] * Iw[2] - wb[2] * Iw[1],
@@ -276,6 +284,99 @@ void orc_euler_from_quat(const double q[4], double rpy[3])
 /* A6 -- _getDroneStateVector (BaseAviary.py:623-643) -> _clipAndNormalizeState             */
 /* (PBDroneEnv.py:338-398) -> _computeObs (PBDroneEnv.py:296-336).  float64, cast at the end. */
 /* ------------------------------------------------------------------------- */
+
+/* ------------------------------------------------------------------------- */
+/* N4 -- force terms of Physics.PYB_GND / PYB_DRAG and ActionType.RPM.  The python halves   */
+/* (numpy dtypes, operation order) are pinned by tests/golden/extra_physics.npz; the Bullet */
+/* halves (p.getLinkStates, p.getMatrixFromQuaternion) are [3P-recall].                      */
+/* ------------------------------------------------------------------------- */
+#define ORC_GND_EFF_COEFF 11.36859      /* cf2x.urdf:5 */
+#define ORC_PROP_RADIUS 2.31348e-2
+#define ORC_DRAG_XY 9.1785e-7
+#define ORC_DRAG_Z 10.311e-7
+#define ORC_GRAVITY (ORC_G * ORC_M)     /* BaseAviary.py:129 */
+
+static double hover_rpm(void) { return sqrt(ORC_GRAVITY / (4 * ORC_KF)); }              /* BaseAviary.py:164 */
+static double max_rpm(void) { return sqrt((2.25 * ORC_GRAVITY) / (4 * ORC_KF)); }        /* :165, thrust2weight 2.25 */
+static double gnd_eff_h_clip(void)
+{   /* BaseAviary.py:175-176 */
+    double mr = max_rpm();
+    double max_thrust = 4 * ORC_KF * (mr * mr);                                          /* :167 */
+    return 0.25 * ORC_PROP_RADIUS * sqrt((15 * (mr * mr) * ORC_KF * ORC_GND_EFF_COEFF) / max_thrust);
+}
+
+void orc_rpm_action(const float a[4], double rpm[4], double forces[4], double *z_torque)
+{
+    const double hr = hover_rpm();
+    double tq[4];
+    for (int i = 0; i < 4; ++i) {
+        float s = 0.05f * a[i];                 /* python float (x) float32 array -> float32 */
+        float u = 1.0f + s;
+        rpm[i] = hr * (double)u;                /* np.float64 scalar (x) float32 array -> float64 */
+        double sq = rpm[i] * rpm[i];            /* BaseAviary.py:776-777 */
+        forces[i] = sq * ORC_KF;
+        tq[i] = sq * ORC_KM;
+    }
+    double z = -tq[0];
+    z = z + tq[1];
+    z = z - tq[2];
+    z = z + tq[3];
+    *z_torque = z;
+}
+
+void orc_ground_effect(const double pos[3], const double quat[4], const double rpy[3], const double rpm[4], int rpm_is_f32,
+                       double out[4])
+{
+    double R[9];
+    quat_to_mat(quat, R);
+    const double hclip = gnd_eff_h_clip();
+    const int ok = fabs(rpy[0]) < ORC_PI / 2 && fabs(rpy[1]) < ORC_PI / 2;               /* :823 */
+    for (int i = 0; i < 4; ++i) {
+        /* p.getLinkStates(...)[i][0][2]: world z of the link's centre of mass = base + R (x_i, y_i, 0) */
+        double h = pos[2] + (R[6] * ORC_PROP_X[i] + R[7] * ORC_PROP_Y[i]);
+        if (h < hclip) h = hclip;                                                        /* :821 */
+        double q = ORC_PROP_RADIUS / (4 * h);
+        double g;
+        if (rpm_is_f32) {
+            float r = (float)rpm[i];
+            float t = r * r;
+            t = t * (float)ORC_KF;
+            t = t * (float)ORC_GND_EFF_COEFF;
+            g = (double)t * (q * q);
+        } else {
+            g = rpm[i] * rpm[i] * ORC_KF * ORC_GND_EFF_COEFF * (q * q);
+        }
+        out[i] = ok ? g : 0.0;
+    }
+}
+
+void orc_drag(const double quat[4], const double vel[3], const double last_rpm[4], int rpm_is_f32, double out[3])
+{
+    double R[9];
+    quat_to_mat(quat, R);                                   /* p.getMatrixFromQuaternion, :850 */
+    double sum;
+    if (rpm_is_f32) {                                       /* np.sum(np.array(2*np.pi*rpm/60)) in float32 */
+        float w[4];
+        for (int i = 0; i < 4; ++i) {
+            float m = (float)(2 * ORC_PI) * (float)last_rpm[i];
+            w[i] = m / 60.0f;
+        }
+        float s = w[0] + w[1];                              /* add.reduce over four elements: left to right */
+        s = s + w[2];
+        s = s + w[3];
+        sum = (double)s;
+    } else {
+        double w[4];
+        for (int i = 0; i < 4; ++i) w[i] = (2 * ORC_PI) * last_rpm[i] / 60;
+        double s = w[0] + w[1];
+        s = s + w[2];
+        sum = s + w[3];
+    }
+    const double k[3] = {-1 * ORC_DRAG_XY * sum, -1 * ORC_DRAG_XY * sum, -1 * ORC_DRAG_Z * sum};   /* :852 */
+    const double u[3] = {k[0] * vel[0], k[1] * vel[1], k[2] * vel[2]};
+    mat_vec(R, u, out);                                     /* np.dot(base_rot, ...) :853 */
+}
+
 static double max_target_dist(const orc_config *c)
 {   /* PBDroneEnv.py:91 */
     double a = fabs(c->dim[0]) + c->dim[3], b = fabs(c->dim[1]) + c->dim[4], z = c->dim[5];
@@ -457,6 +558,7 @@ static void bullet_reset(const orc_config *c, orc_env *e)
     memset(e->vel, 0, sizeof e->vel);
     memset(e->ang_v, 0, sizeof e->ang_v);
     orc_euler_from_quat(e->quat, e->rpy);
+    memset(e->last_clipped_action, 0, sizeof e->last_clipped_action);        /* _housekeeping, BaseAviary.py:545 */
 }
 
 void orc_env_construct(const orc_config *c, orc_env *e)
@@ -486,13 +588,27 @@ void orc_env_reset(const orc_config *c, orc_env *e, float obs[ORC_OBS_DIM])
 /* PBDroneEnv.step (PBDroneEnv.py:171-199) around BaseAviary.step (BaseAviary.py:324-453). */
 void orc_env_step(const orc_config *c, orc_env *e, const float action[4], orc_step_out *out)
 {
-    float cmd[4], rpm[4], f32[4], zt32;
+    float cmd[4], rpm32[4], f32[4], zt32;
+    double rpm[4], f[4], zt, body_force[3] = {0.0, 0.0, 0.0};
     if (c->normalize_actions) orc_rescale_action(action, cmd);               /* :173-176 */
     else memcpy(cmd, action, sizeof cmd);
-    orc_preprocess_action(cmd, rpm);                                         /* BaseAviary.py:408 */
-    orc_rotor_forces(rpm, f32, &zt32);                                       /* :420-421 */
-    double f[4] = {f32[0], f32[1], f32[2], f32[3]};
-    orc_bullet_step(e->pos, e->quat, e->vel, e->ang_v, f, (double)zt32);     /* :439-440 */
+    const int rpm_is_f32 = c->action_type == 0;
+    if (c->action_type == 1) orc_rpm_action(cmd, rpm, f, &zt);               /* ActionType.RPM (N4) */
+    else {
+        orc_preprocess_action(cmd, rpm32);                                   /* BaseAviary.py:408 */
+        orc_rotor_forces(rpm32, f32, &zt32);                                 /* :420-421 */
+        for (int i = 0; i < 4; ++i) { rpm[i] = rpm32[i]; f[i] = f32[i]; }
+        zt = (double)zt32;
+    }
+    if (c->physics == 1 || c->physics == 4) {                                /* _groundEffect, :422-424,431-434 */
+        double g[4];
+        orc_ground_effect(e->pos, e->quat, e->rpy, rpm, rpm_is_f32, g);
+        for (int i = 0; i < 4; ++i) f[i] += g[i];                            /* same link, forces add up in Bullet */
+    }
+    if (c->physics == 2 || c->physics == 4)                                  /* _drag(last_clipped_action), :425-427,435 */
+        orc_drag(e->quat, e->vel, e->last_clipped_action, rpm_is_f32, body_force);
+    orc_bullet_step_ex(e->pos, e->quat, e->vel, e->ang_v, f, zt, body_force);   /* :439-440 */
+    memcpy(e->last_clipped_action, rpm, sizeof rpm);                         /* :442 */
     orc_euler_from_quat(e->quat, e->rpy);                                    /* :444 */
     orc_compute_obs(c, e, out->obs);                                         /* :446 */
     out->reward = orc_compute_reward(c, e);                                  /* :447 */
@@ -585,7 +701,7 @@ static void round_state_f32(orc_env *e)
 #define RF(x) (x) = (double)(float)(x)
     for (int i = 0; i < 3; ++i) { RF(e->pos[i]); RF(e->vel[i]); RF(e->ang_v[i]); RF(e->cur_pos[i]);
                                   RF(e->cur_vel[i]); RF(e->cur_ang_v[i]); RF(e->prev_vel[i]); RF(e->prev_ang_v[i]); }
-    for (int i = 0; i < 4; ++i) RF(e->quat[i]);
+    for (int i = 0; i < 4; ++i) { RF(e->quat[i]); RF(e->last_clipped_action[i]); }
     RF(e->d); RF(e->d_prev); RF(e->ep_ret);
 #undef RF
 }
@@ -728,6 +844,12 @@ void orc_gae(const float *rewards, const float *values, const uint8_t *dones,
             ret[t * N + i] = last + values[t * N + i];
         }
     }
+}
+
+/* test helper (teacher forcing): _updateAndStoreKinematicInformation's rpy cache from the (overwritten) quaternion */
+void orc_vec_refresh_rpy(orc_env *envs, int64_t n)
+{
+    for (int64_t i = 0; i < n; ++i) orc_euler_from_quat(envs[i].quat, envs[i].rpy);
 }
 
 int32_t orc_sizeof_env(void) { return (int32_t)sizeof(orc_env); }

@@ -63,6 +63,13 @@ typedef struct orc_config {
      * TransformReward(clip(-10, 10)) if --clip_rew, then gym NormalizeReward() if --norm_rew */
     int32_t clip_rew;
     int32_t norm_rew;
+    /* N4 -- options present but unreachable in the reference (BaseAviary.step forces Physics.PYB, BaseAviary.py:411;
+     * PBDroneEnv overrides _preprocessAction for ActionType.THRUST only):
+     *   physics     0 PYB | 1 PYB_GND | 2 PYB_DRAG | 3 PYB_DW | 4 PYB_GND_DRAG_DW   (enums.py:12-21, BaseAviary.py:412-437;
+     *               _downwash sums over OTHER drones of the same Bullet world, NUM_DRONES = 1 -> no force)
+     *   action_type 0 THRUST (PBDroneEnv._preprocessAction) | 1 RPM (BaseSingleAgentAviary.py:176-179) */
+    int32_t physics;
+    int32_t action_type;
 } orc_config;
 
 /* Every per-env variable the reference keeps, under the reference's names. */
@@ -88,6 +95,8 @@ typedef struct orc_env {
     uint32_t step_count;
     /* NormalizeReward (normalize.py:100-147): discounted return and its RunningMeanStd(shape=()) */
     double rr_returns, rr_mean, rr_var, rr_count;
+    /* BaseAviary.last_clipped_action (BaseAviary.py:442,545): the rpm of the previous control step, zeros after reset */
+    double last_clipped_action[4];
 } orc_env;
 
 /* Result of one gym-level env.step (PBDroneEnv.step), before vectorisation. */
@@ -107,6 +116,19 @@ void orc_rotor_forces(const float rpm[4], float forces[4], float *z_torque);
 /* ---- A4/A5: rigid body (UNPINNED, Bullet recall) ------------------------- */
 void orc_bullet_step(double pos[3], double quat[4], double vel[3], double ang_v[3],
                      const double forces[4], double z_torque);
+/* same, with an extra LINK_FRAME force on link 4 (centre of mass, BaseAviary._drag) */
+void orc_bullet_step_ex(double pos[3], double quat[4], double vel[3], double ang_v[3],
+                        const double forces[4], double z_torque, const double body_force[3]);
+
+/* ---- N4: extra force terms and the RPM action type (python halves pinned: extra_physics.npz) ---- */
+/* BaseSingleAgentAviary._preprocessAction, ActionType.RPM (BaseSingleAgentAviary.py:176-179) + BaseAviary._physics (:776-780) */
+void orc_rpm_action(const float a[4], double rpm[4], double forces[4], double *z_torque);
+/* BaseAviary._groundEffect (:800-832): the four forceObj z values, or zeros when the attitude test fails.
+ * rpm_is_f32: the rpm array is float32 (THRUST chain) -> numpy works in float32 up to the (PROP_RADIUS/(4h))^2 factor */
+void orc_ground_effect(const double pos[3], const double quat[4], const double rpy[3], const double rpm[4], int rpm_is_f32,
+                       double out[4]);
+/* BaseAviary._drag (:836-862): forceObj handed to link 4 */
+void orc_drag(const double quat[4], const double vel[3], const double last_rpm[4], int rpm_is_f32, double out[3]);
 void orc_euler_from_quat(const double q[4], double rpy[3]);
 
 /* ---- A6-A9: gym-level env -------------------------------------------------- */
@@ -135,6 +157,8 @@ void orc_vec_step(const orc_config *cfg, orc_env *envs, int64_t n, const float *
                   int32_t *ep_len /* [n] valid where done, may be NULL */,
                   uint8_t *terminated /* [n] raw terminated flag, may be NULL */,
                   int threads);
+
+void orc_vec_refresh_rpy(orc_env *envs, int64_t n);   /* teacher-forcing helper: rpy cache <- quat */
 
 /* ---- N1: GAE (cleanRLPPO.py:234-248 + SB3 truncation bootstrap) ------------ */
 void orc_gae(const float *rewards, const float *values, const uint8_t *dones,

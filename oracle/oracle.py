@@ -37,6 +37,8 @@ class OrcConfig(C.Structure):
         ("env_id_offset", C.c_int64),
         ("clip_rew", C.c_int32),
         ("norm_rew", C.c_int32),
+        ("physics", C.c_int32),
+        ("action_type", C.c_int32),
     ]
 
 
@@ -53,6 +55,7 @@ class OrcEnv(C.Structure):
         ("rms_mean", C.c_double * OBS_DIM), ("rms_var", C.c_double * OBS_DIM), ("rms_count", C.c_double),
         ("step_count", C.c_uint32),
         ("rr_returns", C.c_double), ("rr_mean", C.c_double), ("rr_var", C.c_double), ("rr_count", C.c_double),
+        ("last_clipped_action", C.c_double * 4),
     ]
 
 
@@ -71,6 +74,7 @@ ENV_DTYPE = np.dtype([
     ("rms_mean", "f8", OBS_DIM), ("rms_var", "f8", OBS_DIM), ("rms_count", "f8"),
     ("step_count", "u4"),
     ("rr_returns", "f8"), ("rr_mean", "f8"), ("rr_var", "f8"), ("rr_count", "f8"),
+    ("last_clipped_action", "f8", 4),
 ], align=True)
 
 
@@ -102,6 +106,10 @@ def lib():
     L.orc_preprocess_action.argtypes = [fp, fp]
     L.orc_rotor_forces.argtypes = [fp, fp, fp]
     L.orc_bullet_step.argtypes = [dp, dp, dp, dp, dp, C.c_double]
+    L.orc_bullet_step_ex.argtypes = [dp, dp, dp, dp, dp, C.c_double, dp]
+    L.orc_rpm_action.argtypes = [fp, dp, dp, dp]
+    L.orc_ground_effect.argtypes = [dp, dp, dp, dp, C.c_int, dp]
+    L.orc_drag.argtypes = [dp, dp, dp, C.c_int, dp]
     L.orc_euler_from_quat.argtypes = [dp, dp]
     L.orc_env_construct.argtypes = [cfgp, envp]
     L.orc_env_reset.argtypes = [cfgp, envp, fp]
@@ -117,6 +125,7 @@ def lib():
     L.orc_reward_wrappers.argtypes = [cfgp, envp, C.c_double, C.c_int32]
     L.orc_reward_wrappers.restype = C.c_double
     L.orc_vec_create.argtypes = [cfgp, C.c_void_p, C.c_int64]
+    L.orc_vec_refresh_rpy.argtypes = [C.c_void_p, C.c_int64]
     L.orc_vec_reset.argtypes = [cfgp, C.c_void_p, C.c_int64, C.c_void_p, C.c_int]
     L.orc_vec_step.argtypes = [cfgp, C.c_void_p, C.c_int64] + [C.c_void_p] * 10 + [C.c_int]
     L.orc_gae.argtypes = [C.c_void_p] * 5 + [C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
@@ -134,7 +143,7 @@ def lib():
 def make_config(waypoints, spawn, dim, *, threshold=0.3, max_steps=4096, circle=False, cylinder=True,
                 include_distance=True, normalize_actions=True, normalize_obs=False, ground_contact=True,
                 f32_state=False, act_noise_sigma=0.0, obs_noise_sigma=0.0, seed=0, env_id_offset=0, clip_rew=False,
-                norm_rew=False):
+                norm_rew=False, physics=0, action_type=0):
     wp = np.asarray(waypoints, dtype=np.float64).reshape(-1, 3)
     assert 1 <= len(wp) <= MAX_WAYPOINTS
     cfg = OrcConfig()
@@ -153,6 +162,7 @@ def make_config(waypoints, spawn, dim, *, threshold=0.3, max_steps=4096, circle=
     cfg.act_noise_sigma, cfg.obs_noise_sigma = float(act_noise_sigma), float(obs_noise_sigma)
     cfg.seed, cfg.env_id_offset = int(seed), int(env_id_offset)
     cfg.clip_rew, cfg.norm_rew = int(clip_rew), int(norm_rew)
+    cfg.physics, cfg.action_type = int(physics), int(action_type)
     return cfg
 
 
@@ -175,6 +185,10 @@ class OracleVecEnv:
         obs = np.empty((self.n, OBS_DIM), np.float32)
         self.L.orc_vec_reset(C.byref(self.cfg), _p(self.envs), self.n, _p(obs), self.threads)
         return obs
+
+    def refresh_rpy(self):
+        """After overwriting envs["quat"] (teacher forcing): recompute the cached rpy the force terms read."""
+        self.L.orc_vec_refresh_rpy(_p(self.envs), self.n)
 
     def step(self, actions):
         a = np.ascontiguousarray(actions, dtype=np.float32).reshape(self.n, 4)

@@ -113,8 +113,13 @@ class FakeBullet(types.ModuleType):
     # -- the five force calls + the step ----------------------------------------
     def applyExternalForce(self, objectUniqueId, linkIndex, forceObj, posObj, flags, **kw):
         c = self._c(kw)
-        assert flags == self.LINK_FRAME and list(posObj) == [0, 0, 0] and forceObj[0] == 0 and forceObj[1] == 0
-        c["forces"][linkIndex] = float(forceObj[2])          # PyFloat_AsDouble widening
+        assert flags == self.LINK_FRAME and list(posObj) == [0, 0, 0]
+        if linkIndex == 4:                                   # BaseAviary._drag: a general vector on the centre-of-mass link
+            c["body_force"] = np.array([float(v) for v in forceObj])
+            c["applied"].append(("D", linkIndex, type(forceObj[2]).__name__, tuple(float(v) for v in forceObj)))
+            return
+        assert forceObj[0] == 0 and forceObj[1] == 0
+        c["forces"][linkIndex] += float(forceObj[2])         # PyFloat_AsDouble widening; forces on one link add up
         c["applied"].append(("F", linkIndex, type(forceObj[2]).__name__, float(forceObj[2])))
 
     def applyExternalTorque(self, objectUniqueId, linkIndex, torqueObj, flags, **kw):
@@ -153,6 +158,27 @@ class FakeBullet(types.ModuleType):
         dp = C.POINTER(C.c_double)
         self._L.orc_euler_from_quat(q.ctypes.data_as(dp), out.ctypes.data_as(dp))
         return tuple(out.tolist())
+
+    # -- used only by the dead Physics.PYB_GND / PYB_DRAG terms (fixture extra_physics.npz) [3P-recall] --
+    @staticmethod
+    def _matrix(q):
+        x, y, z, w = [float(v) for v in q]
+        s = 2.0 / (x * x + y * y + z * z + w * w)           # btMatrix3x3::setRotation
+        xs, ys, zs = x * s, y * s, z * s
+        wx, wy, wz = w * xs, w * ys, w * zs
+        xx, xy, xz, yy, yz, zz = x * xs, x * ys, x * zs, y * ys, y * zs, z * zs
+        return np.array([[1.0 - (yy + zz), xy - wz, xz + wy], [xy + wz, 1.0 - (xx + zz), yz - wx],
+                         [xz - wy, yz + wx, 1.0 - (xx + yy)]])
+
+    def getMatrixFromQuaternion(self, quat, **kw):
+        return tuple(self._matrix(quat).ravel().tolist())
+
+    def getLinkStates(self, bid, linkIndices, **kw):
+        c = self._c(kw)
+        R = self._matrix(c["quat"])
+        offs = {0: (0.028, -0.028, 0.0), 1: (-0.028, -0.028, 0.0), 2: (-0.028, 0.028, 0.0), 3: (0.028, 0.028, 0.0),
+                4: (0.0, 0.0, 0.0)}                           # Sol/resources/cf2x.urdf:42,54,66,78,90
+        return [(tuple((c["pos"] + R @ np.array(offs[i])).tolist()),) for i in linkIndices]
 
     def getContactPoints(self, *a, **kw):
         return self._clients[self.current]["contacts"]

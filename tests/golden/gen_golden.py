@@ -399,6 +399,65 @@ def gen_reward_wrappers(out):
     out["reward_wrappers"] = dict(rewards=rews, dones=dones.astype(np.uint8), **res)
 
 
+def gen_extra_physics(out):
+    """N4: the force terms of Physics.PYB_GND / PYB_DRAG (BaseAviary._groundEffect / _drag) and ActionType.RPM
+    (BaseSingleAgentAviary._preprocessAction + BaseAviary._physics), called on the reference's own methods with the
+    kinematic caches set by hand.  Pins the numpy halves (dtypes, operation order); p.getLinkStates and
+    p.getMatrixFromQuaternion are the stub's [3P-recall]."""
+    from Sol.PyBullet.BaseSingleAgentAviary import BaseSingleAgentAviary
+    targets, spawn, dim, circle = track_circle(4)
+    env = make_ref_env(targets, spawn, dim, circle)
+    cl = pb._clients[env.CLIENT]
+    rng = np.random.default_rng(11)
+    n = 600
+    pos = rng.uniform([-2, -2, 0.0], [2, 2, 2], (n, 3))
+    pos[:150, 2] = rng.uniform(0.0, 0.08, 150)              # near the ground: clip at GND_EFF_H_CLIP and large effects
+    ang = rng.uniform(-1, 1, (n, 3)) * np.array([2.5, 1.7, np.pi])
+    ang[:100] *= 0.2
+    quat = np.array([pb.getQuaternionFromEuler(a) for a in ang])
+    vel = rng.uniform(-3, 3, (n, 3))
+    acts = rng.uniform(-1, 1, (n, 4)).astype(np.float32)
+    acts[::3] = (0.0922 + 0.003 * rng.standard_normal((len(acts[::3]), 4))).astype(np.float32)
+    rpm32 = np.stack([env._preprocessAction(env.rescale_action(a)) for a in acts])
+    assert rpm32.dtype == np.float32
+    env.ACT_TYPE = ActionType.RPM
+    rpm64 = np.stack([BaseSingleAgentAviary._preprocessAction(env, a) for a in acts])
+    env.ACT_TYPE = ActionType.THRUST
+    assert rpm64.dtype == np.float64
+    res = {}
+    for tag, rpms in (("f32", rpm32), ("f64", rpm64)):
+        gnd = np.zeros((n, 4))
+        drag = np.zeros((n, 3))
+        forces = np.zeros((n, 4))
+        zt = np.zeros(n)
+        rpy = np.zeros((n, 3))
+        for k in range(n):
+            cl["pos"][:] = pos[k]; cl["quat"][:] = quat[k]; cl["vel"][:] = vel[k]
+            quiet(env._updateAndStoreKinematicInformation)
+            rpy[k] = env.rpy[0]
+            cl["applied"].clear()
+            env._groundEffect(rpms[k], 0)
+            for kind, link, tname, val in cl["applied"]:
+                assert kind == "F" and tname == "float64"
+                gnd[k, link] = val
+            cl["applied"].clear()
+            env._drag(rpms[(k + 1) % n], 0)
+            (kind, link, tname, val), = cl["applied"]
+            assert kind == "D"
+            drag[k] = val
+            cl["applied"].clear()
+            env._physics(rpms[k], 0)
+            for kind, link, tname, val in cl["applied"]:
+                if kind == "F":
+                    forces[k, link] = val
+                else:
+                    zt[k] = val
+            cl["forces"][:] = 0
+        res.update({f"gnd_{tag}": gnd, f"drag_{tag}": drag, f"forces_{tag}": forces, f"z_torque_{tag}": zt, f"rpm_{tag}": rpms})
+    out["extra_physics"] = dict(pos=pos, quat=quat, vel=vel, rpy=rpy, actions=acts,
+                                GND_EFF_H_CLIP=np.float64(env.GND_EFF_H_CLIP), HOVER_RPM=np.float64(env.HOVER_RPM), **res)
+
+
 def gen_gae(out):
     """N1: execute the reference's GAE lines (cleanRLPPO.py:234-248) on random buffers."""
     import torch
@@ -458,7 +517,7 @@ def main():
     only = set(sys.argv[1:])
     gens = dict(actions=gen_constants_and_actions, tracks=gen_tracks, obs_pack=gen_obs_pack, closed_loop=gen_closed_loop,
                 scripted=gen_scripted, normalize=gen_normalize, gae=gen_gae, rollout_dump=gen_rollout_dump,
-                reward_wrappers=gen_reward_wrappers)
+                reward_wrappers=gen_reward_wrappers, extra_physics=gen_extra_physics)
     for key, fn in gens.items():          # `python gen_golden.py rollout_dump` regenerates only that group
         if not only or key in only:
             fn(out)

@@ -43,7 +43,7 @@ def test_struct_layouts_match_header(pkg):
     assert C.sizeof(pkg._capi.DnConfig) == 8 + 4 + 4 + 64 * 3 * 8 + 3 * 8 + 6 * 8 + 8 + 8 * 4 + 2 * 4 + 8 + 8 + 2 * 4
     assert C.sizeof(pkg._capi.DnEnvState) == 27 * 4 + 4 + 27 * 8 or C.sizeof(pkg._capi.DnEnvState) % 8 == 0
     assert C.sizeof(pkg._capi.DnStats) == 7 * 8
-    assert pkg._capi.load().dn_abi_version() == 2
+    assert pkg._capi.load().dn_abi_version() == 3
 
 
 def test_config_defaults_follow_the_driver(pkg):

@@ -44,6 +44,7 @@ def gpu_state_to_oracle(st, envs, step_count):
               "just_found", "ep_ret", "ep_len", "rms_mean", "rms_var", "rms_count", "rr_returns", "rr_mean", "rr_var",
               "rr_count"):
         envs[k] = st[k]
+    envs["last_clipped_action"] = st["last_rpm"]
     envs["cur_vel"] = st["vel"]
     envs["cur_ang_v"] = st["ang_v"]
     envs["is_done"] = 0
@@ -891,3 +892,68 @@ def test_reward_wrappers_match_oracle(clip, norm):
         st2 = env.get_state()
         assert np.array_equal(st2["rr_mean"], st["rr_mean"]) and np.array_equal(st2["rr_returns"], st["rr_returns"])
     env.close()
+
+
+@pytest.mark.parametrize("physics,act", [("pyb_gnd", "thrust"), ("pyb_drag", "thrust"), ("pyb_gnd_drag_dw", "thrust"),
+                                         ("pyb_gnd_drag_dw", "rpm"), ("pyb", "rpm"), ("pyb_dw", "thrust")])
+def test_physics_options_match_oracle(physics, act):
+    """N4: the reference's dormant Physics.PYB_GND / PYB_DRAG force terms (BaseAviary.py:800-862) and ActionType.RPM
+    (BaseSingleAgentAviary.py:176-179) against the oracle, whose python halves are pinned to the reference's own methods
+    (extra_physics.npz).  Low spawn (5 cm) with the ground-contact approximation off so that the clipped ground effect
+    is exercised; teacher-forced, then free-running fused K steps against K single steps (bit-identical)."""
+    pkg = _gpu()
+    n, max_steps = 1024, 60
+    wp = np.array([[0.0, 1.0, 0.4], [-1.0, 0.0, 0.8], [0.0, -1.0, 0.4]])
+    spawn, dim = np.array([[1.0, 0.0, 0.05]]), np.array([-2.0, -2.0, 0.0, 2.0, 2.0, 2.0])
+    kw = dict(max_steps=max_steps, normalize_obs=False, ground_contact=False, cylinder=False, normalize_actions=act == "thrust")
+    mk = lambda: pkg.DroneVecEnv(None, n, target_points=wp, initial_xyzs=spawn, aviary_dim=dim, circle=False,    # noqa: E731
+                                 device="cuda:0", physics=physics, act=act, **kw)
+    env = mk()
+    cfg = O.make_config(wp, spawn[0], dim, circle=False, f32_state=False, physics=pkg.vec_env.PHYSICS[physics],
+                        action_type=pkg.vec_env.ACTION_TYPES[act], **kw)
+    ora = O.OracleVecEnv(cfg, n, threads=8)
+    env.reset_tensor()
+    ora.reset()
+    rng = np.random.default_rng(5)
+    dev = torch.device("cuda:0")
+    n_done = 0
+    saw_rpm = 0.0
+    for t in range(150):
+        st = env.get_state()
+        saw_rpm = max(saw_rpm, float(st["last_rpm"].max()))
+        gpu_state_to_oracle(st, ora.envs, env.step_count)
+        ora.refresh_rpy()
+        a = actions_mixed(rng, n) if act == "thrust" else rng.uniform(-1, 1, (n, 4)).astype(np.float32)
+        out = env.step_tensor(torch.from_numpy(a).to(dev))
+        torch.cuda.synchronize()
+        n_done += compare_step(out, ora.step(a), f"{physics}/{act} t={t}")
+    assert n_done > n
+    has_drag = "drag" in physics
+    assert (saw_rpm > 9000.0) == has_drag                   # last_clipped_action is kept only where _drag reads it
+    # the option must change the flight (pyb_dw is a no-op for a single drone per world)
+    if physics != "pyb" and physics != "pyb_dw":
+        base = pkg.DroneVecEnv(None, n, target_points=wp, initial_xyzs=spawn, aviary_dim=dim, circle=False, device="cuda:0",
+                               act=act, **kw)
+        twin = mk()
+        base.reset_tensor(); twin.reset_tensor()
+        a = torch.full((n, 4), 0.0925 if act == "thrust" else 0.3, device=dev)
+        for _ in range(5):
+            base.step_tensor(a); twin.step_tensor(a)
+        pb, pt = base.get_state()["pos"], twin.get_state()["pos"]
+        assert np.abs(pb - pt).max() > 1e-7
+        base.close(); twin.close()
+    # fused K steps == K single steps, bit for bit (state incl. last_rpm, outputs)
+    K = 24
+    twin = mk()
+    twin.set_state(env.get_state())
+    twin.step_count = env.step_count
+    acts = torch.from_numpy(np.stack([actions_mixed(rng, n) if act == "thrust" else rng.uniform(-1, 1, (n, 4)).astype(np.float32)
+                                      for _ in range(K)])).to(dev)
+    many = twin.rollout_tensor(acts.contiguous())
+    for t in range(K):
+        obs, rew, done, info = env.step_tensor(acts[t])
+        assert torch.equal(obs, many["obs"][t]) and torch.equal(rew, many["reward"][t]) and torch.equal(done, many["done"][t])
+    sa, sb = env.get_state(), twin.get_state()
+    for k in sa.dtype.names:
+        assert np.array_equal(sa[k], sb[k]), k
+    env.close(); twin.close()

@@ -223,3 +223,50 @@ def test_reward_wrappers_match_reference(golden):
         assert abs(env.envs["rr_var"][0] - float(g[tag + "_var"])) <= 1e-12 * float(g[tag + "_var"])
         assert env.envs["rr_count"][0] == float(g[tag + "_count"])
         assert abs(env.envs["rr_returns"][0] - float(g[tag + "_returns"])) < 1e-12
+
+
+def test_extra_physics_terms_match_reference(golden):
+    """N4: BaseAviary._groundEffect / _drag and the ActionType.RPM chain, as the reference's own methods compute them
+    (extra_physics.npz).  The RPM chain is bit-exact; the force terms 1e-12 (np.dot / matmul in the stubbed Bullet
+    getters round an ulp differently from a plain C sum)."""
+    g = golden("extra_physics")
+    L = O.lib()
+    n = len(g["pos"])
+    P = lambda a: np.ascontiguousarray(a, dtype=np.float64).ctypes.data_as(DP)   # noqa: E731
+    for tag, is_f32 in (("f32", 1), ("f64", 0)):
+        rpm = g["rpm_" + tag].astype(np.float64)
+        hit = 0
+        for k in range(n):
+            out = np.zeros(4)
+            L.orc_ground_effect(P(g["pos"][k]), P(g["quat"][k]), P(g["rpy"][k]), P(rpm[k]), is_f32, out.ctypes.data_as(DP))
+            ref = g["gnd_" + tag][k]
+            np.testing.assert_allclose(out, ref, rtol=1e-12, atol=0)
+            hit += bool(ref.any())
+            d3 = np.zeros(3)
+            L.orc_drag(P(g["quat"][k]), P(g["vel"][k]), P(rpm[(k + 1) % n]), is_f32, d3.ctypes.data_as(DP))
+            np.testing.assert_allclose(d3, g["drag_" + tag][k], rtol=1e-12, atol=0)
+        assert 0.3 * n < hit < n            # both sides of the |roll|, |pitch| < pi/2 test are covered
+    for k in range(n):
+        a = np.ascontiguousarray(g["actions"][k])
+        rpm, f, zt = np.zeros(4), np.zeros(4), C.c_double()
+        L.orc_rpm_action(a.ctypes.data_as(FP), rpm.ctypes.data_as(DP), f.ctypes.data_as(DP), C.byref(zt))
+        assert np.array_equal(rpm, g["rpm_f64"][k]) and np.array_equal(f, g["forces_f64"][k])
+        assert zt.value == g["z_torque_f64"][k]
+    # a ground-effect force is a second force on the same prop link: the env step adds it to the rotor thrust
+    wp = np.array([[0.0, 1.0, 1.0], [-1.0, 0.0, 1.0]])
+    dim = np.array([-2.0, -2.0, 0.0, 2.0, 2.0, 2.0])
+    for physics, act in ((0, 0), (1, 0), (2, 0), (4, 0), (4, 1)):
+        cfg = O.make_config(wp, np.array([1.0, 0.0, 0.1]), dim, circle=False, cylinder=False, ground_contact=False,
+                            physics=physics, action_type=act, normalize_actions=act == 0)
+        ve = O.OracleVecEnv(cfg, 1)
+        ve.reset()
+        a = np.full((1, 4), 0.0925 if act == 0 else 0.2, np.float32)
+        for _ in range(3):
+            assert not ve.step(a)["done"][0]
+        envs = ve.envs
+        assert np.all(envs["last_clipped_action"][0] > 9000.0)
+        if physics == 0 and act == 0:
+            base = envs["pos"][0].copy()
+        elif act == 0:
+            assert not np.array_equal(envs["pos"][0], base)         # the extra terms act
+            np.testing.assert_allclose(envs["pos"][0], base, atol=1e-4)
