@@ -39,10 +39,34 @@ def test_library_exports_every_declared_symbol(pkg):
 
 
 def test_struct_layouts_match_header(pkg):
-    # sizes computed by hand from include/dronenav.h (natural alignment)
-    assert C.sizeof(pkg._capi.DnConfig) == 8 + 4 + 4 + 64 * 3 * 8 + 3 * 8 + 6 * 8 + 8 + 8 * 4 + 2 * 4 + 8 + 8 + 2 * 4
-    assert C.sizeof(pkg._capi.DnEnvState) == 27 * 4 + 4 + 27 * 8 or C.sizeof(pkg._capi.DnEnvState) % 8 == 0
+    # sizes computed by hand from include/dronenav.h (natural alignment) ...
+    assert C.sizeof(pkg._capi.DnConfig) == 8 + 4 + 4 + 64 * 3 * 8 + 3 * 8 + 6 * 8 + 8 + 8 * 4 + 2 * 4 + 8 + 8 + 4 * 4
     assert C.sizeof(pkg._capi.DnStats) == 7 * 8
+    # ... and by the C compiler from the header itself: sizes and the offsets of the trailing fields
+    import subprocess
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prog = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "dronenav.h"
+int main(void) {
+    printf("%zu %zu %zu %zu %zu %zu %zu %zu %d\n", sizeof(dn_config), sizeof(dn_env_state), sizeof(dn_stats), sizeof(dn_mlp_net),
+           offsetof(dn_config, action_type), offsetof(dn_config, seed), offsetof(dn_env_state, last_rpm),
+           offsetof(dn_env_state, rms_mean), DN_ABI_VERSION);
+    return 0;
+}
+'''
+    with tempfile.TemporaryDirectory() as td:
+        src, exe = os.path.join(td, "abi.c"), os.path.join(td, "abi")
+        with open(src, "w") as f:
+            f.write(prog)
+        subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(root, "include"), src, "-o", exe])
+        got = [int(v) for v in subprocess.check_output([exe]).split()]
+    K = pkg._capi
+    assert got == [C.sizeof(K.DnConfig), C.sizeof(K.DnEnvState), C.sizeof(K.DnStats), C.sizeof(K.DnMlpNet),
+                   K.DnConfig.action_type.offset, K.DnConfig.seed.offset, K.DnEnvState.last_rpm.offset,
+                   K.DnEnvState.rms_mean.offset, K.ABI_VERSION], got
     assert pkg._capi.load().dn_abi_version() == 3
 
 
