@@ -617,13 +617,15 @@ struct Thrust {
 };
 template <typename R> struct Flight {
     R px, py, pz, qx, qy, qz, qw;                            // post-physics pose (before any reset): feeds compares, stays R
+    R fwx, fwy, fwz;                                         // get_forward_vector of that pose (attitude_phase): feeds a compare, stays R
+    float roll32, pitch32, yaw32;                            // p.getEulerFromQuaternion of that pose: observation columns only
     float vx, vy, vz, wx, wy, wz;                            // post-physics velocities as they go back to HBM (float32):
                                                              // the report wave only turns them into observation columns
     float vex, vey, vez, aex, aey, aez;                      // entry velocities = current_vel / current_ang_v (quirk Q4), float32 state
     float d_e, dprev_e;                                      // entry _distance_to_target / _prev_distance_to_target, float32 state
     int idx_e, just_found_e, truncated;                      // entry index / flag; _computeTruncated (entry _steps)
 };
-constexpr int DN_NFLIGHT64 = 7;                              // R-valued fields of Flight (the rest travel as float32)
+constexpr int DN_NMAIL64 = 7;                                // R-valued words that cross to the report wave: position, forward vector, Verdict.d_obs
 template <typename R> struct Verdict {
     R d_obs;           // the distance the reset observation shows (quirk Q2)
     int coll1;         // _computeTerminated inside _computeReward (entry index)
@@ -864,21 +866,11 @@ DN_DEV Verdict<R> rules_phase(const DnParams &p, const DnConsts<R> &c, const R *
     return v;
 }
 
-// What the report wave carries from observe_phase to report_phase.
-template <typename R> struct Observed {
-    float o[DN_OBS_DIM];   // step observation, after sensor noise and the normaliser (also terminal_observation)
-    R r_normal;            // _computeReward's ordinary branch, before /25
-    float r_found32;       // gate-pass branch, float32 as the reference accumulates it
-};
-
-// ---- A5 + A6 + the value side of A7 on the report wave ---------------------------------------------------
-template <typename R, bool NORM, bool NOISE>
-DN_DEV Observed<R> observe_phase(const DnParams &p, const DnConsts<R> &c, const R *s_tab, const Flight<R> &fl,
-                                 const float4 G4, const float4 G5, const unsigned long long gid, const unsigned step_count,
-                                 Rms &rms)
+// ---- A5 on the flight wave: the attitude of the post-physics pose as the observation and the reward read it -----
+template <typename R>
+DN_DEV void attitude_phase(Flight<R> &fl)
 {
 #pragma clang fp contract(fast)
-    Observed<R> ob;
     const R qx = fl.qx, qy = fl.qy, qz = fl.qz, qw = fl.qw;
     // p.getEulerFromQuaternion [3P-recall of pybullet.c].  The three angles only feed observation columns 3..5
     // (float32, bar 1e-5): the quaternion products are formed in R, the inverse trigonometry runs in float32
@@ -900,12 +892,34 @@ DN_DEV Observed<R> observe_phase(const DnParams &p, const DnConsts<R> &c, const 
         } else {
             roll32 = atan2_fast32((float)(R(2.0) * (qy * qz + qw * qx)), (float)(squ - sqx - sqy + sqz));
             yaw32 = atan2_fast32((float)ys, (float)yc);
-            // asin is ill-conditioned towards +-1: beyond 0.95 (pitch > 72 deg, rare) take the R-precision routine
-            if (fabs(sarg) > R(0.95)) pitch32 = (float)asin(sarg);
-            else pitch32 = asinf((float)sarg);
+            // asin(s) is ill-conditioned towards +-1; cos(pitch) = |(r00, r10)| = sqrt(yc^2 + ys^2) for the unit quaternion
+            // of Flight, so pitch = atan2(s, cos pitch) is well conditioned everywhere (tumbling drones sit beyond
+            // 72 deg often enough that a float64 asin tail would run on most wave-steps of a bang-bang workload)
+            pitch32 = atan2_fast32((float)sarg, __builtin_amdgcn_sqrtf((float)(yc * yc + ys * ys)));
             fwx = yc; fwy = ys; fwz = sarg;
         }
     }
+    fl.roll32 = roll32; fl.pitch32 = pitch32; fl.yaw32 = yaw32;
+    fl.fwx = fwx; fl.fwy = fwy; fl.fwz = fwz;
+}
+
+// What the report wave carries from observe_phase to report_phase.
+template <typename R> struct Observed {
+    float o[DN_OBS_DIM];   // step observation, after sensor noise and the normaliser (also terminal_observation)
+    R r_normal;            // _computeReward's ordinary branch, before /25
+    float r_found32;       // gate-pass branch, float32 as the reference accumulates it
+};
+
+// ---- A5 + A6 + the value side of A7 on the report wave ---------------------------------------------------
+template <typename R, bool NORM, bool NOISE>
+DN_DEV Observed<R> observe_phase(const DnParams &p, const DnConsts<R> &c, const R *s_tab, const Flight<R> &fl,
+                                 const float4 G4, const float4 G5, const unsigned long long gid, const unsigned step_count,
+                                 Rms &rms)
+{
+#pragma clang fp contract(fast)
+    Observed<R> ob;
+    const float roll32 = fl.roll32, pitch32 = fl.pitch32, yaw32 = fl.yaw32;    // attitude_phase (flight wave)
+    const R fwx = fl.fwx, fwy = fl.fwy, fwz = fl.fwz;
     // _computeObs (PBDroneEnv.py:296-336, :338-398), stale distance d_e (quirk Q1).  The reference clips position /
     // yaw / distance columns to the float32 range before the cast (:326); positions are bounded by the aviary box
     // plus one step at the velocity cap, so those clips can never bind and are not evaluated.  clip(v, -3, 3)/3 is
@@ -1164,10 +1178,11 @@ __global__ __launch_bounds__(DN_BLOCK) void dn_step_many_1w_kernel(const DnParam
         const StepOut out = block_out(io0, tile_base, (long long)t * n, (long long)t * words);
         const unsigned sc = (unsigned)sc0 + (unsigned)t;
         float4 rpm_now;
-        const Flight<R> fl = fly<R, NOISE, XOPT>(p, gid, sc, A, G0, G1, G2, G3, G7, rpm_now);
+        Flight<R> fl = fly<R, NOISE, XOPT>(p, gid, sc, A, G0, G1, G2, G3, G7, rpm_now);
         const float4 G0e = G0, G3e = G3;
         const Verdict<R> v = rules_phase<R>(p, c, s_tab, fl, G0e, G3e, b.g6, li, active, G0, G1, G2, G3);
         if (XOPT && p.drag) G7 = (v.terminated || fl.truncated) ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : rpm_now;   // BaseAviary.py:442,545
+        attitude_phase<R>(fl);
         Observed<R> ob = observe_phase<R, NORM, NOISE>(p, c, s_tab, fl, G4, G5, gid, sc, rms);
         report_phase<R, NORM, NOISE, XOPT>(p, c, s_tile, out, fl, v, ob, gid, sc, li, lane, rows, active, G4, G5, acc, rms, rn);
         A = A_next;
@@ -1198,33 +1213,58 @@ __global__ __launch_bounds__(DN_BLOCK) void dn_step_many_1w_kernel(const DnParam
 // wave was busy 5610 cycles per step and the flight wave idle for 3040 of its 6410.)
 // -----------------------------------------------------------------------------------------------------
 template <typename R> struct Mail {       // LDS, field-major so that consecutive lanes hit consecutive banks
-    R f64[DN_NFLIGHT64 + 1][DN_BLOCK];    // pose (7) + Verdict.d_obs
-    float4 f32[4][DN_BLOCK];              // 14 float32 fields + the two flag words: four 16-byte stores per lane
+    R f64[DN_NMAIL64][DN_BLOCK];          // position (3), forward vector (3), Verdict.d_obs
+    float4 f32[5][DN_BLOCK];              // 17 float32 fields + the two flag words: five 16-byte stores per lane
 };
 template <typename R> DN_DEV void post_mail(Mail<R> &m, unsigned lane, const Flight<R> &f, const Verdict<R> &v)
 {
-    const R x[DN_NFLIGHT64 + 1] = {f.px, f.py, f.pz, f.qx, f.qy, f.qz, f.qw, v.d_obs};
+    const R x[DN_NMAIL64] = {f.px, f.py, f.pz, f.fwx, f.fwy, f.fwz, v.d_obs};
 #pragma unroll
-    for (int k = 0; k < DN_NFLIGHT64 + 1; ++k) m.f64[k][lane] = x[k];
+    for (int k = 0; k < DN_NMAIL64; ++k) m.f64[k][lane] = x[k];
     const int fb = f.idx_e | (f.just_found_e << 8) | (f.truncated << 9), vb = v.coll1 | (v.terminated << 1);
     m.f32[0][lane] = make_float4(f.vx, f.vy, f.vz, f.wx);
     m.f32[1][lane] = make_float4(f.wy, f.wz, f.vex, f.vey);
     m.f32[2][lane] = make_float4(f.vez, f.aex, f.aey, f.aez);
     m.f32[3][lane] = make_float4(f.d_e, f.dprev_e, __int_as_float(fb), __int_as_float(vb));
+    m.f32[4][lane] = make_float4(f.roll32, f.pitch32, f.yaw32, 0.0f);
 }
 template <typename R> DN_DEV void take_mail(const Mail<R> &m, unsigned lane, Flight<R> &f, Verdict<R> &v)
 {
-    R x[DN_NFLIGHT64 + 1];
+    R x[DN_NMAIL64];
 #pragma unroll
-    for (int k = 0; k < DN_NFLIGHT64 + 1; ++k) x[k] = m.f64[k][lane];
-    f.px = x[0]; f.py = x[1]; f.pz = x[2]; f.qx = x[3]; f.qy = x[4]; f.qz = x[5]; f.qw = x[6];
-    v.d_obs = x[7];
-    const float4 a = m.f32[0][lane], b = m.f32[1][lane], c = m.f32[2][lane], d = m.f32[3][lane];
+    for (int k = 0; k < DN_NMAIL64; ++k) x[k] = m.f64[k][lane];
+    f.px = x[0]; f.py = x[1]; f.pz = x[2]; f.fwx = x[3]; f.fwy = x[4]; f.fwz = x[5];
+    v.d_obs = x[6];
+    f.qx = f.qy = f.qz = R(0.0); f.qw = R(1.0);      // the attitude itself stays on the flight wave
+    const float4 a = m.f32[0][lane], b = m.f32[1][lane], c = m.f32[2][lane], d = m.f32[3][lane], e = m.f32[4][lane];
+    f.roll32 = e.x; f.pitch32 = e.y; f.yaw32 = e.z;
     f.vx = a.x; f.vy = a.y; f.vz = a.z; f.wx = a.w; f.wy = b.x; f.wz = b.y; f.vex = b.z; f.vey = b.w;
     f.vez = c.x; f.aex = c.y; f.aey = c.z; f.aez = c.w; f.d_e = d.x; f.dprev_e = d.y;
     const int bits = __float_as_int(d.z), vb = __float_as_int(d.w);
     f.idx_e = bits & 0xFF; f.just_found_e = (bits >> 8) & 1; f.truncated = (bits >> 9) & 1;
     v.coll1 = vb & 1; v.terminated = (vb >> 1) & 1;
+}
+
+// The thrust of a step depends on the action alone, not on the state: the report wave computes it one step AHEAD
+// (thrust(t+1) during iteration t) and hands it over the same way, which moves a quarter of the flight wave's
+// work off the recurrence.  Double-buffered like the mail: iteration t writes tmail[(t+1) & 1] while the flight
+// wave reads tmail[t & 1].
+struct ThrustMail {
+    float4 f[DN_BLOCK];
+    float zt[DN_BLOCK];
+};
+DN_DEV void post_thrust(ThrustMail &m, unsigned lane, const Thrust &t)
+{
+    m.f[lane] = make_float4(t.f[0], t.f[1], t.f[2], t.f[3]);
+    m.zt[lane] = t.zt;
+}
+DN_DEV Thrust take_thrust(const ThrustMail &m, unsigned lane)
+{
+    const float4 f = m.f[lane];
+    Thrust t;
+    t.f[0] = f.x; t.f[1] = f.y; t.f[2] = f.z; t.f[3] = f.w;
+    t.zt = m.zt[lane];
+    return t;
 }
 
 template <typename R, bool NORM, bool NOISE, bool ONE, bool XOPT>
@@ -1234,6 +1274,8 @@ __global__ __launch_bounds__(2 * DN_BLOCK) void dn_step_many_2w_kernel(const DnP
     __shared__ R s_tab[DN_MAX_WAYPOINTS * DN_T_STRIDE];
     __shared__ __attribute__((aligned(16))) float s_tile[DN_BLOCK * DN_OBS_DIM];
     __shared__ Mail<R> mail[2];
+    __shared__ __attribute__((aligned(16))) ThrustMail tmail[2];
+    constexpr bool THRUST_AHEAD = !XOPT;        // the XOPT thrust carries float64 forces and the rpm: it stays on the flight wave
     const unsigned lane = threadIdx.x & (DN_BLOCK - 1);
     const bool report_wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) != 0;    // wave-uniform role
     const long long tile_base = (long long)blockIdx.x * DN_BLOCK;
@@ -1256,9 +1298,22 @@ __global__ __launch_bounds__(2 * DN_BLOCK) void dn_step_many_2w_kernel(const DnP
         if (NORM) load_rms(p, i, rms);
         RewNorm rn = {0.0, 0.0, 1.0, 1e-4};
         if (XOPT && p.norm_rew) load_rewnorm(p, i, rn);
-        block_lds_barrier();                                               // P: table published
+        const float4 *act = reinterpret_cast<const float4 *>(io0.actions) + tile_base;
+        float4 A = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (THRUST_AHEAD) {
+            A = act[li];
+            const float4 A1 = (act + (long long)(k_steps > 1 ? 1 : 0) * n)[li];
+            post_thrust(tmail[0], lane, thrust_phase<NOISE>(p, gid, (unsigned)sc0, A));
+            A = A1;
+        }
+        block_lds_barrier();                                               // P: table and thrust(0) published
 #pragma clang loop unroll(disable)
         for (int t = 0; t <= k_steps; ++t) {
+            if (THRUST_AHEAD && t + 1 < k_steps) {                         // thrust(t+1), for the flight wave's next iteration
+                const float4 A_next = (act + (long long)(t + 2 < k_steps ? t + 2 : t + 1) * n)[li];
+                post_thrust(tmail[(t + 1) & 1], lane, thrust_phase<NOISE>(p, gid, (unsigned)sc0 + (unsigned)(t + 1), A));
+                A = A_next;
+            }
             if (t > 0) {                                                   // the step the flight wave finished last iteration
                 const int u = t - 1;
                 const unsigned sc = (unsigned)sc0 + (unsigned)u;
@@ -1286,20 +1341,27 @@ __global__ __launch_bounds__(2 * DN_BLOCK) void dn_step_many_2w_kernel(const DnP
         if (active) { b.g4[li] = G4; b.g5[li] = G5; }
     } else {
         const float4 *act = reinterpret_cast<const float4 *>(io0.actions) + tile_base;
-        float4 A = act[li];
+        float4 A = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (!THRUST_AHEAD) A = act[li];
         float4 G0 = b.g0[li], G1 = b.g1[li], G2 = b.g2[li], G3 = b.g3[li];
         float4 G7 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (XOPT && p.drag) G7 = b.g7[li];
         block_lds_barrier();                                               // P
 #pragma clang loop unroll(disable)
         for (int t = 0; t < k_steps; ++t) {
-            // prefetch the next step's action while this step computes
-            const float4 A_next = (act + (long long)(t + 1 < k_steps ? t + 1 : t) * n)[li];
-            float4 rpm_now;
-            const Flight<R> fl = fly<R, NOISE, XOPT>(p, gid, (unsigned)sc0 + (unsigned)t, A, G0, G1, G2, G3, G7, rpm_now);
+            float4 rpm_now = make_float4(0.0f, 0.0f, 0.0f, 0.0f), A_next = A;
+            Flight<R> fl;
+            if (THRUST_AHEAD) {
+                fl = physics_phase<R>(take_thrust(tmail[t & 1], lane), G0, G1, G2, G3, p.max_steps);
+            } else {
+                // prefetch the next step's action while this step computes
+                A_next = (act + (long long)(t + 1 < k_steps ? t + 1 : t) * n)[li];
+                fl = fly<R, NOISE, XOPT>(p, gid, (unsigned)sc0 + (unsigned)t, A, G0, G1, G2, G3, G7, rpm_now);
+            }
             const float4 G0e = G0, G3e = G3;
             const Verdict<R> v = rules_phase<R>(p, c, s_tab, fl, G0e, G3e, b.g6, li, active, G0, G1, G2, G3);
             if (XOPT && p.drag) G7 = (v.terminated || fl.truncated) ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : rpm_now;
+            attitude_phase<R>(fl);
             post_mail<R>(mail[t & 1], lane, fl, v);
             block_lds_barrier();                                           // barrier t
             A = A_next;
