@@ -618,7 +618,8 @@ struct Thrust {
 template <typename R> struct Flight {
     R px, py, pz, qx, qy, qz, qw;                            // post-physics pose (before any reset): feeds compares, stays R
     R fwx, fwy, fwz;                                         // get_forward_vector of that pose (attitude_phase): feeds a compare, stays R
-    float roll32, pitch32, yaw32;                            // p.getEulerFromQuaternion of that pose: observation columns only
+    float roll_num32, roll_den32, pitch32, yaw32;            // p.getEulerFromQuaternion of that pose (observation columns only);
+                                                             // the roll's atan2 is left to the report wave, which has the slack
     float vx, vy, vz, wx, wy, wz;                            // post-physics velocities as they go back to HBM (float32):
                                                              // the report wave only turns them into observation columns
     float vex, vey, vez, aex, aey, aez;                      // entry velocities = current_vel / current_ang_v (quirk Q4), float32 state
@@ -875,7 +876,7 @@ DN_DEV void attitude_phase(Flight<R> &fl)
     // p.getEulerFromQuaternion [3P-recall of pybullet.c].  The three angles only feed observation columns 3..5
     // (float32, bar 1e-5): the quaternion products are formed in R, the inverse trigonometry runs in float32
     // (atan2f ~1e-7 rad).  The forward vector feeds a compare and stays in R.
-    float roll32, pitch32, yaw32;
+    float roll_num32, roll_den32, pitch32, yaw32;
     R fwx, fwy, fwz;
     {
         const R sqx = qx * qx, sqy = qy * qy, sqz = qz * qz, squ = qw * qw;
@@ -883,14 +884,14 @@ DN_DEV void attitude_phase(Flight<R> &fl)
         const R ys = R(2.0) * (qx * qy + qw * qz), yc = squ + sqx - sqy - sqz;
         if (sarg <= R(-0.99999) || sarg >= R(0.99999)) {       // gimbal-lock branches: rare, keep them literal
             R pitch, yaw;
-            roll32 = 0.0f;
+            roll_num32 = 0.0f; roll_den32 = 1.0f;             // roll = 0 = atan2(0, 1)
             if (sarg < R(0.0)) { pitch = R(-0.5) * K<R>::PI; yaw = R(2.0) * atan2(qx, -qy); }
             else { pitch = R(0.5) * K<R>::PI; yaw = R(2.0) * atan2(-qx, qy); }
             const R cpit = cos(pitch);
             fwx = cos(yaw) * cpit; fwy = sin(yaw) * cpit; fwz = sin(pitch);
             pitch32 = (float)pitch; yaw32 = (float)yaw;
         } else {
-            roll32 = atan2_fast32((float)(R(2.0) * (qy * qz + qw * qx)), (float)(squ - sqx - sqy + sqz));
+            roll_num32 = (float)(R(2.0) * (qy * qz + qw * qx)); roll_den32 = (float)(squ - sqx - sqy + sqz);
             yaw32 = atan2_fast32((float)ys, (float)yc);
             // asin(s) is ill-conditioned towards +-1; cos(pitch) = |(r00, r10)| = sqrt(yc^2 + ys^2) for the unit quaternion
             // of Flight, so pitch = atan2(s, cos pitch) is well conditioned everywhere (tumbling drones sit beyond
@@ -899,7 +900,7 @@ DN_DEV void attitude_phase(Flight<R> &fl)
             fwx = yc; fwy = ys; fwz = sarg;
         }
     }
-    fl.roll32 = roll32; fl.pitch32 = pitch32; fl.yaw32 = yaw32;
+    fl.roll_num32 = roll_num32; fl.roll_den32 = roll_den32; fl.pitch32 = pitch32; fl.yaw32 = yaw32;
     fl.fwx = fwx; fl.fwy = fwy; fl.fwz = fwz;
 }
 
@@ -918,7 +919,7 @@ DN_DEV Observed<R> observe_phase(const DnParams &p, const DnConsts<R> &c, const 
 {
 #pragma clang fp contract(fast)
     Observed<R> ob;
-    const float roll32 = fl.roll32, pitch32 = fl.pitch32, yaw32 = fl.yaw32;    // attitude_phase (flight wave)
+    const float roll32 = atan2_fast32(fl.roll_num32, fl.roll_den32), pitch32 = fl.pitch32, yaw32 = fl.yaw32;    // attitude_phase (flight wave)
     const R fwx = fl.fwx, fwy = fl.fwy, fwz = fl.fwz;
     // _computeObs (PBDroneEnv.py:296-336, :338-398), stale distance d_e (quirk Q1).  The reference clips position /
     // yaw / distance columns to the float32 range before the cast (:326); positions are bounded by the aviary box
@@ -1226,7 +1227,7 @@ template <typename R> DN_DEV void post_mail(Mail<R> &m, unsigned lane, const Fli
     m.f32[1][lane] = make_float4(f.wy, f.wz, f.vex, f.vey);
     m.f32[2][lane] = make_float4(f.vez, f.aex, f.aey, f.aez);
     m.f32[3][lane] = make_float4(f.d_e, f.dprev_e, __int_as_float(fb), __int_as_float(vb));
-    m.f32[4][lane] = make_float4(f.roll32, f.pitch32, f.yaw32, 0.0f);
+    m.f32[4][lane] = make_float4(f.roll_num32, f.roll_den32, f.pitch32, f.yaw32);
 }
 template <typename R> DN_DEV void take_mail(const Mail<R> &m, unsigned lane, Flight<R> &f, Verdict<R> &v)
 {
@@ -1237,7 +1238,7 @@ template <typename R> DN_DEV void take_mail(const Mail<R> &m, unsigned lane, Fli
     v.d_obs = x[6];
     f.qx = f.qy = f.qz = R(0.0); f.qw = R(1.0);      // the attitude itself stays on the flight wave
     const float4 a = m.f32[0][lane], b = m.f32[1][lane], c = m.f32[2][lane], d = m.f32[3][lane], e = m.f32[4][lane];
-    f.roll32 = e.x; f.pitch32 = e.y; f.yaw32 = e.z;
+    f.roll_num32 = e.x; f.roll_den32 = e.y; f.pitch32 = e.z; f.yaw32 = e.w;
     f.vx = a.x; f.vy = a.y; f.vz = a.z; f.wx = a.w; f.wy = b.x; f.wz = b.y; f.vex = b.z; f.vey = b.w;
     f.vez = c.x; f.aex = c.y; f.aey = c.z; f.aez = c.w; f.d_e = d.x; f.dprev_e = d.y;
     const int bits = __float_as_int(d.z), vb = __float_as_int(d.w);
