@@ -957,3 +957,36 @@ def test_physics_options_match_oracle(physics, act):
     for k in sa.dtype.names:
         assert np.array_equal(sa[k], sb[k]), k
     env.close(); twin.close()
+
+
+def test_nan_actions_propagate_like_numpy():
+    """np.clip and sqrt hand a NaN action through to the rotor force (the v_med3 clips of the kernel would not): the
+    poisoned drones must carry NaN observations / rewards exactly where the oracle does, never terminate on a NaN
+    compare, get truncated at max_steps and come back clean after the auto-reset; their neighbours are untouched."""
+    track = _tracks().reaching()
+    n = 256
+    env, ora = make_pair(track, n, f32_state=True, max_steps=8, normalize_obs=False)
+    env.reset()
+    ora.reset()
+    rng = np.random.default_rng(3)
+    dev = torch.device("cuda:0")
+    poisoned = np.zeros(n, bool)
+    poisoned[[5, 77, 200]] = True
+    saw_nan = saw_clean_again = False
+    for t in range(24):
+        a = (0.0922 + 0.003 * rng.standard_normal((n, 4))).astype(np.float32)
+        if t == 1:
+            a[5, 2] = np.nan
+            a[77, :] = np.nan
+            a[200, 0] = np.nan
+        out = env.step_tensor(torch.from_numpy(a).to(dev))
+        ref = ora.step(a)
+        compare_step(out, ref, f"nan t={t}", rew_atol=1e-4)
+        obs = out[0].cpu().numpy()
+        bad = np.isnan(obs).any(axis=1)
+        assert np.array_equal(bad, np.isnan(ref["obs"]).any(axis=1))
+        assert not bad[~poisoned].any()
+        saw_nan |= bool(bad[poisoned].all())
+        saw_clean_again |= saw_nan and not bad.any()
+    assert saw_nan and saw_clean_again
+    env.close()
