@@ -58,8 +58,8 @@ def main(d):
             out.append(f"  read  = 2 x FETCH_SIZE = {2 * f * 1024 / 1e6:.3f} MB   (gfx950 wide-load correction x2)")
             out.append(f"  write =     WRITE_SIZE = {w * 1024 / 1e6:.3f} MB")
             out.append(f"  total = {hbm / 1e6:.3f} MB per launch")
-    out.append("\n(dn_step_many_Nw_kernel<R, NORM, NOISE, ONE, REW>: N = waves per 64 drones; ONE = true is the single-step launch "
-               "dn_step, ONE = false the fused K-step launch dn_step_many; REW = reward wrappers compiled in)")
+    out.append("\n(dn_step_many_Nw_kernel<R, NORM, NOISE, ONE, XOPT>: N = waves per 64 drones; ONE = true is the single-step launch "
+               "dn_step, ONE = false the fused K-step launch dn_step_many; XOPT = the rarely used options (reward wrappers, N4 physics terms, RPM actions) compiled in)")
     print("\n".join(out))
 
 
