@@ -379,10 +379,17 @@ def main():
         }
         if sharded is not None:
             line["ppo_rollout_sharded"] = sharded
+        # the two side legs must never cost the headline line: a failure is reported in place of the numbers
         if world == 1 and not args.no_ppo_rollout:
-            line["ppo_rollout"] = ppo_rollout(pkg, track, n, max_steps, dev, rank)
+            try:
+                line["ppo_rollout"] = ppo_rollout(pkg, track, n, max_steps, dev, rank)
+            except Exception as exc:  # noqa: BLE001
+                line["ppo_rollout"] = {"error": f"{type(exc).__name__}: {exc}"}
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(track, n, max_steps, args.cpu_baseline_seconds)
+            try:
+                line["cpu_baseline"] = cpu_baseline(track, n, max_steps, args.cpu_baseline_seconds)
+            except Exception as exc:  # noqa: BLE001
+                line["cpu_baseline"] = {"error": f"{type(exc).__name__}: {exc}"}
         print(json.dumps(line), flush=True)
     env.close()
     if dist is not None:
