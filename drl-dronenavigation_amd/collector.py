@@ -257,9 +257,11 @@ class FusedRolloutCollector:
         dn_mlp_forward (actor + critic, one launch; the value lands in the rollout buffer)
         dn_policy_sample (Gaussian sample from the environment's Philox streams, clip, log-probability -> buffer)
         dn_step (writes the next observation, the reward and the episode-start flag straight into the buffer slots)
-        dn_mlp_forward masked by `truncated` on the terminal observations + dn_add_bootstrap (SB3's TimeLimit bootstrap)
-
-    five launches per step instead of ~25 small torch kernels, then dn_gae; the whole rollout is captured into one
+    three launches per step instead of ~25 small torch kernels; then, once per rollout, SB3's TimeLimit bootstrap
+    (rewards[t] += gamma V(terminal_observation) where TimeLimit.truncated): the step kernel leaves the terminal
+    observations and truncation flags of all n_steps in the buffer, ONE dn_mlp_forward masked by those flags evaluates
+    the critic on the tiles that hold a truncated drone (the weights do not change inside a rollout, so this is the
+    value SB3 computes on the spot) and ONE dn_add_bootstrap adds it; then dn_gae.  The whole rollout is captured into one
     hipGraph on the second call (`use_graph`).  Same results contract as RolloutCollector (SB3 collect_rollouts
     semantics); the action noise comes from Philox (seed, global drone id, step counter), so a rollout is reproducible
     and independent of how the drones are sharded.  Call `policy.refresh()` after optimiser steps and `recapture()`
@@ -288,10 +290,12 @@ class FusedRolloutCollector:
             last_values=torch.empty((n, 1), dtype=f32, device=dev))
         self._mean = torch.empty((n, ACT_DIM), dtype=f32, device=dev)
         self._clipped = torch.empty((n, ACT_DIM), dtype=f32, device=dev)
-        self._trunc = torch.zeros(n, dtype=u8, device=dev)
+        self._trunc = torch.zeros((T, n), dtype=u8, device=dev)
         self._found = torch.zeros(n, dtype=torch.int32, device=dev)
-        self._term_obs = torch.zeros((n, OBS_DIM), dtype=f32, device=dev)
-        self._tv = torch.zeros((n, 1), dtype=f32, device=dev)
+        # terminal observations of every step of the rollout (rows are written where a drone finished; the rest is stale
+        # and never used: the masked forward and the bootstrap select by `truncated`)
+        self._term_obs = torch.zeros((T, n, OBS_DIM), dtype=f32, device=dev) if self.bootstrap_truncated else None
+        self._tv = torch.zeros((T * n, 1), dtype=f32, device=dev)
         self.buf["obs"][0].copy_(env.reset_tensor())
         self.num_timesteps = 0
         self._graph, self._calls = None, 0
@@ -313,12 +317,12 @@ class FusedRolloutCollector:
             _capi.check(lib.dn_policy_sample(h, self._mean.data_ptr(), log_std, self.seed, 0, b["actions"][t].data_ptr(),
                                              self._clipped.data_ptr(), b["log_probs"][t].data_ptr(), stream))
             _capi.check(lib.dn_step(h, self._clipped.data_ptr(), b["obs"][t + 1].data_ptr(), b["rewards"][t].data_ptr(),
-                                    b["episode_starts"][t + 1].data_ptr(), self._trunc.data_ptr(), self._found.data_ptr(),
-                                    self._term_obs.data_ptr() if self.bootstrap_truncated else None, None, None, None, stream))
-            if self.bootstrap_truncated:
-                mlp_forward([pol.vf], self._term_obs, [self._tv], row_mask=self._trunc)
-                _capi.check(lib.dn_add_bootstrap(b["rewards"][t].data_ptr(), self._tv.data_ptr(), self._trunc.data_ptr(),
-                                                 self.gamma, n, dev.index, stream))
+                                    b["episode_starts"][t + 1].data_ptr(), self._trunc[t].data_ptr(), self._found.data_ptr(),
+                                    self._term_obs[t].data_ptr() if self.bootstrap_truncated else None, None, None, None, stream))
+        if self.bootstrap_truncated:
+            mlp_forward([pol.vf], self._term_obs.view(T * n, -1), [self._tv], row_mask=self._trunc.view(T * n))
+            _capi.check(lib.dn_add_bootstrap(b["rewards"].data_ptr(), self._tv.data_ptr(), self._trunc.data_ptr(),
+                                             self.gamma, T * n, dev.index, stream))
         mlp_forward([pol.vf], b["obs"][T], [b["last_values"]])
         _capi.check(lib.dn_gae(b["rewards"].data_ptr(), b["values"].data_ptr(), b["episode_starts"].data_ptr(),
                                b["last_values"].data_ptr(), b["episode_starts"][T].data_ptr(), T, n, self.gamma,
