@@ -419,6 +419,33 @@ DN_DEV bool outside_segment_corridor(const DnConsts<R> &c, const R *tab, R px, R
     return (qx * qx + qy * qy + qz * qz) > lim;
 }
 
+// The table row of a drone's CURRENT waypoint, read at the top of a step (the index is part of the entry state) so
+// that the LDS round trip hides behind the physics instead of stalling the rules that need it.
+template <typename R> struct GateRow {
+    R wp[3], u[3], e1[3], lext, ll;
+};
+template <typename R> DN_DEV GateRow<R> load_gate_row(const R *tab, int idx)
+{
+    const R *e = tab + idx * DN_T_STRIDE;
+    GateRow<R> g;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { g.wp[j] = e[DN_T_WP + j]; g.u[j] = e[DN_T_U + j]; g.e1[j] = e[DN_T_E1 + j]; }
+    g.lext = e[DN_T_LEXT]; g.ll = e[DN_T_LL];
+    return g;
+}
+template <typename R>
+DN_DEV bool outside_segment_corridor_row(const DnConsts<R> &c, const GateRow<R> &g, R px, R py, R pz)
+{   // outside_segment_corridor on a row already in registers (same expressions, same bits)
+#pragma clang fp contract(fast)
+    const R ux = g.u[0], uy = g.u[1], uz = g.u[2];
+    const R dx = px - g.e1[0], dy = py - g.e1[1], dz = pz - g.e1[2];
+    R proj = dx * ux + dy * uy + dz * uz;
+    proj = clipv(proj, R(0.0), g.lext);
+    const R qx = dx - proj * ux, qy = dy - proj * uy, qz = dz - proj * uz;
+    const R lim = g.ll == R(0.0) ? c.thr2 : c.thr_ext2;
+    return (qx * qx + qy * qy + qz * qz) > lim;
+}
+
 // orientation_reward (PBDroneEnv.py:573-586) with get_forward_vector (:588-597).  The reference tests
 // arccos(clip(f . t, -1, 1)) > radians(10); arccos is strictly decreasing, so that is f . t < cos(10 deg)
 // (the clip cannot change the outcome because -1 < cos 10 deg < 1; NaN compares false on both forms).
@@ -680,7 +707,7 @@ DN_DEV Thrust thrust_phase(const DnParams &p, unsigned long long gid, unsigned s
 #pragma unroll
     for (int j = 0; j < 4; ++j) t.f[j] = rotor_force_from_action(a[j], p.normalize_actions != 0, tq[j], nullptr, false);
     // np.clip / sqrt propagate NaN, the v_med3 clips do not: one test per wave, the selects only where it fires
-    if (__ballot(__builtin_isunordered(a[0], a[1]) || __builtin_isunordered(a[2], a[3])) != 0ull) {
+    if (__builtin_expect(__ballot(__builtin_isunordered(a[0], a[1]) || __builtin_isunordered(a[2], a[3])) != 0ull, 0)) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             if (a[j] != a[j]) { t.f[j] = a[j]; tq[j] = a[j]; }
@@ -768,7 +795,7 @@ DN_DEV Flight<R> physics_phase(const TH &th, const float4 G0, const float4 G1, c
     // (thrust/weight = 5.5, damping), so test once per wave and clamp only then.  NaN stays NaN either way.
     const R mv = K<R>::MAX_COORD_VEL;
     const R big = fmax(fmax(fmax(fabs(wx), fabs(wy)), fmax(fabs(wz), fabs(vx))), fmax(fabs(vy), fabs(vz)));
-    if (big > mv) {
+    if (__builtin_expect(big > mv, 0)) {
         wx = clipv(wx, -mv, mv); wy = clipv(wy, -mv, mv); wz = clipv(wz, -mv, mv);
         vx = clipv(vx, -mv, mv); vy = clipv(vy, -mv, mv); vz = clipv(vz, -mv, mv);
     }
@@ -802,9 +829,9 @@ DN_DEV Flight<R> physics_phase(const TH &th, const float4 G0, const float4 G1, c
 // Only the segment corridor depends on the waypoint index, so the common part of the collision test runs once
 // and the segment test once per index that is actually needed.
 template <typename R>
-DN_DEV Verdict<R> rules_phase(const DnParams &p, const DnConsts<R> &c, const R *s_tab, const Flight<R> &fl,
-                              const float4 G0e, const float4 G3e, float4 *g6_blk, const unsigned li, const bool active,
-                              float4 &G0, float4 &G1, float4 &G2, float4 &G3)
+DN_DEV Verdict<R> rules_phase(const DnParams &p, const DnConsts<R> &c, const R *s_tab, const GateRow<R> &row_e, const R (&wp0)[3],
+                              const Flight<R> &fl, const float4 G0e, const float4 G3e, float4 *g6_blk, const unsigned li,
+                              const bool active, float4 &G0, float4 &G1, float4 &G2, float4 &G3)
 {
 #pragma clang fp contract(fast)
     const Meta m_e = unpack_meta(G3e.w);
@@ -814,7 +841,7 @@ DN_DEV Verdict<R> rules_phase(const DnParams &p, const DnConsts<R> &c, const R *
     int idx = m_e.idx, just_found = m_e.just_found;
     const bool seg_track = p.cylinder && !p.circle;
     const bool coll1 = collision_common<R>(p, c, px, py, pz, r22n) ||
-                       (seg_track && outside_segment_corridor<R>(c, s_tab, px, py, pz, idx));
+                       (seg_track && outside_segment_corridor_row<R>(c, row_e, px, py, pz));
     const bool found_now = (R)fl.d_e <= c.threshold;   // :539
     const bool last_gate = idx + 1 == p.num_waypoints;
     R d_prev = (R)fl.dprev_e;
@@ -836,8 +863,12 @@ DN_DEV Verdict<R> rules_phase(const DnParams &p, const DnConsts<R> &c, const R *
     R d = (R)fl.d_e;
     if (!terminated) {                                 // _update_state_post_step
         steps += 1;
-        const R *wp = s_tab + idx * DN_T_STRIDE;
-        const R ex = wp[0] - px, ey = wp[1] - py, ez = wp[2] - pz;
+        R wx = row_e.wp[0], wy = row_e.wp[1], wz = row_e.wp[2];
+        if (idx != m_e.idx) {                          // a gate was passed this step: the next waypoint (rare)
+            const R *wp = s_tab + idx * DN_T_STRIDE;
+            wx = wp[0]; wy = wp[1]; wz = wp[2];
+        }
+        const R ex = wx - px, ey = wy - py, ez = wz - pz;
         d = FM<R>::sqrt0(ex * ex + ey * ey + ez * ez);
     }
     Verdict<R> v;
@@ -852,14 +883,14 @@ DN_DEV Verdict<R> rules_phase(const DnParams &p, const DnConsts<R> &c, const R *
         if (done) {
             R cpx, cpy, cpz;
             if (!terminated) { cpx = px; cpy = py; cpz = pz; }            // post-step ran: it is the new position
-            else if (m_e.steps > 0) { cpx = G0e.x; cpy = G0e.y; cpz = G0e.z; }
+            else if (__builtin_expect(m_e.steps > 0, 1)) { cpx = G0e.x; cpy = G0e.y; cpz = G0e.z; }
             else { const float4 G6 = g6_blk[li]; cpx = G6.x; cpy = G6.y; cpz = G6.z; }
             if (active && !(terminated && m_e.steps == 0)) g6_blk[li] = make_float4((float)cpx, (float)cpy, (float)cpz, 0.0f);
             // freshly loaded body at the spawn pose, at rest
             S0 = make_float4((float)c.spawn[0], (float)c.spawn[1], (float)c.spawn[2], 0.0f);
             S1 = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
             S2 = S3 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            const R ex = cpx - s_tab[0], ey = cpy - s_tab[1], ez = cpz - s_tab[2];
+            const R ex = cpx - wp0[0], ey = cpy - wp0[1], ez = cpz - wp0[2];
             d = FM<R>::sqrt0(ex * ex + ey * ey + ez * ez);                // :651
             d_prev = d;                                                   // :652
             idx = 0; steps = 0; just_found = 0;
@@ -885,7 +916,7 @@ DN_DEV void attitude_phase(Flight<R> &fl)
         const R sqx = qx * qx, sqy = qy * qy, sqz = qz * qz, squ = qw * qw;
         const R sarg = R(-2.0) * (qx * qz - qw * qy);
         const R ys = R(2.0) * (qx * qy + qw * qz), yc = squ + sqx - sqy - sqz;
-        if (sarg <= R(-0.99999) || sarg >= R(0.99999)) {       // gimbal-lock branches: rare, keep them literal
+        if (__builtin_expect(sarg <= R(-0.99999) || sarg >= R(0.99999), 0)) {   // gimbal-lock branches: rare, keep them literal (and out of line)
             R pitch, yaw;
             roll_num32 = 0.0f; roll_den32 = 1.0f;             // roll = 0 = atan2(0, 1)
             if (sarg < R(0.0)) { pitch = R(-0.5) * K<R>::PI; yaw = R(2.0) * atan2(qx, -qy); }
@@ -1170,6 +1201,7 @@ __global__ __launch_bounds__(DN_BLOCK) void dn_step_many_1w_kernel(const DnParam
     block_lds_barrier();
     const long long n = p.n, words = (p.n + 63) / 64;
     const unsigned long long sc0 = p.st.stats[blockIdx.x].step_count;      // this tile's vector-step counter
+    const R wp0[3] = {s_tab[DN_T_WP], s_tab[DN_T_WP + 1], s_tab[DN_T_WP + 2]};   // waypoint 0: every reset measures against it
     StatAcc acc;
     Rms rms;
     if (NORM) load_rms(p, i, rms);
@@ -1182,9 +1214,10 @@ __global__ __launch_bounds__(DN_BLOCK) void dn_step_many_1w_kernel(const DnParam
         const StepOut out = block_out(io0, tile_base, (long long)t * n, (long long)t * words);
         const unsigned sc = (unsigned)sc0 + (unsigned)t;
         float4 rpm_now;
+        const GateRow<R> row_e = load_gate_row<R>(s_tab, unpack_meta(G3.w).idx);
         Flight<R> fl = fly<R, NOISE, XOPT>(p, gid, sc, A, G0, G1, G2, G3, G7, rpm_now);
         const float4 G0e = G0, G3e = G3;
-        const Verdict<R> v = rules_phase<R>(p, c, s_tab, fl, G0e, G3e, b.g6, li, active, G0, G1, G2, G3);
+        const Verdict<R> v = rules_phase<R>(p, c, s_tab, row_e, wp0, fl, G0e, G3e, b.g6, li, active, G0, G1, G2, G3);
         if (XOPT && p.drag) G7 = (v.terminated || fl.truncated) ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : rpm_now;   // BaseAviary.py:442,545
         attitude_phase<R>(fl);
         Observed<R> ob = observe_phase<R, NORM, NOISE>(p, c, s_tab, fl, G4, G5, gid, sc, rms);
@@ -1351,9 +1384,11 @@ __global__ __launch_bounds__(2 * DN_BLOCK) void dn_step_many_2w_kernel(const DnP
         float4 G7 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (XOPT && p.drag) G7 = b.g7[li];
         block_lds_barrier();                                               // P
+        const R wp0[3] = {s_tab[DN_T_WP], s_tab[DN_T_WP + 1], s_tab[DN_T_WP + 2]};   // waypoint 0: every reset measures against it
 #pragma clang loop unroll(disable)
         for (int t = 0; t < k_steps; ++t) {
             float4 rpm_now = make_float4(0.0f, 0.0f, 0.0f, 0.0f), A_next = A;
+            const GateRow<R> row_e = load_gate_row<R>(s_tab, unpack_meta(G3.w).idx);
             Flight<R> fl;
             if (THRUST_AHEAD) {
                 fl = physics_phase<R>(take_thrust(tmail[t & 1], lane), G0, G1, G2, G3, p.max_steps);
@@ -1363,7 +1398,7 @@ __global__ __launch_bounds__(2 * DN_BLOCK) void dn_step_many_2w_kernel(const DnP
                 fl = fly<R, NOISE, XOPT>(p, gid, (unsigned)sc0 + (unsigned)t, A, G0, G1, G2, G3, G7, rpm_now);
             }
             const float4 G0e = G0, G3e = G3;
-            const Verdict<R> v = rules_phase<R>(p, c, s_tab, fl, G0e, G3e, b.g6, li, active, G0, G1, G2, G3);
+            const Verdict<R> v = rules_phase<R>(p, c, s_tab, row_e, wp0, fl, G0e, G3e, b.g6, li, active, G0, G1, G2, G3);
             if (XOPT && p.drag) G7 = (v.terminated || fl.truncated) ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : rpm_now;
             attitude_phase<R>(fl);
             post_mail<R>(mail[t & 1], lane, fl, v);
