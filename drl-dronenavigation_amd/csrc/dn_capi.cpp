@@ -234,15 +234,21 @@ int32_t dn_create(const dn_config *cfg, dn_env **out)
     e->cfg = *cfg;
     const long long n = cfg->num_envs;
     e->blocks = (n + DN_BLOCK - 1) / DN_BLOCK;
-    // Measured on MI355X (profiles/r01_f_sweep_shapes.txt): the fused K-step kernel is instruction-issue bound, and
-    // two waves per tile win while the tiles alone leave SIMDs idle (<= 1024 tiles = 65536 drones on 1024 SIMDs);
-    // the single-step launch is latency bound (launch + load round trip) and one wave is never slower.
-    // DN_WAVES=1|2 forces one shape for every launch (A/B measurements, the bit-identity test).
-    e->waves_fused = e->blocks <= DN_TWO_WAVE_MAX_TILES ? 2 : 1;
+    // Measured on MI355X (profiles/r01_r_sweep_shapes.txt): the fused K-step kernel is bound by the dependent
+    // instruction stream of a wave, and two or three waves per tile win while the tiles alone leave SIMDs idle
+    // (<= 1024 tiles = 65536 drones on 1024 SIMDs); the single-step launch is latency bound (launch + load round
+    // trip) and one wave is never slower.  DN_WAVES=1|2|3 forces a shape (A/B measurements, the bit-identity test).
+    // The three-wave shape (flight / aux / report) exists for plain fused launches: no normaliser, no XOPT options.
+    const bool plain = !cfg->normalize_obs && !cfg->clip_rew && !cfg->norm_rew && cfg->physics == 0 && cfg->action_type == 0;
+    e->waves_fused = e->blocks <= DN_TWO_WAVE_MAX_TILES ? (plain ? 3 : 2) : 1;
     e->waves_single = 1;
     if (const char *w = getenv("DN_WAVES")) {
         if (w[0] == '1') e->waves_fused = e->waves_single = 1;
         else if (w[0] == '2') e->waves_fused = e->waves_single = 2;
+        else if (w[0] == '3') {
+            e->waves_fused = plain ? 3 : 2;
+            e->waves_single = 1;
+        }
     }
     const int drag = cfg->physics == 2 || cfg->physics == 4;
     const Layout L = make_layout(n, cfg->normalize_obs, cfg->norm_rew, drag);
@@ -342,7 +348,7 @@ int32_t dn_step(dn_env *env, const float *actions, float *obs, float *reward, ui
     io.actions = actions; io.obs = obs; io.reward = reward; io.done = done; io.truncated = truncated;
     io.found_targets = found_targets; io.terminal_obs = terminal_obs; io.ep_return = ep_return;
     io.ep_length = ep_length; io.done_mask = (unsigned long long *)done_mask;
-    DN_HIP(dn_launch_step_many(env->p, io, 1, env->cfg.compute_f32 != 0, env->waves_single == 2, (hipStream_t)stream));
+    DN_HIP(dn_launch_step_many(env->p, io, 1, env->cfg.compute_f32 != 0, env->waves_single, (hipStream_t)stream));
     return DN_OK;
 }
 
@@ -367,7 +373,7 @@ int32_t dn_step_many(dn_env *env, int64_t k, const float *actions, float *obs, f
     io.actions = actions; io.obs = obs; io.reward = reward; io.done = done; io.truncated = truncated;
     io.found_targets = found_targets; io.terminal_obs = terminal_obs; io.ep_return = ep_return;
     io.ep_length = ep_length; io.done_mask = (unsigned long long *)done_mask;
-    DN_HIP(dn_launch_step_many(env->p, io, (int)k, env->cfg.compute_f32 != 0, env->waves_fused == 2, (hipStream_t)stream));
+    DN_HIP(dn_launch_step_many(env->p, io, (int)k, env->cfg.compute_f32 != 0, env->waves_fused, (hipStream_t)stream));
     return DN_OK;
 }
 

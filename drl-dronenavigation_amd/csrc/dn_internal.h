@@ -99,7 +99,7 @@ struct DnParams {
     DnConsts<float> c32;
 };
 
-hipError_t dn_launch_step_many(const DnParams &p, const DnStepIO &io, int k, bool f32, bool two_wave, hipStream_t stream);
+hipError_t dn_launch_step_many(const DnParams &p, const DnStepIO &io, int k, bool f32, int waves, hipStream_t stream);
 hipError_t dn_launch_reset(const DnParams &p, float *obs, bool f32, hipStream_t stream);
 hipError_t dn_launch_gae(const float *rewards, const float *values, const uint8_t *dones,
                          const float *last_values, const uint8_t *last_dones, long long T, long long N,

@@ -1410,6 +1410,183 @@ __global__ __launch_bounds__(2 * DN_BLOCK) void dn_step_many_2w_kernel(const DnP
     }
 }
 
+// -----------------------------------------------------------------------------------------------------
+// Three-wave kernel (fused launches without the normaliser / the XOPT options): the side work is cut once more, so
+// that the recurrence (physics + rules) is alone on its wave and every SIMD of a CU has more than one wave's worth of
+// independent instructions to pick from.  192 threads = flight (0..63) + aux (64..127) + report (128..191):
+//
+//   flight, iteration t:  thrust(t) from the aux wave | physics(t) | rules(t)            -> MailQ[t & 1]      == barrier t ==
+//   aux,    iteration t:  thrust(t+1) -> tmail | MailQ[(t-1) & 1] -> attitude(t-1) | observe(t-1) -> MailA[(t-1) & 1]
+//   report, iteration t:  MailA[(t-2) & 1] -> report(t-2), streams the observation tile of step t-3
+//
+// The aux wave keeps prev_vel / prev_ang_v (the .xyz of g4 / g5: what the smoothness term reads), the report wave the
+// Monitor accumulators (the .w of g4 / g5).  Same functions, same typed values across LDS: bit-identical to the others.
+// -----------------------------------------------------------------------------------------------------
+template <typename R> struct MailQ {      // flight -> aux: the post-physics pose with the attitude quaternion
+    R f64[8][DN_BLOCK];                   // position (3), quaternion (4), Verdict.d_obs
+    float4 f32[4][DN_BLOCK];
+};
+template <typename R> DN_DEV void post_mailq(MailQ<R> &m, unsigned lane, const Flight<R> &f, const Verdict<R> &v)
+{
+    const R x[8] = {f.px, f.py, f.pz, f.qx, f.qy, f.qz, f.qw, v.d_obs};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) m.f64[k][lane] = x[k];
+    const int fb = f.idx_e | (f.just_found_e << 8) | (f.truncated << 9), vb = v.coll1 | (v.terminated << 1);
+    m.f32[0][lane] = make_float4(f.vx, f.vy, f.vz, f.wx);
+    m.f32[1][lane] = make_float4(f.wy, f.wz, f.vex, f.vey);
+    m.f32[2][lane] = make_float4(f.vez, f.aex, f.aey, f.aez);
+    m.f32[3][lane] = make_float4(f.d_e, f.dprev_e, __int_as_float(fb), __int_as_float(vb));
+}
+template <typename R> DN_DEV void take_mailq(const MailQ<R> &m, unsigned lane, Flight<R> &f, Verdict<R> &v)
+{
+    R x[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) x[k] = m.f64[k][lane];
+    f.px = x[0]; f.py = x[1]; f.pz = x[2]; f.qx = x[3]; f.qy = x[4]; f.qz = x[5]; f.qw = x[6];
+    v.d_obs = x[7];
+    const float4 a = m.f32[0][lane], b = m.f32[1][lane], c = m.f32[2][lane], d = m.f32[3][lane];
+    f.vx = a.x; f.vy = a.y; f.vz = a.z; f.wx = a.w; f.wy = b.x; f.wz = b.y; f.vex = b.z; f.vey = b.w;
+    f.vez = c.x; f.aex = c.y; f.aey = c.z; f.aez = c.w; f.d_e = d.x; f.dprev_e = d.y;
+    const int bits = __float_as_int(d.z), vb = __float_as_int(d.w);
+    f.idx_e = bits & 0xFF; f.just_found_e = (bits >> 8) & 1; f.truncated = (bits >> 9) & 1;
+    v.coll1 = vb & 1; v.terminated = (vb >> 1) & 1;
+}
+template <typename R> struct MailA {      // aux -> report: the observation, the reward candidates and what the verdict needs
+    R f64[2][DN_BLOCK];                   // Observed.r_normal, Verdict.d_obs
+    float4 f32[4][DN_BLOCK];              // o[0..11], then (o[12], r_found32, d_e, flag word)
+};
+template <typename R> DN_DEV void post_maila(MailA<R> &m, unsigned lane, const Flight<R> &f, const Verdict<R> &v, const Observed<R> &ob)
+{
+    m.f64[0][lane] = ob.r_normal; m.f64[1][lane] = v.d_obs;
+    const int bits = f.idx_e | (f.truncated << 9) | (v.coll1 << 10) | (v.terminated << 11);
+    m.f32[0][lane] = make_float4(ob.o[0], ob.o[1], ob.o[2], ob.o[3]);
+    m.f32[1][lane] = make_float4(ob.o[4], ob.o[5], ob.o[6], ob.o[7]);
+    m.f32[2][lane] = make_float4(ob.o[8], ob.o[9], ob.o[10], ob.o[11]);
+    m.f32[3][lane] = make_float4(ob.o[12], ob.r_found32, f.d_e, __int_as_float(bits));
+}
+template <typename R> DN_DEV void take_maila(const MailA<R> &m, unsigned lane, Flight<R> &f, Verdict<R> &v, Observed<R> &ob)
+{
+    ob.r_normal = m.f64[0][lane]; v.d_obs = m.f64[1][lane];
+    const float4 a = m.f32[0][lane], b = m.f32[1][lane], c = m.f32[2][lane], d = m.f32[3][lane];
+    ob.o[0] = a.x; ob.o[1] = a.y; ob.o[2] = a.z; ob.o[3] = a.w; ob.o[4] = b.x; ob.o[5] = b.y; ob.o[6] = b.z; ob.o[7] = b.w;
+    ob.o[8] = c.x; ob.o[9] = c.y; ob.o[10] = c.z; ob.o[11] = c.w; ob.o[12] = d.x;
+    ob.r_found32 = d.y; f.d_e = d.z;
+    const int bits = __float_as_int(d.w);
+    f.idx_e = bits & 0xFF; f.truncated = (bits >> 9) & 1; v.coll1 = (bits >> 10) & 1; v.terminated = (bits >> 11) & 1;
+    f.vex = f.vey = f.vez = f.aex = f.aey = f.aez = 0.0f;     // prev_vel / prev_ang_v live on the aux wave
+}
+
+template <typename R, bool NOISE>
+__global__ __launch_bounds__(3 * DN_BLOCK) void dn_step_many_3w_kernel(const DnParams p, const DnStepIO io0, const int k_steps)
+{
+    __shared__ R s_tab[DN_MAX_WAYPOINTS * DN_T_STRIDE];
+    __shared__ __attribute__((aligned(16))) float s_tile[DN_BLOCK * DN_OBS_DIM];
+    __shared__ MailQ<R> mailq[2];
+    __shared__ MailA<R> maila[2];
+    __shared__ __attribute__((aligned(16))) ThrustMail tmail[2];
+    const unsigned lane = threadIdx.x & (DN_BLOCK - 1);
+    const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // 0 flight, 1 aux, 2 report (wave-uniform)
+    const long long tile_base = (long long)blockIdx.x * DN_BLOCK;
+    const long long left = p.n - tile_base;
+    const unsigned rows = left < DN_BLOCK ? (unsigned)left : DN_BLOCK;
+    const bool active = lane < rows;
+    const unsigned li = active ? lane : rows - 1;
+    __builtin_assume(li < DN_BLOCK);
+    const long long i = tile_base + li;
+    const unsigned long long gid = (unsigned long long)(p.env_id_offset + i);
+    const BlockState b = block_state(p.st, tile_base);
+    const DnConsts<R> &c = consts<R>(p);
+    const long long n = p.n, words = (p.n + 63) / 64;
+    const unsigned long long sc0 = p.st.stats[blockIdx.x].step_count;
+    stage_table<R>(p, s_tab);
+    // every wave passes barrier P and the barriers of iterations 0 .. k_steps (k_steps + 1 of them)
+    if (role == 0) {
+        float4 G0 = b.g0[li], G1 = b.g1[li], G2 = b.g2[li], G3 = b.g3[li];
+        block_lds_barrier();                                               // P
+        const R wp0[3] = {s_tab[DN_T_WP], s_tab[DN_T_WP + 1], s_tab[DN_T_WP + 2]};
+#pragma clang loop unroll(disable)
+        for (int t = 0; t <= k_steps; ++t) {
+            if (t < k_steps) {
+                const GateRow<R> row_e = load_gate_row<R>(s_tab, unpack_meta(G3.w).idx);
+                const Flight<R> fl = physics_phase<R>(take_thrust(tmail[t & 1], lane), G0, G1, G2, G3, p.max_steps);
+                const float4 G0e = G0, G3e = G3;
+                const Verdict<R> v = rules_phase<R>(p, c, s_tab, row_e, wp0, fl, G0e, G3e, b.g6, li, active, G0, G1, G2, G3);
+                post_mailq<R>(mailq[t & 1], lane, fl, v);
+            }
+            block_lds_barrier();                                           // barrier t
+        }
+        if (active) { b.g0[li] = G0; b.g1[li] = G1; b.g2[li] = G2; b.g3[li] = G3; }
+    } else if (role == 1) {
+        float4 P4 = b.g4[li], P5 = b.g5[li];                               // .xyz: prev_vel, prev_ang_v
+        Rms rms;                                                           // NORM = false: never touched
+        const float4 *act = reinterpret_cast<const float4 *>(io0.actions) + tile_base;
+        float4 A = act[li];
+        {
+            const float4 A1 = (act + (long long)(k_steps > 1 ? 1 : 0) * n)[li];
+            post_thrust(tmail[0], lane, thrust_phase<NOISE>(p, gid, (unsigned)sc0, A));
+            A = A1;
+        }
+        block_lds_barrier();                                               // P: table and thrust(0) published
+#pragma clang loop unroll(disable)
+        for (int t = 0; t <= k_steps; ++t) {
+            if (t + 1 < k_steps) {                                         // thrust(t+1), for the flight wave's next iteration
+                const float4 A_next = (act + (long long)(t + 2 < k_steps ? t + 2 : t + 1) * n)[li];
+                post_thrust(tmail[(t + 1) & 1], lane, thrust_phase<NOISE>(p, gid, (unsigned)sc0 + (unsigned)(t + 1), A));
+                A = A_next;
+            }
+            if (t > 0) {                                                   // the step the flight wave finished last iteration
+                const int u = t - 1;
+                Flight<R> fl;
+                Verdict<R> v;
+                take_mailq<R>(mailq[u & 1], lane, fl, v);
+                attitude_phase<R>(fl);
+                const Observed<R> ob = observe_phase<R, false, NOISE>(p, c, s_tab, fl, P4, P5, gid, (unsigned)sc0 + (unsigned)u, rms);
+                post_maila<R>(maila[u & 1], lane, fl, v, ob);
+                // prev_vel / prev_ang_v: _update_state_post_step (skipped on a terminated step, quirk Q5), zero after a reset
+                if (!v.terminated) { P4 = make_float4(fl.vex, fl.vey, fl.vez, 0.0f); P5 = make_float4(fl.aex, fl.aey, fl.aez, 0.0f); }
+                if (v.terminated || fl.truncated) P4 = P5 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+            block_lds_barrier();                                           // barrier t
+        }
+        if (active) {
+            float *g4 = reinterpret_cast<float *>(b.g4 + li), *g5 = reinterpret_cast<float *>(b.g5 + li);
+            g4[0] = P4.x; g4[1] = P4.y; g4[2] = P4.z; g5[0] = P5.x; g5[1] = P5.y; g5[2] = P5.z;
+        }
+    } else {
+        float4 G4 = b.g4[li], G5 = b.g5[li];                               // .w: Monitor return / length
+        StatAcc acc;
+        Rms rms;
+        RewNorm rn = {0.0, 0.0, 1.0, 1e-4};
+        block_lds_barrier();                                               // P
+#pragma clang loop unroll(disable)
+        for (int t = 0; t <= k_steps + 1; ++t) {
+            if (t > 1) {                                                   // the step the aux wave finished last iteration
+                const int u = t - 2;
+                const unsigned sc = (unsigned)sc0 + (unsigned)u;
+                TileRegs tile;
+                if (u > 0) tile = tile_fetch(s_tile, lane);
+                Flight<R> fl;
+                Verdict<R> v;
+                Observed<R> ob;
+                take_maila<R>(maila[u & 1], lane, fl, v, ob);
+                if (u > 0) tile_stream(tile, s_tile, io0.obs + ((long long)(u - 1) * n + tile_base) * DN_OBS_DIM, rows, lane);
+                const StepOut out = block_out(io0, tile_base, (long long)u * n, (long long)u * words);
+                report_phase<R, false, NOISE, false, true>(p, c, s_tile, out, fl, v, ob, gid, sc, li, lane, rows, active, G4, G5, acc, rms, rn);
+            }
+            if (t <= k_steps) block_lds_barrier();                         // barrier t
+        }
+        {   // the last step's tile
+            const TileRegs tile = tile_fetch(s_tile, lane);
+            tile_stream(tile, s_tile, io0.obs + ((long long)(k_steps - 1) * n + tile_base) * DN_OBS_DIM, rows, lane);
+        }
+        flush_stats(p, acc, sc0 + (unsigned long long)k_steps, lane);
+        if (active) {
+            reinterpret_cast<float *>(b.g4 + li)[3] = G4.w;
+            reinterpret_cast<float *>(b.g5 + li)[3] = G5.w;
+        }
+    }
+}
+
 // =====================================================================================================
 // VecEnv.reset(): every drone goes through Monitor.reset / NormalizeObservation.reset / PBDroneEnv.reset.
 // =====================================================================================================
@@ -1618,8 +1795,9 @@ hipError_t dn_launch_filld(double *dst, double v, long long n, hipStream_t strea
 // Kernel shape: two waves per 64 drones where the chip would otherwise idle (the step is issue-bound and the
 // second wave runs on another SIMD), one wave per 64 drones where there are enough drones to fill every SIMD with
 // whole steps.  Both produce identical bits (tests/test_gpu_parity.py::test_kernel_shapes_are_bit_identical).
-hipError_t dn_launch_step_many(const DnParams &p, const DnStepIO &io, int k, bool f32, bool two_wave, hipStream_t stream)
+hipError_t dn_launch_step_many(const DnParams &p, const DnStepIO &io, int k, bool f32, int waves, hipStream_t stream)
 {
+    const bool two_wave = waves >= 2;       // three waves: plain fused launches only (below), otherwise the two-wave kernels
     const unsigned grid = (unsigned)((p.n + DN_BLOCK - 1) / DN_BLOCK);
     const bool norm = p.normalize_obs != 0;
     const bool noise = p.act_noise_sigma > 0.0f || p.obs_noise_sigma > 0.0f;
@@ -1640,6 +1818,17 @@ hipError_t dn_launch_step_many(const DnParams &p, const DnStepIO &io, int k, boo
     } while (0)
     // the rarely used options share one set of instantiations (runtime switches inside): reward wrappers, N4 physics terms
     const bool rew = p.clip_rew != 0 || p.norm_rew != 0 || p.gnd != 0 || p.drag != 0 || p.rpm_actions != 0;
+    if (waves == 3 && k > 1 && !norm && !rew) {            // three waves per tile: fused launches of the plain configuration
+        const dim3 blk(3 * DN_BLOCK);
+        if (f32) {
+            if (noise) hipLaunchKernelGGL((dn_step_many_3w_kernel<float, true>), dim3(grid), blk, 0, stream, p, io, k);
+            else hipLaunchKernelGGL((dn_step_many_3w_kernel<float, false>), dim3(grid), blk, 0, stream, p, io, k);
+        } else {
+            if (noise) hipLaunchKernelGGL((dn_step_many_3w_kernel<double, true>), dim3(grid), blk, 0, stream, p, io, k);
+            else hipLaunchKernelGGL((dn_step_many_3w_kernel<double, false>), dim3(grid), blk, 0, stream, p, io, k);
+        }
+        return hipGetLastError();
+    }
     if (f32) {
         if (norm) { if (noise) DN_LAUNCH(float, true, true); else DN_LAUNCH(float, true, false); }
         else { if (noise) DN_LAUNCH(float, false, true); else DN_LAUNCH(float, false, false); }

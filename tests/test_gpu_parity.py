@@ -542,10 +542,12 @@ def test_kernel_shapes_are_bit_identical(norm, noise, monkeypatch):
     n, K = 1000, 70                       # ragged last tile on purpose
     kw = dict(normalize_obs=norm, max_steps=30, obs_noise_sigma=noise, act_noise_sigma=noise / 10, seed=5)
     envs = {}
-    for shape in ("1", "2"):
+    for shape in ("1", "2", "3"):
         monkeypatch.setenv("DN_WAVES", shape)
         envs[shape] = pkg.DroneVecEnv(track, n, device="cuda:0", **kw)
         envs[shape].reset()
+        # the three-wave kernel (flight / aux / report) exists for plain fused launches; otherwise DN_WAVES=3 means two
+        assert envs[shape].kernel_waves(fused=True) == (int(shape) if shape != "3" or not norm else 2)
     monkeypatch.delenv("DN_WAVES")
     rng = np.random.default_rng(21)
     dev = torch.device("cuda:0")
@@ -556,7 +558,14 @@ def test_kernel_shapes_are_bit_identical(norm, noise, monkeypatch):
         first = [(o.clone(), r.clone(), d.clone(), {k: v.clone() for k, v in i.items()}) for o, r, d, i in first[-1:]]
         rest = env.rollout_tensor(acts[6:].contiguous(), want_terminal=True)   # ... then one fused launch (n % 4 == 0)
         outs[shape] = (first, rest, env.get_state(), env.stats())
-    (f1, r1, s1, st1), (f2, r2, s2, st2) = outs["1"], outs["2"]
+    for other in ("2", "3"):
+        _assert_same_rollout(outs["1"], outs[other], n)
+    for env in envs.values():
+        env.close()
+
+
+def _assert_same_rollout(o1, o2, n):
+    (f1, r1, s1, st1), (f2, r2, s2, st2) = o1, o2
     for a, b in zip(f1, f2):
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
         for k in a[3]:
@@ -570,8 +579,6 @@ def test_kernel_shapes_are_bit_identical(norm, noise, monkeypatch):
     for k in s1.dtype.names:
         assert np.ascontiguousarray(s1[k]).tobytes() == np.ascontiguousarray(s2[k]).tobytes(), k
     assert st1 == st2 and st1["episodes"] > n
-    for env in envs.values():
-        env.close()
 
 
 def test_graph_replayed_rollouts_equal_eager_rollouts():
