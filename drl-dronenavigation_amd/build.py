@@ -10,16 +10,19 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libdronenav.so")
-SOURCES = ["dn_kernels.hip", "dn_mlp.hip", "dn_capi.cpp"]
+SOURCES = ["dn_kernels.hip", "dn_kernels_mw.hip", "dn_mlp.hip", "dn_capi.cpp"]
 HEADERS = ["dn_internal.h", os.path.join("..", "..", "include", "dronenav.h")]
 # -ffp-contract=off: the reference (numpy, Bullet) rounds every operation, so no fused multiply-add.
 # Correctly rounded float32 divide/sqrt is hipcc's default; stated explicitly because parity relies on it.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-         "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-Wall", "-Wno-unused-function",
-         # The fused K-step kernel loops over the whole step body; machine LICM would hoist every float64
-         # literal of the body out of that loop and keep them live (256 VGPRs, 1 wave/SIMD).  Measured on
-         # MI355X: 2M drones fused 200 us -> 131 us per step, single-step kernels unchanged.
-         "-mllvm", "-disable-machine-licm"]
+         "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+# The fused K-step kernel loops over the whole step body; machine LICM would hoist every float64 literal of the body
+# out of that loop and keep them live.  That costs the one-wave kernels, which run several waves per SIMD at large
+# fleets, their occupancy (2 M drones fused: 72 -> 107 us per step) and is a gain for the multi-wave kernels, which
+# are (nearly) alone on their SIMD (32768 drones, three waves: 1.48 -> 1.37 us per step).  So the multi-wave kernels
+# of the plain configuration are a translation unit of their own (dn_kernels_mw.hip includes dn_kernels.hip).
+NO_LICM = ["-mllvm", "-disable-machine-licm"]
+FLAGS_OF = {"dn_kernels_mw.hip": []}             # everything else: NO_LICM
 
 
 EXTRA = os.environ.get("DN_EXTRA_HIPCC_FLAGS", "").split()
@@ -44,14 +47,19 @@ def build_library(force=False, verbose=False):
     """Compile csrc/*.{hip,cpp} -> csrc/libdronenav.so.  Returns the library path."""
     if not force and not is_stale():
         return LIB_PATH
-    objs = []
+    objs, cmds = [], []
     for src in SOURCES:
         obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
-        cmd = [hipcc()] + FLAGS + EXTRA + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc()] + FLAGS + FLAGS_OF.get(src, NO_LICM) + EXTRA + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
-        subprocess.check_call(cmd)
         objs.append(obj)
+        cmds.append(cmd)
+    procs = [subprocess.Popen(c) for c in cmds]              # the translation units are independent: compile them side by side
+    codes = [p.wait() for p in procs]
+    for c, rc in zip(cmds, codes):
+        if rc != 0:
+            raise subprocess.CalledProcessError(rc, c)
     cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
     if verbose:
         print(" ".join(cmd))

@@ -19,6 +19,10 @@
 //   env_utils.py = Sol/Model/env_utils.py, normalize.py = Sol/Model/Environments/normalize.py.
 #include "dn_internal.h"
 
+#ifndef DN_TU
+#define DN_TU 1      // see dn_launch_step_many: 1 = this file as such, 2 = through dn_kernels_mw.hip
+#endif
+
 #include <float.h>
 
 #define DN_DEV __device__ __forceinline__
@@ -1781,6 +1785,7 @@ __global__ __launch_bounds__(256) void dn_filld_kernel(double *dst, double v, lo
 
 }  // namespace
 
+#if DN_TU == 1
 hipError_t dn_launch_fill4(float4 *dst, float4 v, long long n, hipStream_t stream)
 {
     if (n <= 0) return hipSuccess;
@@ -1797,15 +1802,17 @@ hipError_t dn_launch_filld(double *dst, double v, long long n, hipStream_t strea
     return hipGetLastError();
 }
 
-// Kernel shape: two waves per 64 drones where the chip would otherwise idle (the step is issue-bound and the
-// second wave runs on another SIMD), one wave per 64 drones where there are enough drones to fill every SIMD with
-// whole steps.  Both produce identical bits (tests/test_gpu_parity.py::test_kernel_shapes_are_bit_identical).
-hipError_t dn_launch_step_many(const DnParams &p, const DnStepIO &io, int k, bool f32, int waves, hipStream_t stream)
-{
-    const bool two_wave = waves >= 2;       // three waves: plain fused launches only (below), otherwise the two-wave kernels
-    const unsigned grid = (unsigned)((p.n + DN_BLOCK - 1) / DN_BLOCK);
-    const bool norm = p.normalize_obs != 0;
-    const bool noise = p.act_noise_sigma > 0.0f || p.obs_noise_sigma > 0.0f;
+#endif
+
+// Kernel shape: two or three waves per 64 drones where the chip would otherwise idle (the step is bound by one wave's
+// dependent instruction stream and the other waves run on other SIMDs), one wave per 64 drones where there are enough
+// drones to fill every SIMD with whole steps.  All produce identical bits (test_kernel_shapes_are_bit_identical).
+//
+// This file is compiled twice (build.py).  DN_TU == 1 (with -mllvm -disable-machine-licm): everything except the
+// multi-wave kernels of the configuration without the normaliser; those live in DN_TU == 2 (dn_kernels_mw.hip, machine
+// LICM on).  Hoisting the float64 literals of the step body out of the K-step loop costs registers: it slows the
+// one-wave kernels that run several waves per SIMD (2 M drones fused: 72 -> 107 us per step) and speeds up the
+// kernels that are alone or nearly alone on their SIMD (32768 drones, three waves: 1.48 -> 1.37 us per step).
 #define DN_LAUNCH3(R, NORM, NOISE, ONE, XOPT)                                                                           \
     do {                                                                                                                \
         if (two_wave)                                                                                                   \
@@ -1821,9 +1828,16 @@ hipError_t dn_launch_step_many(const DnParams &p, const DnStepIO &io, int k, boo
     do {                                                                                                                \
         if (k == 1) DN_LAUNCH2(R, NORM, NOISE, true); else DN_LAUNCH2(R, NORM, NOISE, false);                           \
     } while (0)
+
+#if DN_TU == 2
+hipError_t dn_launch_step_many_mw(const DnParams &p, const DnStepIO &io, int k, bool f32, int waves, hipStream_t stream)
+{   // multi-wave kernels, normaliser off
+    constexpr bool two_wave = true;
+    const unsigned grid = (unsigned)((p.n + DN_BLOCK - 1) / DN_BLOCK);
+    const bool noise = p.act_noise_sigma > 0.0f || p.obs_noise_sigma > 0.0f;
     // the rarely used options share one set of instantiations (runtime switches inside): reward wrappers, N4 physics terms
     const bool rew = p.clip_rew != 0 || p.norm_rew != 0 || p.gnd != 0 || p.drag != 0 || p.rpm_actions != 0;
-    if (waves == 3 && k > 1 && !norm && !rew) {            // three waves per tile: fused launches of the plain configuration
+    if (waves == 3 && k > 1 && !rew) {                     // three waves per tile: fused launches of the plain configuration
         const dim3 blk(3 * DN_BLOCK);
         if (f32) {
             if (noise) hipLaunchKernelGGL((dn_step_many_3w_kernel<float, true>), dim3(grid), blk, 0, stream, p, io, k);
@@ -1834,6 +1848,24 @@ hipError_t dn_launch_step_many(const DnParams &p, const DnStepIO &io, int k, boo
         }
         return hipGetLastError();
     }
+    if (f32) { if (noise) DN_LAUNCH(float, false, true); else DN_LAUNCH(float, false, false); }
+    else { if (noise) DN_LAUNCH(double, false, true); else DN_LAUNCH(double, false, false); }
+    return hipGetLastError();
+}
+#else
+hipError_t dn_launch_step_many(const DnParams &p, const DnStepIO &io, int k, bool f32, int waves, hipStream_t stream)
+{
+    const bool norm = p.normalize_obs != 0;
+    if (waves >= 2 && !norm) return dn_launch_step_many_mw(p, io, k, f32, waves, stream);
+    const bool two_wave = waves >= 2;       // with the normaliser: the two-wave kernels (there is no three-wave one)
+    const unsigned grid = (unsigned)((p.n + DN_BLOCK - 1) / DN_BLOCK);
+    const bool noise = p.act_noise_sigma > 0.0f || p.obs_noise_sigma > 0.0f;
+    const bool rew = p.clip_rew != 0 || p.norm_rew != 0 || p.gnd != 0 || p.drag != 0 || p.rpm_actions != 0;
+    if (two_wave) {                         // normaliser on
+        if (f32) { if (noise) DN_LAUNCH(float, true, true); else DN_LAUNCH(float, true, false); }
+        else { if (noise) DN_LAUNCH(double, true, true); else DN_LAUNCH(double, true, false); }
+        return hipGetLastError();
+    }
     if (f32) {
         if (norm) { if (noise) DN_LAUNCH(float, true, true); else DN_LAUNCH(float, true, false); }
         else { if (noise) DN_LAUNCH(float, false, true); else DN_LAUNCH(float, false, false); }
@@ -1841,12 +1873,14 @@ hipError_t dn_launch_step_many(const DnParams &p, const DnStepIO &io, int k, boo
         if (norm) { if (noise) DN_LAUNCH(double, true, true); else DN_LAUNCH(double, true, false); }
         else { if (noise) DN_LAUNCH(double, false, true); else DN_LAUNCH(double, false, false); }
     }
+    return hipGetLastError();
+}
+#endif
 #undef DN_LAUNCH
 #undef DN_LAUNCH2
 #undef DN_LAUNCH3
-    return hipGetLastError();
-}
 
+#if DN_TU == 1
 hipError_t dn_launch_reset(const DnParams &p, float *obs, bool f32, hipStream_t stream)
 {
     const unsigned grid = (unsigned)((p.n + DN_BLOCK - 1) / DN_BLOCK);
@@ -1905,3 +1939,4 @@ hipError_t dn_launch_compact(const unsigned long long *mask, long long n, int32_
     hipLaunchKernelGGL(dn_compact_kernel, dim3(1), dim3(1024), 0, stream, mask, n, indices, count);
     return hipGetLastError();
 }
+#endif  // DN_TU == 1
