@@ -546,8 +546,7 @@ def test_kernel_shapes_are_bit_identical(norm, noise, monkeypatch):
         monkeypatch.setenv("DN_WAVES", shape)
         envs[shape] = pkg.DroneVecEnv(track, n, device="cuda:0", **kw)
         envs[shape].reset()
-        # the three-wave kernel (flight / aux / report) exists for plain fused launches; otherwise DN_WAVES=3 means two
-        assert envs[shape].kernel_waves(fused=True) == (int(shape) if shape != "3" or not norm else 2)
+        assert envs[shape].kernel_waves(fused=True) == int(shape)     # three waves: flight / report / aux (fused launches)
     monkeypatch.delenv("DN_WAVES")
     rng = np.random.default_rng(21)
     dev = torch.device("cuda:0")
