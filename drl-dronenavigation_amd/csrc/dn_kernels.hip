@@ -720,6 +720,26 @@ DN_DEV Thrust thrust_phase(const DnParams &p, unsigned long long gid, unsigned s
     return t;
 }
 
+// Body-frame resultant of the four rotor thrusts (A3), in the expressions physics_phase uses on a Thrust: the
+// multi-wave kernels form it on the wave that computes the thrust and mail these four values instead of five floats.
+template <typename R> struct Resultant {
+    R fz, tx, ty, zt;
+};
+template <typename T> struct IsResultant { static constexpr bool value = false; };
+template <typename R> struct IsResultant<Resultant<R>> { static constexpr bool value = true; };
+template <typename R>
+DN_DEV Resultant<R> rotor_resultant(const Thrust &th)
+{
+#pragma clang fp contract(fast)
+    const R F0 = th.f[0], F1 = th.f[1], F2 = th.f[2], F3 = th.f[3];
+    Resultant<R> r;
+    r.fz = (F0 + F1) + (F2 + F3);
+    r.tx = K<R>::ARM * ((F2 + F3) - (F0 + F1));
+    r.ty = K<R>::ARM * ((F1 + F2) - (F0 + F3));
+    r.zt = (R)th.zt;
+    return r;
+}
+
 // ---- A4: p.stepSimulation, one free rigid body [3P-recall of Bullet3 btMultiBody] -------------------------
 template <typename R, typename TH = Thrust, bool XOPT = false>
 DN_DEV Flight<R> physics_phase(const TH &th, const float4 G0, const float4 G1, const float4 G2, const float4 G3,
@@ -747,8 +767,12 @@ DN_DEV Flight<R> physics_phase(const TH &th, const float4 G0, const float4 G1, c
     const R r10 = xy + wzs, r11 = R(1.0) - (xx + zz), r12 = yz - wxs;
     const R r20 = xz - wys, r21 = yz + wxs, r22 = R(1.0) - (xx + yy);
     // rotor thrusts along body z at the prop offsets (+,-) (-,-) (-,+) (+,+) * 0.028 (cf2x.urdf:42,54,66,78)
-    R F0 = th.f[0], F1 = th.f[1], F2 = th.f[2], F3 = th.f[3];
+    R fz, tx, ty, ztq;
     R dax = R(0.0), day = R(0.0), daz = R(0.0);
+    if constexpr (IsResultant<TH>::value) {               // the multi-wave kernels: summed one step ahead by another wave
+        fz = th.fz; tx = th.tx; ty = th.ty; ztq = th.zt;
+    } else {
+    R F0 = th.f[0], F1 = th.f[1], F2 = th.f[2], F3 = th.f[3];
     if (XOPT) {
         if (x->gnd) {   // BaseAviary._groundEffect (BaseAviary.py:800-832): a second +z force on each prop link
             // |roll| < pi/2 and |pitch| < pi/2 on the cached rpy (getEulerFromQuaternion [3P-recall]): roll =
@@ -776,9 +800,11 @@ DN_DEV Flight<R> physics_phase(const TH &th, const float4 G0, const float4 G1, c
             daz = (r20 * bx + r21 * by + r22 * bz) * K<R>::INV_M;
         }
     }
-    const R fz = (F0 + F1) + (F2 + F3);
-    const R tx = K<R>::ARM * ((F2 + F3) - (F0 + F1));
-    const R ty = K<R>::ARM * ((F1 + F2) - (F0 + F3));
+    fz = (F0 + F1) + (F2 + F3);
+    tx = K<R>::ARM * ((F2 + F3) - (F0 + F1));
+    ty = K<R>::ARM * ((F1 + F2) - (F0 + F3));
+    ztq = (R)th.zt;
+    }
     // linear: a = R[:,2] fz/M - (0,0,G) - v (c + c|v|)
     // the damping norms enter the velocity update at dt * 0.04: a float32 root moves it by 1e-12 relative
     const R kl = K<R>::LIN_DAMP + K<R>::LIN_DAMP * (R)__builtin_amdgcn_sqrtf((float)(vx * vx + vy * vy + vz * vz));
@@ -791,7 +817,7 @@ DN_DEV Flight<R> physics_phase(const TH &th, const float4 G0, const float4 G1, c
     const R Iwx = K<R>::IXX * wbx, Iwy = K<R>::IYY * wby, Iwz = K<R>::IZZ * wbz;
     const R gx = wby * Iwz - wbz * Iwy, gy = wbz * Iwx - wbx * Iwz, gz = wbx * Iwy - wby * Iwx;
     const R dbx = (tx - gx - Iwx * ka) * K<R>::INV_IXX, dby = (ty - gy - Iwy * ka) * K<R>::INV_IYY,
-            dbz = ((R)th.zt - gz - Iwz * ka) * K<R>::INV_IZZ;
+            dbz = (ztq - gz - Iwz * ka) * K<R>::INV_IZZ;
     const R dwx = r00 * dbx + r01 * dby + r02 * dbz, dwy = r10 * dbx + r11 * dby + r12 * dbz, dwz = r20 * dbx + r21 * dby + r22 * dbz;
     wx += dwx * dt; wy += dwy * dt; wz += dwz * dt;       // applyDeltaVeeMultiDof
     vx += awx * dt; vy += awy * dt; vz += awz * dt;
@@ -1295,22 +1321,19 @@ template <typename R> DN_DEV void take_mail(const Mail<R> &m, unsigned lane, Fli
 // (thrust(t+1) during iteration t) and hands it over the same way, which moves a quarter of the flight wave's
 // work off the recurrence.  Double-buffered like the mail: iteration t writes tmail[(t+1) & 1] while the flight
 // wave reads tmail[t & 1].
-struct ThrustMail {
-    float4 f[DN_BLOCK];
-    float zt[DN_BLOCK];
+template <typename R> struct ThrustMail {
+    R v[4][DN_BLOCK];                     // Resultant: fz, tx, ty, zt
 };
-DN_DEV void post_thrust(ThrustMail &m, unsigned lane, const Thrust &t)
+template <typename R> DN_DEV void post_thrust(ThrustMail<R> &m, unsigned lane, const Thrust &t)
 {
-    m.f[lane] = make_float4(t.f[0], t.f[1], t.f[2], t.f[3]);
-    m.zt[lane] = t.zt;
+    const Resultant<R> r = rotor_resultant<R>(t);
+    m.v[0][lane] = r.fz; m.v[1][lane] = r.tx; m.v[2][lane] = r.ty; m.v[3][lane] = r.zt;
 }
-DN_DEV Thrust take_thrust(const ThrustMail &m, unsigned lane)
+template <typename R> DN_DEV Resultant<R> take_thrust(const ThrustMail<R> &m, unsigned lane)
 {
-    const float4 f = m.f[lane];
-    Thrust t;
-    t.f[0] = f.x; t.f[1] = f.y; t.f[2] = f.z; t.f[3] = f.w;
-    t.zt = m.zt[lane];
-    return t;
+    Resultant<R> r;
+    r.fz = m.v[0][lane]; r.tx = m.v[1][lane]; r.ty = m.v[2][lane]; r.zt = m.v[3][lane];
+    return r;
 }
 
 template <typename R, bool NORM, bool NOISE, bool ONE, bool XOPT>
@@ -1320,7 +1343,7 @@ __global__ __launch_bounds__(2 * DN_BLOCK) void dn_step_many_2w_kernel(const DnP
     __shared__ R s_tab[DN_MAX_WAYPOINTS * DN_T_STRIDE];
     __shared__ __attribute__((aligned(16))) float s_tile[DN_BLOCK * DN_OBS_DIM];
     __shared__ Mail<R> mail[2];
-    __shared__ __attribute__((aligned(16))) ThrustMail tmail[2];
+    __shared__ __attribute__((aligned(16))) ThrustMail<R> tmail[2];
     constexpr bool THRUST_AHEAD = !XOPT;        // the XOPT thrust carries float64 forces and the rpm: it stays on the flight wave
     const unsigned lane = threadIdx.x & (DN_BLOCK - 1);
     const bool report_wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) != 0;    // wave-uniform role
@@ -1349,7 +1372,7 @@ __global__ __launch_bounds__(2 * DN_BLOCK) void dn_step_many_2w_kernel(const DnP
         if (THRUST_AHEAD) {
             A = act[li];
             const float4 A1 = (act + (long long)(k_steps > 1 ? 1 : 0) * n)[li];
-            post_thrust(tmail[0], lane, thrust_phase<NOISE>(p, gid, (unsigned)sc0, A));
+            post_thrust<R>(tmail[0], lane, thrust_phase<NOISE>(p, gid, (unsigned)sc0, A));
             A = A1;
         }
         block_lds_barrier();                                               // P: table and thrust(0) published
@@ -1357,7 +1380,7 @@ __global__ __launch_bounds__(2 * DN_BLOCK) void dn_step_many_2w_kernel(const DnP
         for (int t = 0; t <= k_steps; ++t) {
             if (THRUST_AHEAD && t + 1 < k_steps) {                         // thrust(t+1), for the flight wave's next iteration
                 const float4 A_next = (act + (long long)(t + 2 < k_steps ? t + 2 : t + 1) * n)[li];
-                post_thrust(tmail[(t + 1) & 1], lane, thrust_phase<NOISE>(p, gid, (unsigned)sc0 + (unsigned)(t + 1), A));
+                post_thrust<R>(tmail[(t + 1) & 1], lane, thrust_phase<NOISE>(p, gid, (unsigned)sc0 + (unsigned)(t + 1), A));
                 A = A_next;
             }
             if (t > 0) {                                                   // the step the flight wave finished last iteration
@@ -1400,7 +1423,7 @@ __global__ __launch_bounds__(2 * DN_BLOCK) void dn_step_many_2w_kernel(const DnP
             const GateRow<R> row_e = load_gate_row<R>(s_tab, unpack_meta(G3.w).idx);
             Flight<R> fl;
             if (THRUST_AHEAD) {
-                fl = physics_phase<R>(take_thrust(tmail[t & 1], lane), G0, G1, G2, G3, p.max_steps);
+                fl = physics_phase<R, Resultant<R>>(take_thrust<R>(tmail[t & 1], lane), G0, G1, G2, G3, p.max_steps);
             } else {
                 // prefetch the next step's action while this step computes
                 A_next = (act + (long long)(t + 1 < k_steps ? t + 1 : t) * n)[li];
@@ -1510,7 +1533,7 @@ __global__ __launch_bounds__(3 * DN_BLOCK) void dn_step_many_3w_kernel(const DnP
     __shared__ __attribute__((aligned(16))) float s_tile[DN_BLOCK * DN_OBS_DIM];
     __shared__ MailQ<R> mailq[2];
     __shared__ MailA<R> maila[2];
-    __shared__ __attribute__((aligned(16))) ThrustMail tmail[2];
+    __shared__ __attribute__((aligned(16))) ThrustMail<R> tmail[2];
     const unsigned lane = threadIdx.x & (DN_BLOCK - 1);
     // role of this wave: 0 flight, 1 aux, 2 report.  The order of the waves inside the workgroup decides which of them
     // end up sharing a SIMD when a CU holds two tiles (six waves on four SIMDs, dealt round-robin): with the waves
@@ -1540,7 +1563,7 @@ __global__ __launch_bounds__(3 * DN_BLOCK) void dn_step_many_3w_kernel(const DnP
         for (int t = 0; t <= k_steps; ++t) {
             if (t < k_steps) {
                 const GateRow<R> row_e = load_gate_row<R>(s_tab, unpack_meta(G3.w).idx);
-                const Flight<R> fl = physics_phase<R>(take_thrust(tmail[t & 1], lane), G0, G1, G2, G3, p.max_steps);
+                const Flight<R> fl = physics_phase<R, Resultant<R>>(take_thrust<R>(tmail[t & 1], lane), G0, G1, G2, G3, p.max_steps);
                 const float4 G0e = G0, G3e = G3;
                 const Verdict<R> v = rules_phase<R>(p, c, s_tab, row_e, wp0, fl, G0e, G3e, b.g6, li, active, G0, G1, G2, G3);
                 post_mailq<R>(mailq[t & 1], lane, fl, v);
@@ -1557,7 +1580,7 @@ __global__ __launch_bounds__(3 * DN_BLOCK) void dn_step_many_3w_kernel(const DnP
         if (!THRUST_ON_REPORT) {
             A = act[li];
             const float4 A1 = (act + (long long)(k_steps > 1 ? 1 : 0) * n)[li];
-            post_thrust(tmail[0], lane, thrust_phase<NOISE>(p, gid, (unsigned)sc0, A));
+            post_thrust<R>(tmail[0], lane, thrust_phase<NOISE>(p, gid, (unsigned)sc0, A));
             A = A1;
         }
         block_lds_barrier();                                               // P: table and thrust(0) published
@@ -1565,7 +1588,7 @@ __global__ __launch_bounds__(3 * DN_BLOCK) void dn_step_many_3w_kernel(const DnP
         for (int t = 0; t <= k_steps; ++t) {
             if (!THRUST_ON_REPORT && t + 1 < k_steps) {                    // thrust(t+1), for the flight wave's next iteration
                 const float4 A_next = (act + (long long)(t + 2 < k_steps ? t + 2 : t + 1) * n)[li];
-                post_thrust(tmail[(t + 1) & 1], lane, thrust_phase<NOISE>(p, gid, (unsigned)sc0 + (unsigned)(t + 1), A));
+                post_thrust<R>(tmail[(t + 1) & 1], lane, thrust_phase<NOISE>(p, gid, (unsigned)sc0 + (unsigned)(t + 1), A));
                 A = A_next;
             }
             if (t > 0) {                                                   // the step the flight wave finished last iteration
@@ -1611,7 +1634,7 @@ __global__ __launch_bounds__(3 * DN_BLOCK) void dn_step_many_3w_kernel(const DnP
         if (THRUST_ON_REPORT) {
             A = act[li];
             const float4 A1 = (act + (long long)(k_steps > 1 ? 1 : 0) * n)[li];
-            post_thrust(tmail[0], lane, thrust_phase<NOISE>(p, gid, (unsigned)sc0, A));
+            post_thrust<R>(tmail[0], lane, thrust_phase<NOISE>(p, gid, (unsigned)sc0, A));
             A = A1;
         }
         block_lds_barrier();                                               // P
@@ -1619,7 +1642,7 @@ __global__ __launch_bounds__(3 * DN_BLOCK) void dn_step_many_3w_kernel(const DnP
         for (int t = 0; t <= k_steps + 1; ++t) {
             if (THRUST_ON_REPORT && t + 1 < k_steps) {                     // thrust(t+1), for the flight wave's next iteration
                 const float4 A_next = (act + (long long)(t + 2 < k_steps ? t + 2 : t + 1) * n)[li];
-                post_thrust(tmail[(t + 1) & 1], lane, thrust_phase<NOISE>(p, gid, (unsigned)sc0 + (unsigned)(t + 1), A));
+                post_thrust<R>(tmail[(t + 1) & 1], lane, thrust_phase<NOISE>(p, gid, (unsigned)sc0 + (unsigned)(t + 1), A));
                 A = A_next;
             }
             if (t > 1) {                                                   // the step the aux wave finished last iteration

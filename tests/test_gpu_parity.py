@@ -996,3 +996,34 @@ def test_nan_actions_propagate_like_numpy():
         saw_clean_again |= saw_nan and not bad.any()
     assert saw_nan and saw_clean_again
     env.close()
+
+
+@pytest.mark.parametrize("n,K", [(12, 2), (64, 3), (100, 5), (4096, 2)])
+def test_three_wave_kernel_short_rollouts_and_ragged_tiles(n, K, monkeypatch):
+    """The three-wave kernel trails its report wave two steps behind the flight wave: rollouts shorter than the skew,
+    a single ragged tile and one drone short of a tile must still match the one-wave kernel bit for bit."""
+    pkg = _gpu()
+    track = _tracks().reaching()
+    kw = dict(normalize_obs=False, max_steps=4)
+    monkeypatch.setenv("DN_WAVES", "1")
+    ref = pkg.DroneVecEnv(track, n, device="cuda:0", **kw)
+    monkeypatch.delenv("DN_WAVES")
+    env = pkg.DroneVecEnv(track, n, device="cuda:0", **kw)
+    assert env.kernel_waves(fused=True) == 3 and ref.kernel_waves(fused=True) == 1
+    ref.reset(); env.reset()
+    rng = np.random.default_rng(n + K)
+    dev = torch.device("cuda:0")
+    for rep in range(4):                                  # several launches: state, statistics and counters carry over
+        acts = torch.from_numpy(np.stack([actions_mixed(rng, n) for _ in range(K)])).to(dev)
+        a, b = ref.rollout_tensor(acts, want_terminal=True), env.rollout_tensor(acts, want_terminal=True)
+        for k in a:
+            if k in ("terminal_obs", "ep_return", "ep_length"):
+                d = a["done"].bool()
+                assert torch.equal(a[k][d], b[k][d]), (k, rep)
+            else:
+                assert torch.equal(a[k], b[k]), (k, rep)
+    sa, sb = ref.get_state(), env.get_state()
+    for k in sa.dtype.names:
+        assert np.ascontiguousarray(sa[k]).tobytes() == np.ascontiguousarray(sb[k]).tobytes(), k
+    assert ref.stats() == env.stats() and ref.step_count == env.step_count == 4 * K
+    ref.close(); env.close()
