@@ -37,6 +37,7 @@ int32_t fail(dn_status st, const char *fmt, ...)
 inline double norm3d(const double v[3]) { return std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
 
 constexpr long long DN_TWO_WAVE_MAX_TILES = 1024;   // 65536 drones: one tile per SIMD
+constexpr long long DN_THREE_WAVE_MAX_TILES = 512;  // 32768 drones: two tiles = six waves per CU; beyond, two waves per tile win
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -242,7 +243,7 @@ int32_t dn_create(const dn_config *cfg, dn_env **out)
     // normaliser on it is built and bit-identical, but the aux wave then carries both normaliser passes of a step
     // (3.2 us per step against 2.2 us for two waves at 32768 drones): chosen by default only without the normaliser.
     const bool plain = !cfg->clip_rew && !cfg->norm_rew && cfg->physics == 0 && cfg->action_type == 0;
-    e->waves_fused = e->blocks <= DN_TWO_WAVE_MAX_TILES ? (plain && !cfg->normalize_obs ? 3 : 2) : 1;
+    e->waves_fused = e->blocks <= DN_TWO_WAVE_MAX_TILES ? (plain && !cfg->normalize_obs && e->blocks <= DN_THREE_WAVE_MAX_TILES ? 3 : 2) : 1;
     e->waves_single = 1;
     if (const char *w = getenv("DN_WAVES")) {
         if (w[0] == '1') e->waves_fused = e->waves_single = 1;
