@@ -239,11 +239,13 @@ int32_t dn_create(const dn_config *cfg, dn_env **out)
     // instruction stream of a wave, and two or three waves per tile win while the tiles alone leave SIMDs idle
     // (<= 1024 tiles = 65536 drones on 1024 SIMDs); the single-step launch is latency bound (launch + load round
     // trip) and one wave is never slower.  DN_WAVES=1|2|3 forces a shape (A/B measurements, the bit-identity test).
-    // The three-wave shape (flight / report / aux) exists for fused launches without the XOPT options.  With the
-    // normaliser on it is built and bit-identical, but the aux wave then carries both normaliser passes of a step
-    // (3.2 us per step against 2.2 us for two waves at 32768 drones): chosen by default only without the normaliser.
+    // The three-wave shape (flight / report / aux) exists for fused launches without the XOPT options.  It wins while
+    // the waves of a CU find SIMDs of their own: two tiles per CU (512 tiles) without the normaliser, one tile per CU
+    // (256 tiles) with it -- the normaliser makes the report wave as heavy as the other two (32768 drones, normaliser
+    // on: 2.9 us per step with three waves, 2.3 us with two; 16384 drones: 1.5 us against 2.2 us).
     const bool plain = !cfg->clip_rew && !cfg->norm_rew && cfg->physics == 0 && cfg->action_type == 0;
-    e->waves_fused = e->blocks <= DN_TWO_WAVE_MAX_TILES ? (plain && !cfg->normalize_obs && e->blocks <= DN_THREE_WAVE_MAX_TILES ? 3 : 2) : 1;
+    const long long max3 = cfg->normalize_obs ? DN_THREE_WAVE_MAX_TILES / 2 : DN_THREE_WAVE_MAX_TILES;
+    e->waves_fused = e->blocks <= DN_TWO_WAVE_MAX_TILES ? (plain && e->blocks <= max3 ? 3 : 2) : 1;
     e->waves_single = 1;
     if (const char *w = getenv("DN_WAVES")) {
         if (w[0] == '1') e->waves_fused = e->waves_single = 1;

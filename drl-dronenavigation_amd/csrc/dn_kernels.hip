@@ -1093,11 +1093,11 @@ DN_DEV void flush_stats(const DnParams &p, const StatAcc &a, unsigned long long 
 }
 
 // ---- A7 select + A10/A11 on the report wave: Monitor, SubprocVecEnv worker, outputs ---------------------------
-template <typename R, bool NORM, bool NOISE, bool REW, bool DEFER_TILE = false, bool RESET_GIVEN = false>
+template <typename R, bool NORM, bool NOISE, bool REW, bool DEFER_TILE = false>
 DN_DEV void report_phase(const DnParams &p, const DnConsts<R> &c, float *s_tile, const StepOut &out, const Flight<R> &fl,
                          const Verdict<R> &v, Observed<R> &ob, const unsigned long long gid, const unsigned step_count,
                          const unsigned li, const unsigned lane, const unsigned rows, const bool active,
-                         float4 &G4, float4 &G5, StatAcc &acc, Rms &rms, RewNorm &rn, const float *o_reset = nullptr)
+                         float4 &G4, float4 &G5, StatAcc &acc, Rms &rms, RewNorm &rn)
 {
 #pragma clang fp contract(fast)
     const bool coll1 = v.coll1 != 0, terminated = v.terminated != 0, truncated = fl.truncated != 0;
@@ -1133,14 +1133,9 @@ DN_DEV void report_phase(const DnParams &p, const DnConsts<R> &c, float *s_tile,
                 if (out.ep_return) out.ep_return[li] = (float)ep_ret;
                 if (out.ep_length) out.ep_length[li] = ep_len;
             }
-            if (RESET_GIVEN) {                                            // made by the wave that owns the normaliser (three-wave kernel)
-#pragma unroll
-                for (int k = 0; k < DN_OBS_DIM; ++k) o[k] = o_reset[k];
-            } else {
-                reset_obs<R>(p, c, v.d_obs, o);                           // BaseAviary.py:318 before :617-658 (Q2)
-                if (NOISE && p.obs_noise_sigma > 0.0f) add_obs_noise(p, gid, step_count, 5u, o);
-                if (NORM) normalize_obs(rms, o);
-            }
+            reset_obs<R>(p, c, v.d_obs, o);                               // BaseAviary.py:318 before :617-658 (Q2)
+            if (NOISE && p.obs_noise_sigma > 0.0f) add_obs_noise(p, gid, step_count, 5u, o);
+            if (NORM) normalize_obs(rms, o);
             S4 = S5 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             ep_ret = R(0.0); ep_len = 0;
         }
@@ -1486,21 +1481,7 @@ template <typename R> DN_DEV void take_mailq(const MailQ<R> &m, unsigned lane, F
 template <typename R> struct MailA {      // aux -> report: the observation, the reward candidates and what the verdict needs
     R f64[2][DN_BLOCK];                   // Observed.r_normal, Verdict.d_obs
     float4 f32[4][DN_BLOCK];              // o[0..11], then (o[12], r_found32, d_e, flag word)
-    float4 rst[4][DN_BLOCK];              // normaliser on: the reset observation of the drones that finished (made by the aux wave)
 };
-template <typename R> DN_DEV void post_reset_obs(MailA<R> &m, unsigned lane, const float o[DN_OBS_DIM])
-{
-    m.rst[0][lane] = make_float4(o[0], o[1], o[2], o[3]);
-    m.rst[1][lane] = make_float4(o[4], o[5], o[6], o[7]);
-    m.rst[2][lane] = make_float4(o[8], o[9], o[10], o[11]);
-    m.rst[3][lane] = make_float4(o[12], 0.0f, 0.0f, 0.0f);
-}
-template <typename R> DN_DEV void take_reset_obs(const MailA<R> &m, unsigned lane, float o[DN_OBS_DIM])
-{
-    const float4 a = m.rst[0][lane], b = m.rst[1][lane], c = m.rst[2][lane], d = m.rst[3][lane];
-    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
-    o[8] = c.x; o[9] = c.y; o[10] = c.z; o[11] = c.w; o[12] = d.x;
-}
 template <typename R> DN_DEV void post_maila(MailA<R> &m, unsigned lane, const Flight<R> &f, const Verdict<R> &v, const Observed<R> &ob)
 {
     m.f64[0][lane] = ob.r_normal; m.f64[1][lane] = v.d_obs;
@@ -1522,13 +1503,11 @@ template <typename R> DN_DEV void take_maila(const MailA<R> &m, unsigned lane, F
     f.vex = f.vey = f.vez = f.aex = f.aey = f.aez = 0.0f;     // prev_vel / prev_ang_v live on the aux wave
 }
 
-// NORM (per-drone observation normaliser): its statistics live on the aux wave, which then also makes the reset
-// observation of a finished drone (the normaliser sees the terminal observation first, then the reset observation), and
-// the thrust-ahead moves to the report wave, which has the slack.
+// NORM (per-drone observation normaliser): the aux wave hands over the raw observation and the report wave, which
+// owns the statistics, normalises it (and then, for a finished drone, the reset observation: the reference's order).
 template <typename R, bool NORM, bool NOISE>
 __global__ __launch_bounds__(3 * DN_BLOCK) void dn_step_many_3w_kernel(const DnParams p, const DnStepIO io0, const int k_steps)
 {
-    constexpr bool THRUST_ON_REPORT = NORM;
     __shared__ R s_tab[DN_MAX_WAYPOINTS * DN_T_STRIDE];
     __shared__ __attribute__((aligned(16))) float s_tile[DN_BLOCK * DN_OBS_DIM];
     __shared__ MailQ<R> mailq[2];
@@ -1573,12 +1552,10 @@ __global__ __launch_bounds__(3 * DN_BLOCK) void dn_step_many_3w_kernel(const DnP
         if (active) { b.g0[li] = G0; b.g1[li] = G1; b.g2[li] = G2; b.g3[li] = G3; }
     } else if (role == 1) {
         float4 P4 = b.g4[li], P5 = b.g5[li];                               // .xyz: prev_vel, prev_ang_v
-        Rms rms;
-        if (NORM) load_rms(p, i, rms);
+        Rms rms;                                                           // never touched here: the observation leaves raw
         const float4 *act = reinterpret_cast<const float4 *>(io0.actions) + tile_base;
-        float4 A = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (!THRUST_ON_REPORT) {
-            A = act[li];
+        float4 A = act[li];
+        {
             const float4 A1 = (act + (long long)(k_steps > 1 ? 1 : 0) * n)[li];
             post_thrust<R>(tmail[0], lane, thrust_phase<NOISE>(p, gid, (unsigned)sc0, A));
             A = A1;
@@ -1586,7 +1563,7 @@ __global__ __launch_bounds__(3 * DN_BLOCK) void dn_step_many_3w_kernel(const DnP
         block_lds_barrier();                                               // P: table and thrust(0) published
 #pragma clang loop unroll(disable)
         for (int t = 0; t <= k_steps; ++t) {
-            if (!THRUST_ON_REPORT && t + 1 < k_steps) {                    // thrust(t+1), for the flight wave's next iteration
+            if (t + 1 < k_steps) {                                         // thrust(t+1), for the flight wave's next iteration
                 const float4 A_next = (act + (long long)(t + 2 < k_steps ? t + 2 : t + 1) * n)[li];
                 post_thrust<R>(tmail[(t + 1) & 1], lane, thrust_phase<NOISE>(p, gid, (unsigned)sc0 + (unsigned)(t + 1), A));
                 A = A_next;
@@ -1597,29 +1574,14 @@ __global__ __launch_bounds__(3 * DN_BLOCK) void dn_step_many_3w_kernel(const DnP
                 Verdict<R> v;
                 take_mailq<R>(mailq[u & 1], lane, fl, v);
                 attitude_phase<R>(fl);
-                const Observed<R> ob = observe_phase<R, NORM, NOISE>(p, c, s_tab, fl, P4, P5, gid, (unsigned)sc0 + (unsigned)u, rms);
+                const Observed<R> ob = observe_phase<R, false, NOISE>(p, c, s_tab, fl, P4, P5, gid, (unsigned)sc0 + (unsigned)u, rms);
                 post_maila<R>(maila[u & 1], lane, fl, v, ob);
-                if (NORM) {                                                // the reset observation, after the terminal one (normaliser order)
-                    const bool done = (v.terminated || fl.truncated) && active;
-                    float o2[DN_OBS_DIM];
-#pragma unroll
-                    for (int k = 0; k < DN_OBS_DIM; ++k) o2[k] = 0.0f;
-                    if (__ballot(done) != 0ull) {
-                        if (done) {
-                            reset_obs<R>(p, c, v.d_obs, o2);                  // BaseAviary.py:318 before :617-658 (Q2)
-                            if (NOISE && p.obs_noise_sigma > 0.0f) add_obs_noise(p, gid, (unsigned)sc0 + (unsigned)u, 5u, o2);
-                            normalize_obs(rms, o2);
-                        }
-                        post_reset_obs<R>(maila[u & 1], lane, o2);
-                    }
-                }
                 // prev_vel / prev_ang_v: _update_state_post_step (skipped on a terminated step, quirk Q5), zero after a reset
                 if (!v.terminated) { P4 = make_float4(fl.vex, fl.vey, fl.vez, 0.0f); P5 = make_float4(fl.aex, fl.aey, fl.aez, 0.0f); }
                 if (v.terminated || fl.truncated) P4 = P5 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             }
             block_lds_barrier();                                           // barrier t
         }
-        if (NORM && active) store_rms(p, i, rms);
         if (active) {
             float *g4 = reinterpret_cast<float *>(b.g4 + li), *g5 = reinterpret_cast<float *>(b.g5 + li);
             g4[0] = P4.x; g4[1] = P4.y; g4[2] = P4.z; g5[0] = P5.x; g5[1] = P5.y; g5[2] = P5.z;
@@ -1628,23 +1590,11 @@ __global__ __launch_bounds__(3 * DN_BLOCK) void dn_step_many_3w_kernel(const DnP
         float4 G4 = b.g4[li], G5 = b.g5[li];                               // .w: Monitor return / length
         StatAcc acc;
         Rms rms;
+        if (NORM) load_rms(p, i, rms);
         RewNorm rn = {0.0, 0.0, 1.0, 1e-4};
-        const float4 *act = reinterpret_cast<const float4 *>(io0.actions) + tile_base;
-        float4 A = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (THRUST_ON_REPORT) {
-            A = act[li];
-            const float4 A1 = (act + (long long)(k_steps > 1 ? 1 : 0) * n)[li];
-            post_thrust<R>(tmail[0], lane, thrust_phase<NOISE>(p, gid, (unsigned)sc0, A));
-            A = A1;
-        }
         block_lds_barrier();                                               // P
 #pragma clang loop unroll(disable)
         for (int t = 0; t <= k_steps + 1; ++t) {
-            if (THRUST_ON_REPORT && t + 1 < k_steps) {                     // thrust(t+1), for the flight wave's next iteration
-                const float4 A_next = (act + (long long)(t + 2 < k_steps ? t + 2 : t + 1) * n)[li];
-                post_thrust<R>(tmail[(t + 1) & 1], lane, thrust_phase<NOISE>(p, gid, (unsigned)sc0 + (unsigned)(t + 1), A));
-                A = A_next;
-            }
             if (t > 1) {                                                   // the step the aux wave finished last iteration
                 const int u = t - 2;
                 const unsigned sc = (unsigned)sc0 + (unsigned)u;
@@ -1654,17 +1604,10 @@ __global__ __launch_bounds__(3 * DN_BLOCK) void dn_step_many_3w_kernel(const DnP
                 Verdict<R> v;
                 Observed<R> ob;
                 take_maila<R>(maila[u & 1], lane, fl, v, ob);
-                float o2[DN_OBS_DIM];
-                if (NORM) {
-                    if (__ballot((v.terminated || fl.truncated) && active) != 0ull) take_reset_obs<R>(maila[u & 1], lane, o2);
-                    else {
-#pragma unroll
-                        for (int k = 0; k < DN_OBS_DIM; ++k) o2[k] = 0.0f;
-                    }
-                }
+                if (NORM) normalize_obs(rms, ob.o);                            // the step observation (= terminal_observation)
                 if (u > 0) tile_stream(tile, s_tile, io0.obs + ((long long)(u - 1) * n + tile_base) * DN_OBS_DIM, rows, lane);
                 const StepOut out = block_out(io0, tile_base, (long long)u * n, (long long)u * words);
-                report_phase<R, false, NOISE, false, true, NORM>(p, c, s_tile, out, fl, v, ob, gid, sc, li, lane, rows, active, G4, G5, acc, rms, rn, o2);
+                report_phase<R, NORM, NOISE, false, true>(p, c, s_tile, out, fl, v, ob, gid, sc, li, lane, rows, active, G4, G5, acc, rms, rn);
             }
             if (t <= k_steps) block_lds_barrier();                         // barrier t
         }
@@ -1673,6 +1616,7 @@ __global__ __launch_bounds__(3 * DN_BLOCK) void dn_step_many_3w_kernel(const DnP
             tile_stream(tile, s_tile, io0.obs + ((long long)(k_steps - 1) * n + tile_base) * DN_OBS_DIM, rows, lane);
         }
         flush_stats(p, acc, sc0 + (unsigned long long)k_steps, lane);
+        if (NORM && active) store_rms(p, i, rms);
         if (active) {
             reinterpret_cast<float *>(b.g4 + li)[3] = G4.w;
             reinterpret_cast<float *>(b.g5 + li)[3] = G5.w;
