@@ -90,19 +90,19 @@ DN_DEV float sqrt_rn32(float x)
     out = rp > 0.0f ? sp : out;
     return out;
 }
-DN_DEV float rescale_action32(float a)
-{   // PBDroneEnv.rescale_action, PBDroneEnv.py:949-971
+DN_DEV float rescale_unclipped32(float a)
+{   // PBDroneEnv.rescale_action, PBDroneEnv.py:949-971, before its final clip to [-1, 1]
     const float ac = __builtin_amdgcn_fmed3f(a, -2.0f, 2.0f);   // beyond +-2 the result is saturated anyway
     const float num = ac - A_LOW32;
     const float q = div_const32(num, DEN32, INV_DEN32);
     const float m = 2.0f * q;                // (high - low) = 1 - (-1)
-    const float r = -1.0f + m;
-    return __builtin_amdgcn_fmed3f(r, -1.0f, 1.0f);
+    return -1.0f + m;
 }
-DN_DEV float rotor_force_from_action(float a, bool normalize_actions, float &torque, float *rpm_out = nullptr, bool nan_check = true)
+DN_DEV float rescale_action32(float a) { return __builtin_amdgcn_fmed3f(rescale_unclipped32(a), -1.0f, 1.0f); }
+// cmd: the (rescaled) action.  rescale_action's own clip to [-1, 1] may be left out by the caller: the thrust clip below
+// is to [a_low, a_high], a sub-interval, and clip(clip(x, -1, 1), lo, hi) = clip(x, lo, hi).  a: the raw action (NaN test).
+DN_DEV float rotor_force_from_cmd(float cmd, float a, float &torque, float *rpm_out = nullptr, bool nan_check = true)
 {
-    float cmd = a;
-    if (normalize_actions) cmd = rescale_action32(a);
     // PBDroneEnv._preprocessAction, PBDroneEnv.py:889.  The clip makes thrust >= a_low > 0, so cmd2pwm's
     // maximum(thrust, 0) (env_utils.py:29) is the identity.
     const float thrust = __builtin_amdgcn_fmed3f(cmd, A_LOW32, A_HIGH32);
@@ -117,6 +117,10 @@ DN_DEV float rotor_force_from_action(float a, bool normalize_actions, float &tor
     if (rpm_out) *rpm_out = nan ? a : rpm;
     torque = nan ? a : sq * KM32;
     return nan ? a : sq * KF32;
+}
+DN_DEV float rotor_force_from_action(float a, bool normalize_actions, float &torque, float *rpm_out = nullptr, bool nan_check = true)
+{
+    return rotor_force_from_cmd(normalize_actions ? rescale_unclipped32(a) : a, a, torque, rpm_out, nan_check);
 }
 
 DN_DEV float z_torque32(const float tq[4])
@@ -708,8 +712,16 @@ DN_DEV Thrust thrust_phase(const DnParams &p, unsigned long long gid, unsigned s
     if (NOISE && p.act_noise_sigma > 0.0f) add_act_noise(p, gid, step_count, a);
     Thrust t;
     float tq[4];
+    float cmd[4];
+    if (p.normalize_actions) {                         // one wave-uniform branch for the four rotors
 #pragma unroll
-    for (int j = 0; j < 4; ++j) t.f[j] = rotor_force_from_action(a[j], p.normalize_actions != 0, tq[j], nullptr, false);
+        for (int j = 0; j < 4; ++j) cmd[j] = rescale_unclipped32(a[j]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cmd[j] = a[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) t.f[j] = rotor_force_from_cmd(cmd[j], a[j], tq[j], nullptr, false);
     // np.clip / sqrt propagate NaN, the v_med3 clips do not: one test per wave, the selects only where it fires
     if (__builtin_expect(__ballot(__builtin_isunordered(a[0], a[1]) || __builtin_isunordered(a[2], a[3])) != 0ull, 0)) {
 #pragma unroll
