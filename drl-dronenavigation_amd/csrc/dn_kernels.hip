@@ -462,9 +462,11 @@ DN_DEV int orientation_reward(R fx, R fy, R fz, R px, R py, R pz, const R *wp)
 {
 #pragma clang fp contract(fast)
     const R tx = wp[0] - px, ty = wp[1] - py, tz = wp[2] - pz;
-    const R rn = FM<R>::rsq(tx * tx + ty * ty + tz * tz);
-    const R dot = (fx * tx + fy * ty + fz * tz) * rn;
-    return dot < K<R>::COS_10DEG ? -1 : 0;
+    // f . t / |t| < cos(10 deg), without the root: cos(10 deg) > 0, so the test holds iff f . t < 0 or (f . t)^2 < cos^2 |t|^2.
+    // (|t| = 0: the reference divides 0 by 0, NaN compares false -> 0; here 0 < 0 is false as well.)
+    const R t2 = tx * tx + ty * ty + tz * tz;
+    const R dot = fx * tx + fy * ty + fz * tz;
+    return (dot < R(0.0) || dot * dot < (K<R>::COS_10DEG * K<R>::COS_10DEG) * t2) ? -1 : 0;
 }
 
 // sin(h)/h and cos(h) for the quaternion half-angle h = |w| dt / 2 <= pi/8 (Bullet clamps |w| dt at pi/4):
