@@ -1107,7 +1107,19 @@ DN_DEV void flush_stats(const DnParams &p, const StatAcc &a, unsigned long long 
 }
 
 // ---- A7 select + A10/A11 on the report wave: Monitor, SubprocVecEnv worker, outputs ---------------------------
-template <typename R, bool NORM, bool NOISE, bool REW, bool DEFER_TILE = false>
+// TILE: how the observation rows leave -- 0 through the LDS tile, written at once (one-wave kernels); 1 parked in the LDS tile
+// and streamed out by the caller one step later (two-wave kernels); 2 straight from the lane's registers, 52 contiguous
+// bytes per lane as three 16-byte stores and one 4-byte store at 4-byte alignment (three-wave kernel: the report wave
+// has no phase to hide the tile's LDS round trip behind, and 17 fewer instructions per step is what counts there).
+struct __attribute__((packed, aligned(4))) ObsQuad { float x, y, z, w; };
+DN_DEV void store_obs_direct(float *row, const float o[DN_OBS_DIM])
+{
+    *reinterpret_cast<ObsQuad *>(row) = ObsQuad{o[0], o[1], o[2], o[3]};
+    *reinterpret_cast<ObsQuad *>(row + 4) = ObsQuad{o[4], o[5], o[6], o[7]};
+    *reinterpret_cast<ObsQuad *>(row + 8) = ObsQuad{o[8], o[9], o[10], o[11]};
+    row[12] = o[12];
+}
+template <typename R, bool NORM, bool NOISE, bool REW, int TILE = 0>
 DN_DEV void report_phase(const DnParams &p, const DnConsts<R> &c, float *s_tile, const StepOut &out, const Flight<R> &fl,
                          const Verdict<R> &v, Observed<R> &ob, const unsigned long long gid, const unsigned step_count,
                          const unsigned li, const unsigned lane, const unsigned rows, const bool active,
@@ -1180,7 +1192,8 @@ DN_DEV void report_phase(const DnParams &p, const DnConsts<R> &c, float *s_tile,
         out.found[li] = found;
     }
     if (out.done_word && lane == 0) *out.done_word = done_ballot;
-    if (DEFER_TILE) tile_park(s_tile, lane, o);            // streamed out by the caller one step later
+    if (TILE == 2) { if (active) store_obs_direct(out.obs + li * DN_OBS_DIM, o); }
+    else if (TILE == 1) tile_park(s_tile, lane, o);        // streamed out by the caller one step later
     else store_obs_tile(s_tile, out.obs, rows, lane, o);
 }
 
@@ -1405,7 +1418,7 @@ __global__ __launch_bounds__(2 * DN_BLOCK) void dn_step_many_2w_kernel(const DnP
                 Observed<R> ob = observe_phase<R, NORM, NOISE>(p, c, s_tab, fl, G4, G5, gid, sc, rms);
                 if (u > 0) tile_stream(tile, s_tile, io0.obs + ((long long)(u - 1) * n + tile_base) * DN_OBS_DIM, rows, lane);
                 const StepOut out = block_out(io0, tile_base, (long long)u * n, (long long)u * words);
-                report_phase<R, NORM, NOISE, XOPT, true>(p, c, s_tile, out, fl, v, ob, gid, sc, li, lane, rows, active, G4, G5, acc, rms, rn);
+                report_phase<R, NORM, NOISE, XOPT, 1>(p, c, s_tile, out, fl, v, ob, gid, sc, li, lane, rows, active, G4, G5, acc, rms, rn);
             }
             if (t < k_steps) block_lds_barrier();                          // barrier t
         }
@@ -1612,22 +1625,15 @@ __global__ __launch_bounds__(3 * DN_BLOCK) void dn_step_many_3w_kernel(const DnP
             if (t > 1) {                                                   // the step the aux wave finished last iteration
                 const int u = t - 2;
                 const unsigned sc = (unsigned)sc0 + (unsigned)u;
-                TileRegs tile;
-                if (u > 0) tile = tile_fetch(s_tile, lane);
                 Flight<R> fl;
                 Verdict<R> v;
                 Observed<R> ob;
                 take_maila<R>(maila[u & 1], lane, fl, v, ob);
                 if (NORM) normalize_obs(rms, ob.o);                            // the step observation (= terminal_observation)
-                if (u > 0) tile_stream(tile, s_tile, io0.obs + ((long long)(u - 1) * n + tile_base) * DN_OBS_DIM, rows, lane);
                 const StepOut out = block_out(io0, tile_base, (long long)u * n, (long long)u * words);
-                report_phase<R, NORM, NOISE, false, true>(p, c, s_tile, out, fl, v, ob, gid, sc, li, lane, rows, active, G4, G5, acc, rms, rn);
+                report_phase<R, NORM, NOISE, false, 2>(p, c, s_tile, out, fl, v, ob, gid, sc, li, lane, rows, active, G4, G5, acc, rms, rn);
             }
             if (t <= k_steps) block_lds_barrier();                         // barrier t
-        }
-        {   // the last step's tile
-            const TileRegs tile = tile_fetch(s_tile, lane);
-            tile_stream(tile, s_tile, io0.obs + ((long long)(k_steps - 1) * n + tile_base) * DN_OBS_DIM, rows, lane);
         }
         flush_stats(p, acc, sc0 + (unsigned long long)k_steps, lane);
         if (NORM && active) store_rms(p, i, rms);
