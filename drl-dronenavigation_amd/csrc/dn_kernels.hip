@@ -1089,6 +1089,14 @@ DN_DEV double reward_wrappers(const DnParams &p, RewNorm &rn, double r, bool don
     return r;
 }
 
+// llrint(x * 1e6) for |x| < 2^51 * 1e-6 (any episode return), round to nearest even: adding 1.5 * 2^52 leaves the integer
+// in the low mantissa bits -- four instructions instead of the fifteen of a float64 -> int64 conversion.
+DN_DEV long long fixed6(double x)
+{
+    const double m = x * 1e6 + 6755399441055744.0;
+    return __double_as_longlong(m) - 0x4338000000000000ll;
+}
+
 // Episode statistics of one tile, accumulated in (wave-uniform) registers over all the steps of a launch and added
 // to the tile's slot in HBM once, at the end: the slot read-modify-write would otherwise put an HBM/L2 round trip
 // on the report wave's critical path in every step that finishes an episode.
@@ -1150,7 +1158,7 @@ DN_DEV void report_phase(const DnParams &p, const DnConsts<R> &c, float *s_tile,
     float *o = ob.o;
     const unsigned long long done_ballot = __ballot(done && active);
     if (done_ballot != 0ull) {                         // wave-uniform: waves without a finished drone skip all of this
-        const long long fix = llrint((double)ep_ret * 1e6);                       // Monitor 'r' in 1e-6 fixed point
+        const long long fix = fixed6((double)ep_ret);                             // Monitor 'r' in 1e-6 fixed point
         if (done) {
             if (active) {
                 if (out.terminal_obs) {
