@@ -1027,3 +1027,67 @@ def test_three_wave_kernel_short_rollouts_and_ragged_tiles(n, K, monkeypatch):
         assert np.ascontiguousarray(sa[k]).tobytes() == np.ascontiguousarray(sb[k]).tobytes(), k
     assert ref.stats() == env.stats() and ref.step_count == env.step_count == 4 * K
     ref.close(); env.close()
+
+
+@pytest.mark.parametrize("opts", [
+    dict(track="circle4"), dict(track="circle6", cylinder=False), dict(include_distance=False),
+    dict(normalize_actions=False), dict(obs_noise_sigma=0.02, act_noise_sigma=0.01, seed=9),
+    dict(threshold=5.0), dict(ground_contact=False, max_steps=7), dict(normalize_obs=True),
+])
+def test_fused_default_shape_equals_single_steps_over_options(opts):
+    """Whatever shape the library picks for a fused launch (three waves for these sizes), K fused steps must equal K
+    single-step launches bit for bit under every environment option that changes a code path.  (float64 arithmetic, the
+    default: with compute_dtype="float32", the speed option, the compiler fuses multiply-adds across phases that sit in
+    one wave and cannot across waves, so shapes agree to float32 rounding only -- see the next test.)"""
+    pkg = _gpu()
+    opts = dict(opts)
+    track = _tracks().REGISTRY[opts.pop("track", "reaching")]()
+    n, K = 2048, 40
+    kw = dict(normalize_obs=False, max_steps=25)
+    kw.update(opts)
+    a, b = pkg.DroneVecEnv(track, n, device="cuda:0", **kw), pkg.DroneVecEnv(track, n, device="cuda:0", **kw)
+    assert b.kernel_waves(fused=True) == 3 and a.kernel_waves(fused=False) == 1
+    a.reset(); b.reset()
+    rng = np.random.default_rng(17)
+    dev = torch.device("cuda:0")
+    for rep in range(2):
+        acts = torch.from_numpy(np.stack([actions_mixed(rng, n) for _ in range(K)])).to(dev)
+        out = b.rollout_tensor(acts, want_terminal=True)
+        for t in range(K):
+            obs, rew, done, info = a.step_tensor(acts[t])
+            w = obs.shape[1]                              # 12 columns when include_distance is off
+            assert torch.equal(obs, out["obs"][t][:, :w]) and torch.equal(rew, out["reward"][t]) and torch.equal(done, out["done"][t]), (rep, t)
+            assert torch.equal(info["found_targets"], out["found_targets"][t]) and torch.equal(info["truncated"], out["truncated"][t])
+            d = done.bool()
+            assert torch.equal(info["terminal_obs"][d][:, :w], out["terminal_obs"][t][d][:, :w]), (rep, t)
+    sa, sb = a.get_state(), b.get_state()
+    for k in sa.dtype.names:
+        assert np.ascontiguousarray(sa[k]).tobytes() == np.ascontiguousarray(sb[k]).tobytes(), k
+    assert a.stats() == b.stats() and a.stats()["episodes"] > 0
+    a.close(); b.close()
+
+
+def test_float32_compute_shapes_agree_to_rounding(monkeypatch):
+    """compute_dtype="float32" (speed option, hardware approximations): one step from the same state must agree
+    between the one-wave and the multi-wave kernels to float32 rounding (they are not bit-identical there)."""
+    pkg = _gpu()
+    track = _tracks().reaching()
+    n = 2048
+    kw = dict(normalize_obs=False, max_steps=25, compute_dtype="float32")
+    rng = np.random.default_rng(23)
+    dev = torch.device("cuda:0")
+    monkeypatch.setenv("DN_WAVES", "1")
+    a = pkg.DroneVecEnv(track, n, device="cuda:0", **kw)
+    monkeypatch.delenv("DN_WAVES")
+    b = pkg.DroneVecEnv(track, n, device="cuda:0", **kw)
+    a.reset(); b.reset()
+    for _ in range(30):                                   # teacher-forced: both sides start every launch from a's state
+        b.set_state(a.get_state())
+        b.step_count = a.step_count
+        acts = torch.from_numpy(np.stack([actions_mixed(rng, n) for _ in range(2)])).to(dev)
+        oa, ob = a.rollout_tensor(acts), b.rollout_tensor(acts)
+        same = (oa["done"][0] == ob["done"][0]) & (oa["done"][1] == ob["done"][1])
+        assert float(same.float().mean()) > 0.999          # a threshold compare may flip on a float32 ulp
+        np.testing.assert_allclose(oa["obs"][0][same].cpu().numpy(), ob["obs"][0][same].cpu().numpy(), rtol=0, atol=2e-5)
+        np.testing.assert_allclose(oa["reward"][0][same].cpu().numpy(), ob["reward"][0][same].cpu().numpy(), rtol=1e-4, atol=2e-4)
+    a.close(); b.close()
