@@ -1034,12 +1034,13 @@ def test_three_wave_kernel_short_rollouts_and_ragged_tiles(n, K, monkeypatch):
     dict(normalize_actions=False), dict(obs_noise_sigma=0.02, act_noise_sigma=0.01, seed=9),
     dict(threshold=5.0), dict(ground_contact=False, max_steps=7), dict(normalize_obs=True),
 ])
-def test_fused_default_shape_equals_single_steps_over_options(opts):
+def test_fused_default_shape_equals_single_steps_over_options(opts, monkeypatch):
     """Whatever shape the library picks for a fused launch (three waves for these sizes), K fused steps must equal K
     single-step launches bit for bit under every environment option that changes a code path.  (float64 arithmetic, the
     default: with compute_dtype="float32", the speed option, the compiler fuses multiply-adds across phases that sit in
     one wave and cannot across waves, so shapes agree to float32 rounding only -- see the next test.)"""
     pkg = _gpu()
+    monkeypatch.delenv("DN_WAVES", raising=False)         # the library's own choice of shape is what is under test
     opts = dict(opts)
     track = _tracks().REGISTRY[opts.pop("track", "reaching")]()
     n, K = 2048, 40
