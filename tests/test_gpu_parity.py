@@ -1092,3 +1092,41 @@ def test_float32_compute_shapes_agree_to_rounding(monkeypatch):
         np.testing.assert_allclose(oa["obs"][0][same].cpu().numpy(), ob["obs"][0][same].cpu().numpy(), rtol=0, atol=2e-5)
         np.testing.assert_allclose(oa["reward"][0][same].cpu().numpy(), ob["reward"][0][same].cpu().numpy(), rtol=1e-4, atol=2e-4)
     a.close(); b.close()
+
+
+def test_sharding_invariance_with_noise():
+    """BASELINE configs 4/5: a fleet split over ranks (env_id_offset = rank * num_envs) must produce, drone for drone, the
+    bits of the unsplit fleet -- physics, auto-reset and the Philox action/observation noise (keyed by the GLOBAL drone id
+    and the vector-step counter) -- in fused and in single-step launches."""
+    pkg = _gpu()
+    track = _tracks().reaching()
+    n, K = 4096, 24
+    kw = dict(normalize_obs=True, max_steps=30, act_noise_sigma=0.01, obs_noise_sigma=0.02, seed=77)
+    whole = pkg.DroneVecEnv(track, n, device="cuda:0", **kw)
+    parts = [pkg.DroneVecEnv(track, n // 2, device="cuda:0", env_id_offset=r * (n // 2), **kw) for r in range(2)]
+    ow = whole.reset_tensor().clone()
+    op = torch.cat([p.reset_tensor() for p in parts])
+    assert torch.equal(ow, op)
+    rng = np.random.default_rng(31)
+    dev = torch.device("cuda:0")
+    for rep in range(2):
+        acts = torch.from_numpy(np.stack([actions_mixed(rng, n) for _ in range(K)])).to(dev)
+        a = whole.rollout_tensor(acts)
+        bs = [p.rollout_tensor(acts[:, r * (n // 2):(r + 1) * (n // 2)].contiguous()) for r, p in enumerate(parts)]
+        for k in ("obs", "reward", "done", "truncated", "found_targets"):
+            assert torch.equal(a[k], torch.cat([b[k] for b in bs], dim=1)), (k, rep)
+        one = actions_mixed(rng, n)
+        o, r_, d, i = whole.step_tensor(torch.from_numpy(one).to(dev))
+        o, r_, d = o.clone(), r_.clone(), d.clone()
+        ps = [p.step_tensor(torch.from_numpy(one[r * (n // 2):(r + 1) * (n // 2)]).to(dev)) for r, p in enumerate(parts)]
+        assert torch.equal(o, torch.cat([x[0] for x in ps])) and torch.equal(r_, torch.cat([x[1] for x in ps]))
+        assert torch.equal(d, torch.cat([x[2] for x in ps]))
+    sw = whole.get_state()
+    sp = np.concatenate([p.get_state() for p in parts])
+    for k in sw.dtype.names:
+        assert np.ascontiguousarray(sw[k]).tobytes() == np.ascontiguousarray(sp[k]).tobytes(), k
+    ew, e0, e1 = whole.stats(), parts[0].stats(), parts[1].stats()
+    assert ew["episodes"] == e0["episodes"] + e1["episodes"] and ew["env_steps"] == e0["env_steps"] + e1["env_steps"]
+    whole.close()
+    for p in parts:
+        p.close()
