@@ -780,6 +780,34 @@ def test_baseline_full_size_matches_oracle_free_running():
     env.close()
 
 
+def test_baseline_full_size_fused_launch_matches_oracle():
+    """The bench's own launch -- 32768 drones, race track, 64 steps of U(-1,1)^4 actions in ONE dn_step_many (the
+    three-wave kernel) -- against the oracle, every drone, every step, every output; then the mixed stream."""
+    track = _tracks().reaching()
+    n, K = 32768, 64
+    env, ora = make_pair(track, n, f32_state=True, max_steps=4096, normalize_obs=False)
+    assert env.kernel_waves(fused=True) == 3
+    np.testing.assert_allclose(env.reset_tensor().cpu().numpy(), ora.reset(), rtol=0, atol=1e-6)
+    rng = np.random.default_rng(64)
+    dev = torch.device("cuda:0")
+    n_done = 0
+    for stream in ("uniform", "mixed"):
+        acts = np.stack([rng.uniform(-1, 1, (n, 4)).astype(np.float32) if stream == "uniform" else actions_mixed(rng, n)
+                         for _ in range(K)])
+        out = env.rollout_tensor(torch.from_numpy(acts).to(dev), want_terminal=True)
+        torch.cuda.synchronize()
+        for t in range(K):
+            info = dict(truncated=out["truncated"][t], found_targets=out["found_targets"][t], terminal_obs=out["terminal_obs"][t],
+                        ep_length=out["ep_length"][t], ep_return=out["ep_return"][t])
+            # free-running (both sides keep their own float32 state): a one-ulp difference in a stored attitude is amplified
+            # by a tumbling drone, one observation in 4e5 reaches 1.3e-5 -- the per-step bar (1e-5) is the teacher-forced tests'
+            n_done += compare_step((out["obs"][t], out["reward"][t], out["done"][t], info), ora.step(acts[t]),
+                                   f"fused full-size {stream} t={t}", obs_atol=1e-4, rew_atol=2e-4)
+    assert n_done > n // 2
+    assert env.stats()["episodes"] == n_done
+    env.close()
+
+
 def test_fused_rollout_collector_against_oracle_and_graph_replay():
     """FusedRolloutCollector (dn_mlp_forward -> dn_policy_sample -> dn_step -> masked bootstrap, five launches per step,
     no copies): the sampled actions are mean + std * z with z from the environment's Philox stream 9 (checked against
