@@ -273,8 +273,7 @@ DN_DEV double rcp_f64(double x)
     return __builtin_fma(r, e, r);
 }
 DN_DEV void normalize_obs(Rms &r, float o[DN_OBS_DIM])
-{
-#pragma clang fp contract(fast)
+{   // explicit fused multiply-adds, no contraction licence (one arithmetic sequence for every kernel that inlines this)
     const double tot = r.count + 1.0;
     const double inv = rcp_f64(tot);
     const double cw = r.count * inv;
@@ -282,8 +281,8 @@ DN_DEV void normalize_obs(Rms &r, float o[DN_OBS_DIM])
     for (int k = 0; k < DN_OBS_DIM; ++k) {
         const double x = (double)o[k];
         const double delta = x - r.mean[k];
-        const double new_mean = r.mean[k] + delta * inv;
-        const double new_var = (r.var[k] + delta * delta * inv) * cw;
+        const double new_mean = __builtin_fma(delta, inv, r.mean[k]);
+        const double new_var = __builtin_fma(delta * delta, inv, r.var[k]) * cw;
         r.mean[k] = new_mean;
         r.var[k] = new_var;
         const double s = new_var + 1e-8;
@@ -392,39 +391,24 @@ DN_DEV float atan2_fast32(float y, float x)
 template <typename R>
 DN_DEV bool collision_common(const DnParams &p, const DnConsts<R> &c, R px, R py, R pz, R r22)
 {   // everything in _has_collision_occurred that does not depend on the waypoint index
-#pragma clang fp contract(fast)
+    // (explicit fused multiply-adds, no contraction licence: see physics_phase)
     bool out = px > c.dim[3] || px < c.dim[0] || py > c.dim[4] || py < c.dim[1] || pz > c.dim[5];
     if (p.ground_contact) {
         // len(p.getContactPoints()) > 0 against plane.urdf, APPROXIMATED [3P-recall]: lowest point of the
         // collision cylinder within Bullet's 0.02 contact-breaking threshold of z = 0:
         //   pz - (H/2 |r22| + R sqrt(1 - r22^2)) <= 0.02   <=>   m <= 0  or  m^2 <= R^2 (1 - r22^2),
         //   m = pz - H/2 |r22| - 0.02
-        R s2 = R(1.0) - r22 * r22;
+        R s2 = FM<R>::fma(-r22, r22, R(1.0));
         s2 = s2 > R(0.0) ? s2 : R(0.0);
-        const R m = pz - R(0.5) * K<R>::COLL_H * fabs(r22) - R(0.02);
+        const R m = FM<R>::fma(R(-0.5) * K<R>::COLL_H, fabs(r22), pz) - R(0.02);
         out = out || m <= R(0.0) || m * m <= (K<R>::COLL_R * K<R>::COLL_R) * s2;
     }
     if (p.cylinder && p.circle) {                     // :723-741, centre (0,0,1), radius 1
-        const R rn = FM<R>::rsq(px * px + py * py);   // 0 -> NaN -> the compare below is false, as in the reference
-        const R ex = px - px * rn, ey = py - py * rn, ez = pz - R(1.0);
-        out = out || (ex * ex + ey * ey + ez * ez) > c.thr2;
+        const R rn = FM<R>::rsq(FM<R>::fma(py, py, px * px));   // 0 -> NaN -> the compare below is false, as in the reference
+        const R ex = FM<R>::fma(-px, rn, px), ey = FM<R>::fma(-py, rn, py), ez = pz - R(1.0);
+        out = out || FM<R>::fma(ez, ez, FM<R>::fma(ey, ey, ex * ex)) > c.thr2;
     }
     return out;
-}
-template <typename R>
-DN_DEV bool outside_segment_corridor(const DnConsts<R> &c, const R *tab, R px, R py, R pz, int idx)
-{   // :746-786, the corridor around the segment that ends at waypoint idx (non-circle tracks)
-#pragma clang fp contract(fast)
-    const R *e = tab + idx * DN_T_STRIDE;
-    const R ux = e[DN_T_U], uy = e[DN_T_U + 1], uz = e[DN_T_U + 2];
-    const R dx = px - e[DN_T_E1], dy = py - e[DN_T_E1 + 1], dz = pz - e[DN_T_E1 + 2];   // :776
-    R proj = dx * ux + dy * uy + dz * uz;              // :778
-    proj = clipv(proj, R(0.0), e[DN_T_LEXT]);          // :780
-    // distance to the clamped projection (:782-786); a zero-length segment has u = 0, e1 = base1, lext = 0, so the
-    // same expression is |pos - base1|, which the reference tests against the bare threshold (:756-757)
-    const R qx = dx - proj * ux, qy = dy - proj * uy, qz = dz - proj * uz;
-    const R lim = e[DN_T_LL] == R(0.0) ? c.thr2 : c.thr_ext2;
-    return (qx * qx + qy * qy + qz * qz) > lim;
 }
 
 // The table row of a drone's CURRENT waypoint, read at the top of a step (the index is part of the entry state) so
@@ -443,15 +427,22 @@ template <typename R> DN_DEV GateRow<R> load_gate_row(const R *tab, int idx)
 }
 template <typename R>
 DN_DEV bool outside_segment_corridor_row(const DnConsts<R> &c, const GateRow<R> &g, R px, R py, R pz)
-{   // outside_segment_corridor on a row already in registers (same expressions, same bits)
-#pragma clang fp contract(fast)
+{   // :746-786 on a table row in registers (explicit fused multiply-adds, no contraction licence: see physics_phase)
     const R ux = g.u[0], uy = g.u[1], uz = g.u[2];
-    const R dx = px - g.e1[0], dy = py - g.e1[1], dz = pz - g.e1[2];
-    R proj = dx * ux + dy * uy + dz * uz;
-    proj = clipv(proj, R(0.0), g.lext);
-    const R qx = dx - proj * ux, qy = dy - proj * uy, qz = dz - proj * uz;
+    const R dx = px - g.e1[0], dy = py - g.e1[1], dz = pz - g.e1[2];                       // :776
+    R proj = FM<R>::fma(dz, uz, FM<R>::fma(dy, uy, dx * ux));                              // :778
+    proj = clipv(proj, R(0.0), g.lext);                                                     // :780
+    // distance to the clamped projection (:782-786); a zero-length segment has u = 0, e1 = base1, lext = 0, so the
+    // same expression is |pos - base1|, which the reference tests against the bare threshold (:756-757)
+    const R qx = FM<R>::fma(-proj, ux, dx), qy = FM<R>::fma(-proj, uy, dy), qz = FM<R>::fma(-proj, uz, dz);
     const R lim = g.ll == R(0.0) ? c.thr2 : c.thr_ext2;
-    return (qx * qx + qy * qy + qz * qz) > lim;
+    return FM<R>::fma(qz, qz, FM<R>::fma(qy, qy, qx * qx)) > lim;
+}
+
+template <typename R>
+DN_DEV bool outside_segment_corridor(const DnConsts<R> &c, const R *tab, R px, R py, R pz, int idx)
+{   // :746-786, the corridor around the segment that ends at waypoint idx (non-circle tracks)
+    return outside_segment_corridor_row<R>(c, load_gate_row<R>(tab, idx), px, py, pz);
 }
 
 // orientation_reward (PBDroneEnv.py:573-586) with get_forward_vector (:588-597).  The reference tests
@@ -460,12 +451,11 @@ DN_DEV bool outside_segment_corridor_row(const DnConsts<R> &c, const GateRow<R> 
 template <typename R>
 DN_DEV int orientation_reward(R fx, R fy, R fz, R px, R py, R pz, const R *wp)
 {
-#pragma clang fp contract(fast)
     const R tx = wp[0] - px, ty = wp[1] - py, tz = wp[2] - pz;
     // f . t / |t| < cos(10 deg), without the root: cos(10 deg) > 0, so the test holds iff f . t < 0 or (f . t)^2 < cos^2 |t|^2.
     // (|t| = 0: the reference divides 0 by 0, NaN compares false -> 0; here 0 < 0 is false as well.)
-    const R t2 = tx * tx + ty * ty + tz * tz;
-    const R dot = fx * tx + fy * ty + fz * tz;
+    const R t2 = FM<R>::fma(tz, tz, FM<R>::fma(ty, ty, tx * tx));                  // explicit order, see attitude_phase
+    const R dot = FM<R>::fma(fz, tz, FM<R>::fma(fy, ty, fx * tx));
     return (dot < R(0.0) || dot * dot < (K<R>::COS_10DEG * K<R>::COS_10DEG) * t2) ? -1 : 0;
 }
 
@@ -744,7 +734,6 @@ template <typename R> struct IsResultant<Resultant<R>> { static constexpr bool v
 template <typename R>
 DN_DEV Resultant<R> rotor_resultant(const Thrust &th)
 {
-#pragma clang fp contract(fast)
     const R F0 = th.f[0], F1 = th.f[1], F2 = th.f[2], F3 = th.f[3];
     Resultant<R> r;
     r.fz = (F0 + F1) + (F2 + F3);
@@ -759,7 +748,11 @@ template <typename R, typename TH = Thrust, bool XOPT = false>
 DN_DEV Flight<R> physics_phase(const TH &th, const float4 G0, const float4 G1, const float4 G2, const float4 G3,
                                const int max_steps, const Extras *x = nullptr)
 {
-#pragma clang fp contract(fast)
+    // No `fp contract` licence in the recurrence: every fused multiply-add is spelled out (F), in one order.  Left to the
+    // compiler, WHICH product of a sum of products gets fused is picked per instantiation, and the picks differed between
+    // the kernel shapes (found by a soak run: one float32 ulp in a component of 1e-6 rad/s, which then diverges) -- the
+    // shapes, and with them every split of a fleet over ranks, are bit-identical only if the arithmetic is one sequence.
+#define F(a, b, c) FM<R>::fma((a), (b), (c))
     Flight<R> fl;
     R px = G0.x, py = G0.y, pz = G0.z;
     R qx = G1.x, qy = G1.y, qz = G1.z, qw = G1.w;
@@ -772,14 +765,13 @@ DN_DEV Flight<R> physics_phase(const TH &th, const float4 G0, const float4 G1, c
     fl.vex = G2.x; fl.vey = G2.y; fl.vez = G2.z; fl.aex = G3.x; fl.aey = G3.y; fl.aez = G3.z;
     const R dt = K<R>::DT;
     // btMatrix3x3::setRotation: s = 2 / |q|^2
-    const R s = R(2.0) * FM<R>::rcp(qx * qx + qy * qy + qz * qz + qw * qw);
+    const R s = R(2.0) * FM<R>::rcp(F(qw, qw, F(qz, qz, F(qy, qy, qx * qx))));
     const R xs = qx * s, ys = qy * s, zs = qz * s;
     const R wxs = qw * xs, wys = qw * ys, wzs = qw * zs;
-    const R xx = qx * xs, xy = qx * ys, xz = qx * zs;
-    const R yy = qy * ys, yz = qy * zs, zz = qz * zs;
-    const R r00 = R(1.0) - (yy + zz), r01 = xy - wzs, r02 = xz + wys;
-    const R r10 = xy + wzs, r11 = R(1.0) - (xx + zz), r12 = yz - wxs;
-    const R r20 = xz - wys, r21 = yz + wxs, r22 = R(1.0) - (xx + yy);
+    const R yy = qy * ys, zz = qz * zs;
+    const R r00 = R(1.0) - F(qy, ys, zz), r01 = F(qx, ys, -wzs), r02 = F(qx, zs, wys);
+    const R r10 = F(qx, ys, wzs), r11 = R(1.0) - F(qx, xs, zz), r12 = F(qy, zs, -wxs);
+    const R r20 = F(qx, zs, -wys), r21 = F(qy, zs, wxs), r22 = R(1.0) - F(qx, xs, yy);
     // rotor thrusts along body z at the prop offsets (+,-) (-,-) (-,+) (+,+) * 0.028 (cf2x.urdf:42,54,66,78)
     R fz, tx, ty, ztq;
     R dax = R(0.0), day = R(0.0), daz = R(0.0);
@@ -821,20 +813,20 @@ DN_DEV Flight<R> physics_phase(const TH &th, const float4 G0, const float4 G1, c
     }
     // linear: a = R[:,2] fz/M - (0,0,G) - v (c + c|v|)
     // the damping norms enter the velocity update at dt * 0.04: a float32 root moves it by 1e-12 relative
-    const R kl = K<R>::LIN_DAMP + K<R>::LIN_DAMP * (R)__builtin_amdgcn_sqrtf((float)(vx * vx + vy * vy + vz * vz));
+    const R kl = F(K<R>::LIN_DAMP, (R)__builtin_amdgcn_sqrtf((float)F(vz, vz, F(vy, vy, vx * vx))), K<R>::LIN_DAMP);
     const R fm = fz * K<R>::INV_M;
-    R awx = r02 * fm - vx * kl, awy = r12 * fm - vy * kl, awz = (r22 * fm - K<R>::G) - vz * kl;
+    R awx = F(r02, fm, -(vx * kl)), awy = F(r12, fm, -(vy * kl)), awz = F(-vz, kl, F(r22, fm, -K<R>::G));
     if (XOPT) { awx += dax; awy += day; awz += daz; }
     // angular, in the body frame: I dw = tau - w x (I w) - I w (c + c|w|)
-    const R wbx = r00 * wx + r10 * wy + r20 * wz, wby = r01 * wx + r11 * wy + r21 * wz, wbz = r02 * wx + r12 * wy + r22 * wz;
-    const R ka = K<R>::ANG_DAMP + K<R>::ANG_DAMP * (R)__builtin_amdgcn_sqrtf((float)(wx * wx + wy * wy + wz * wz));
+    const R wbx = F(r20, wz, F(r10, wy, r00 * wx)), wby = F(r21, wz, F(r11, wy, r01 * wx)), wbz = F(r22, wz, F(r12, wy, r02 * wx));
+    const R ka = F(K<R>::ANG_DAMP, (R)__builtin_amdgcn_sqrtf((float)F(wz, wz, F(wy, wy, wx * wx))), K<R>::ANG_DAMP);
     const R Iwx = K<R>::IXX * wbx, Iwy = K<R>::IYY * wby, Iwz = K<R>::IZZ * wbz;
-    const R gx = wby * Iwz - wbz * Iwy, gy = wbz * Iwx - wbx * Iwz, gz = wbx * Iwy - wby * Iwx;
-    const R dbx = (tx - gx - Iwx * ka) * K<R>::INV_IXX, dby = (ty - gy - Iwy * ka) * K<R>::INV_IYY,
-            dbz = (ztq - gz - Iwz * ka) * K<R>::INV_IZZ;
-    const R dwx = r00 * dbx + r01 * dby + r02 * dbz, dwy = r10 * dbx + r11 * dby + r12 * dbz, dwz = r20 * dbx + r21 * dby + r22 * dbz;
-    wx += dwx * dt; wy += dwy * dt; wz += dwz * dt;       // applyDeltaVeeMultiDof
-    vx += awx * dt; vy += awy * dt; vz += awz * dt;
+    const R gx = F(wby, Iwz, -(wbz * Iwy)), gy = F(wbz, Iwx, -(wbx * Iwz)), gz = F(wbx, Iwy, -(wby * Iwx));
+    const R dbx = F(-Iwx, ka, tx - gx) * K<R>::INV_IXX, dby = F(-Iwy, ka, ty - gy) * K<R>::INV_IYY,
+            dbz = F(-Iwz, ka, ztq - gz) * K<R>::INV_IZZ;
+    const R dwx = F(r02, dbz, F(r01, dby, r00 * dbx)), dwy = F(r12, dbz, F(r11, dby, r10 * dbx)), dwz = F(r22, dbz, F(r21, dby, r20 * dbx));
+    wx = F(dwx, dt, wx); wy = F(dwy, dt, wy); wz = F(dwz, dt, wz);       // applyDeltaVeeMultiDof
+    vx = F(awx, dt, vx); vy = F(awy, dt, vy); vz = F(awz, dt, vz);
     // btMultiBody clamps every velocity coordinate at m_maxCoordinateVelocity; no reachable state gets there
     // (thrust/weight = 5.5, damping), so test once per wave and clamp only then.  NaN stays NaN either way.
     const R mv = K<R>::MAX_COORD_VEL;
@@ -843,27 +835,28 @@ DN_DEV Flight<R> physics_phase(const TH &th, const float4 G0, const float4 G1, c
         wx = clipv(wx, -mv, mv); wy = clipv(wy, -mv, mv); wz = clipv(wz, -mv, mv);
         vx = clipv(vx, -mv, mv); vy = clipv(vy, -mv, mv); vz = clipv(vz, -mv, mv);
     }
-    px += dt * vx; py += dt * vy; pz += dt * vz;          // stepPositionsMultiDof
+    px = F(dt, vx, px); py = F(dt, vy, py); pz = F(dt, vz, pz);          // stepPositionsMultiDof
     // exponential map: Bullet clamps the angle rate, fAngle = min(|w|, (pi/4)/dt), and takes
     // axis = w sin(h)/fAngle with h = fAngle dt/2, i.e. w (dt/2) sinc(h), and cos(h): both are even in h, so only
     // h^2 = min(|w|^2 dt^2/4, (pi/8)^2) is needed and the sqrt of |w|^2 never is.  (Bullet's |w| < 1e-3 Taylor
     // branch is the same function to 1e-24.)
-    R h2 = (R(0.25) * dt * dt) * (wx * wx + wy * wy + wz * wz);
+    R h2 = (R(0.25) * dt * dt) * F(wz, wz, F(wy, wy, wx * wx));
     const R h2max = R(0.015625) * K<R>::PI * K<R>::PI;     // (pi/8)^2
     h2 = h2 > h2max ? h2max : h2;
     R sinc, aw;
     sinc_cos_small<R>(h2, sinc, aw);
     const R k = (R(0.5) * dt) * sinc;
     const R ax = wx * k, ay = wy * k, az = wz * k;
-    const R nx = aw * qx + ax * qw + ay * qz - az * qy;
-    const R ny = aw * qy + ay * qw + az * qx - ax * qz;
-    const R nz = aw * qz + az * qw + ax * qy - ay * qx;
-    const R nw_ = aw * qw - ax * qx - ay * qy - az * qz;
-    const R inv = FM<R>::rsq(nx * nx + ny * ny + nz * nz + nw_ * nw_);
+    const R nx = F(-az, qy, F(ay, qz, F(ax, qw, aw * qx)));
+    const R ny = F(-ax, qz, F(az, qx, F(ay, qw, aw * qy)));
+    const R nz = F(-ay, qx, F(ax, qy, F(az, qw, aw * qz)));
+    const R nw_ = F(-az, qz, F(-ay, qy, F(-ax, qx, aw * qw)));
+    const R inv = FM<R>::rsq(F(nw_, nw_, F(nz, nz, F(ny, ny, nx * nx))));
     fl.px = px; fl.py = py; fl.pz = pz;
     fl.qx = nx * inv; fl.qy = ny * inv; fl.qz = nz * inv; fl.qw = nw_ * inv;
     fl.vx = (float)vx; fl.vy = (float)vy; fl.vz = (float)vz; fl.wx = (float)wx; fl.wy = (float)wy; fl.wz = (float)wz;
     return fl;
+#undef F
 }
 
 // ---- A8 + A9 on the flight wave: _computeTerminated (PBDroneEnv.py:456-473) as evaluated inside _computeReward
@@ -877,11 +870,11 @@ DN_DEV Verdict<R> rules_phase(const DnParams &p, const DnConsts<R> &c, const R *
                               const Flight<R> &fl, const float4 G0e, const float4 G3e, float4 *g6_blk, const unsigned li,
                               const bool active, float4 &G0, float4 &G1, float4 &G2, float4 &G3)
 {
-#pragma clang fp contract(fast)
+// (explicit fused multiply-adds, no contraction licence: see physics_phase)
     const Meta m_e = unpack_meta(G3e.w);
     const R px = fl.px, py = fl.py, pz = fl.pz;
     // rotation entry R[2][2] of the new (unit) attitude, for the ground-contact approximation only
-    const R r22n = R(1.0) - R(2.0) * (fl.qx * fl.qx + fl.qy * fl.qy);
+    const R r22n = FM<R>::fma(R(-2.0), FM<R>::fma(fl.qy, fl.qy, fl.qx * fl.qx), R(1.0));
     int idx = m_e.idx, just_found = m_e.just_found;
     const bool seg_track = p.cylinder && !p.circle;
     const bool coll1 = collision_common<R>(p, c, px, py, pz, r22n) ||
@@ -913,7 +906,7 @@ DN_DEV Verdict<R> rules_phase(const DnParams &p, const DnConsts<R> &c, const R *
             wx = wp[0]; wy = wp[1]; wz = wp[2];
         }
         const R ex = wx - px, ey = wy - py, ez = wz - pz;
-        d = FM<R>::sqrt0(ex * ex + ey * ey + ez * ez);
+        d = FM<R>::sqrt0(FM<R>::fma(ez, ez, FM<R>::fma(ey, ey, ex * ex)));
     }
     Verdict<R> v;
     v.d_obs = d; v.coll1 = coll1; v.terminated = terminated;
@@ -935,7 +928,7 @@ DN_DEV Verdict<R> rules_phase(const DnParams &p, const DnConsts<R> &c, const R *
             S1 = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
             S2 = S3 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             const R ex = cpx - wp0[0], ey = cpy - wp0[1], ez = cpz - wp0[2];
-            d = FM<R>::sqrt0(ex * ex + ey * ey + ez * ez);                // :651
+            d = FM<R>::sqrt0(FM<R>::fma(ez, ez, FM<R>::fma(ey, ey, ex * ex)));    // :651
             d_prev = d;                                                   // :652
             idx = 0; steps = 0; just_found = 0;
         }
@@ -949,7 +942,6 @@ DN_DEV Verdict<R> rules_phase(const DnParams &p, const DnConsts<R> &c, const R *
 template <typename R>
 DN_DEV void attitude_phase(Flight<R> &fl)
 {
-#pragma clang fp contract(fast)
     const R qx = fl.qx, qy = fl.qy, qz = fl.qz, qw = fl.qw;
     // p.getEulerFromQuaternion [3P-recall of pybullet.c].  The three angles only feed observation columns 3..5
     // (float32, bar 1e-5): the quaternion products are formed in R, the inverse trigonometry runs in float32
@@ -957,9 +949,13 @@ DN_DEV void attitude_phase(Flight<R> &fl)
     float roll_num32, roll_den32, pitch32, yaw32;
     R fwx, fwy, fwz;
     {
-        const R sqx = qx * qx, sqy = qy * qy, sqz = qz * qz, squ = qw * qw;
-        const R sarg = R(-2.0) * (qx * qz - qw * qy);
-        const R ys = R(2.0) * (qx * qy + qw * qz), yc = squ + sqx - sqy - sqz;
+        // Sums of several products are written as explicit fused multiply-adds in ONE order: left to `fp contract`, the
+        // compiler picks which product of a sum to fuse per instantiation, and the pick can differ between the kernel
+        // shapes (a value that arrives through LDS ranks differently from one computed in place) -- one float32 ulp in
+        // one observation value per ~1e9, found by a soak run.
+        const R sarg = R(-2.0) * FM<R>::fma(qx, qz, -(qw * qy));
+        const R ys = R(2.0) * FM<R>::fma(qx, qy, qw * qz);
+        const R yc = FM<R>::fma(qw, qw, FM<R>::fma(qx, qx, -FM<R>::fma(qy, qy, qz * qz)));     // w^2 + x^2 - y^2 - z^2
         if (__builtin_expect(sarg <= R(-0.99999) || sarg >= R(0.99999), 0)) {   // gimbal-lock branches: rare, keep them literal (and out of line)
             R pitch, yaw;
             roll_num32 = 0.0f; roll_den32 = 1.0f;             // roll = 0 = atan2(0, 1)
@@ -969,12 +965,13 @@ DN_DEV void attitude_phase(Flight<R> &fl)
             fwx = cos(yaw) * cpit; fwy = sin(yaw) * cpit; fwz = sin(pitch);
             pitch32 = (float)pitch; yaw32 = (float)yaw;
         } else {
-            roll_num32 = (float)(R(2.0) * (qy * qz + qw * qx)); roll_den32 = (float)(squ - sqx - sqy + sqz);
+            roll_num32 = (float)(R(2.0) * FM<R>::fma(qy, qz, qw * qx));
+            roll_den32 = (float)FM<R>::fma(qw, qw, FM<R>::fma(qz, qz, -FM<R>::fma(qx, qx, qy * qy)));   // w^2 - x^2 - y^2 + z^2
             yaw32 = atan2_fast32((float)ys, (float)yc);
             // asin(s) is ill-conditioned towards +-1; cos(pitch) = |(r00, r10)| = sqrt(yc^2 + ys^2) for the unit quaternion
             // of Flight, so pitch = atan2(s, cos pitch) is well conditioned everywhere (tumbling drones sit beyond
             // 72 deg often enough that a float64 asin tail would run on most wave-steps of a bang-bang workload)
-            pitch32 = atan2_fast32((float)sarg, __builtin_amdgcn_sqrtf((float)(yc * yc + ys * ys)));
+            pitch32 = atan2_fast32((float)sarg, __builtin_amdgcn_sqrtf((float)FM<R>::fma(yc, yc, ys * ys)));
             fwx = yc; fwy = ys; fwz = sarg;
         }
     }
@@ -995,7 +992,6 @@ DN_DEV Observed<R> observe_phase(const DnParams &p, const DnConsts<R> &c, const 
                                  const float4 G4, const float4 G5, const unsigned long long gid, const unsigned step_count,
                                  Rms &rms)
 {
-#pragma clang fp contract(fast)
     Observed<R> ob;
     const float roll32 = atan2_fast32(fl.roll_num32, fl.roll_den32), pitch32 = fl.pitch32, yaw32 = fl.yaw32;    // attitude_phase (flight wave)
     const R fwx = fl.fwx, fwy = fl.fwy, fwz = fl.fwz;
@@ -1016,7 +1012,7 @@ DN_DEV Observed<R> observe_phase(const DnParams &p, const DnConsts<R> &c, const 
         o[6] = clipv((float)((R)fl.vx * K<R>::THIRD), -1.0f, 1.0f);
         o[7] = clipv((float)((R)fl.vy * K<R>::THIRD), -1.0f, 1.0f);
         o[8] = clipv((float)((R)fl.vz * K<R>::THIRD), -third32, third32);
-        const R w2 = (R)fl.wx * (R)fl.wx + (R)fl.wy * (R)fl.wy + (R)fl.wz * (R)fl.wz;
+        const R w2 = FM<R>::fma((R)fl.wz, (R)fl.wz, FM<R>::fma((R)fl.wy, (R)fl.wy, (R)fl.wx * (R)fl.wx));   // explicit order, see attitude_phase
         if (w2 != R(0.0)) {                                   // ang_v / |ang_v|, zero stays zero (:383-384)
             const R rw = FM<R>::rsq_f32grade(w2);
             o[9] = (float)((R)fl.wx * rw); o[10] = (float)((R)fl.wy * rw); o[11] = (float)((R)fl.wz * rw);
@@ -1034,13 +1030,14 @@ DN_DEV Observed<R> observe_phase(const DnParams &p, const DnConsts<R> &c, const 
         if (last_gate) r32 = r32 + 200.0f;                                        // :542-546
         else { r32 = r32 + 75.0f; r32 = r32 + (float)(ori * 5); }                 // :548-552
         ob.r_found32 = r32;
-        R r = R(3.0) * (R)__builtin_amdgcn_exp2f((float)(R(-2.0 * 1.4426950408889634) * (R)fl.d_e));   // :555 3 e^{-2d} (v_exp_f32: 1e-7 rel, 1e-8 in the reward)
-        r = r + (fl.just_found_e ? R(0.0) : ((R)fl.dprev_e - (R)fl.d_e) * R(3000.0));   // :556
+        // :555 3 e^{-2d} (v_exp_f32: 1e-7 rel, 1e-8 in the reward) + :556
+        const R gain = fl.just_found_e ? R(0.0) : ((R)fl.dprev_e - (R)fl.d_e) * R(3000.0);
+        R r = FM<R>::fma(R(3.0), (R)__builtin_amdgcn_exp2f((float)(R(-2.0 * 1.4426950408889634) * (R)fl.d_e)), gain);
         r = r + (R)(ori * 3);                                                     // :557
         // smoothness_reward (:599-607) on the stale post-step copies (quirk Q4): -|dv| if |dv| > 0.7, -|dw| if > 0.3
         const R lx = (R)fl.vex - (R)G4.x, ly = (R)fl.vey - (R)G4.y, lz = (R)fl.vez - (R)G4.z;
         const R ax_ = (R)fl.aex - (R)G5.x, ay_ = (R)fl.aey - (R)G5.y, az_ = (R)fl.aez - (R)G5.z;
-        const R la2 = lx * lx + ly * ly + lz * lz, aa2 = ax_ * ax_ + ay_ * ay_ + az_ * az_;
+        const R la2 = FM<R>::fma(lz, lz, FM<R>::fma(ly, ly, lx * lx)), aa2 = FM<R>::fma(az_, az_, FM<R>::fma(ay_, ay_, ax_ * ax_));
         // the penalties enter the reward at 1/25: a float32 root (1e-7 relative) is far inside the reward's 1e-5 bar
         if (la2 > R(0.7) * R(0.7)) r = r - (R)__builtin_amdgcn_sqrtf((float)la2);     // needs > 160 m/s^2: rare
         if (aa2 > R(0.3) * R(0.3)) r = r - (R)__builtin_amdgcn_sqrtf((float)aa2);
@@ -1069,15 +1066,14 @@ DN_DEV void store_rewnorm(const DnParams &p, long long i, const RewNorm &r)
 }
 DN_DEV double reward_wrappers(const DnParams &p, RewNorm &rn, double r, bool done)
 {
-#pragma clang fp contract(fast)
     if (p.clip_rew) r = clipv(r, -10.0, 10.0);
     if (p.norm_rew) {
-        rn.returns = rn.returns * 0.99 + r;
+        rn.returns = __builtin_fma(rn.returns, 0.99, r);
         const double tot = rn.count + 1.0;
         const double inv = rcp_f64(tot);
         const double delta = rn.returns - rn.mean;
-        rn.mean = rn.mean + delta * inv;
-        rn.var = (rn.var + delta * delta * inv) * (rn.count * inv);
+        rn.mean = __builtin_fma(delta, inv, rn.mean);
+        rn.var = __builtin_fma(delta * delta, inv, rn.var) * (rn.count * inv);
         rn.count = tot;
         const double s = rn.var + 1e-8;
         double y = __builtin_amdgcn_rsq(s);
@@ -1134,7 +1130,6 @@ DN_DEV void report_phase(const DnParams &p, const DnConsts<R> &c, float *s_tile,
                          const unsigned li, const unsigned lane, const unsigned rows, const bool active,
                          float4 &G4, float4 &G5, StatAcc &acc, Rms &rms, RewNorm &rn)
 {
-#pragma clang fp contract(fast)
     const bool coll1 = v.coll1 != 0, terminated = v.terminated != 0, truncated = fl.truncated != 0;
     const bool found_now = !coll1 && (R)fl.d_e <= c.threshold;
     const bool is_done = found_now && fl.idx_e + 1 == p.num_waypoints;
@@ -1659,7 +1654,6 @@ __global__ __launch_bounds__(3 * DN_BLOCK) void dn_step_many_3w_kernel(const DnP
 template <typename R>
 __global__ __launch_bounds__(DN_BLOCK) void dn_reset_kernel(const DnParams p, float *obs)
 {
-#pragma clang fp contract(fast)
     __shared__ R s_tab[DN_MAX_WAYPOINTS * DN_T_STRIDE];
     __shared__ __attribute__((aligned(16))) float s_tile[DN_BLOCK * DN_OBS_DIM];
     const unsigned lane = threadIdx.x;
@@ -1689,7 +1683,7 @@ __global__ __launch_bounds__(DN_BLOCK) void dn_reset_kernel(const DnParams p, fl
         if (active) store_rms(p, i, rms);
     }
     const R ex = cpx - s_tab[0], ey = cpy - s_tab[1], ez = cpz - s_tab[2];
-    const R d = FM<R>::sqrt0(ex * ex + ey * ey + ez * ez);
+    const R d = FM<R>::sqrt0(FM<R>::fma(ez, ez, FM<R>::fma(ey, ey, ex * ex)));
     if (active) {
         b.g0[li] = make_float4((float)c.spawn[0], (float)c.spawn[1], (float)c.spawn[2], (float)d);
         b.g1[li] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
