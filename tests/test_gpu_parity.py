@@ -1161,3 +1161,53 @@ def test_sharding_invariance_with_noise(n, K, norm):
     whole.close()
     for p in parts:
         p.close()
+
+
+def test_random_configurations_all_shapes_bit_identical(monkeypatch):
+    """A slice of the soak run that found the fused-multiply-add ambiguity: random fleet sizes, rollout
+    lengths, tracks and option switches; whatever shape the library picks must reproduce the one-wave kernels bit for bit
+    -- outputs, state, statistics.  (The full soak, scratch-only, ran 50 000 configurations.)"""
+    pkg = _gpu()
+    tr = _tracks()
+    rng = np.random.default_rng(77)
+    dev = torch.device("cuda:0")
+    shapes = set()
+    for it in range(70):
+        n = int(rng.choice([1000, 4096, 16384, 32768, 49152, 65536]))
+        K = int(rng.integers(2, 50))
+        trk = str(rng.choice(["reaching", "circle4", "circle6"]))
+        kw = dict(normalize_obs=bool(rng.integers(0, 2)), max_steps=int(rng.integers(3, 60)), seed=int(rng.integers(1, 1000)),
+                  cylinder=bool(rng.integers(0, 4) > 0), include_distance=bool(rng.integers(0, 4) > 0),
+                  normalize_actions=bool(rng.integers(0, 4) > 0), threshold=float(rng.choice([0.3, 0.3, 1.0, 5.0])),
+                  ground_contact=bool(rng.integers(0, 2)))
+        if rng.integers(0, 3) == 0:
+            kw.update(obs_noise_sigma=0.02, act_noise_sigma=0.005)
+        if rng.integers(0, 4) == 0:
+            kw.update(physics=str(rng.choice(["pyb_gnd", "pyb_drag", "pyb_gnd_drag_dw"])))
+        if rng.integers(0, 6) == 0:
+            kw.update(act="rpm", normalize_actions=False)
+        if rng.integers(0, 5) == 0:
+            kw.update(clip_rew=bool(rng.integers(0, 2)), norm_rew=True)
+        monkeypatch.setenv("DN_WAVES", "1")
+        ref = pkg.DroneVecEnv(tr.REGISTRY[trk](), n, device=dev, **kw)
+        monkeypatch.delenv("DN_WAVES")
+        env = pkg.DroneVecEnv(tr.REGISTRY[trk](), n, device=dev, **kw)
+        shapes.add(env.kernel_waves(fused=True))
+        ref.reset(); env.reset()
+        torch.manual_seed(it)
+        for rep in range(2):
+            u = torch.rand((K, n, 4), device=dev)
+            acts = (u * 2 - 1) if rng.integers(0, 2) else (0.0922 + 0.01 * (u - 0.5))
+            a, b = ref.rollout_tensor(acts, want_terminal=True), env.rollout_tensor(acts, want_terminal=True)
+            for k in a:
+                x, y = a[k], b[k]
+                if k in ("terminal_obs", "ep_return", "ep_length"):
+                    d = a["done"].bool()
+                    x, y = x[d], y[d]
+                assert torch.equal(x, y), (it, n, K, trk, kw, k, rep)
+        sa, sb = ref.get_state(), env.get_state()
+        for k in sa.dtype.names:
+            assert np.ascontiguousarray(sa[k]).tobytes() == np.ascontiguousarray(sb[k]).tobytes(), (it, k)
+        assert ref.stats() == env.stats()
+        ref.close(); env.close()
+    assert shapes == {1, 2, 3}
