@@ -1,0 +1,57 @@
+"""Soak run: random tracks / option switches / sizes, the HIP path teacher-forced against the CPU oracle (state from the
+GPU every step, outputs compared at the parity bars of tests/test_gpu_parity.py).  python profiles/soak_parity.py <seconds>"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+import drl_dronenavigation_amd as pkg
+from drl_dronenavigation_amd import tracks
+from oracle import oracle as O
+import test_gpu_parity as T
+
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 5)
+dev = torch.device("cuda:0")
+t_end = time.time() + float(sys.argv[1])
+it = 0
+while time.time() < t_end:
+    n = int(rng.choice([64, 1000, 2048]))
+    steps = int(rng.integers(20, 90))
+    trk = str(rng.choice(["reaching", "circle4", "circle6"]))
+    track = tracks.REGISTRY[trk]()
+    kw = dict(normalize_obs=bool(rng.integers(0, 2)), max_steps=int(rng.integers(3, 60)), seed=int(rng.integers(1, 1000)),
+              cylinder=bool(rng.integers(0, 4) > 0), include_distance=bool(rng.integers(0, 4) > 0),
+              normalize_actions=bool(rng.integers(0, 4) > 0), threshold=float(rng.choice([0.3, 0.3, 1.0, 5.0])),
+              ground_contact=bool(rng.integers(0, 2)))
+    if rng.integers(0, 3) == 0:
+        kw.update(obs_noise_sigma=0.02, act_noise_sigma=0.005)
+    if rng.integers(0, 5) == 0:
+        kw.update(clip_rew=bool(rng.integers(0, 2)), norm_rew=True)
+    okw = dict(kw)
+    phys = act = None
+    if rng.integers(0, 4) == 0:
+        phys = str(rng.choice(["pyb_gnd", "pyb_drag", "pyb_gnd_drag_dw"]))
+    if rng.integers(0, 6) == 0:
+        act = "rpm"; kw["normalize_actions"] = okw["normalize_actions"] = False
+    env = pkg.DroneVecEnv(track, n, device=dev, **kw, **({"physics": phys} if phys else {}), **({"act": act} if act else {}))
+    cfg = O.make_config(track.targets(), track.initial_xyzs, track.aviary_dim, circle=track.is_circle, f32_state=False,
+                        physics=pkg.vec_env.PHYSICS[phys or "pyb"], action_type=pkg.vec_env.ACTION_TYPES[act or "thrust"], **okw)
+    ora = O.OracleVecEnv(cfg, n, threads=8)
+    env.reset_tensor(); ora.reset()
+    for t in range(steps):
+        st = env.get_state()
+        T.gpu_state_to_oracle(st, ora.envs, env.step_count)
+        ora.refresh_rpy()
+        a = T.actions_mixed(rng, n) if act is None else rng.uniform(-1, 1, (n, 4)).astype(np.float32)
+        out = env.step_tensor(torch.from_numpy(a).to(dev))
+        torch.cuda.synchronize()
+        try:
+            T.compare_step(out, ora.step(a), f"it={it} t={t}", obs_atol=1e-4 if kw["normalize_obs"] else 1e-5, rew_atol=2e-4 if kw.get("norm_rew") else 1e-5)
+        except AssertionError as e:
+            print("PARITY MISMATCH it", it, "n", n, "track", trk, "kw", kw, "physics", phys, "act", act, "t", t, flush=True)
+            print(str(e)[:1500], flush=True)
+            raise SystemExit(1)
+    env.close()
+    it += 1
+    if it % 20 == 0:
+        print(it, "configs ok", flush=True)
+print("soak_parity ok:", it, "configurations")
