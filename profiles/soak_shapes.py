@@ -30,7 +30,11 @@ while time.time() < t_end:
     os.environ["DN_WAVES"] = "1"
     ref = pkg.DroneVecEnv(tracks.REGISTRY[trk](), n, device=dev, **kw)
     del os.environ["DN_WAVES"]
+    forced = str(rng.choice(["", "", "2", "3"]))           # the library's own pick, or a forced shape
+    if forced:
+        os.environ["DN_WAVES"] = forced
     env = pkg.DroneVecEnv(tracks.REGISTRY[trk](), n, device=dev, **kw)
+    os.environ.pop("DN_WAVES", None)
     w = env.kernel_waves(fused=True)
     shapes[w] = shapes.get(w, 0) + 1
     ref.reset(); env.reset()
