@@ -1469,16 +1469,17 @@ __global__ __launch_bounds__(2 * DN_BLOCK) void dn_step_many_2w_kernel(const DnP
 }
 
 // -----------------------------------------------------------------------------------------------------
-// Three-wave kernel (fused launches without the normaliser / the XOPT options): the side work is cut once more, so
+// Three-wave kernel (fused launches without the XOPT options): the side work is cut once more, so
 // that the recurrence (physics + rules) is alone on its wave and every SIMD of a CU has more than one wave's worth of
 // independent instructions to pick from.  192 threads = flight (0..63) + report (64..127) + aux (128..191):
 //
 //   flight, iteration t:  thrust(t) from the aux wave | physics(t) | rules(t)            -> MailQ[t & 1]      == barrier t ==
 //   aux,    iteration t:  thrust(t+1) -> tmail | MailQ[(t-1) & 1] -> attitude(t-1) | observe(t-1) -> MailA[(t-1) & 1]
-//   report, iteration t:  MailA[(t-2) & 1] -> report(t-2), streams the observation tile of step t-3
+//   report, iteration t:  MailA[(t-2) & 1] -> [normaliser] report(t-2), observation rows stored straight from registers
 //
 // The aux wave keeps prev_vel / prev_ang_v (the .xyz of g4 / g5: what the smoothness term reads), the report wave the
-// Monitor accumulators (the .w of g4 / g5).  Same functions, same typed values across LDS: bit-identical to the others.
+// Monitor accumulators (the .w of g4 / g5) and, with NORM, the normaliser statistics.  Same functions, same typed values
+// across LDS, one spelled-out arithmetic sequence (see physics_phase): bit-identical to the other shapes.
 // -----------------------------------------------------------------------------------------------------
 template <typename R> struct MailQ {      // flight -> aux: the post-physics pose with the attitude quaternion
     R f64[8][DN_BLOCK];                   // position (3), quaternion (4), Verdict.d_obs
