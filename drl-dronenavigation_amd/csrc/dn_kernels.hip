@@ -1567,6 +1567,7 @@ __global__ __launch_bounds__(3 * DN_BLOCK) void dn_step_many_3w_kernel(const DnP
     stage_table<R>(p, s_tab);
     // every wave passes barrier P and the barriers of iterations 0 .. k_steps (k_steps + 1 of them)
     if (role == 0) {
+        __builtin_amdgcn_s_setprio(3);                                     // the recurrence: first pick where it shares a SIMD
         float4 G0 = b.g0[li], G1 = b.g1[li], G2 = b.g2[li], G3 = b.g3[li];
         block_lds_barrier();                                               // P
         const R wp0[3] = {s_tab[DN_T_WP], s_tab[DN_T_WP + 1], s_tab[DN_T_WP + 2]};
@@ -1583,6 +1584,7 @@ __global__ __launch_bounds__(3 * DN_BLOCK) void dn_step_many_3w_kernel(const DnP
         }
         if (active) { b.g0[li] = G0; b.g1[li] = G1; b.g2[li] = G2; b.g3[li] = G3; }
     } else if (role == 1) {
+        __builtin_amdgcn_s_setprio(2);
         float4 P4 = b.g4[li], P5 = b.g5[li];                               // .xyz: prev_vel, prev_ang_v
         Rms rms;                                                           // never touched here: the observation leaves raw
         const float4 *act = reinterpret_cast<const float4 *>(io0.actions) + tile_base;
