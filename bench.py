@@ -137,8 +137,8 @@ def ppo_rollout(pkg, track, n, max_steps, dev, rank):
         res[label] = n * n_steps * reps / dt
         env.close()
     return {"value": round(res["fused_graph"], 1), "unit": "env-steps/s",
-            "policy": "fused MFMA MLP (dn_mlp_forward, bf16 weights/activations, float32 accumulate) + dn_policy_sample + "
-                      "dn_step: three launches per step, the truncation bootstrap as one masked critic pass per rollout, hipGraph replay",
+            "policy": "fused MFMA MLP (dn_mlp_forward, bf16 weights/activations, float32 accumulate) + dn_step_sampled "
+                      "(Gaussian sample + step): two launches per step, the truncation bootstrap as one masked critic pass per rollout, hipGraph replay",
             "variants": {"torch fp32 eager": round(res["eager"], 1), "torch fp32 hipGraph": round(res["graph"], 1),
                          "torch bf16 trunks hipGraph": round(res["graph_bf16"], 1),
                          "fused MFMA policy, torch glue, eager": round(res["eager_mfma"], 1),

@@ -255,9 +255,9 @@ class FusedRolloutCollector:
     """The on-policy rollout with every per-step operation on a purpose-built kernel and no intermediate copies:
 
         dn_mlp_forward (actor + critic, one launch; the value lands in the rollout buffer)
-        dn_policy_sample (Gaussian sample from the environment's Philox streams, clip, log-probability -> buffer)
-        dn_step (writes the next observation, the reward and the episode-start flag straight into the buffer slots)
-    three launches per step instead of ~25 small torch kernels; then, once per rollout, SB3's TimeLimit bootstrap
+        dn_step_sampled (Gaussian sample from the environment's Philox streams, clip, log-probability -> buffer, and the
+                         step itself: next observation, reward and episode-start flag straight into the buffer slots)
+    two launches per step instead of ~25 small torch kernels; then, once per rollout, SB3's TimeLimit bootstrap
     (rewards[t] += gamma V(terminal_observation) where TimeLimit.truncated): the step kernel leaves the terminal
     observations and truncation flags of all n_steps in the buffer, ONE dn_mlp_forward masked by those flags evaluates
     the critic on the tiles that hold a truncated drone (the weights do not change inside a rollout, so this is the
@@ -289,7 +289,6 @@ class FusedRolloutCollector:
             advantages=torch.empty((T, n), dtype=f32, device=dev), returns=torch.empty((T, n), dtype=f32, device=dev),
             last_values=torch.empty((n, 1), dtype=f32, device=dev))
         self._mean = torch.empty((n, ACT_DIM), dtype=f32, device=dev)
-        self._clipped = torch.empty((n, ACT_DIM), dtype=f32, device=dev)
         self._trunc = torch.zeros((T, n), dtype=u8, device=dev)
         self._found = torch.zeros(n, dtype=torch.int32, device=dev)
         # terminal observations of every step of the rollout (rows are written where a drone finished; the rest is stale
@@ -314,11 +313,11 @@ class FusedRolloutCollector:
         for t in range(T):
             obs_t = b["obs"][t]
             mlp_forward([pol.pi, pol.vf], obs_t, [self._mean, b["values"][t].view(n, 1)])
-            _capi.check(lib.dn_policy_sample(h, self._mean.data_ptr(), log_std, self.seed, 0, b["actions"][t].data_ptr(),
-                                             self._clipped.data_ptr(), b["log_probs"][t].data_ptr(), stream))
-            _capi.check(lib.dn_step(h, self._clipped.data_ptr(), b["obs"][t + 1].data_ptr(), b["rewards"][t].data_ptr(),
-                                    b["episode_starts"][t + 1].data_ptr(), self._trunc[t].data_ptr(), self._found.data_ptr(),
-                                    self._term_obs[t].data_ptr() if self.bootstrap_truncated else None, None, None, None, stream))
+            # Gaussian sample (Philox), clip, log-probability and the environment step in ONE launch (dn_step_sampled)
+            _capi.check(lib.dn_step_sampled(h, self._mean.data_ptr(), log_std, self.seed, 0, b["actions"][t].data_ptr(),
+                                            b["log_probs"][t].data_ptr(), b["obs"][t + 1].data_ptr(), b["rewards"][t].data_ptr(),
+                                            b["episode_starts"][t + 1].data_ptr(), self._trunc[t].data_ptr(), self._found.data_ptr(),
+                                            self._term_obs[t].data_ptr() if self.bootstrap_truncated else None, None, None, None, stream))
         if self.bootstrap_truncated:
             mlp_forward([pol.vf], self._term_obs.view(T * n, -1), [self._tv], row_mask=self._trunc.view(T * n))
             _capi.check(lib.dn_add_bootstrap(b["rewards"].data_ptr(), self._tv.data_ptr(), self._trunc.data_ptr(),

@@ -356,7 +356,30 @@ int32_t dn_step(dn_env *env, const float *actions, float *obs, float *reward, ui
     io.actions = actions; io.obs = obs; io.reward = reward; io.done = done; io.truncated = truncated;
     io.found_targets = found_targets; io.terminal_obs = terminal_obs; io.ep_return = ep_return;
     io.ep_length = ep_length; io.done_mask = (unsigned long long *)done_mask;
+    io.mean = nullptr; io.act_out = nullptr; io.logp_out = nullptr;
     DN_HIP(dn_launch_step_many(env->p, io, 1, env->cfg.compute_f32 != 0, env->waves_single, (hipStream_t)stream));
+    return DN_OK;
+}
+
+int32_t dn_step_sampled(dn_env *env, const float *mean, const float *log_std, uint64_t seed, int32_t deterministic,
+                        float *actions_out, float *log_prob_out, float *obs, float *reward, uint8_t *done, uint8_t *truncated,
+                        int32_t *found_targets, float *terminal_obs, float *ep_return, int32_t *ep_length,
+                        uint64_t *done_mask, void *stream)
+{
+    if (!env) return fail(DN_ERR_INVALID_ARGUMENT, "env is NULL");
+    if (!mean || !log_std || !actions_out || !log_prob_out || !obs || !reward || !done || !truncated || !found_targets)
+        return fail(DN_ERR_INVALID_ARGUMENT, "mean, log_std, actions_out, log_prob_out, obs, reward, done, truncated and found_targets are required");
+    if (((uintptr_t)mean & 15u) || ((uintptr_t)actions_out & 15u) || ((uintptr_t)obs & 15u))
+        return fail(DN_ERR_INVALID_ARGUMENT, "mean, actions_out and obs must be 16-byte aligned");
+    DnStepIO io;
+    io.actions = nullptr; io.obs = obs; io.reward = reward; io.done = done; io.truncated = truncated;
+    io.found_targets = found_targets; io.terminal_obs = terminal_obs; io.ep_return = ep_return;
+    io.ep_length = ep_length; io.done_mask = (unsigned long long *)done_mask;
+    io.mean = mean; io.act_out = actions_out; io.logp_out = log_prob_out;
+    for (int j = 0; j < 4; ++j) io.log_std[j] = log_std[j];
+    io.sample_seed = seed; io.sample_deterministic = deterministic != 0;
+    // the sampling lives in the one-wave single-step kernel
+    DN_HIP(dn_launch_step_many(env->p, io, 1, env->cfg.compute_f32 != 0, 1, (hipStream_t)stream));
     return DN_OK;
 }
 
@@ -381,6 +404,7 @@ int32_t dn_step_many(dn_env *env, int64_t k, const float *actions, float *obs, f
     io.actions = actions; io.obs = obs; io.reward = reward; io.done = done; io.truncated = truncated;
     io.found_targets = found_targets; io.terminal_obs = terminal_obs; io.ep_return = ep_return;
     io.ep_length = ep_length; io.done_mask = (unsigned long long *)done_mask;
+    io.mean = nullptr; io.act_out = nullptr; io.logp_out = nullptr;
     DN_HIP(dn_launch_step_many(env->p, io, (int)k, env->cfg.compute_f32 != 0, env->waves_fused, (hipStream_t)stream));
     return DN_OK;
 }

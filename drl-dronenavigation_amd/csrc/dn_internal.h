@@ -67,6 +67,13 @@ struct DnStepIO {
     float *ep_return;
     int32_t *ep_length;
     unsigned long long *done_mask;
+    // dn_step_sampled (single-step launches only): the action is drawn in the kernel from the policy's mean instead of read
+    const float *mean;                 // [N][4] or nullptr (then `actions` is read)
+    float *act_out;                    // [N][4] the sampled, UNclipped action (what SB3 stores in the rollout buffer)
+    float *logp_out;                   // [N]    log N(action; mean, std) summed over the four dims
+    float log_std[4];
+    unsigned long long sample_seed;
+    int sample_deterministic;
 };
 
 // Scalars of the environment, in both precisions (the float32 build must not touch float64).

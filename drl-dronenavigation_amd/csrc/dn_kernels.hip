@@ -1229,6 +1229,29 @@ DN_DEV Flight<R> fly(const DnParams &p, unsigned long long gid, unsigned sc, con
     return physics_phase<R>(th, G0, G1, G2, G3, p.max_steps);
 }
 
+// dn_step_sampled: SB3 DiagGaussianDistribution.sample / log_prob and the np.clip of collect_rollouts [3P-recall], drawn
+// where the action is consumed: action = mean + exp(log_std) z, z ~ N(0,1) from the environment's Philox stream (seed,
+// global drone id, the tile's vector-step counter, stream 9); the unclipped action and its log-probability go to the
+// rollout buffer, the clipped one into the step.  Same expressions as dn_policy_sample_kernel (same bits).
+DN_DEV float4 sample_action(const DnStepIO &io, const unsigned long long gid, const unsigned step, const long long i, const bool active)
+{
+    const float4 m = reinterpret_cast<const float4 *>(io.mean)[i];
+    const float mu[4] = {m.x, m.y, m.z, m.w};
+    float z[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (!io.sample_deterministic) noise4(io.sample_seed, gid, step, 9u, z);
+    float a[4], lp = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        a[j] = mu[j] + expf(io.log_std[j]) * z[j];
+        lp += -0.5f * z[j] * z[j] - io.log_std[j] - 0.91893853320467274178f;
+    }
+    if (active) {
+        reinterpret_cast<float4 *>(io.act_out)[i] = make_float4(a[0], a[1], a[2], a[3]);
+        io.logp_out[i] = lp;
+    }
+    return make_float4(clipv(a[0], -1.0f, 1.0f), clipv(a[1], -1.0f, 1.0f), clipv(a[2], -1.0f, 1.0f), clipv(a[3], -1.0f, 1.0f));
+}
+
 // -----------------------------------------------------------------------------------------------------
 // One-wave kernels: all four phases on one wavefront, messages in registers.  Used where there are enough
 // drones to fill the chip with whole steps (see dn_launch_step) and as the cross-check of the two-wave kernels.
@@ -1254,7 +1277,8 @@ __global__ __launch_bounds__(DN_BLOCK) void dn_step_many_1w_kernel(const DnParam
     const DnConsts<R> &c = consts<R>(p);
     const float4 *act = reinterpret_cast<const float4 *>(io0.actions) + tile_base;
     // issue every load up front (6 x 16 B state + 16 B action per lane), then stage the table
-    float4 A = act[li];
+    const bool sampled = ONE && io0.mean != nullptr;      // dn_step_sampled: the action comes from the policy's mean
+    float4 A = sampled ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : act[li];
     float4 G0 = b.g0[li], G1 = b.g1[li], G2 = b.g2[li], G3 = b.g3[li], G4 = b.g4[li], G5 = b.g5[li];
     float4 G7 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (XOPT && p.drag) G7 = b.g7[li];
@@ -1262,6 +1286,7 @@ __global__ __launch_bounds__(DN_BLOCK) void dn_step_many_1w_kernel(const DnParam
     block_lds_barrier();
     const long long n = p.n, words = (p.n + 63) / 64;
     const unsigned long long sc0 = p.st.stats[blockIdx.x].step_count;      // this tile's vector-step counter
+    if (sampled) A = sample_action(io0, gid, (unsigned)sc0, i, active);
     const R wp0[3] = {s_tab[DN_T_WP], s_tab[DN_T_WP + 1], s_tab[DN_T_WP + 2]};   // waypoint 0: every reset measures against it
     StatAcc acc;
     Rms rms;
@@ -1271,7 +1296,7 @@ __global__ __launch_bounds__(DN_BLOCK) void dn_step_many_1w_kernel(const DnParam
 #pragma clang loop unroll(disable)
     for (int t = 0; t < k_steps; ++t) {
         // prefetch the next step's action while this step computes
-        const float4 A_next = (act + (long long)(t + 1 < k_steps ? t + 1 : t) * n)[li];
+        const float4 A_next = sampled ? A : (act + (long long)(t + 1 < k_steps ? t + 1 : t) * n)[li];
         const StepOut out = block_out(io0, tile_base, (long long)t * n, (long long)t * words);
         const unsigned sc = (unsigned)sc0 + (unsigned)t;
         float4 rpm_now;

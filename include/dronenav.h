@@ -233,6 +233,14 @@ int32_t dn_policy_sample(dn_env *env, const float *mean, const float *log_std, u
                          float *actions, float *clipped, float *log_prob, void *stream);
 int32_t dn_add_bootstrap(float *reward, const float *terminal_value, const uint8_t *truncated, double gamma,
                          int64_t num_envs, int32_t device_id, void *stream);
+/* dn_policy_sample + dn_step in one launch (the rollout loop's per-step pair): the action is drawn inside the step kernel
+ * from `mean` exactly as dn_policy_sample draws it (same Philox stream, same bits); actions_out receives the UNclipped
+ * action (what SB3's collect_rollouts stores), log_prob_out its log-probability, the clipped action goes into the step.
+ * Other arguments as dn_step. */
+int32_t dn_step_sampled(dn_env *env, const float *mean, const float *log_std, uint64_t seed, int32_t deterministic,
+                        float *actions_out, float *log_prob_out, float *obs, float *reward, uint8_t *done, uint8_t *truncated,
+                        int32_t *found_targets, float *terminal_obs, float *ep_return, int32_t *ep_length,
+                        uint64_t *done_mask, void *stream);
 
 /* Bytes of HBM the persistent state of `num_envs` drones occupies (capacity planning). */
 int64_t dn_state_bytes(int64_t num_envs, int32_t normalize_obs);
