@@ -1211,3 +1211,45 @@ def test_random_configurations_all_shapes_bit_identical(monkeypatch):
         assert ref.stats() == env.stats()
         ref.close(); env.close()
     assert shapes == {1, 2, 3}
+
+
+@pytest.mark.parametrize("deterministic", [0, 1])
+def test_step_sampled_equals_policy_sample_then_step(deterministic):
+    """dn_step_sampled draws the action inside the step kernel: it must reproduce dn_policy_sample followed by dn_step bit
+    for bit -- stored (unclipped) actions, log-probabilities and every step output -- over several steps."""
+    pkg = _gpu()
+    import ctypes as C
+    from drl_dronenavigation_amd import _capi
+    lib = _capi.load()
+    track = _tracks().reaching()
+    n = 1000
+    dev = torch.device("cuda:0")
+    kw = dict(normalize_obs=True, max_steps=12, obs_noise_sigma=0.01, act_noise_sigma=0.002, seed=21, env_id_offset=4096)
+    a, b = pkg.DroneVecEnv(track, n, device=dev, **kw), pkg.DroneVecEnv(track, n, device=dev, **kw)
+    a.reset(); b.reset()
+    f32 = torch.float32
+    mk = lambda *shape, dt=f32: torch.zeros(shape, dtype=dt, device=dev)        # noqa: E731
+    bufs = [dict(obs=mk(n, 13), rew=mk(n), done=mk(n, dt=torch.uint8), trunc=mk(n, dt=torch.uint8), found=mk(n, dt=torch.int32),
+                 act=mk(n, 4), logp=mk(n), clipped=mk(n, 4)) for _ in range(2)]
+    log_std = (C.c_float * 4)(-1.0, -2.0, -0.5, -3.0)
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    for t in range(30):
+        mean = (torch.rand((n, 4), generator=g) * 0.4 - 0.1).to(dev)
+        A, B = bufs
+        _capi.check(lib.dn_policy_sample(a._handle, mean.data_ptr(), log_std, 99, deterministic, A["act"].data_ptr(),
+                                         A["clipped"].data_ptr(), A["logp"].data_ptr(), stream))
+        _capi.check(lib.dn_step(a._handle, A["clipped"].data_ptr(), A["obs"].data_ptr(), A["rew"].data_ptr(), A["done"].data_ptr(),
+                                A["trunc"].data_ptr(), A["found"].data_ptr(), None, None, None, None, stream))
+        _capi.check(lib.dn_step_sampled(b._handle, mean.data_ptr(), log_std, 99, deterministic, B["act"].data_ptr(), B["logp"].data_ptr(),
+                                        B["obs"].data_ptr(), B["rew"].data_ptr(), B["done"].data_ptr(), B["trunc"].data_ptr(),
+                                        B["found"].data_ptr(), None, None, None, None, stream))
+        torch.cuda.synchronize()
+        for k in ("act", "logp", "obs", "rew", "done", "trunc", "found"):
+            assert torch.equal(A[k], B[k]), (t, k)
+        if deterministic:
+            assert torch.equal(A["act"], mean)
+    sa, sb = a.get_state(), b.get_state()
+    for k in sa.dtype.names:
+        assert np.ascontiguousarray(sa[k]).tobytes() == np.ascontiguousarray(sb[k]).tobytes(), k
+    a.close(); b.close()
