@@ -289,6 +289,9 @@ class FusedRolloutCollector:
             advantages=torch.empty((T, n), dtype=f32, device=dev), returns=torch.empty((T, n), dtype=f32, device=dev),
             last_values=torch.empty((n, 1), dtype=f32, device=dev))
         self._mean = torch.empty((n, ACT_DIM), dtype=f32, device=dev)
+        cfg = env.cfg
+        self._sampled_step = not (cfg.clip_rew or cfg.norm_rew or cfg.physics or cfg.action_type)   # dn_step_sampled's scope
+        self._clipped = None if self._sampled_step else torch.empty((n, ACT_DIM), dtype=f32, device=dev)
         self._trunc = torch.zeros((T, n), dtype=u8, device=dev)
         self._found = torch.zeros(n, dtype=torch.int32, device=dev)
         # terminal observations of every step of the rollout (rows are written where a drone finished; the rest is stale
@@ -313,11 +316,19 @@ class FusedRolloutCollector:
         for t in range(T):
             obs_t = b["obs"][t]
             mlp_forward([pol.pi, pol.vf], obs_t, [self._mean, b["values"][t].view(n, 1)])
-            # Gaussian sample (Philox), clip, log-probability and the environment step in ONE launch (dn_step_sampled)
-            _capi.check(lib.dn_step_sampled(h, self._mean.data_ptr(), log_std, self.seed, 0, b["actions"][t].data_ptr(),
-                                            b["log_probs"][t].data_ptr(), b["obs"][t + 1].data_ptr(), b["rewards"][t].data_ptr(),
-                                            b["episode_starts"][t + 1].data_ptr(), self._trunc[t].data_ptr(), self._found.data_ptr(),
-                                            self._term_obs[t].data_ptr() if self.bootstrap_truncated else None, None, None, None, stream))
+            term = self._term_obs[t].data_ptr() if self.bootstrap_truncated else None
+            if self._sampled_step:
+                # Gaussian sample (Philox), clip, log-probability and the environment step in ONE launch (dn_step_sampled)
+                _capi.check(lib.dn_step_sampled(h, self._mean.data_ptr(), log_std, self.seed, 0, b["actions"][t].data_ptr(),
+                                                b["log_probs"][t].data_ptr(), b["obs"][t + 1].data_ptr(), b["rewards"][t].data_ptr(),
+                                                b["episode_starts"][t + 1].data_ptr(), self._trunc[t].data_ptr(),
+                                                self._found.data_ptr(), term, None, None, None, stream))
+            else:                                              # reward wrappers / extra physics terms / RPM actions: two launches
+                _capi.check(lib.dn_policy_sample(h, self._mean.data_ptr(), log_std, self.seed, 0, b["actions"][t].data_ptr(),
+                                                 self._clipped.data_ptr(), b["log_probs"][t].data_ptr(), stream))
+                _capi.check(lib.dn_step(h, self._clipped.data_ptr(), b["obs"][t + 1].data_ptr(), b["rewards"][t].data_ptr(),
+                                        b["episode_starts"][t + 1].data_ptr(), self._trunc[t].data_ptr(), self._found.data_ptr(),
+                                        term, None, None, None, stream))
         if self.bootstrap_truncated:
             mlp_forward([pol.vf], self._term_obs.view(T * n, -1), [self._tv], row_mask=self._trunc.view(T * n))
             _capi.check(lib.dn_add_bootstrap(b["rewards"].data_ptr(), self._tv.data_ptr(), self._trunc.data_ptr(),

@@ -371,6 +371,9 @@ int32_t dn_step_sampled(dn_env *env, const float *mean, const float *log_std, ui
         return fail(DN_ERR_INVALID_ARGUMENT, "mean, log_std, actions_out, log_prob_out, obs, reward, done, truncated and found_targets are required");
     if (((uintptr_t)mean & 15u) || ((uintptr_t)actions_out & 15u) || ((uintptr_t)obs & 15u))
         return fail(DN_ERR_INVALID_ARGUMENT, "mean, actions_out and obs must be 16-byte aligned");
+    if (env->cfg.clip_rew || env->cfg.norm_rew || env->cfg.physics != 0 || env->cfg.action_type != 0)
+        return fail(DN_ERR_INVALID_ARGUMENT, "dn_step_sampled is built for the configuration without reward wrappers / extra physics terms / RPM actions; "
+                                             "use dn_policy_sample + dn_step there");
     DnStepIO io;
     io.actions = nullptr; io.obs = obs; io.reward = reward; io.done = done; io.truncated = truncated;
     io.found_targets = found_targets; io.terminal_obs = terminal_obs; io.ep_return = ep_return;

@@ -1258,7 +1258,7 @@ DN_DEV float4 sample_action(const DnStepIO &io, const unsigned long long gid, co
 // -----------------------------------------------------------------------------------------------------
 // ONE = true is the single-step launch (dn_step): k_steps is the constant 1, and the kernel gets its own name in
 // profiles (dn_step_many_*_kernel<..., true> = one control step per launch, <..., false> = k_arg steps per launch).
-template <typename R, bool NORM, bool NOISE, bool ONE, bool XOPT>
+template <typename R, bool NORM, bool NOISE, bool ONE, bool XOPT, bool SAMPLE = false>
 __global__ __launch_bounds__(DN_BLOCK) void dn_step_many_1w_kernel(const DnParams p, const DnStepIO io0, const int k_arg)
 {
     const int k_steps = ONE ? 1 : k_arg;
@@ -1277,7 +1277,8 @@ __global__ __launch_bounds__(DN_BLOCK) void dn_step_many_1w_kernel(const DnParam
     const DnConsts<R> &c = consts<R>(p);
     const float4 *act = reinterpret_cast<const float4 *>(io0.actions) + tile_base;
     // issue every load up front (6 x 16 B state + 16 B action per lane), then stage the table
-    const bool sampled = ONE && io0.mean != nullptr;      // dn_step_sampled: the action comes from the policy's mean
+    constexpr bool sampled = SAMPLE;                      // dn_step_sampled: the action comes from the policy's mean (own instantiations:
+                                                          // the sampler's Box-Muller code costs the plain single step 9 % if it is merely linked in)
     float4 A = sampled ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : act[li];
     float4 G0 = b.g0[li], G1 = b.g1[li], G2 = b.g2[li], G3 = b.g3[li], G4 = b.g4[li], G5 = b.g5[li];
     float4 G7 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -1937,6 +1938,20 @@ hipError_t dn_launch_step_many_mw(const DnParams &p, const DnStepIO &io, int k, 
 hipError_t dn_launch_step_many(const DnParams &p, const DnStepIO &io, int k, bool f32, int waves, hipStream_t stream)
 {
     const bool norm = p.normalize_obs != 0;
+    if (io.mean) {                          // dn_step_sampled: one-wave single-step kernels with the sampler compiled in
+        const unsigned grid = (unsigned)((p.n + DN_BLOCK - 1) / DN_BLOCK);
+        const bool noise = p.act_noise_sigma > 0.0f || p.obs_noise_sigma > 0.0f;
+#define DN_LS(R, NORM, NOISE) hipLaunchKernelGGL((dn_step_many_1w_kernel<R, NORM, NOISE, true, false, true>), dim3(grid), dim3(DN_BLOCK), 0, stream, p, io, 1)
+        if (f32) {
+            if (norm) { if (noise) DN_LS(float, true, true); else DN_LS(float, true, false); }
+            else { if (noise) DN_LS(float, false, true); else DN_LS(float, false, false); }
+        } else {
+            if (norm) { if (noise) DN_LS(double, true, true); else DN_LS(double, true, false); }
+            else { if (noise) DN_LS(double, false, true); else DN_LS(double, false, false); }
+        }
+#undef DN_LS
+        return hipGetLastError();
+    }
     const bool xopt = p.clip_rew != 0 || p.norm_rew != 0 || p.gnd != 0 || p.drag != 0 || p.rpm_actions != 0;
     if ((waves >= 2 && !norm) || (waves == 3 && k > 1 && !xopt)) return dn_launch_step_many_mw(p, io, k, f32, waves, stream);
     const bool two_wave = waves >= 2;       // with the normaliser: the two-wave kernels (there is no three-wave one)

@@ -236,7 +236,8 @@ int32_t dn_add_bootstrap(float *reward, const float *terminal_value, const uint8
 /* dn_policy_sample + dn_step in one launch (the rollout loop's per-step pair): the action is drawn inside the step kernel
  * from `mean` exactly as dn_policy_sample draws it (same Philox stream, same bits); actions_out receives the UNclipped
  * action (what SB3's collect_rollouts stores), log_prob_out its log-probability, the clipped action goes into the step.
- * Other arguments as dn_step. */
+ * Other arguments as dn_step.  Built for the configuration without reward wrappers / extra physics terms / RPM actions
+ * (DN_ERR_INVALID_ARGUMENT otherwise: use dn_policy_sample + dn_step there). */
 int32_t dn_step_sampled(dn_env *env, const float *mean, const float *log_std, uint64_t seed, int32_t deterministic,
                         float *actions_out, float *log_prob_out, float *obs, float *reward, uint8_t *done, uint8_t *truncated,
                         int32_t *found_targets, float *terminal_obs, float *ep_return, int32_t *ep_length,
