@@ -239,14 +239,13 @@ int32_t dn_create(const dn_config *cfg, dn_env **out)
     // instruction stream of a wave, and two or three waves per tile win while the tiles alone leave SIMDs idle
     // (<= 1024 tiles = 65536 drones on 1024 SIMDs); the single-step launch is latency bound (launch + load round
     // trip) and one wave is never slower.  DN_WAVES=1|2|3 forces a shape (A/B measurements, the bit-identity test).
-    // The three-wave shape (flight / report / aux) exists for fused launches without the XOPT options.  It wins while
-    // the waves of a CU find SIMDs of their own: two tiles per CU (512 tiles) without the normaliser, one tile per CU
-    // (256 tiles) with it -- the normaliser makes the report wave as heavy as the other two (32768 drones, normaliser
-    // on: 2.9 us per step with three waves, 2.3 us with two; 16384 drones: 1.5 us against 2.2 us).
+    // The three-wave shape (flight / report / aux) exists for fused launches without the XOPT options.  It wins up to two
+    // tiles per CU (512 tiles = 32768 drones), with or without the normaliser (32768 drones, normaliser on: 1.8 us per
+    // step against 2.1 us with two waves, once the report wave yields to the other two by s_setprio).  Beyond that two
+    // waves per tile win up to 1024 tiles -- 512 with the normaliser, whose 27 float64 per drone make a wave heavy
+    // (49152 drones: 4.1 us per step with two waves against 3.4 us with one).
     const bool plain = !cfg->clip_rew && !cfg->norm_rew && cfg->physics == 0 && cfg->action_type == 0;
-    const long long max3 = cfg->normalize_obs ? DN_THREE_WAVE_MAX_TILES / 2 : DN_THREE_WAVE_MAX_TILES;
-    // with the normaliser a wave carries 27 more float64 per drone: two waves per tile stop paying at two tiles per CU
-    // (49152 drones: 4.1 us per step against 3.4 us with one wave; 32768 drones: 2.2 against 3.4)
+    const long long max3 = DN_THREE_WAVE_MAX_TILES;
     const long long max2 = cfg->normalize_obs ? DN_TWO_WAVE_MAX_TILES / 2 : DN_TWO_WAVE_MAX_TILES;
     e->waves_fused = e->blocks <= max2 ? (plain && e->blocks <= max3 ? 3 : 2) : 1;
     e->waves_single = 1;
