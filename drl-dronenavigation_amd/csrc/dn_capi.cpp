@@ -37,7 +37,6 @@ int32_t fail(dn_status st, const char *fmt, ...)
 inline double norm3d(const double v[3]) { return std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
 
 constexpr long long DN_TWO_WAVE_MAX_TILES = 1024;   // 65536 drones: one tile per SIMD
-constexpr long long DN_THREE_WAVE_MAX_TILES = 512;  // 32768 drones: two tiles = six waves per CU; beyond, two waves per tile win
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -239,15 +238,14 @@ int32_t dn_create(const dn_config *cfg, dn_env **out)
     // instruction stream of a wave, and two or three waves per tile win while the tiles alone leave SIMDs idle
     // (<= 1024 tiles = 65536 drones on 1024 SIMDs); the single-step launch is latency bound (launch + load round
     // trip) and one wave is never slower.  DN_WAVES=1|2|3 forces a shape (A/B measurements, the bit-identity test).
-    // The three-wave shape (flight / report / aux) exists for fused launches without the XOPT options.  It wins up to two
-    // tiles per CU (512 tiles = 32768 drones), with or without the normaliser (32768 drones, normaliser on: 1.8 us per
-    // step against 2.1 us with two waves, once the report wave yields to the other two by s_setprio).  Beyond that two
-    // waves per tile win up to 1024 tiles -- 512 with the normaliser, whose 27 float64 per drone make a wave heavy
-    // (49152 drones: 4.1 us per step with two waves against 3.4 us with one).
+    // The three-wave shape (flight / report / aux) exists for fused launches without the XOPT options.  Measured
+    // (profiles/r01_r_sweep_shapes.txt, with the report wave yielding to the other two by s_setprio): without the
+    // normaliser it wins wherever more than one wave per tile wins, i.e. up to 1024 tiles (65536 drones: 2.3 us per step
+    // against 2.5 with two waves and 2.9 with one); with the normaliser (27 more float64 per drone in a wave) up to 512
+    // tiles (32768 drones: 1.8 us against 2.1 with two waves), one wave beyond (49152 drones: 3.3 us against 3.5).
     const bool plain = !cfg->clip_rew && !cfg->norm_rew && cfg->physics == 0 && cfg->action_type == 0;
-    const long long max3 = DN_THREE_WAVE_MAX_TILES;
-    const long long max2 = cfg->normalize_obs ? DN_TWO_WAVE_MAX_TILES / 2 : DN_TWO_WAVE_MAX_TILES;
-    e->waves_fused = e->blocks <= max2 ? (plain && e->blocks <= max3 ? 3 : 2) : 1;
+    const long long max_multi = cfg->normalize_obs ? DN_TWO_WAVE_MAX_TILES / 2 : DN_TWO_WAVE_MAX_TILES;
+    e->waves_fused = e->blocks <= max_multi ? (plain ? 3 : 2) : 1;
     e->waves_single = 1;
     if (const char *w = getenv("DN_WAVES")) {
         if (w[0] == '1') e->waves_fused = e->waves_single = 1;
