@@ -195,6 +195,9 @@ def main():
     torch.cuda.set_device(dev)
     dist = None
     if world > 1 or args.force_dist:
+        # the GPU boxes export NCCL_DEBUG=VERSION: RCCL then prints its banner / warnings on STDOUT from every rank (C stdio,
+        # flushed at exit, i.e. after the JSON line).  The bench's stdout is one JSON line: RCCL's log goes to stderr.
+        os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
@@ -394,10 +397,19 @@ def main():
                 line["cpu_baseline"] = cpu_baseline(track, n, max_steps, args.cpu_baseline_seconds)
             except Exception as exc:  # noqa: BLE001
                 line["cpu_baseline"] = {"error": f"{type(exc).__name__}: {exc}"}
-        print(json.dumps(line), flush=True)
     env.close()
     if dist is not None:
+        # RCCL writes its NCCL_DEBUG=VERSION banner to STDOUT through C stdio (buffered on a pipe, flushed at exit): push every
+        # rank's out now, then let rank 0 print the one JSON line after everybody has done so
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        dist.barrier(device_ids=[local_rank])
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if dist is not None:
         dist.destroy_process_group()
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
 
 
 if __name__ == "__main__":
