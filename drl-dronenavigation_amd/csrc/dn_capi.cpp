@@ -238,20 +238,23 @@ int32_t dn_create(const dn_config *cfg, dn_env **out)
     // instruction stream of a wave, and two or three waves per tile win while the tiles alone leave SIMDs idle
     // (<= 1024 tiles = 65536 drones on 1024 SIMDs); the single-step launch is latency bound (launch + load round
     // trip) and one wave is never slower.  DN_WAVES=1|2|3 forces a shape (A/B measurements, the bit-identity test).
-    // The three-wave shape (flight / report / aux) exists for fused launches without the XOPT options.  Measured
-    // (profiles/r01_r_sweep_shapes.txt, with the report wave yielding to the other two by s_setprio): without the
+    // The three-wave shape (flight / report / aux) exists for fused launches.  Measured (profiles/r01_r_sweep_shapes.txt,
+    // profiles/r01_r_sweep_options.txt, with the report wave yielding to the other two by s_setprio): without the
     // normaliser it wins wherever more than one wave per tile wins, i.e. up to 1024 tiles (65536 drones: 2.3 us per step
     // against 2.5 with two waves and 2.9 with one); with the normaliser (27 more float64 per drone in a wave) up to 512
     // tiles (32768 drones: 1.8 us against 2.1 with two waves), one wave beyond (49152 drones: 3.3 us against 3.5).
+    // With the XOPT options (reward wrappers, extra force terms, rpm actions) the flight wave is wider in registers:
+    // three waves win up to 512 tiles (32768 drones, all options: 2.1 us against 3.0 with two waves), two waves from
+    // there to 1024 tiles (65536 drones: 3.2 us against 4.8 with three).
     const bool plain = !cfg->clip_rew && !cfg->norm_rew && cfg->physics == 0 && cfg->action_type == 0;
     const long long max_multi = cfg->normalize_obs ? DN_TWO_WAVE_MAX_TILES / 2 : DN_TWO_WAVE_MAX_TILES;
-    e->waves_fused = e->blocks <= max_multi ? (plain ? 3 : 2) : 1;
+    e->waves_fused = e->blocks <= max_multi ? ((plain || e->blocks <= DN_TWO_WAVE_MAX_TILES / 2) ? 3 : 2) : 1;
     e->waves_single = 1;
     if (const char *w = getenv("DN_WAVES")) {
         if (w[0] == '1') e->waves_fused = e->waves_single = 1;
         else if (w[0] == '2') e->waves_fused = e->waves_single = 2;
         else if (w[0] == '3') {
-            e->waves_fused = plain ? 3 : 2;
+            e->waves_fused = 3;
             e->waves_single = 1;
         }
     }

@@ -1561,11 +1561,31 @@ template <typename R> DN_DEV void take_maila(const MailA<R> &m, unsigned lane, F
     f.vex = f.vey = f.vez = f.aex = f.aey = f.aez = 0.0f;     // prev_vel / prev_ang_v live on the aux wave
 }
 
+// XOPT: the aux wave's thrust goes over as the float64 carriers with this step's rpm (what the ground-effect and drag
+// terms read); the flight wave keeps last_clipped_action (g7), the report wave the reward normaliser.
+template <bool XOPT> struct ThrustMailX { double v[9][DN_BLOCK]; };
+template <> struct ThrustMailX<false> { double v[1][1]; };
+DN_DEV void post_thrust_x(ThrustMailX<true> &m, unsigned lane, const ThrustX &t, const Extras &x)
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { m.v[j][lane] = t.f[j]; m.v[5 + j][lane] = x.rpm[j]; }
+    m.v[4][lane] = t.zt;
+}
+DN_DEV void take_thrust_x(const ThrustMailX<true> &m, unsigned lane, ThrustX &t, Extras &x)
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { t.f[j] = m.v[j][lane]; x.rpm[j] = m.v[5 + j][lane]; }
+    t.zt = m.v[4][lane];
+}
+DN_DEV void post_thrust_x(ThrustMailX<false> &, unsigned, const ThrustX &, const Extras &) {}
+DN_DEV void take_thrust_x(const ThrustMailX<false> &, unsigned, ThrustX &, Extras &) {}
+
 // NORM (per-drone observation normaliser): the aux wave hands over the raw observation and the report wave, which
 // owns the statistics, normalises it (and then, for a finished drone, the reset observation: the reference's order).
-template <typename R, bool NORM, bool NOISE>
+template <typename R, bool NORM, bool NOISE, bool XOPT>
 __global__ __launch_bounds__(3 * DN_BLOCK) void dn_step_many_3w_kernel(const DnParams p, const DnStepIO io0, const int k_steps)
 {
+    __shared__ ThrustMailX<XOPT> tmx[2];
     __shared__ R s_tab[DN_MAX_WAYPOINTS * DN_T_STRIDE];
     __shared__ __attribute__((aligned(16))) float s_tile[DN_BLOCK * DN_OBS_DIM];
     __shared__ MailQ<R> mailq[2];
@@ -1595,20 +1615,36 @@ __global__ __launch_bounds__(3 * DN_BLOCK) void dn_step_many_3w_kernel(const DnP
     if (role == 0) {
         __builtin_amdgcn_s_setprio(3);                                     // the recurrence: first pick where it shares a SIMD
         float4 G0 = b.g0[li], G1 = b.g1[li], G2 = b.g2[li], G3 = b.g3[li];
+        float4 G7 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (XOPT && p.drag) G7 = b.g7[li];
         block_lds_barrier();                                               // P
         const R wp0[3] = {s_tab[DN_T_WP], s_tab[DN_T_WP + 1], s_tab[DN_T_WP + 2]};
 #pragma clang loop unroll(disable)
         for (int t = 0; t <= k_steps; ++t) {
             if (t < k_steps) {
                 const GateRow<R> row_e = load_gate_row<R>(s_tab, unpack_meta(G3.w).idx);
-                const Flight<R> fl = physics_phase<R, Resultant<R>>(take_thrust<R>(tmail[t & 1], lane), G0, G1, G2, G3, p.max_steps);
+                Flight<R> fl;
+                float4 rpm_now = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (XOPT) {                                                // fly<R, NOISE, true> with its thrust half on the aux wave
+                    Extras x;
+                    ThrustX th;
+                    take_thrust_x(tmx[t & 1], lane, th, x);
+                    x.gnd = p.gnd; x.drag = p.drag; x.rpm_f32 = !p.rpm_actions;
+                    x.last = G7;
+                    rpm_now = make_float4((float)x.rpm[0], (float)x.rpm[1], (float)x.rpm[2], (float)x.rpm[3]);
+                    fl = physics_phase<R, ThrustX, true>(th, G0, G1, G2, G3, p.max_steps, &x);
+                } else {
+                    fl = physics_phase<R, Resultant<R>>(take_thrust<R>(tmail[t & 1], lane), G0, G1, G2, G3, p.max_steps);
+                }
                 const float4 G0e = G0, G3e = G3;
                 const Verdict<R> v = rules_phase<R>(p, c, s_tab, row_e, wp0, fl, G0e, G3e, b.g6, li, active, G0, G1, G2, G3);
+                if (XOPT && p.drag) G7 = (v.terminated || fl.truncated) ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : rpm_now;
                 post_mailq<R>(mailq[t & 1], lane, fl, v);
             }
             block_lds_barrier();                                           // barrier t
         }
         if (active) { b.g0[li] = G0; b.g1[li] = G1; b.g2[li] = G2; b.g3[li] = G3; }
+        if (XOPT && p.drag && active) b.g7[li] = G7;
     } else if (role == 1) {
         __builtin_amdgcn_s_setprio(2);
         float4 P4 = b.g4[li], P5 = b.g5[li];                               // .xyz: prev_vel, prev_ang_v
@@ -1617,7 +1653,13 @@ __global__ __launch_bounds__(3 * DN_BLOCK) void dn_step_many_3w_kernel(const DnP
         float4 A = act[li];
         {
             const float4 A1 = (act + (long long)(k_steps > 1 ? 1 : 0) * n)[li];
-            post_thrust<R>(tmail[0], lane, thrust_phase<NOISE>(p, gid, (unsigned)sc0, A));
+            if (XOPT) {
+                Extras x;
+                const ThrustX th = thrust_phase_x<NOISE>(p, gid, (unsigned)sc0, A, x);
+                post_thrust_x(tmx[0], lane, th, x);
+            } else {
+                post_thrust<R>(tmail[0], lane, thrust_phase<NOISE>(p, gid, (unsigned)sc0, A));
+            }
             A = A1;
         }
         block_lds_barrier();                                               // P: table and thrust(0) published
@@ -1625,7 +1667,13 @@ __global__ __launch_bounds__(3 * DN_BLOCK) void dn_step_many_3w_kernel(const DnP
         for (int t = 0; t <= k_steps; ++t) {
             if (t + 1 < k_steps) {                                         // thrust(t+1), for the flight wave's next iteration
                 const float4 A_next = (act + (long long)(t + 2 < k_steps ? t + 2 : t + 1) * n)[li];
-                post_thrust<R>(tmail[(t + 1) & 1], lane, thrust_phase<NOISE>(p, gid, (unsigned)sc0 + (unsigned)(t + 1), A));
+                if (XOPT) {
+                    Extras x;
+                    const ThrustX th = thrust_phase_x<NOISE>(p, gid, (unsigned)sc0 + (unsigned)(t + 1), A, x);
+                    post_thrust_x(tmx[(t + 1) & 1], lane, th, x);
+                } else {
+                    post_thrust<R>(tmail[(t + 1) & 1], lane, thrust_phase<NOISE>(p, gid, (unsigned)sc0 + (unsigned)(t + 1), A));
+                }
                 A = A_next;
             }
             if (t > 0) {                                                   // the step the flight wave finished last iteration
@@ -1652,6 +1700,7 @@ __global__ __launch_bounds__(3 * DN_BLOCK) void dn_step_many_3w_kernel(const DnP
         Rms rms;
         if (NORM) load_rms(p, i, rms);
         RewNorm rn = {0.0, 0.0, 1.0, 1e-4};
+        if (XOPT && p.norm_rew) load_rewnorm(p, i, rn);
         block_lds_barrier();                                               // P
 #pragma clang loop unroll(disable)
         for (int t = 0; t <= k_steps + 1; ++t) {
@@ -1664,12 +1713,13 @@ __global__ __launch_bounds__(3 * DN_BLOCK) void dn_step_many_3w_kernel(const DnP
                 take_maila<R>(maila[u & 1], lane, fl, v, ob);
                 if (NORM) normalize_obs(rms, ob.o);                            // the step observation (= terminal_observation)
                 const StepOut out = block_out(io0, tile_base, (long long)u * n, (long long)u * words);
-                report_phase<R, NORM, NOISE, false, 2>(p, c, s_tile, out, fl, v, ob, gid, sc, li, lane, rows, active, G4, G5, acc, rms, rn);
+                report_phase<R, NORM, NOISE, XOPT, 2>(p, c, s_tile, out, fl, v, ob, gid, sc, li, lane, rows, active, G4, G5, acc, rms, rn);
             }
             if (t <= k_steps) block_lds_barrier();                         // barrier t
         }
         flush_stats(p, acc, sc0 + (unsigned long long)k_steps, lane);
         if (NORM && active) store_rms(p, i, rms);
+        if (XOPT && p.norm_rew && active) store_rewnorm(p, i, rn);
         if (active) {
             reinterpret_cast<float *>(b.g4 + li)[3] = G4.w;
             reinterpret_cast<float *>(b.g5 + li)[3] = G5.w;
@@ -1917,17 +1967,22 @@ hipError_t dn_launch_step_many_mw(const DnParams &p, const DnStepIO &io, int k, 
     const bool noise = p.act_noise_sigma > 0.0f || p.obs_noise_sigma > 0.0f;
     // the rarely used options share one set of instantiations (runtime switches inside): reward wrappers, N4 physics terms
     const bool rew = p.clip_rew != 0 || p.norm_rew != 0 || p.gnd != 0 || p.drag != 0 || p.rpm_actions != 0;
-    if (waves == 3 && k > 1 && !rew) {                     // three waves per tile: fused launches without the XOPT options
+    if (waves == 3 && k > 1) {                             // three waves per tile: fused launches
         const dim3 blk(3 * DN_BLOCK);
         const bool norm = p.normalize_obs != 0;
+#define DN_L3X(R, NORM, NOISE)                                                                                              \
+        do {                                                                                                                \
+            if (rew) hipLaunchKernelGGL((dn_step_many_3w_kernel<R, NORM, NOISE, true>), dim3(grid), blk, 0, stream, p, io, k);   \
+            else hipLaunchKernelGGL((dn_step_many_3w_kernel<R, NORM, NOISE, false>), dim3(grid), blk, 0, stream, p, io, k);      \
+        } while (0)
 #define DN_L3(R, NORM)                                                                                                      \
         do {                                                                                                                \
-            if (noise) hipLaunchKernelGGL((dn_step_many_3w_kernel<R, NORM, true>), dim3(grid), blk, 0, stream, p, io, k);   \
-            else hipLaunchKernelGGL((dn_step_many_3w_kernel<R, NORM, false>), dim3(grid), blk, 0, stream, p, io, k);        \
+            if (noise) DN_L3X(R, NORM, true); else DN_L3X(R, NORM, false);                                                  \
         } while (0)
         if (f32) { if (norm) DN_L3(float, true); else DN_L3(float, false); }
         else { if (norm) DN_L3(double, true); else DN_L3(double, false); }
 #undef DN_L3
+#undef DN_L3X
         return hipGetLastError();
     }
     if (f32) { if (noise) DN_LAUNCH(float, false, true); else DN_LAUNCH(float, false, false); }
@@ -1952,8 +2007,7 @@ hipError_t dn_launch_step_many(const DnParams &p, const DnStepIO &io, int k, boo
 #undef DN_LS
         return hipGetLastError();
     }
-    const bool xopt = p.clip_rew != 0 || p.norm_rew != 0 || p.gnd != 0 || p.drag != 0 || p.rpm_actions != 0;
-    if ((waves >= 2 && !norm) || (waves == 3 && k > 1 && !xopt)) return dn_launch_step_many_mw(p, io, k, f32, waves, stream);
+    if ((waves >= 2 && !norm) || (waves == 3 && k > 1)) return dn_launch_step_many_mw(p, io, k, f32, waves, stream);
     const bool two_wave = waves >= 2;       // with the normaliser: the two-wave kernels (there is no three-wave one)
     const unsigned grid = (unsigned)((p.n + DN_BLOCK - 1) / DN_BLOCK);
     const bool noise = p.act_noise_sigma > 0.0f || p.obs_noise_sigma > 0.0f;

@@ -173,9 +173,9 @@ int32_t dn_get_stats(dn_env *env, dn_stats *out, void *stream);
 int32_t dn_reset_stats(dn_env *env, void *stream);
 
 /* Kernel shape chosen for this environment's launches (fused != 0: dn_step_many with k > 1; fused == 0: dn_step):
- * 3 = flight + report + aux wave per 64 drones (fused launches of small fleets without the normaliser and the
- * optional terms), 2 = a flight wave + a report wave (small fleets otherwise: the step is bound by one wave's
- * dependent instruction stream and the other waves run on otherwise idle SIMDs), 1 = one wave per 64 drones.  All
+ * 3 = flight + report + aux wave per 64 drones (fused launches of small fleets: the step is bound by one wave's
+ * dependent instruction stream and the other waves run on otherwise idle SIMDs), 2 = a flight wave + a report wave
+ * (mid-size fleets with the optional terms, where three waves cost occupancy), 1 = one wave per 64 drones.  All
  * shapes produce identical bits.  Environment variable DN_WAVES=1|2|3 (read by dn_create) forces a shape. */
 int32_t dn_get_kernel_waves(const dn_env *env, int32_t fused);
 

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""A/B of the kernel shapes (DN_WAVES=1|2|3) for the option configurations (reward wrappers, extra physics terms, rpm
+actions): python profiles/sweep_options.py > gpurun_out/sweep_options.txt     (GPU; us per vector step, fused K=64)"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import drl_dronenavigation_amd as pkg
+from drl_dronenavigation_amd import tracks
+
+dev = torch.device("cuda:0")
+K = 64
+OPTIONS = {"clip_rew+norm_rew": dict(clip_rew=True, norm_rew=True), "pyb_gnd_drag_dw": dict(physics="pyb_gnd_drag_dw"),
+           "rpm": dict(act="rpm", normalize_actions=False), "all": dict(clip_rew=True, norm_rew=True, physics="pyb_gnd_drag_dw")}
+sizes = [int(x) for x in sys.argv[1:]] or [4096, 16384, 32768, 49152, 65536]
+print(f"{'options':>18} {'norm':>5} {'drones':>7} | {'1w':>7} {'2w':>7} {'3w':>7}   (us per vector step, fused K={K})")
+for name, kw in OPTIONS.items():
+    for norm in (False, True):
+        for n in sizes:
+            acts = 0.0922 + 0.02 * (torch.rand((K, n, 4), device=dev) - 0.5)
+            row = []
+            for w in ("1", "2", "3"):
+                os.environ["DN_WAVES"] = w
+                env = pkg.DroneVecEnv(tracks.reaching(), n, device=dev, normalize_obs=norm, **kw)
+                os.environ.pop("DN_WAVES")
+                env.reset()
+                reps = max(4, min(64, (1 << 22) // n))
+                for _ in range(2):
+                    env.rollout_tensor(acts)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    env.rollout_tensor(acts)
+                e1.record()
+                torch.cuda.synchronize()
+                row.append(e0.elapsed_time(e1) * 1e3 / (reps * K))
+                env.close()
+            print(f"{name:>18} {int(norm):5d} {n:7d} | {row[0]:7.3f} {row[1]:7.3f} {row[2]:7.3f}", flush=True)

@@ -1061,6 +1061,8 @@ def test_three_wave_kernel_short_rollouts_and_ragged_tiles(n, K, monkeypatch):
     dict(track="circle4"), dict(track="circle6", cylinder=False), dict(include_distance=False),
     dict(normalize_actions=False), dict(obs_noise_sigma=0.02, act_noise_sigma=0.01, seed=9),
     dict(threshold=5.0), dict(ground_contact=False, max_steps=7), dict(normalize_obs=True),
+    dict(clip_rew=True, norm_rew=True), dict(physics="pyb_gnd_drag_dw"), dict(physics="pyb_drag", normalize_obs=True),
+    dict(act="rpm", normalize_actions=False), dict(physics="pyb_gnd", norm_rew=True, obs_noise_sigma=0.02, act_noise_sigma=0.01),
 ])
 def test_fused_default_shape_equals_single_steps_over_options(opts, monkeypatch):
     """Whatever shape the library picks for a fused launch (three waves for these sizes), K fused steps must equal K
