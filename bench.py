@@ -372,7 +372,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
                          "traffic_frac": (round(traffic / (launch_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 5) if traffic else None),
-                         "kernel": ("dn_step_many_3w_kernel<%s, %s, false>" % ("double" if args.compute_dtype == "float64" else "float",
+                         "kernel": ("dn_step_many_3w_kernel<%s, %s, false, false>" % ("double" if args.compute_dtype == "float64" else "float",
                                                                                       "true" if args.normalize_obs else "false")
                                     if waves == 3 else
                                     "dn_step_many_%dw_kernel<%s, %s, false, %s, false>" % (

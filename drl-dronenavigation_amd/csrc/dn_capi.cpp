@@ -243,12 +243,21 @@ int32_t dn_create(const dn_config *cfg, dn_env **out)
     // normaliser it wins wherever more than one wave per tile wins, i.e. up to 1024 tiles (65536 drones: 2.3 us per step
     // against 2.5 with two waves and 2.9 with one); with the normaliser (27 more float64 per drone in a wave) up to 512
     // tiles (32768 drones: 1.8 us against 2.1 with two waves), one wave beyond (49152 drones: 3.3 us against 3.5).
-    // With the XOPT options (reward wrappers, extra force terms, rpm actions) the flight wave is wider in registers:
-    // three waves win up to 512 tiles (32768 drones, all options: 2.1 us against 3.0 with two waves), two waves from
-    // there to 1024 tiles (65536 drones: 3.2 us against 4.8 with three).
+    // The option kernels are wider in registers (the three-wave kernels are compiled for three waves per SIMD, two with
+    // the normaliser: __launch_bounds__), so their crossovers sit lower (profiles/r01_r_sweep_options.txt, us per step):
+    //   XOPT options (reward wrappers, force terms, rpm actions), all on: 32768 drones 2.15 (3w) / 2.97 (2w) / 3.70 (1w);
+    //     49152: 2.43 / 2.99 / 3.66; 65536: 4.48 / 3.14 / 3.72  -> three waves up to 768 tiles, two up to 1024;
+    //     with the normaliser 32768: 2.43 / 2.80 / 4.50; 65536: 4.74 / 5.42 / 4.56 -> three up to 512 tiles, one beyond;
+    //   noise (Philox + Box-Muller per observation column): 16384 drones 3.51 / 4.63 / 5.86; 32768: 4.86 / 4.78 / 6.02;
+    //     49152: 5.36 / 4.88 / 6.04 -> three waves up to 256 tiles, two beyond (same with the normaliser, up to 512);
+    //     noise + XOPT without the normaliser follows the XOPT row (49152: 5.75 / 6.23 / 6.99).
     const bool plain = !cfg->clip_rew && !cfg->norm_rew && cfg->physics == 0 && cfg->action_type == 0;
+    const bool noisy = cfg->act_noise_sigma > 0.0f || cfg->obs_noise_sigma > 0.0f;
     const long long max_multi = cfg->normalize_obs ? DN_TWO_WAVE_MAX_TILES / 2 : DN_TWO_WAVE_MAX_TILES;
-    e->waves_fused = e->blocks <= max_multi ? ((plain || e->blocks <= DN_TWO_WAVE_MAX_TILES / 2) ? 3 : 2) : 1;
+    long long max_three = max_multi;
+    if (!plain && !cfg->normalize_obs) max_three = DN_TWO_WAVE_MAX_TILES * 3 / 4;
+    else if (noisy) max_three = DN_TWO_WAVE_MAX_TILES / 4;
+    e->waves_fused = e->blocks <= max_multi ? (e->blocks <= max_three ? 3 : 2) : 1;
     e->waves_single = 1;
     if (const char *w = getenv("DN_WAVES")) {
         if (w[0] == '1') e->waves_fused = e->waves_single = 1;

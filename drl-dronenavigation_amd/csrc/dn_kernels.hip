@@ -195,19 +195,73 @@ DN_DEV void philox4x32(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsig
     }
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
+// Box-Muller on one pair of Philox words, float64 throughout, every operation spelled out (no libm call: the device
+// library's log / sin / cos carry argument-reduction paths for inputs that cannot occur here and cost ~300 instructions
+// a pair; this is ~80).  u = (r + 0.5) / 2^32 lies strictly inside (0, 1).
+//   ln u1:  u1 = m 2^e, m in [sqrt(1/2), sqrt(2)),  ln m = 2 atanh(s) = 2 s (1 + s^2/3 + ... + s^14/15),  s = (m-1)/(m+1),
+//           |s| <= 0.1716: truncation 3e-14 relative, and no cancellation as u1 -> 1 (e = 0, m - 1 exact);
+//   angle:  2 pi u2 = k pi/2 + theta, k = rint(4 u2), theta = 2 pi (u2 - k/4) in [-pi/4, pi/4] (the subtraction is
+//           exact), sin / cos Taylor to theta^13 / theta^14 (2e-14), quadrant fix-up by k.
+// Equal to the libm form (the oracle's) to ~1e-13 before the float32 cast.
+DN_DEV void box_muller_pair(unsigned ra, unsigned rb, float &z0, float &z1)
+{
+    const double u1 = ((double)ra + 0.5) * (1.0 / 4294967296.0);
+    const double u2 = ((double)rb + 0.5) * (1.0 / 4294967296.0);
+    double m = __builtin_amdgcn_frexp_mant(u1);            // [0.5, 1)
+    int e = __builtin_amdgcn_frexp_exp(u1);
+    if (m < 0.70710678118654752440) { m = m + m; e = e - 1; }
+    const double num = m - 1.0, den = m + 1.0;
+    double r = __builtin_amdgcn_rcp(den);
+    double q = __builtin_fma(-den, r, 1.0);
+    r = __builtin_fma(r, q, r);
+    q = __builtin_fma(-den, r, 1.0);
+    r = __builtin_fma(r, q, r);
+    const double sv = num * r, s2 = sv * sv;
+    double pl = 1.0 / 15.0;
+    pl = __builtin_fma(pl, s2, 1.0 / 13.0);
+    pl = __builtin_fma(pl, s2, 1.0 / 11.0);
+    pl = __builtin_fma(pl, s2, 1.0 / 9.0);
+    pl = __builtin_fma(pl, s2, 1.0 / 7.0);
+    pl = __builtin_fma(pl, s2, 1.0 / 5.0);
+    pl = __builtin_fma(pl, s2, 1.0 / 3.0);
+    pl = __builtin_fma(pl, s2, 1.0);
+    const double ln_u1 = __builtin_fma((double)e, 0.69314718055994530942, (sv + sv) * pl);
+    const double t = -2.0 * ln_u1;                         // > 0
+    double y = __builtin_amdgcn_rsq(t);
+    y = y * __builtin_fma(-0.5 * t * y, y, 1.5);
+    y = y * __builtin_fma(-0.5 * t * y, y, 1.5);
+    const double rad = t * y;
+    const double k4 = __builtin_rint(u2 * 4.0);
+    const double th = (2.0 * 3.14159265358979323846) * __builtin_fma(k4, -0.25, u2);
+    const double t2 = th * th;
+    double ps = 1.0 / 6227020800.0;                        //  1/13!
+    ps = __builtin_fma(ps, t2, -1.0 / 39916800.0);         // -1/11!
+    ps = __builtin_fma(ps, t2, 1.0 / 362880.0);
+    ps = __builtin_fma(ps, t2, -1.0 / 5040.0);
+    ps = __builtin_fma(ps, t2, 1.0 / 120.0);
+    ps = __builtin_fma(ps, t2, -1.0 / 6.0);
+    const double sn = __builtin_fma(th * t2, ps, th);
+    double pc = -1.0 / 87178291200.0;                      // -1/14!
+    pc = __builtin_fma(pc, t2, 1.0 / 479001600.0);         //  1/12!
+    pc = __builtin_fma(pc, t2, -1.0 / 3628800.0);
+    pc = __builtin_fma(pc, t2, 1.0 / 40320.0);
+    pc = __builtin_fma(pc, t2, -1.0 / 720.0);
+    pc = __builtin_fma(pc, t2, 1.0 / 24.0);
+    pc = __builtin_fma(pc, t2, -0.5);
+    const double cs = __builtin_fma(pc, t2, 1.0);
+    const int k = (int)k4 & 3;
+    const double c = (k & 1) ? sn : cs, d = (k & 1) ? cs : sn;          // odd quadrants swap the two ...
+    const double cosv = (k == 1 || k == 2) ? -c : c;                    // ... and the signs follow cos(a + pi/2) = -sin a
+    const double sinv = (k >= 2) ? -d : d;
+    z0 = (float)(rad * cosv);
+    z1 = (float)(rad * sinv);
+}
 DN_DEV void noise4(unsigned long long seed, unsigned long long gid, unsigned step, unsigned stream, float z[4])
 {
     unsigned r[4];
     philox4x32((unsigned)gid, (unsigned)(gid >> 32), step, stream, (unsigned)seed, (unsigned)(seed >> 32), r);
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        double u1 = ((double)r[2 * h] + 0.5) * (1.0 / 4294967296.0);
-        double u2 = ((double)r[2 * h + 1] + 0.5) * (1.0 / 4294967296.0);
-        double rad = sqrt(-2.0 * log(u1));
-        double ang = 2.0 * 3.14159265358979323846 * u2;
-        z[2 * h] = (float)(rad * cos(ang));
-        z[2 * h + 1] = (float)(rad * sin(ang));
-    }
+    box_muller_pair(r[0], r[1], z[0], z[1]);
+    box_muller_pair(r[2], r[3], z[2], z[3]);
 }
 DN_DEV void add_act_noise(const DnParams &p, unsigned long long gid, unsigned step, float a[4])
 {   // float32, unfused (its own function: the fused-multiply-add licence of step_body must not reach it)
@@ -1579,18 +1633,23 @@ DN_DEV void take_thrust_x(const ThrustMailX<true> &m, unsigned lane, ThrustX &t,
 }
 DN_DEV void post_thrust_x(ThrustMailX<false> &, unsigned, const ThrustX &, const Extras &) {}
 DN_DEV void take_thrust_x(const ThrustMailX<false> &, unsigned, ThrustX &, Extras &) {}
+// the plain thrust mail is not needed with XOPT (LDS decides how many tiles a CU holds)
+template <typename R, bool XOPT> struct ThrustMailP : ThrustMail<R> {};
+template <typename R> struct ThrustMailP<R, true> { R v[1][1]; };
+template <typename R> DN_DEV void post_thrust(ThrustMailP<R, true> &, unsigned, const Thrust &) {}
+template <typename R> DN_DEV Resultant<R> take_thrust(const ThrustMailP<R, true> &, unsigned) { return Resultant<R>(); }
 
 // NORM (per-drone observation normaliser): the aux wave hands over the raw observation and the report wave, which
 // owns the statistics, normalises it (and then, for a finished drone, the reset observation: the reference's order).
 template <typename R, bool NORM, bool NOISE, bool XOPT>
-__global__ __launch_bounds__(3 * DN_BLOCK) void dn_step_many_3w_kernel(const DnParams p, const DnStepIO io0, const int k_steps)
+__global__ __launch_bounds__(3 * DN_BLOCK, NORM ? 2 : 3) void dn_step_many_3w_kernel(const DnParams p, const DnStepIO io0, const int k_steps)
 {
     __shared__ ThrustMailX<XOPT> tmx[2];
     __shared__ R s_tab[DN_MAX_WAYPOINTS * DN_T_STRIDE];
     __shared__ __attribute__((aligned(16))) float s_tile[DN_BLOCK * DN_OBS_DIM];
     __shared__ MailQ<R> mailq[2];
     __shared__ MailA<R> maila[2];
-    __shared__ __attribute__((aligned(16))) ThrustMail<R> tmail[2];
+    __shared__ __attribute__((aligned(16))) ThrustMailP<R, XOPT> tmail[2];
     const unsigned lane = threadIdx.x & (DN_BLOCK - 1);
     // role of this wave: 0 flight, 1 aux, 2 report.  The order of the waves inside the workgroup decides which of them
     // end up sharing a SIMD when a CU holds two tiles (six waves on four SIMDs, dealt round-robin): with the waves

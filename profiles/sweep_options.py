@@ -13,7 +13,12 @@ from drl_dronenavigation_amd import tracks
 dev = torch.device("cuda:0")
 K = 64
 OPTIONS = {"clip_rew+norm_rew": dict(clip_rew=True, norm_rew=True), "pyb_gnd_drag_dw": dict(physics="pyb_gnd_drag_dw"),
-           "rpm": dict(act="rpm", normalize_actions=False), "all": dict(clip_rew=True, norm_rew=True, physics="pyb_gnd_drag_dw")}
+           "rpm": dict(act="rpm", normalize_actions=False), "all": dict(clip_rew=True, norm_rew=True, physics="pyb_gnd_drag_dw"),
+           "noise": dict(obs_noise_sigma=0.02, act_noise_sigma=0.005),
+           "noise+all": dict(obs_noise_sigma=0.02, act_noise_sigma=0.005, clip_rew=True, norm_rew=True, physics="pyb_gnd_drag_dw"),
+           "none": {}}
+if os.environ.get("OPTS"):                       # OPTS=noise,all restricts the rows
+    OPTIONS = {k: OPTIONS[k] for k in os.environ["OPTS"].split(",")}
 sizes = [int(x) for x in sys.argv[1:]] or [4096, 16384, 32768, 49152, 65536]
 print(f"{'options':>18} {'norm':>5} {'drones':>7} | {'1w':>7} {'2w':>7} {'3w':>7}   (us per vector step, fused K={K})")
 for name, kw in OPTIONS.items():

@@ -1129,7 +1129,7 @@ def test_sharding_invariance_with_noise(n, K, norm):
     """BASELINE configs 4/5: a fleet split over ranks (env_id_offset = rank * num_envs) must produce, drone for drone, the
     bits of the unsplit fleet -- physics, auto-reset and the Philox action/observation noise (keyed by the GLOBAL drone id
     and the vector-step counter) -- in fused and in single-step launches.  In the two large cases the whole fleet and its
-    halves also run different kernel shapes (one wave against three), which must not show."""
+    halves also run different kernel shapes (one wave against two), which must not show."""
     pkg = _gpu()
     track = _tracks().reaching()
     kw = dict(normalize_obs=norm, max_steps=30, act_noise_sigma=0.01, obs_noise_sigma=0.02, seed=77)
