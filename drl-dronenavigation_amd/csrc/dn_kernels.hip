@@ -202,7 +202,7 @@ DN_DEV void philox4x32(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsig
 //           |s| <= 0.1716: truncation 3e-14 relative, and no cancellation as u1 -> 1 (e = 0, m - 1 exact);
 //   angle:  2 pi u2 = k pi/2 + theta, k = rint(4 u2), theta = 2 pi (u2 - k/4) in [-pi/4, pi/4] (the subtraction is
 //           exact), sin / cos Taylor to theta^13 / theta^14 (2e-14), quadrant fix-up by k.
-// Equal to the libm form (the oracle's) to ~1e-13 before the float32 cast.
+// Equal to the libm form (log, sqrt, cos, sin of the C library) to ~1e-13 before the float32 cast.
 DN_DEV void box_muller_pair(unsigned ra, unsigned rb, float &z0, float &z1)
 {
     const double u1 = ((double)ra + 0.5) * (1.0 / 4294967296.0);
