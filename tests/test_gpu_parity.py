@@ -780,9 +780,10 @@ def test_baseline_full_size_matches_oracle_free_running():
     env.close()
 
 
-def test_baseline_full_size_fused_launch_matches_oracle():
+def test_baseline_full_size_fused_launch_matches_oracle(monkeypatch):
     """The bench's own launch -- 32768 drones, race track, 64 steps of U(-1,1)^4 actions in ONE dn_step_many (the
     three-wave kernel) -- against the oracle, every drone, every step, every output; then the mixed stream."""
+    monkeypatch.delenv("DN_WAVES", raising=False)         # the bench's shape is the library's own pick
     track = _tracks().reaching()
     n, K = 32768, 64
     env, ora = make_pair(track, n, f32_state=True, max_steps=4096, normalize_obs=False)
@@ -1125,12 +1126,13 @@ def test_float32_compute_shapes_agree_to_rounding(monkeypatch):
 
 
 @pytest.mark.parametrize("n,K,norm", [(4096, 24, True), (131072, 6, False), (65536, 6, True)])
-def test_sharding_invariance_with_noise(n, K, norm):
+def test_sharding_invariance_with_noise(n, K, norm, monkeypatch):
     """BASELINE configs 4/5: a fleet split over ranks (env_id_offset = rank * num_envs) must produce, drone for drone, the
     bits of the unsplit fleet -- physics, auto-reset and the Philox action/observation noise (keyed by the GLOBAL drone id
     and the vector-step counter) -- in fused and in single-step launches.  In the two large cases the whole fleet and its
     halves also run different kernel shapes (one wave against two), which must not show."""
     pkg = _gpu()
+    monkeypatch.delenv("DN_WAVES", raising=False)         # whole fleet and halves must get the library's own, different shapes
     track = _tracks().reaching()
     kw = dict(normalize_obs=norm, max_steps=30, act_noise_sigma=0.01, obs_noise_sigma=0.02, seed=77)
     whole = pkg.DroneVecEnv(track, n, device="cuda:0", **kw)
