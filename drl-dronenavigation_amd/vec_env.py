@@ -164,6 +164,7 @@ class DroneVecEnv(_VecEnvBase):
         self._t_start = time.time()
         self._pending = False
         self._infos = [{} for _ in range(n)]
+        self._dirty = []                       # sparse info mode: the dicts filled by the previous step
         self._closed = False
 
     # ------------------------------------------------------------------ tensor-native API
@@ -262,11 +263,12 @@ class DroneVecEnv(_VecEnvBase):
         done = self._done.cpu().numpy().astype(bool)
         found = self._found.cpu().numpy()
         if self.info_mode == "full":
-            infos = [{"found_targets": int(f), "TimeLimit.truncated": False} for f in found]
+            infos = [{"found_targets": f, "TimeLimit.truncated": False} for f in found.tolist()]
         else:
-            infos = self._infos
-            for d in infos:
-                d.clear()
+            infos = self._infos                # one persistent list; only the dicts the last step filled are cleared
+            for i in self._dirty:
+                infos[i].clear()
+            self._dirty = []
         if done.any():
             idx = self.done_indices()
             sel = torch.from_numpy(idx.astype(np.int64)).to(self.device)
@@ -275,8 +277,10 @@ class DroneVecEnv(_VecEnvBase):
             ep_l = self._ep_len.index_select(0, sel).cpu().numpy()
             trunc = self._trunc.index_select(0, sel).cpu().numpy()
             t = round(time.time() - self._t_start, 6)
-            for j, i in enumerate(idx):
-                info = infos[int(i)]
+            if self.info_mode != "full":
+                self._dirty = idx.tolist()
+            for j, i in enumerate(idx.tolist()):
+                info = infos[i]
                 info["found_targets"] = int(found[i])
                 info["terminal_observation"] = term[j]
                 info["TimeLimit.truncated"] = bool(trunc[j])

@@ -364,6 +364,36 @@ def test_sb3_step_surface_and_infos():
     env.close()
 
 
+def test_sparse_info_mode_matches_full():
+    """info_mode="sparse" (one persistent list of dicts, filled for finished drones only, cleared before the next step)
+    carries exactly what info_mode="full" carries for the drones that finished, and nothing for the others."""
+    pkg = _gpu()
+    track = _tracks().circle(1, 4, 1)
+    n = 300
+    full = pkg.DroneVecEnv(track, n, device="cuda:0", max_steps=25, info_mode="full")
+    sparse = pkg.DroneVecEnv(track, n, device="cuda:0", max_steps=25, info_mode="sparse")
+    assert np.array_equal(full.reset(), sparse.reset())
+    rng = np.random.default_rng(12)
+    finished = 0
+    for t in range(60):
+        a = actions_mixed(rng, n)
+        of, rf, df, inf_f = full.step(a)
+        os_, rs, ds, inf_s = sparse.step(a)
+        assert np.array_equal(of, os_) and np.array_equal(rf, rs) and np.array_equal(df, ds) and len(inf_s) == n
+        for i in range(n):
+            if df[i]:
+                finished += 1
+                assert set(inf_s[i]) == {"found_targets", "terminal_observation", "TimeLimit.truncated", "episode"}
+                assert inf_s[i]["found_targets"] == inf_f[i]["found_targets"]
+                assert inf_s[i]["TimeLimit.truncated"] == inf_f[i]["TimeLimit.truncated"]
+                assert np.array_equal(inf_s[i]["terminal_observation"], inf_f[i]["terminal_observation"])
+                assert inf_s[i]["episode"]["r"] == inf_f[i]["episode"]["r"] and inf_s[i]["episode"]["l"] == inf_f[i]["episode"]["l"]
+            else:
+                assert inf_s[i] == {}, (t, i, inf_s[i])          # last step's entries are gone
+    assert finished > n
+    full.close(); sparse.close()
+
+
 def test_full_size_properties():
     """BASELINE size (32768 drones, race track): size-independent properties -- determinism, unit
     quaternions, reset rows, the done ballot words vs the byte flags vs the compacted index list, and the
