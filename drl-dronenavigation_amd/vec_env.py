@@ -150,14 +150,21 @@ class DroneVecEnv(_VecEnvBase):
         with torch.cuda.device(self.device):
             f32, dev = torch.float32, self.device
             self._actions = torch.zeros((n, ACT_DIM), dtype=f32, device=dev)
-            self._obs = torch.zeros((n, OBS_DIM), dtype=f32, device=dev)
-            self._reward = torch.zeros(n, dtype=f32, device=dev)
-            self._done = torch.zeros(n, dtype=torch.uint8, device=dev)
-            self._trunc = torch.zeros(n, dtype=torch.uint8, device=dev)
-            self._found = torch.zeros(n, dtype=torch.int32, device=dev)
-            self._term_obs = torch.zeros((n, OBS_DIM), dtype=f32, device=dev)
-            self._ep_ret = torch.zeros(n, dtype=f32, device=dev)
-            self._ep_len = torch.zeros(n, dtype=torch.int32, device=dev)
+            # the per-step outputs live in ONE device allocation, so that the NumPy step() brings them to the host with
+            # one copy into a pinned mirror (eight separate .cpu() calls and four gathers cost ~0.4 ms at 32768 drones)
+            fields = [("_obs", (n, OBS_DIM), f32), ("_reward", (n,), f32), ("_found", (n,), torch.int32),
+                      ("_term_obs", (n, OBS_DIM), f32), ("_ep_ret", (n,), f32), ("_ep_len", (n,), torch.int32),
+                      ("_done", (n,), torch.uint8), ("_trunc", (n,), torch.uint8)]
+            offs, total = [], 0
+            for _, shape, dt in fields:
+                offs.append(total)
+                total += (int(np.prod(shape)) * torch.empty((), dtype=dt).element_size() + 255) // 256 * 256
+            self._out_blob = torch.zeros(total, dtype=torch.uint8, device=dev)
+            self._host_blob = torch.zeros(total, dtype=torch.uint8, pin_memory=True)
+            for (name, shape, dt), off in zip(fields, offs):
+                nbytes = int(np.prod(shape)) * torch.empty((), dtype=dt).element_size()
+                setattr(self, name, self._out_blob[off:off + nbytes].view(dt).view(shape))
+                setattr(self, "_h" + name, self._host_blob[off:off + nbytes].view(dt).view(shape).numpy())
             self._done_mask = torch.zeros((n + 63) // 64, dtype=torch.int64, device=dev)
             self._done_idx = torch.zeros(n, dtype=torch.int32, device=dev)
             self._done_cnt = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -258,10 +265,14 @@ class DroneVecEnv(_VecEnvBase):
         if not self._pending:
             raise RuntimeError("step_wait() without step_async()")
         self._pending = False
-        obs = self._obs[:, :self.obs_dim].cpu().numpy()
-        rew = self._reward.cpu().numpy()
-        done = self._done.cpu().numpy().astype(bool)
-        found = self._found.cpu().numpy()
+        with torch.cuda.device(self.device):
+            self._host_blob.copy_(self._out_blob, non_blocking=True)          # one D2H copy on the step's stream
+            torch.cuda.current_stream(self.device).synchronize()
+        # fresh arrays: the pinned mirror is overwritten by the next step
+        obs = self._h_obs[:, :self.obs_dim].copy()
+        rew = self._h_reward.copy()
+        done = self._h_done.astype(bool)
+        found = self._h_found
         if self.info_mode == "full":
             infos = [{"found_targets": f, "TimeLimit.truncated": False} for f in found.tolist()]
         else:
@@ -269,22 +280,22 @@ class DroneVecEnv(_VecEnvBase):
             for i in self._dirty:
                 infos[i].clear()
             self._dirty = []
-        if done.any():
-            idx = self.done_indices()
-            sel = torch.from_numpy(idx.astype(np.int64)).to(self.device)
-            term = self._term_obs[:, :self.obs_dim].index_select(0, sel).cpu().numpy()
-            ep_r = self._ep_ret.index_select(0, sel).cpu().numpy()
-            ep_l = self._ep_len.index_select(0, sel).cpu().numpy()
-            trunc = self._trunc.index_select(0, sel).cpu().numpy()
+        idx = np.flatnonzero(done)              # the done flags are on the host already (== done_indices())
+        if idx.size:
+            term = self._h_term_obs[idx, :self.obs_dim]                       # fancy indexing: copies
+            ep_r, ep_l, trunc = self._h_ep_ret[idx], self._h_ep_len[idx], self._h_trunc[idx]
             t = round(time.time() - self._t_start, 6)
+            idx_l = idx.tolist()                # plain Python scalars: this loop is what a 32768-drone step() costs
             if self.info_mode != "full":
-                self._dirty = idx.tolist()
-            for j, i in enumerate(idx.tolist()):
+                self._dirty = idx_l
+            found_l, trunc_l = found[idx].tolist(), trunc.astype(bool).tolist()
+            ep_r_l, ep_l_l = ep_r.tolist(), ep_l.tolist()
+            for j, i in enumerate(idx_l):
                 info = infos[i]
-                info["found_targets"] = int(found[i])
+                info["found_targets"] = found_l[j]
                 info["terminal_observation"] = term[j]
-                info["TimeLimit.truncated"] = bool(trunc[j])
-                info["episode"] = {"r": round(float(ep_r[j]), 6), "l": int(ep_l[j]), "t": t}
+                info["TimeLimit.truncated"] = trunc_l[j]
+                info["episode"] = {"r": round(ep_r_l[j], 6), "l": ep_l_l[j], "t": t}
         return obs, rew, done, infos
 
     def step(self, actions):
