@@ -839,6 +839,38 @@ def test_baseline_full_size_fused_launch_matches_oracle(monkeypatch):
     env.close()
 
 
+def test_gaussian_draws_match_oracle_to_float32_rounding():
+    """The device Box-Muller (explicit float64 series, no libm calls) against the oracle's libm form on the same Philox
+    words: dn_policy_sample with mean 0 and log_std 0 returns the N(0,1) draws themselves.  Bar: one float32 ulp of the
+    largest draw (|z| < 8: 4.8e-7), at least 99.99 % of the draws bit-equal; global drone ids above 2^32 (the counter's
+    high word) included."""
+    pkg = _gpu()
+    import ctypes as C
+    L = O.lib()
+    track = _tracks().circle(1, 4, 1)
+    n, seed = 16384, 20240917
+    dev = torch.device("cuda:0")
+    for offset in (0, (1 << 33) + 12345):
+        env = pkg.DroneVecEnv(track, n, device="cuda:0", env_id_offset=offset, normalize_obs=False)
+        env.reset()
+        mean = torch.zeros((n, 4), dtype=torch.float32, device=dev)
+        acts, clipped, logp = torch.empty_like(mean), torch.empty_like(mean), torch.empty(n, dtype=torch.float32, device=dev)
+        log_std = (C.c_float * 4)(0.0, 0.0, 0.0, 0.0)
+        pkg._capi.check(env._lib.dn_policy_sample(env._handle, mean.data_ptr(), log_std, seed, 0, acts.data_ptr(),
+                                                  clipped.data_ptr(), logp.data_ptr(), env._stream()))
+        torch.cuda.synchronize()
+        z_dev = acts.cpu().numpy()
+        z_ref = np.zeros((n, 4), np.float32)
+        for i in range(n):
+            L.orc_noise4(seed, offset + i, 0, 9, z_ref[i].ctypes.data_as(C.POINTER(C.c_float)))
+        assert np.abs(z_dev - z_ref).max() <= 4.8e-7
+        assert (z_dev.view(np.uint32) == z_ref.view(np.uint32)).mean() >= 0.9999
+        assert abs(float(z_dev.mean())) < 0.02 and abs(float(z_dev.var()) - 1.0) < 0.03 and np.abs(z_dev).max() > 3.5
+        np.testing.assert_array_equal(clipped.cpu().numpy(), np.clip(z_dev, -1.0, 1.0))
+        np.testing.assert_allclose(logp.cpu().numpy(), (-0.5 * z_dev.astype(np.float64) ** 2 - 0.9189385332046727).sum(1), rtol=0, atol=1e-5)
+        env.close()
+
+
 def test_fused_rollout_collector_against_oracle_and_graph_replay():
     """FusedRolloutCollector (dn_mlp_forward -> dn_policy_sample -> dn_step -> masked bootstrap, five launches per step,
     no copies): the sampled actions are mean + std * z with z from the environment's Philox stream 9 (checked against
