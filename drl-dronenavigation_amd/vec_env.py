@@ -160,7 +160,10 @@ class DroneVecEnv(_VecEnvBase):
                 offs.append(total)
                 total += (int(np.prod(shape)) * torch.empty((), dtype=dt).element_size() + 255) // 256 * 256
             self._out_blob = torch.zeros(total, dtype=torch.uint8, device=dev)
-            self._host_blob = torch.zeros(total, dtype=torch.uint8, pin_memory=True)
+            try:
+                self._host_blob = torch.zeros(total, dtype=torch.uint8, pin_memory=True)
+            except RuntimeError:                               # no pinned memory to be had: a pageable mirror still works
+                self._host_blob = torch.zeros(total, dtype=torch.uint8)
             for (name, shape, dt), off in zip(fields, offs):
                 nbytes = int(np.prod(shape)) * torch.empty((), dtype=dt).element_size()
                 setattr(self, name, self._out_blob[off:off + nbytes].view(dt).view(shape))
