@@ -11,7 +11,7 @@ from . import build as _build
 MAX_WAYPOINTS = 64
 OBS_DIM = 13
 ACT_DIM = 4
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 DN_OK = 0
 STATUS_NAMES = {0: "DN_OK", -1: "DN_ERR_INVALID_ARGUMENT", -2: "DN_ERR_HIP", -3: "DN_ERR_OUT_OF_MEMORY",
@@ -76,6 +76,7 @@ PROTOTYPES = {
     "dn_reset": (_I32, [_VP, _VP, _VP]),
     "dn_step": (_I32, [_VP] * 12),
     "dn_step_many": (_I32, [_VP, _I64] + [_VP] * 11),
+    "dn_eval_kinematics": (_I32, [_VP] * 11),
     "dn_compact_done": (_I32, [_VP, _I64, _VP, _VP, _I32, _VP]),
     "dn_get_state": (_I32, [_VP, _VP, _I64]),
     "dn_set_state": (_I32, [_VP, _VP, _I64]),

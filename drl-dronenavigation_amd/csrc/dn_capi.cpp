@@ -395,6 +395,26 @@ int32_t dn_step_sampled(dn_env *env, const float *mean, const float *log_std, ui
     return DN_OK;
 }
 
+int32_t dn_eval_kinematics(dn_env *env, const double *kinematics, float *obs, float *reward, uint8_t *done, uint8_t *truncated,
+                           int32_t *found_targets, float *terminal_obs, float *ep_return, int32_t *ep_length, void *stream)
+{
+    if (!env) return fail(DN_ERR_INVALID_ARGUMENT, "env is NULL");
+    if (!kinematics || !obs || !reward || !done || !truncated || !found_targets)
+        return fail(DN_ERR_INVALID_ARGUMENT, "kinematics, obs, reward, done, truncated and found_targets are required");
+    if (((uintptr_t)kinematics & 7u) || ((uintptr_t)obs & 15u))
+        return fail(DN_ERR_INVALID_ARGUMENT, "kinematics must be 8-byte and obs 16-byte aligned");
+    const dn_config &c = env->cfg;
+    if (c.act_noise_sigma > 0.0f || c.obs_noise_sigma > 0.0f || c.clip_rew || c.norm_rew || c.physics != 0 || c.action_type != 0)
+        return fail(DN_ERR_INVALID_ARGUMENT, "dn_eval_kinematics is built for the reference configuration (no noise, no reward wrappers, "
+                                             "Physics.PYB, ActionType.THRUST)");
+    DnStepIO io;
+    memset(&io, 0, sizeof io);
+    io.obs = obs; io.reward = reward; io.done = done; io.truncated = truncated; io.found_targets = found_targets;
+    io.terminal_obs = terminal_obs; io.ep_return = ep_return; io.ep_length = ep_length;
+    DN_HIP(dn_launch_eval_kinematics(env->p, io, kinematics, c.compute_f32 != 0, (hipStream_t)stream));
+    return DN_OK;
+}
+
 int32_t dn_step_many(dn_env *env, int64_t k, const float *actions, float *obs, float *reward, uint8_t *done,
                      uint8_t *truncated, int32_t *found_targets, float *terminal_obs, float *ep_return,
                      int32_t *ep_length, uint64_t *done_mask, void *stream)

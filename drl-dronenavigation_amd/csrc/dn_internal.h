@@ -109,6 +109,7 @@ struct DnParams {
 hipError_t dn_launch_step_many(const DnParams &p, const DnStepIO &io, int k, bool f32, int waves, hipStream_t stream);
 hipError_t dn_launch_step_many_mw(const DnParams &p, const DnStepIO &io, int k, bool f32, int waves, hipStream_t stream);   // dn_kernels_mw.hip
 hipError_t dn_launch_reset(const DnParams &p, float *obs, bool f32, hipStream_t stream);
+hipError_t dn_launch_eval_kinematics(const DnParams &p, const DnStepIO &io, const double *kin, bool f32, hipStream_t stream);
 hipError_t dn_launch_gae(const float *rewards, const float *values, const uint8_t *dones,
                          const float *last_values, const uint8_t *last_dones, long long T, long long N,
                          float gamma, float gl, float *adv, float *ret, hipStream_t stream);

@@ -797,6 +797,19 @@ DN_DEV Resultant<R> rotor_resultant(const Thrust &th)
     return r;
 }
 
+// What a step reads of the drone's ENTRY state besides the rigid body itself: the stale distance pair (quirk Q1), the
+// gate index / just_found flag, _computeTruncated on the un-incremented _steps (PBDroneEnv.py:444-454) and the entry
+// velocities = current_vel / current_ang_v (quirk Q4).
+template <typename R>
+DN_DEV void flight_entry(Flight<R> &fl, const float4 G0, const float4 G2, const float4 G3, const int max_steps)
+{
+    const Meta m_e = unpack_meta(G3.w);
+    fl.d_e = G0.w; fl.dprev_e = G2.w;
+    fl.idx_e = m_e.idx; fl.just_found_e = m_e.just_found;
+    fl.truncated = max_steps <= m_e.steps;             // PBDroneEnv.py:444-454, evaluated on the un-incremented _steps
+    fl.vex = G2.x; fl.vey = G2.y; fl.vez = G2.z; fl.aex = G3.x; fl.aey = G3.y; fl.aez = G3.z;
+}
+
 // ---- A4: p.stepSimulation, one free rigid body [3P-recall of Bullet3 btMultiBody] -------------------------
 template <typename R, typename TH = Thrust, bool XOPT = false>
 DN_DEV Flight<R> physics_phase(const TH &th, const float4 G0, const float4 G1, const float4 G2, const float4 G3,
@@ -812,11 +825,7 @@ DN_DEV Flight<R> physics_phase(const TH &th, const float4 G0, const float4 G1, c
     R qx = G1.x, qy = G1.y, qz = G1.z, qw = G1.w;
     R vx = G2.x, vy = G2.y, vz = G2.z;
     R wx = G3.x, wy = G3.y, wz = G3.z;
-    const Meta m_e = unpack_meta(G3.w);
-    fl.d_e = G0.w; fl.dprev_e = G2.w;
-    fl.idx_e = m_e.idx; fl.just_found_e = m_e.just_found;
-    fl.truncated = max_steps <= m_e.steps;             // PBDroneEnv.py:444-454, evaluated on the un-incremented _steps
-    fl.vex = G2.x; fl.vey = G2.y; fl.vez = G2.z; fl.aex = G3.x; fl.aey = G3.y; fl.aez = G3.z;
+    flight_entry<R>(fl, G0, G2, G3, max_steps);
     const R dt = K<R>::DT;
     // btMatrix3x3::setRotation: s = 2 / |q|^2
     const R s = R(2.0) * FM<R>::rcp(F(qw, qw, F(qz, qz, F(qy, qy, qx * qx))));
@@ -1372,6 +1381,62 @@ __global__ __launch_bounds__(DN_BLOCK) void dn_step_many_1w_kernel(const DnParam
         b.g0[li] = G0; b.g1[li] = G1; b.g2[li] = G2; b.g3[li] = G3; b.g4[li] = G4; b.g5[li] = G5;
         if (XOPT && p.drag) b.g7[li] = G7;
     }
+}
+
+// -----------------------------------------------------------------------------------------------------
+// dn_eval_kinematics: rows A5-A9 (+ A10/A11) of a control step on their own.  The rigid-body transition (A4,
+// p.stepSimulation) is GIVEN -- pos, quat, vel, ang_v after the physics step, float64 as the reference holds them --
+// and everything downstream of it runs through the SAME device functions as dn_step: rules_phase, attitude_phase,
+// observe_phase, report_phase, with the same entry bookkeeping and the same auto-reset.  It exists so that the
+// reference-generated fixtures that script a kinematic sequence (tests/golden/obs_pack.npz, script_*.npz: gimbal-lock
+// attitudes, clip edges, gate passes, the last gate, corridor exits, truncation, the reset quirks) reach the HIP path
+// directly (the CPU checker is not in between).
+// -----------------------------------------------------------------------------------------------------
+template <typename R, bool NORM>
+__global__ __launch_bounds__(DN_BLOCK) void dn_eval_kinematics_kernel(const DnParams p, const DnStepIO io0, const double *__restrict__ kin)
+{
+    __shared__ R s_tab[DN_MAX_WAYPOINTS * DN_T_STRIDE];
+    __shared__ __attribute__((aligned(16))) float s_tile[DN_BLOCK * DN_OBS_DIM];
+    const unsigned lane = threadIdx.x;
+    const long long tile_base = (long long)blockIdx.x * DN_BLOCK;
+    const long long left = p.n - tile_base;
+    const unsigned rows = left < DN_BLOCK ? (unsigned)left : DN_BLOCK;
+    const bool active = lane < rows;
+    const unsigned li = active ? lane : rows - 1;
+    __builtin_assume(li < DN_BLOCK);
+    const long long i = tile_base + li;
+    const unsigned long long gid = (unsigned long long)(p.env_id_offset + i);
+    const BlockState b = block_state(p.st, tile_base);
+    const DnConsts<R> &c = consts<R>(p);
+    float4 G0 = b.g0[li], G1 = b.g1[li], G2 = b.g2[li], G3 = b.g3[li], G4 = b.g4[li], G5 = b.g5[li];
+    const double *kr = kin + i * 13;
+    double kv[13];
+#pragma unroll
+    for (int k = 0; k < 13; ++k) kv[k] = kr[k];
+    stage_table<R>(p, s_tab);
+    block_lds_barrier();
+    const unsigned long long sc0 = p.st.stats[blockIdx.x].step_count;
+    const R wp0[3] = {s_tab[DN_T_WP], s_tab[DN_T_WP + 1], s_tab[DN_T_WP + 2]};
+    StatAcc acc;
+    Rms rms;
+    if (NORM) load_rms(p, i, rms);
+    RewNorm rn = {0.0, 0.0, 1.0, 1e-4};
+    const StepOut out = block_out(io0, tile_base, 0, 0);
+    const GateRow<R> row_e = load_gate_row<R>(s_tab, unpack_meta(G3.w).idx);
+    Flight<R> fl;
+    flight_entry<R>(fl, G0, G2, G3, p.max_steps);
+    fl.px = (R)kv[0]; fl.py = (R)kv[1]; fl.pz = (R)kv[2];
+    fl.qx = (R)kv[3]; fl.qy = (R)kv[4]; fl.qz = (R)kv[5]; fl.qw = (R)kv[6];
+    fl.vx = (float)kv[7]; fl.vy = (float)kv[8]; fl.vz = (float)kv[9];          // velocities leave physics_phase as float32 words
+    fl.wx = (float)kv[10]; fl.wy = (float)kv[11]; fl.wz = (float)kv[12];
+    const float4 G0e = G0, G3e = G3;
+    const Verdict<R> v = rules_phase<R>(p, c, s_tab, row_e, wp0, fl, G0e, G3e, b.g6, li, active, G0, G1, G2, G3);
+    attitude_phase<R>(fl);
+    Observed<R> ob = observe_phase<R, NORM, false>(p, c, s_tab, fl, G4, G5, gid, (unsigned)sc0, rms);
+    report_phase<R, NORM, false, false>(p, c, s_tile, out, fl, v, ob, gid, (unsigned)sc0, li, lane, rows, active, G4, G5, acc, rms, rn);
+    flush_stats(p, acc, sc0 + 1ull, lane);
+    if (NORM && active) store_rms(p, i, rms);
+    if (active) { b.g0[li] = G0; b.g1[li] = G1; b.g2[li] = G2; b.g3[li] = G3; b.g4[li] = G4; b.g5[li] = G5; }
 }
 
 // -----------------------------------------------------------------------------------------------------
@@ -2096,6 +2161,20 @@ hipError_t dn_launch_reset(const DnParams &p, float *obs, bool f32, hipStream_t 
     const unsigned grid = (unsigned)((p.n + DN_BLOCK - 1) / DN_BLOCK);
     if (f32) hipLaunchKernelGGL(dn_reset_kernel<float>, dim3(grid), dim3(DN_BLOCK), 0, stream, p, obs);
     else hipLaunchKernelGGL(dn_reset_kernel<double>, dim3(grid), dim3(DN_BLOCK), 0, stream, p, obs);
+    return hipGetLastError();
+}
+
+hipError_t dn_launch_eval_kinematics(const DnParams &p, const DnStepIO &io, const double *kin, bool f32, hipStream_t stream)
+{
+    const unsigned grid = (unsigned)((p.n + DN_BLOCK - 1) / DN_BLOCK);
+    const bool norm = p.normalize_obs != 0;
+    if (f32) {
+        if (norm) hipLaunchKernelGGL((dn_eval_kinematics_kernel<float, true>), dim3(grid), dim3(DN_BLOCK), 0, stream, p, io, kin);
+        else hipLaunchKernelGGL((dn_eval_kinematics_kernel<float, false>), dim3(grid), dim3(DN_BLOCK), 0, stream, p, io, kin);
+    } else {
+        if (norm) hipLaunchKernelGGL((dn_eval_kinematics_kernel<double, true>), dim3(grid), dim3(DN_BLOCK), 0, stream, p, io, kin);
+        else hipLaunchKernelGGL((dn_eval_kinematics_kernel<double, false>), dim3(grid), dim3(DN_BLOCK), 0, stream, p, io, kin);
+    }
     return hipGetLastError();
 }
 

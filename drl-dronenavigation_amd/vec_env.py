@@ -221,6 +221,21 @@ class DroneVecEnv(_VecEnvBase):
         if rc:
             _capi.check(rc)
 
+    def eval_kinematics_tensor(self, kinematics):
+        """Rows A5-A9 of one control step with the rigid-body transition given (dn_eval_kinematics): `kinematics` is a
+        float64 CUDA tensor [N, 13] = pos(3) quat(4, xyzw) vel(3) ang_v(3) after the physics step.  Returns what
+        step_tensor returns; the persistent state advances as in a step."""
+        if kinematics.device != self.device or kinematics.dtype != torch.float64 or tuple(kinematics.shape) != (self.num_envs, 13):
+            raise ValueError(f"kinematics must be a float64 [{self.num_envs}, 13] tensor on {self.device}")
+        k = kinematics.contiguous()
+        p = self._ptrs
+        with torch.cuda.device(self.device):
+            _capi.check(self._lib.dn_eval_kinematics(self._handle, k.data_ptr(), *p[0], *p[1], self._stream()))
+        v = self._views
+        info = dict(truncated=self._trunc, found_targets=self._found, terminal_obs=v[1],
+                    ep_return=self._ep_ret, ep_length=self._ep_len)
+        return v[0], self._reward, self._done, info
+
     def rollout_tensor(self, actions, out=None, want_terminal=False):
         """K open-loop control steps in one C call (dn_step_many).  `actions`: float32 CUDA tensor [K, N, 4].
         Returns a dict of step-major device tensors (obs [K,N,13], reward [K,N], done [K,N] uint8,

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define DN_ABI_VERSION 3
+#define DN_ABI_VERSION 4
 #define DN_MAX_WAYPOINTS 64
 #define DN_OBS_DIM 13      /* 12 kinematic + distance, PBDroneEnv._computeObs, PBDroneEnv.py:296-336 */
 #define DN_ACT_DIM 4       /* four rotor thrust commands, PBDroneEnv._actionSpace, PBDroneEnv.py:225-243 */
@@ -157,6 +157,20 @@ int32_t dn_step(dn_env *env, const float *actions, float *obs, float *reward, ui
 int32_t dn_step_many(dn_env *env, int64_t k, const float *actions, float *obs, float *reward, uint8_t *done,
                      uint8_t *truncated, int32_t *found_targets, float *terminal_obs, float *ep_return,
                      int32_t *ep_length, uint64_t *done_mask, void *stream);
+
+/* Rows A5-A9 of a control step on their own (plus the A10/A11 wrappers): the rigid-body transition of the step -- what
+ * p.stepSimulation (BaseAviary.py:439-440) leaves in Bullet -- is GIVEN, and everything the reference does with it runs
+ * through the same device code as dn_step: _updateAndStoreKinematicInformation / getEulerFromQuaternion
+ * (BaseAviary.py:588-598), _computeObs (PBDroneEnv.py:296-398), _computeReward (:475-607), _computeTerminated /
+ * _computeTruncated (:444-473, :678-786), _update_state_post_step (:196-223), and on done the SubprocVecEnv auto-reset
+ * (:609-665) with Monitor's record.  The persistent state advances exactly as in dn_step (the given pose and velocities
+ * become the body state).  Exists so that fixtures which script a kinematic sequence reach the HIP path directly.
+ *   kinematics    const double[N*13]  per drone pos(3) quat(4: x,y,z,w, unit) vel(3) ang_v(3), world frame, float64 as
+ *                                     the reference holds them (the velocities are rounded to float32, the state's type)
+ *   other buffers as in dn_step.  Reference configuration only (no noise / reward wrappers / extra physics). */
+int32_t dn_eval_kinematics(dn_env *env, const double *kinematics, float *obs, float *reward, uint8_t *done,
+                           uint8_t *truncated, int32_t *found_targets, float *terminal_obs, float *ep_return,
+                           int32_t *ep_length, void *stream);
 
 /* Episode-done compaction: expands the per-wave ballot words written by dn_step into the ordered
  * list of finished drones (what the host needs to build the per-env `infos` of SubprocVecEnv

@@ -1,0 +1,216 @@
+"""The Bullet rows (SURVEY.md section 8(a) A4 `p.stepSimulation`, A5 `p.getEulerFromQuaternion`) on the HIP path:
+dn_set_state -> dn_step -> dn_get_state through the C ABI, against closed-form one-step results and against the
+independent world-frame integrator of tests/rigid_body_ref.py -- NOT against the oracle (tests/test_bullet_invariants.py
+holds the oracle's twins of these cases).  Bar: float32 state within 1e-5 (north_star); exact where stated.
+"""
+import numpy as np
+import pytest
+from scipy.spatial.transform import Rotation
+
+import rigid_body_ref as RB
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+HOVER_F = RB.M * RB.G / 4.0
+WIDE = [-1e4, -1e4, -1e4, 1e4, 1e4, 1e4]
+
+
+def _env(n, **kw):
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU: the HIP path has no CPU fallback")
+    import drl_dronenavigation_amd as pkg
+    # thrust commands in newton (normalize_actions=False), no corridor / ground / box to end the episode, no gate in reach
+    opts = dict(target_points=np.array([[5e3, 5e3, 5e3]]), initial_xyzs=np.array([[0.0, 0.0, 1.0]]), aviary_dim=WIDE,
+                circle=False, cylinder=False, ground_contact=False, normalize_actions=False, normalize_obs=False,
+                threshold=0.0, max_steps=1 << 20, device="cuda:0")
+    opts.update(kw)
+    return pkg.DroneVecEnv(None, n, **opts)
+
+
+def one_step(pos, quat, vel, ang_v, thrust, **kw):
+    """Set n body states, apply one control step with the given per-rotor thrust commands, return the new states + obs."""
+    pos, quat, vel, ang_v, thrust = (np.atleast_2d(np.asarray(a, dtype=np.float32)) for a in (pos, quat, vel, ang_v, thrust))
+    n = len(pos)
+    env = _env(n, **kw)
+    env.reset_tensor()
+    st = env.get_state()
+    st["pos"], st["quat"], st["vel"], st["ang_v"] = pos, quat, vel, ang_v
+    st["cur_pos"] = pos
+    env.set_state(st)
+    obs, rew, done, info = env.step_tensor(torch.from_numpy(np.ascontiguousarray(thrust)).to("cuda:0"))
+    torch.cuda.synchronize()
+    assert not done.any().item(), "the Bullet cases must not end an episode"
+    out = env.get_state()
+    obs = obs.cpu().numpy().copy()
+    env.close()
+    return out, obs
+
+
+def chain(thrust):
+    """Rotor forces and yaw torque the float32 action chain produces for a thrust command (float64 evaluation)."""
+    f, tq = RB.thrust_to_force(np.asarray(thrust, dtype=np.float32).astype(np.float64))
+    return f, (tq * RB.YAW_SIGN).sum(-1)
+
+
+REST = dict(pos=[0.3, -0.2, 1.0], quat=[0.0, 0.0, 0.0, 1.0], vel=[0.0, 0.0, 0.0], ang_v=[0.0, 0.0, 0.0])
+
+
+def test_bullet_hover_equilibrium_gpu():
+    st, _ = one_step(**REST, thrust=[HOVER_F] * 4)
+    f, _ = chain([HOVER_F] * 4)
+    resid = (f.sum() / RB.M - RB.G) / 240.0                   # float32 rounding of the rotor force: ~1e-9 m/s
+    assert abs(resid) < 1e-7
+    np.testing.assert_allclose(st["vel"][0], [0, 0, resid], atol=1e-9)
+    np.testing.assert_array_equal(st["ang_v"][0], 0.0)
+    np.testing.assert_allclose(st["pos"][0], np.float32(REST["pos"]), atol=1e-7)
+    np.testing.assert_array_equal(st["quat"][0], [0, 0, 0, 1])
+
+
+def test_bullet_min_thrust_fall_gpu():
+    """A zero command is clipped to the motors' minimum thrust (PBDroneEnv.py:889): v_z = (4 F_min / M - 9.8) / 240,
+    z += v_z / 240 (semi-implicit Euler) -- the reachable twin of the oracle's free-fall case."""
+    st, _ = one_step(**REST, thrust=[0.0] * 4)
+    f, zt = chain([0.0] * 4)
+    np.testing.assert_allclose(f, 3.16e-10 * (0.2685 * 20000 + 4070.3) ** 2, rtol=1e-6)
+    vz = (f.sum() / RB.M - RB.G) / 240.0
+    assert vz < -0.02
+    np.testing.assert_allclose(st["vel"][0], [0, 0, vz], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(st["pos"][0][2], 1.0 + vz / 240.0, rtol=1e-7)
+    assert zt == 0.0 and np.all(st["ang_v"][0] == 0.0)
+
+
+def test_bullet_pure_yaw_gpu():
+    th = [HOVER_F * 1.2, HOVER_F * 0.8, HOVER_F * 1.2, HOVER_F * 0.8]
+    st, _ = one_step(**REST, thrust=th)
+    f, zt = chain(th)
+    assert zt < 0
+    wz = zt / 2.17e-5 / 240.0
+    np.testing.assert_allclose(st["ang_v"][0], [0, 0, wz], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(st["vel"][0][:2], 0.0, atol=1e-9)
+    a = wz / 240.0
+    np.testing.assert_allclose(st["quat"][0], [0, 0, np.sin(a / 2), np.cos(a / 2)], atol=1e-7)
+
+
+def test_bullet_damping_and_gyroscopic_terms_gpu():
+    v0 = np.array([[1.5, 0, 0], [0.3, -0.4, 0], [0, 0, 0], [0, 0, 0]], np.float32)
+    w0 = np.array([[0, 0, 0], [0, 0, 0], [0, 0, 3.0], [0, 4.0, 5.0]], np.float32)
+    n = len(v0)
+    st, _ = one_step(np.tile(REST["pos"], (n, 1)), np.tile(REST["quat"], (n, 1)), v0, w0, np.full((n, 4), HOVER_F))
+    for k in range(2):                                         # v <- v (1 - (c + c |v|) dt)
+        kk = 0.04 + 0.04 * np.linalg.norm(v0[k].astype(np.float64))
+        np.testing.assert_allclose(st["vel"][k][:2], v0[k][:2].astype(np.float64) * (1 - kk / 240.0), rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(st["ang_v"][2], [0, 0, 3.0 * (1 - (0.04 + 0.12) / 240.0)], rtol=1e-6)
+    Ix, Iy, Iz = RB.J
+    w = w0[3].astype(np.float64)
+    kk = 0.04 + 0.04 * np.linalg.norm(w)
+    exp = w + np.array([(Iy - Iz) * w[1] * w[2] / Ix, (Iz - Ix) * w[2] * w[0] / Iy, 0.0]) / 240.0 - w * kk / 240.0
+    np.testing.assert_allclose(st["ang_v"][3], exp, rtol=1e-6, atol=1e-7)
+    assert st["ang_v"][3][0] < 0.0                             # gyroscopic sign
+
+
+def test_bullet_velocity_clamp_fires_gpu():
+    """m_maxCoordinateVelocity = 100 per coordinate; and with it |w| dt <= 100 sqrt(3)/240 < pi/4, so Bullet's angle
+    clamp cannot run: at the cap the attitude turns by exactly |w| dt."""
+    st, _ = one_step([REST["pos"]] * 2, [REST["quat"]] * 2, [[150.0, -170.0, 30.0], [0, 0, 0]],
+                     [[-300.0, 20.0, 120.0], [400.0, 400.0, 0.0]], np.full((2, 4), HOVER_F))
+    v, w = st["vel"][0], st["ang_v"][0]
+    assert v[0] == 100.0 and v[1] == -100.0 and abs(v[2]) < 100.0
+    assert w[0] == -100.0 and abs(w[1]) < 100.0 and w[2] == 100.0
+    np.testing.assert_allclose(st["pos"][0], np.float32(REST["pos"]).astype(np.float64) + v.astype(np.float64) / 240.0, rtol=1e-6)
+    np.testing.assert_array_equal(st["ang_v"][1], [100.0, 100.0, 0.0])
+    q = st["quat"][1].astype(np.float64)
+    np.testing.assert_allclose(2 * np.arccos(q[3]), 100.0 * np.sqrt(2.0) / 240.0, rtol=1e-5)
+    np.testing.assert_allclose(np.linalg.norm(q), 1.0, atol=2e-7)
+
+
+def test_bullet_step_matches_independent_integrator_gpu():
+    """4096 random tumbling states over the whole thrust range: the HIP step against tests/rigid_body_ref.py fed the
+    same float32 inputs and the float64 evaluation of the action chain.  1e-5 absolute + 1e-6 relative."""
+    rng = np.random.default_rng(21)
+    n = 4096
+    quat = Rotation.random(n, random_state=4).as_quat().astype(np.float32)
+    quat /= np.linalg.norm(quat.astype(np.float64), axis=1, keepdims=True).astype(np.float32)
+    pos = (rng.uniform(-2, 2, (n, 3)) + [0, 0, 3]).astype(np.float32)
+    vel = rng.normal(0, 2.0, (n, 3)).astype(np.float32)
+    ang_v = rng.normal(0, 8.0, (n, 3)).astype(np.float32)
+    thrust = rng.uniform(0.02, 0.16, (n, 4)).astype(np.float32)      # beyond both clip edges
+    pos[:4], vel[:4], ang_v[:4] = REST["pos"], 0.0, 0.0
+    st, _ = one_step(pos, quat, vel, ang_v, thrust)
+    f, zt = chain(thrust)
+    worst = 0.0
+    for k in range(n):
+        ref = RB.step(pos[k], quat[k].astype(np.float64), vel[k], ang_v[k], f[k], zt[k])
+        for name, r in zip(("pos", "quat", "vel", "ang_v"), ref):
+            got = st[name][k].astype(np.float64)
+            if name == "quat" and np.dot(got, r) < 0:
+                r = -r
+            err = np.abs(got - r)
+            worst = max(worst, err.max())
+            assert np.all(err <= 1e-5 + 1e-6 * np.abs(r)), f"state {k}: {name} {got} vs {r}"
+        assert abs(np.linalg.norm(st["quat"][k].astype(np.float64)) - 1.0) < 2e-7
+    print(f"HIP step vs independent integrator: max |err| = {worst:.3e}")
+
+
+def test_bullet_one_second_trajectory_matches_independent_integrator_gpu():
+    """240 free-running steps of 64 kicked drones: float32 state on the device, float64 in the reference; the gap is
+    the accumulated float32 storage rounding (1e-4 after a second of flight)."""
+    rng = np.random.default_rng(8)
+    n, T = 64, 240
+    env = _env(n)
+    env.reset_tensor()
+    st = env.get_state()
+    st["ang_v"] = rng.normal(0, 0.4, (n, 3)).astype(np.float32)
+    st["pos"][:, 2] = 5.0
+    st["cur_pos"] = st["pos"]
+    env.set_state(st)
+    ref = [(st["pos"][k].astype(np.float64), st["quat"][k].astype(np.float64), st["vel"][k].astype(np.float64),
+            st["ang_v"][k].astype(np.float64)) for k in range(n)]
+    for _ in range(T):
+        th = (HOVER_F * (1.0 + 0.2 * rng.standard_normal((n, 4)))).astype(np.float32)
+        _, _, done, _ = env.step_tensor(torch.from_numpy(th).to("cuda:0"))
+        f, zt = chain(th)
+        ref = [RB.step(*ref[k], f[k], zt[k]) for k in range(n)]
+    torch.cuda.synchronize()
+    assert not done.any().item()
+    out = env.get_state()
+    for k in range(n):
+        for name, r in zip(("pos", "quat", "vel", "ang_v"), ref[k]):
+            np.testing.assert_allclose(out[name][k], r, rtol=0, atol=2e-4, err_msg=f"drone {k}: {name}")
+    env.close()
+
+
+@pytest.mark.parametrize("sign", [1.0, -1.0])
+def test_euler_gimbal_lock_branches_fire_on_gpu(sign):
+    """p.getEulerFromQuaternion's |sarg| >= 0.99999 branches (roll := 0, pitch := +-pi/2, yaw := 2 atan2(-+x, +-y)) reached
+    through a real step: nose-up / nose-down drones at rest keep their attitude for one step, and observation columns
+    3..5 are rpy / pi (PBDroneEnv.py:379-380).  Expected values from scipy + the branch's published formula."""
+    yaws = np.linspace(-1.4, 1.4, 15)                         # |yaw + roll| < pi/2: 2 atan2 stays inside (-pi, pi]
+    eps = np.array([0.0, 1e-4, 2e-3, 1e-2])
+    quat, want = [], []
+    for yaw in yaws:
+        for e in eps:
+            q = Rotation.from_euler("ZYX", [yaw, sign * (np.pi / 2 - e), 0.2]).as_quat()
+            q = (-q if q[3] < 0 else q).astype(np.float32)
+            q64 = q.astype(np.float64)
+            sarg = -2.0 * (q64[0] * q64[2] - q64[3] * q64[1]) / np.dot(q64, q64)
+            if abs(sarg) >= 0.99999:
+                rpy = [0.0, sign * np.pi / 2, 2.0 * np.arctan2(-sign * q64[0], sign * q64[1])]
+            else:
+                rpy = RB.euler_from_quat(q64)
+            quat.append(q)
+            want.append((rpy, abs(sarg) >= 0.99999))
+    n = len(quat)
+    st, obs = one_step(np.tile([0.0, 0.0, 50.0], (n, 1)), np.array(quat), np.zeros((n, 3)), np.zeros((n, 3)),
+                       np.full((n, 4), HOVER_F))
+    locked = 0
+    for k, (rpy, lock) in enumerate(want):
+        np.testing.assert_allclose(st["quat"][k], quat[k], atol=1e-7)      # at rest, no torque: attitude kept
+        if lock:
+            locked += 1
+            assert obs[k, 3] == 0.0 and abs(obs[k, 4] - sign * 0.5) < 1e-7
+            np.testing.assert_allclose(obs[k, 5], rpy[2] / np.pi, atol=1e-5)
+        elif abs(abs(rpy[1]) - np.pi / 2) > 5e-3:                          # away from the branch edge (float32 quaternion)
+            np.testing.assert_allclose(obs[k, 3:6], np.array(rpy) / np.pi, atol=2e-5)
+    assert locked >= 15, locked
