@@ -13,9 +13,17 @@ generator (the bang-bang regime that exercises the auto-r
 The path shards embarrassingly (no data-path collective): weak scaling, 32 768 drones per rank.
 
 Extra objects on the JSON line:
-  roofline     -- HBM roofline of the step kernel: 288 algorithmic bytes per drone-step x
-                  drones per launch / average launch-to-launch time measured with HIP events on the launch
-                  stream over the timed region; peak 8 TB/s (MI355X_MICROARCH.md).
+  roofline     -- HBM roofline of the kernel the timed region launches.  ALGORITHMIC bytes over the average
+                  launch duration measured with HIP events on the launch stream over the timed region; peak 8 TB/s
+                  (MI355X_MICROARCH.md).  Per drone a single-step launch (dn_step) moves 288 B (+432 B with the obs
+                  normaliser); a fused K-step launch (dn_step_many) keeps the state in registers, so its algorithmic bytes
+                  are 78 B per step (action 16 + outputs 62) + 210 B of state once per launch (+432 B of statistics once):
+                  pricing a fused launch at 288 B per step would count bytes it never moves.  `traffic` = HBM bytes per
+                  launch from the committed rocprofv3 --pmc passes (profiles/hbm_traffic.json; exact key, or the linear
+                  model fitted to those passes for other K), `traffic_frac` the same fraction with measured bytes.
+  single_step / normalize_obs_on -- the closed-loop launch (one dn_step per policy step) and the configuration the
+                  reference actually runs (NormalizeObservation always on, PBDroneSimulator.py:181), each timed with HIP
+                  events over its own >= 25 ms region, with kernel name, us, algorithmic and counter fractions.
   cpu_baseline -- the CPU oracle (a port; the reference's PyBullet path cannot run here) timed on this
                   box's host cores on a bounded sample of the same workload, rank 0, N = 1 only.
 """
@@ -31,8 +39,45 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 ALGO_BYTES_PER_ENV_STEP = 288          # state R+W 104, bookkeeping R+W 106, action 16, outputs 62
-ALGO_BYTES_NORMALISER = 432            # per-drone NormalizeObservation statistics, 27 float64 R+W
+ALGO_BYTES_IO_PER_STEP = 78            # of which per step whatever the launch shape: action 16 + outputs 62
+ALGO_BYTES_STATE = 210                 # and once per LAUNCH: state R+W 104 + bookkeeping R+W 106 (registers hold it between fused steps)
+ALGO_BYTES_NORMALISER = 432            # per-drone NormalizeObservation statistics, 27 float64 R+W (once per launch)
 HBM_PEAK_GBPS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PREROLL_SECONDS = 0.5                  # untimed fused stepping before the warm-up: the GPU clock needs ~50 ms of load to settle
+
+
+def algo_bytes_per_launch(n, steps_per_launch, norm):
+    """Algorithmic HBM bytes of one launch over n drones."""
+    return n * (ALGO_BYTES_IO_PER_STEP * steps_per_launch + ALGO_BYTES_STATE + (ALGO_BYTES_NORMALISER if norm else 0))
+
+
+def kernel_name(waves, dtype, norm, fused):
+    r, nm = ("double" if dtype == "float64" else "float"), ("true" if norm else "false")
+    if waves >= 3 and fused:
+        return f"dn_step_many_3w_kernel<{r}, {nm}, false, false>"
+    if waves >= 3:
+        return f"dn_step_{waves}w_kernel<{r}, {nm}, false>"
+    return f"dn_step_many_{waves}w_kernel<{r}, {nm}, false, {'false' if fused else 'true'}, false, false>"
+
+
+def traffic_per_launch(track, n, dtype, norm, fused_steps, waves):
+    """HBM bytes per launch from the committed PMC passes: the exact key if that launch was profiled, else the linear
+    model bytes = n (a K + b) fitted to the profiled fused launches of the same configuration (state once per launch,
+    I/O per step).  Returns (bytes or None, source string)."""
+    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        tj = json.load(open(path))
+    except Exception:  # noqa: BLE001
+        return None, "profiles/hbm_traffic.json missing"
+    base = f"{track}_{n}_{dtype}" + ("_norm" if norm else "")
+    key = base + ("_single" if fused_steps == 0 else f"_fused{fused_steps}") + f"_{waves}w"
+    if key in tj:
+        return tj[key]["bytes_per_launch"], f"pmc:{key}"
+    if fused_steps:
+        model = tj.get("_fused_model", {}).get(base)
+        if model:
+            return int(n * (model["per_step"] * fused_steps + model["per_launch"])), f"model:{base} ({model['per_step']} B x K + {model['per_launch']} B per drone, fitted to {model['fitted_on']})"
+    return None, f"no PMC pass for {key}"
 
 
 def parse():
@@ -290,6 +335,14 @@ def main():
         torch.cuda.synchronize(dev)
         return e0.elapsed_time(e1) * 1e3 / k           # us per step on the GPU timeline
 
+    # untimed pre-roll, independent of --warmup: the clock of an idle GPU takes ~50 ms of load to settle, and the
+    # driver's default (--steps 20 --warmup 5) is a 40 us timed region
+    t_pre = time.perf_counter()
+    pre_steps = 0
+    while time.perf_counter() - t_pre < PREROLL_SECONDS:
+        run_many(64 * A)
+        torch.cuda.synchronize(dev)
+        pre_steps += 64 * A
     run(W)
     torch.cuda.synchronize(dev)
     barrier()
@@ -309,19 +362,75 @@ def main():
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
         wall, gpu_ms = float(tw[0]), float(tw[1])
     st = env.stats()
-    # the other launch shapes, outside the timed region, for the record: "single" = one dn_step launch per step from
-    # Python (what a policy-in-the-loop VecEnv.step_tensor() costs incl. host launch overhead), "graph" = the same
-    # launches replayed from a hipGraph (GPU timeline only), "many" = the fused K-step kernel
-    k2 = max(A, min(K, 4096) // A * A)
+    waves = env.kernel_waves(fused=args.mode == "many")
+    waves_single = env.kernel_waves(fused=False)
+
+    def leg(label, fn, steps, steps_per_launch, norm, wv):
+        """One launch shape timed on its own (HIP events over >= 25 ms of launches), with both byte accountings."""
+        fn(max(A, 64))
+        us = timed(fn, steps)
+        launch_us = us * max(1, steps_per_launch)
+        algo = algo_bytes_per_launch(n, max(1, steps_per_launch), norm)
+        traffic, src = traffic_per_launch(args.track, n, args.compute_dtype, norm, steps_per_launch if steps_per_launch > 1 else 0, wv)
+        d = {"kernel": kernel_name(wv, args.compute_dtype, norm, steps_per_launch > 1), "us_per_vector_step": round(us, 4),
+             "avg_launch_us": round(launch_us, 4), "vector_steps_per_launch": max(1, steps_per_launch),
+             "value": round(n * world / (us * 1e-6), 1), "unit": "env-steps/s", "timed_vector_steps": steps,
+             "algorithmic_bytes_per_launch": algo,
+             "frac": round(algo / (launch_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 5),
+             "traffic": traffic, "traffic_source": src,
+             "traffic_frac": (round(traffic / (launch_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 5) if traffic else None)}
+        return d
+
+    # the other launch shapes, outside the timed region: "single" = one dn_step launch per step from Python (what a
+    # policy-in-the-loop VecEnv.step_tensor() costs incl. host launch gaps), "graph" = the same launches replayed from a
+    # hipGraph (GPU timeline only), "many" = the fused K-step kernel
+    k_single = 8192 // A * A if A <= 8192 else A
     others = {}
     for m_ in ("many", "single", "graph"):
-        if m_ != args.mode and not (world > 1 and m_ == "graph"):
-            fn = {"many": run_many, "single": run_single, "graph": run_graph}[m_]
-            fn(A)
-            us = timed(fn, k2)
-            others[m_] = {"us_per_vector_step": round(us, 4), "value": round(n * world / (us * 1e-6), 1),
-                          "roofline_frac": round(ALGO_BYTES_PER_ENV_STEP * n / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 5)}
-    waves = env.kernel_waves(fused=args.mode == "many")
+        if world > 1 and m_ == "graph":
+            continue
+        fn = {"many": run_many, "single": run_single, "graph": run_graph}[m_]
+        spl = A if m_ == "many" else 1
+        wv = env.kernel_waves(fused=m_ == "many")
+        d = leg(m_, fn, k_single if m_ != "many" else max(A, 32768 // A * A), spl, args.normalize_obs, wv)
+        others[m_] = d
+    single_step = dict(others["graph"] if "graph" in others else others["single"])
+    single_step["launched_from"] = "hipGraph replay of dn_step launches" if "graph" in others else "python loop of dn_step calls"
+    single_step["python_loop_us_per_vector_step"] = others["single"]["us_per_vector_step"]
+
+    # the configuration the reference actually runs: NormalizeObservation on every env (PBDroneSimulator.py:181)
+    norm_on = None
+    if world == 1 and not args.normalize_obs:
+        try:
+            env_n = pkg.DroneVecEnv(track, n, max_steps=max_steps, normalize_obs=True, compute_dtype=args.compute_dtype,
+                                    env_id_offset=rank * n, device=dev)
+            env_n.reset_tensor()
+            hn = env_n._handle
+
+            def many_n(k):
+                done = 0
+                while done < k:
+                    c = min(A, k - done)
+                    pkg._capi.check(lib.dn_step_many(hn, c, acts.data_ptr(), o["obs"].data_ptr(), o["reward"].data_ptr(),
+                                                     o["done"].data_ptr(), o["trunc"].data_ptr(), o["found"].data_ptr(),
+                                                     None, None, None, None, sptr))
+                    done += c
+
+            def single_n(k):
+                for t in range(k):
+                    p = ptrs[t % A]
+                    rc = lib.dn_step(hn, p[0], p[1], p[2], p[3], p[4], p[5], None, None, None, None, sptr)
+                    if rc:
+                        pkg._capi.check(rc)
+
+            norm_on = {"fused": leg("many", many_n, max(A, 32768 // A * A), A, True, env_n.kernel_waves(fused=True)),
+                       "single_step": leg("single", single_n, k_single, 1, True, env_n.kernel_waves(fused=False)),
+                       "what": "same workload with the per-drone NormalizeObservation fused in (the reference always wraps it, "
+                               "PBDroneSimulator.py:181): +432 B of statistics per drone and launch"}
+            env_n.close()
+        except Exception as exc:  # noqa: BLE001
+            norm_on = {"error": f"{type(exc).__name__}: {exc}"}
+
     # the SB3 NumPy surface (PCIe-inclusive: H2D actions, D2H obs/reward/done/found, N info dicts built in Python);
     # host bound, reported for the record only
     if world == 1:
@@ -340,25 +449,17 @@ def main():
     sharded = None
     if args.ppo_sharded and dist is not None:
         sharded = ppo_rollout_sharded(pkg, track, n, max_steps, dev, rank, world, dist)
-    algo = ALGO_BYTES_PER_ENV_STEP + (ALGO_BYTES_NORMALISER if args.normalize_obs else 0)
-    for o_ in others.values():
-        o_["roofline_frac"] = round(algo * n / (o_["us_per_vector_step"] * 1e-6) / 1e9 / HBM_PEAK_GBPS, 5)
     if rank == 0:
         value = n * world * K / wall
         step_us = gpu_ms * 1e3 / K
         steps_per_launch = A if args.mode == "many" else 1
-        launch_us = step_us * steps_per_launch
-        achieved = algo * n / (step_us * 1e-6) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):                          # per-launch HBM bytes from the committed rocprofv3 --pmc passes
-            try:
-                tj = json.load(open(tpath))
-                key = f"{args.track}_{n}_{args.compute_dtype}" + ("_norm" if args.normalize_obs else "") + \
-                    ("_single" if args.mode in ("single", "graph") else f"_fused{A}") + f"_{waves}w"
-                traffic = tj.get(key, {}).get("bytes_per_launch")
-            except Exception:  # noqa: BLE001
-                traffic = None
+        launches = (K + steps_per_launch - 1) // steps_per_launch
+        launch_us = gpu_ms * 1e3 / launches
+        algo_launch = algo_bytes_per_launch(n, steps_per_launch, args.normalize_obs)
+        achieved = algo_launch / (launch_us * 1e-6) / 1e9
+        wv = waves if args.mode == "many" else waves_single
+        traffic, tsrc = traffic_per_launch(args.track, n, args.compute_dtype, args.normalize_obs,
+                                           steps_per_launch if args.mode == "many" else 0, wv)
         line = {
             "metric": "env_steps_per_sec", "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world,
             "steps": K, "warmup": W, "ms_per_step": round(wall * 1e3 / K, 6), "higher_is_better": True,
@@ -368,20 +469,24 @@ def main():
                                    f"norm_rew off, obs normaliser {'on' if args.normalize_obs else 'off'}, auto-reset on",
                        "num_envs_per_gpu": n, "global_num_envs": n * world, "track": args.track,
                        "state_dtype": "f32", "launch_mode": args.mode, "parallelism": f"env-shard x{world} (no data-path collective)",
-                       "episodes_finished_rank0": st["episodes"]},
+                       "episodes_finished_rank0": st["episodes"],
+                       "preroll": {"seconds": PREROLL_SECONDS, "vector_steps": pre_steps,
+                                   "what": "untimed fused stepping before --warmup so that the timed region runs at a settled clock"}},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": tsrc,
                          "traffic_frac": (round(traffic / (launch_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 5) if traffic else None),
-                         "kernel": ("dn_step_many_3w_kernel<%s, %s, false, false>" % ("double" if args.compute_dtype == "float64" else "float",
-                                                                                      "true" if args.normalize_obs else "false")
-                                    if waves == 3 else
-                                    "dn_step_many_%dw_kernel<%s, %s, false, %s, false>" % (
-                                        waves, "double" if args.compute_dtype == "float64" else "float",
-                                        "true" if args.normalize_obs else "false", "false" if args.mode == "many" else "true")),
-                         "waves_per_64_drones": waves,
+                         "kernel": kernel_name(wv, args.compute_dtype, args.normalize_obs, args.mode == "many"),
+                         "waves_per_64_drones": wv,
                          "env_steps_per_launch": n * steps_per_launch, "vector_steps_per_launch": steps_per_launch,
-                         "algorithmic_bytes_per_launch": algo * n * steps_per_launch, "algorithmic_bytes_per_env_step": algo,
-                         "avg_launch_us": round(launch_us, 4), "us_per_vector_step": round(step_us, 4)},
+                         "algorithmic_bytes_per_launch": algo_launch,
+                         "algorithmic_bytes_model": (f"{ALGO_BYTES_IO_PER_STEP} B x {steps_per_launch} steps + {ALGO_BYTES_STATE} B state"
+                                                     + (f" + {ALGO_BYTES_NORMALISER} B statistics" if args.normalize_obs else "")
+                                                     + " per drone and launch (SURVEY 8(d) split into per-step I/O and per-launch state)"),
+                         "avg_launch_us": round(launch_us, 4), "us_per_vector_step": round(step_us, 4),
+                         "note": "at 32768 drones neither launch shape is bandwidth bound: the fused launch is bound by the dependent "
+                                 "instruction stream of the flight wave, the single-step launch by load + launch latency (DESIGN.md 4.3)"},
+            "single_step": single_step,
+            "normalize_obs_on": norm_on,
             "other_launch_shapes": others,
         }
         if sharded is not None:

