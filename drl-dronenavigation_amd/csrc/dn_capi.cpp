@@ -205,7 +205,7 @@ void dn_config_default(dn_config *cfg)
     cfg->cylinder = 1;                // PBDroneSimulator.py:167
     cfg->include_distance = 1;        // PBDroneSimulator.py:661
     cfg->normalize_actions = 1;       // PBDroneSimulator.py:662
-    cfg->ground_contact = 1;
+    cfg->ground_contact = 0;          // the contact test is an approximation (include/dronenav.h); off unless asked for
     cfg->aviary_dim[0] = cfg->aviary_dim[1] = -1.0;   // make_env default aviary_dim, PBDroneSimulator.py:141
     cfg->aviary_dim[3] = cfg->aviary_dim[4] = cfg->aviary_dim[5] = 1.0;
 }

@@ -256,14 +256,17 @@ DN_DEV void box_muller_pair(unsigned ra, unsigned rb, float &z0, float &z1)
     z0 = (float)(rad * cosv);
     z1 = (float)(rad * sinv);
 }
-DN_DEV void noise4(unsigned long long seed, unsigned long long gid, unsigned step, unsigned stream, float z[4])
+// Philox counter = (drone id lo, drone id hi, vector step lo, stream | vector step hi << 8): the 64-bit vector-step counter
+// enters whole, so the streams do not repeat when its low word wraps (2^32 vector steps = hours of fused stepping);
+// stream ids are below 256.
+DN_DEV void noise4(unsigned long long seed, unsigned long long gid, unsigned long long step, unsigned stream, float z[4])
 {
     unsigned r[4];
-    philox4x32((unsigned)gid, (unsigned)(gid >> 32), step, stream, (unsigned)seed, (unsigned)(seed >> 32), r);
+    philox4x32((unsigned)gid, (unsigned)(gid >> 32), (unsigned)step, stream | ((unsigned)(step >> 32) << 8), (unsigned)seed, (unsigned)(seed >> 32), r);
     box_muller_pair(r[0], r[1], z[0], z[1]);
     box_muller_pair(r[2], r[3], z[2], z[3]);
 }
-DN_DEV void add_act_noise(const DnParams &p, unsigned long long gid, unsigned step, float a[4])
+DN_DEV void add_act_noise(const DnParams &p, unsigned long long gid, unsigned long long step, float a[4])
 {   // float32, unfused (its own function: the fused-multiply-add licence of step_body must not reach it)
     float z[4];
     noise4(p.seed, gid, step, 0u, z);
@@ -273,7 +276,7 @@ DN_DEV void add_act_noise(const DnParams &p, unsigned long long gid, unsigned st
         a[j] = clipv(a[j] + s, -1.0f, 1.0f);
     }
 }
-DN_DEV void add_obs_noise(const DnParams &p, unsigned long long gid, unsigned step, unsigned stream0, float o[DN_OBS_DIM])
+DN_DEV void add_obs_noise(const DnParams &p, unsigned long long gid, unsigned long long step, unsigned stream0, float o[DN_OBS_DIM])
 {
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
@@ -716,7 +719,7 @@ struct ThrustX {       // XOPT kernels: float64 carriers (ActionType.RPM works i
     double zt;
 };
 template <bool NOISE>
-DN_DEV ThrustX thrust_phase_x(const DnParams &p, unsigned long long gid, unsigned step_count, const float4 A, Extras &x)
+DN_DEV ThrustX thrust_phase_x(const DnParams &p, unsigned long long gid, unsigned long long step_count, const float4 A, Extras &x)
 {
     float a[4] = {A.x, A.y, A.z, A.w};
     if (NOISE && p.act_noise_sigma > 0.0f) add_act_noise(p, gid, step_count, a);
@@ -752,7 +755,7 @@ DN_DEV ThrustX thrust_phase_x(const DnParams &p, unsigned long long gid, unsigne
     return t;
 }
 template <bool NOISE>
-DN_DEV Thrust thrust_phase(const DnParams &p, unsigned long long gid, unsigned step_count, const float4 A)
+DN_DEV Thrust thrust_phase(const DnParams &p, unsigned long long gid, unsigned long long step_count, const float4 A)
 {   // float32, unfused: bit-exact numpy
     float a[4] = {A.x, A.y, A.z, A.w};
     if (NOISE && p.act_noise_sigma > 0.0f) add_act_noise(p, gid, step_count, a);
@@ -1052,7 +1055,7 @@ template <typename R> struct Observed {
 // ---- A5 + A6 + the value side of A7 on the report wave ---------------------------------------------------
 template <typename R, bool NORM, bool NOISE>
 DN_DEV Observed<R> observe_phase(const DnParams &p, const DnConsts<R> &c, const R *s_tab, const Flight<R> &fl,
-                                 const float4 G4, const float4 G5, const unsigned long long gid, const unsigned step_count,
+                                 const float4 G4, const float4 G5, const unsigned long long gid, const unsigned long long step_count,
                                  Rms &rms)
 {
     Observed<R> ob;
@@ -1189,7 +1192,7 @@ DN_DEV void store_obs_direct(float *row, const float o[DN_OBS_DIM])
 }
 template <typename R, bool NORM, bool NOISE, bool REW, int TILE = 0>
 DN_DEV void report_phase(const DnParams &p, const DnConsts<R> &c, float *s_tile, const StepOut &out, const Flight<R> &fl,
-                         const Verdict<R> &v, Observed<R> &ob, const unsigned long long gid, const unsigned step_count,
+                         const Verdict<R> &v, Observed<R> &ob, const unsigned long long gid, const unsigned long long step_count,
                          const unsigned li, const unsigned lane, const unsigned rows, const bool active,
                          float4 &G4, float4 &G5, StatAcc &acc, Rms &rms, RewNorm &rn)
 {
@@ -1278,7 +1281,7 @@ DN_DEV BlockState block_state(const DnState &st, long long tile_base)
 
 // thrust + physics of one step; the XOPT kernels take the float64 carriers and the optional force terms (N4)
 template <typename R, bool NOISE, bool XOPT>
-DN_DEV Flight<R> fly(const DnParams &p, unsigned long long gid, unsigned sc, const float4 A, const float4 G0, const float4 G1,
+DN_DEV Flight<R> fly(const DnParams &p, unsigned long long gid, unsigned long long sc, const float4 A, const float4 G0, const float4 G1,
                      const float4 G2, const float4 G3, const float4 G7, float4 &rpm_now)
 {
     if (XOPT) {
@@ -1296,7 +1299,7 @@ DN_DEV Flight<R> fly(const DnParams &p, unsigned long long gid, unsigned sc, con
 // where the action is consumed: action = mean + exp(log_std) z, z ~ N(0,1) from the environment's Philox stream (seed,
 // global drone id, the tile's vector-step counter, stream 9); the unclipped action and its log-probability go to the
 // rollout buffer, the clipped one into the step.  Same expressions as dn_policy_sample_kernel (same bits).
-DN_DEV float4 sample_action(const DnStepIO &io, const unsigned long long gid, const unsigned step, const long long i, const bool active)
+DN_DEV float4 sample_action(const DnStepIO &io, const unsigned long long gid, const unsigned long long step, const long long i, const bool active)
 {
     const float4 m = reinterpret_cast<const float4 *>(io.mean)[i];
     const float mu[4] = {m.x, m.y, m.z, m.w};
@@ -1350,7 +1353,7 @@ __global__ __launch_bounds__(DN_BLOCK) void dn_step_many_1w_kernel(const DnParam
     block_lds_barrier();
     const long long n = p.n, words = (p.n + 63) / 64;
     const unsigned long long sc0 = p.st.stats[blockIdx.x].step_count;      // this tile's vector-step counter
-    if (sampled) A = sample_action(io0, gid, (unsigned)sc0, i, active);
+    if (sampled) A = sample_action(io0, gid, sc0, i, active);
     const R wp0[3] = {s_tab[DN_T_WP], s_tab[DN_T_WP + 1], s_tab[DN_T_WP + 2]};   // waypoint 0: every reset measures against it
     StatAcc acc;
     Rms rms;
@@ -1362,7 +1365,7 @@ __global__ __launch_bounds__(DN_BLOCK) void dn_step_many_1w_kernel(const DnParam
         // prefetch the next step's action while this step computes
         const float4 A_next = sampled ? A : (act + (long long)(t + 1 < k_steps ? t + 1 : t) * n)[li];
         const StepOut out = block_out(io0, tile_base, (long long)t * n, (long long)t * words);
-        const unsigned sc = (unsigned)sc0 + (unsigned)t;
+        const unsigned long long sc = sc0 + (unsigned long long)t;
         float4 rpm_now;
         const GateRow<R> row_e = load_gate_row<R>(s_tab, unpack_meta(G3.w).idx);
         Flight<R> fl = fly<R, NOISE, XOPT>(p, gid, sc, A, G0, G1, G2, G3, G7, rpm_now);
@@ -1432,8 +1435,8 @@ __global__ __launch_bounds__(DN_BLOCK) void dn_eval_kinematics_kernel(const DnPa
     const float4 G0e = G0, G3e = G3;
     const Verdict<R> v = rules_phase<R>(p, c, s_tab, row_e, wp0, fl, G0e, G3e, b.g6, li, active, G0, G1, G2, G3);
     attitude_phase<R>(fl);
-    Observed<R> ob = observe_phase<R, NORM, false>(p, c, s_tab, fl, G4, G5, gid, (unsigned)sc0, rms);
-    report_phase<R, NORM, false, false>(p, c, s_tile, out, fl, v, ob, gid, (unsigned)sc0, li, lane, rows, active, G4, G5, acc, rms, rn);
+    Observed<R> ob = observe_phase<R, NORM, false>(p, c, s_tab, fl, G4, G5, gid, sc0, rms);
+    report_phase<R, NORM, false, false>(p, c, s_tile, out, fl, v, ob, gid, sc0, li, lane, rows, active, G4, G5, acc, rms, rn);
     flush_stats(p, acc, sc0 + 1ull, lane);
     if (NORM && active) store_rms(p, i, rms);
     if (active) { b.g0[li] = G0; b.g1[li] = G1; b.g2[li] = G2; b.g3[li] = G3; b.g4[li] = G4; b.g5[li] = G5; }
@@ -1543,7 +1546,7 @@ __global__ __launch_bounds__(2 * DN_BLOCK) void dn_step_many_2w_kernel(const DnP
         if (THRUST_AHEAD) {
             A = act[li];
             const float4 A1 = (act + (long long)(k_steps > 1 ? 1 : 0) * n)[li];
-            post_thrust<R>(tmail[0], lane, thrust_phase<NOISE>(p, gid, (unsigned)sc0, A));
+            post_thrust<R>(tmail[0], lane, thrust_phase<NOISE>(p, gid, sc0, A));
             A = A1;
         }
         block_lds_barrier();                                               // P: table and thrust(0) published
@@ -1551,12 +1554,12 @@ __global__ __launch_bounds__(2 * DN_BLOCK) void dn_step_many_2w_kernel(const DnP
         for (int t = 0; t <= k_steps; ++t) {
             if (THRUST_AHEAD && t + 1 < k_steps) {                         // thrust(t+1), for the flight wave's next iteration
                 const float4 A_next = (act + (long long)(t + 2 < k_steps ? t + 2 : t + 1) * n)[li];
-                post_thrust<R>(tmail[(t + 1) & 1], lane, thrust_phase<NOISE>(p, gid, (unsigned)sc0 + (unsigned)(t + 1), A));
+                post_thrust<R>(tmail[(t + 1) & 1], lane, thrust_phase<NOISE>(p, gid, sc0 + (unsigned long long)(t + 1), A));
                 A = A_next;
             }
             if (t > 0) {                                                   // the step the flight wave finished last iteration
                 const int u = t - 1;
-                const unsigned sc = (unsigned)sc0 + (unsigned)u;
+                const unsigned long long sc = sc0 + (unsigned long long)u;
                 // step u-1's observation tile was parked in LDS at the end of the previous iteration: fetch it now,
                 // stream it to HBM after observe(u) -- its LDS round trip hides behind that phase
                 TileRegs tile;
@@ -1598,7 +1601,7 @@ __global__ __launch_bounds__(2 * DN_BLOCK) void dn_step_many_2w_kernel(const DnP
             } else {
                 // prefetch the next step's action while this step computes
                 A_next = (act + (long long)(t + 1 < k_steps ? t + 1 : t) * n)[li];
-                fl = fly<R, NOISE, XOPT>(p, gid, (unsigned)sc0 + (unsigned)t, A, G0, G1, G2, G3, G7, rpm_now);
+                fl = fly<R, NOISE, XOPT>(p, gid, sc0 + (unsigned long long)t, A, G0, G1, G2, G3, G7, rpm_now);
             }
             const float4 G0e = G0, G3e = G3;
             const Verdict<R> v = rules_phase<R>(p, c, s_tab, row_e, wp0, fl, G0e, G3e, b.g6, li, active, G0, G1, G2, G3);
@@ -1779,10 +1782,10 @@ __global__ __launch_bounds__(3 * DN_BLOCK, NORM ? 2 : 3) void dn_step_many_3w_ke
             const float4 A1 = (act + (long long)(k_steps > 1 ? 1 : 0) * n)[li];
             if (XOPT) {
                 Extras x;
-                const ThrustX th = thrust_phase_x<NOISE>(p, gid, (unsigned)sc0, A, x);
+                const ThrustX th = thrust_phase_x<NOISE>(p, gid, sc0, A, x);
                 post_thrust_x(tmx[0], lane, th, x);
             } else {
-                post_thrust<R>(tmail[0], lane, thrust_phase<NOISE>(p, gid, (unsigned)sc0, A));
+                post_thrust<R>(tmail[0], lane, thrust_phase<NOISE>(p, gid, sc0, A));
             }
             A = A1;
         }
@@ -1793,10 +1796,10 @@ __global__ __launch_bounds__(3 * DN_BLOCK, NORM ? 2 : 3) void dn_step_many_3w_ke
                 const float4 A_next = (act + (long long)(t + 2 < k_steps ? t + 2 : t + 1) * n)[li];
                 if (XOPT) {
                     Extras x;
-                    const ThrustX th = thrust_phase_x<NOISE>(p, gid, (unsigned)sc0 + (unsigned)(t + 1), A, x);
+                    const ThrustX th = thrust_phase_x<NOISE>(p, gid, sc0 + (unsigned long long)(t + 1), A, x);
                     post_thrust_x(tmx[(t + 1) & 1], lane, th, x);
                 } else {
-                    post_thrust<R>(tmail[(t + 1) & 1], lane, thrust_phase<NOISE>(p, gid, (unsigned)sc0 + (unsigned)(t + 1), A));
+                    post_thrust<R>(tmail[(t + 1) & 1], lane, thrust_phase<NOISE>(p, gid, sc0 + (unsigned long long)(t + 1), A));
                 }
                 A = A_next;
             }
@@ -1806,7 +1809,7 @@ __global__ __launch_bounds__(3 * DN_BLOCK, NORM ? 2 : 3) void dn_step_many_3w_ke
                 Verdict<R> v;
                 take_mailq<R>(mailq[u & 1], lane, fl, v);
                 attitude_phase<R>(fl);
-                const Observed<R> ob = observe_phase<R, false, NOISE>(p, c, s_tab, fl, P4, P5, gid, (unsigned)sc0 + (unsigned)u, rms);
+                const Observed<R> ob = observe_phase<R, false, NOISE>(p, c, s_tab, fl, P4, P5, gid, sc0 + (unsigned long long)u, rms);
                 post_maila<R>(maila[u & 1], lane, fl, v, ob);
                 // prev_vel / prev_ang_v: _update_state_post_step (skipped on a terminated step, quirk Q5), zero after a reset
                 if (!v.terminated) { P4 = make_float4(fl.vex, fl.vey, fl.vez, 0.0f); P5 = make_float4(fl.aex, fl.aey, fl.aez, 0.0f); }
@@ -1830,7 +1833,7 @@ __global__ __launch_bounds__(3 * DN_BLOCK, NORM ? 2 : 3) void dn_step_many_3w_ke
         for (int t = 0; t <= k_steps + 1; ++t) {
             if (t > 1) {                                                   // the step the aux wave finished last iteration
                 const int u = t - 2;
-                const unsigned sc = (unsigned)sc0 + (unsigned)u;
+                const unsigned long long sc = sc0 + (unsigned long long)u;
                 Flight<R> fl;
                 Verdict<R> v;
                 Observed<R> ob;
@@ -1878,7 +1881,7 @@ __global__ __launch_bounds__(DN_BLOCK) void dn_reset_kernel(const DnParams p, fl
     float o[DN_OBS_DIM];
     reset_obs<R>(p, c, (R)G0.w, o);
     const unsigned long long gid = (unsigned long long)(p.env_id_offset + i);
-    if (p.obs_noise_sigma > 0.0f) add_obs_noise(p, gid, (unsigned)p.st.stats[blockIdx.x].step_count, 5u, o);
+    if (p.obs_noise_sigma > 0.0f) add_obs_noise(p, gid, p.st.stats[blockIdx.x].step_count, 5u, o);
     if (p.normalize_obs) {
         Rms rms;
         load_rms(p, i, rms);
@@ -2002,7 +2005,7 @@ __global__ __launch_bounds__(256) void dn_policy_sample_kernel(const DnParams p,
     const float ls[4] = {log_std.x, log_std.y, log_std.z, log_std.w};
     float z[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     if (!deterministic)
-        noise4(seed, (unsigned long long)(p.env_id_offset + i), (unsigned)p.st.stats[i / DN_BLOCK].step_count, 9u, z);
+        noise4(seed, (unsigned long long)(p.env_id_offset + i), p.st.stats[i / DN_BLOCK].step_count, 9u, z);
     float a[4], lp = 0.0f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {

@@ -18,7 +18,13 @@ import numpy as np
 
 def format_rollout_lines(obs, rewards):
     """Text of PBDroneEnv.collect_rollout for observation rows `obs` [M, 13] and rewards [M]: every observation
-    value as a 32-decimal positional float32, comma separated, then str(reward)."""
+    value as a 32-decimal positional float32, comma separated, then str(reward).
+
+    Same layout as the reference's file, byte-identical when `rewards` carries the reference's own float64 values
+    (tests/test_metrics.py).  Fed from the device, the reward is the step's float32 output: the reference prints
+    str() of a float64 on the ordinary reward branch (17 significant digits, PBDroneEnv.py:555-571), of a float32 on
+    the gate-pass branch and the literal -10.0 on a crash, so device-fed lines equal the reference's on the last two
+    branches and agree to float32 precision (1e-7 relative) on the first."""
     obs = np.asarray(obs, dtype=np.float32).reshape(len(rewards), -1)
     out = []
     for row, r in zip(obs, rewards):
@@ -81,6 +87,17 @@ class EpisodeLog:
         return {"episodes": len(self.rows), "ep_rew_mean": float(r.mean()), "ep_len_mean": float(l.mean()),
                 "found_targets_mean": float(np.mean([x[3] for x in self.rows])),
                 "truncated_frac": float(np.mean([x[4] for x in self.rows])), "found_targets_hist": self.found_hist.tolist()}
+
+
+def found_targets_series(found_targets, log_freq, first_call=1):
+    """What FoundTargetsCallback._on_step logs (Sol/Utilities/Callbacks.py:55-61): every `log_freq`-th callback call the
+    scalar infos[0]["found_targets"], i.e. drone 0's running gate count.  `found_targets` is the step-major [K, N]
+    (or [K]) output of dn_step / dn_step_many; call number of row k is first_call + k.  Returns (n_calls, values)."""
+    f = found_targets.detach().cpu().numpy() if hasattr(found_targets, "detach") else np.asarray(found_targets)
+    f0 = f.reshape(f.shape[0], -1)[:, 0]
+    calls = np.arange(first_call, first_call + len(f0))
+    keep = calls % int(log_freq) == 0
+    return calls[keep], f0[keep].astype(np.int64)
 
 
 def save_evaluations(path, timesteps, results, ep_lengths):

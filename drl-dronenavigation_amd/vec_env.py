@@ -54,7 +54,7 @@ def _enum_value(v):
 
 def make_config(*, num_envs, target_points, initial_xyzs, aviary_dim, threshold=0.3, max_steps=4096, circle=False,
                 cylinder=True, include_distance=True, normalize_actions=True, normalize_obs=True,
-                ground_contact=True, compute_dtype="float64", act_noise_sigma=0.0, obs_noise_sigma=0.0, seed=0,
+                ground_contact=False, compute_dtype="float64", act_noise_sigma=0.0, obs_noise_sigma=0.0, seed=0,
                 env_id_offset=0, device_id=0, clip_rew=False, norm_rew=False, physics="pyb", act="thrust"):
     """Fill a dn_config (include/dronenav.h) from PBDroneEnv-style arguments."""
     wp = np.asarray(target_points, dtype=np.float64).reshape(-1, 3)
@@ -95,7 +95,7 @@ class DroneVecEnv(_VecEnvBase):
 
     def __init__(self, track=None, num_envs=12, *, target_points=None, initial_xyzs=None, aviary_dim=None,
                  circle=None, target_factor=0, threshold=0.3, discount=0.999, max_steps=4096, cylinder=True,
-                 include_distance=True, normalize_actions=True, normalize_obs=True, ground_contact=True,
+                 include_distance=True, normalize_actions=True, normalize_obs=True, ground_contact=False,
                  compute_dtype="float64", act_noise_sigma=0.0, obs_noise_sigma=0.0, seed=0, env_id_offset=0,
                  device=None, info_mode="full", clip_rew=False, norm_rew=False, physics="pyb", act="thrust"):
         if track is not None:
@@ -146,6 +146,10 @@ class DroneVecEnv(_VecEnvBase):
         self.reset_infos = [{} for _ in range(n)]
         self._seeds = [None] * n
         self._options = [{} for _ in range(n)]
+        if _VecEnvBase is not object:
+            # SB3's VecEnv.__init__ (num_envs, observation_space, action_space): sets the same attributes and asks
+            # get_attr("render_mode") of every env, which get_attr answers without touching the device
+            _VecEnvBase.__init__(self, n, self.observation_space, self.action_space)
 
         with torch.cuda.device(self.device):
             f32, dev = torch.float32, self.device
@@ -346,7 +350,10 @@ class DroneVecEnv(_VecEnvBase):
     def seed(self, seed=None):
         # the reference env has no randomness ("Seeding not implemented on pybullet side",
         # PBDroneSimulator.py:690); the seed only keys the optional noise streams at construction.
-        self._seeds = [None if seed is None else seed + i for i in range(self.num_envs)]
+        # SB3's VecEnv.seed [3P-recall]: a missing seed is drawn, env i gets seed + i, the list is returned.
+        if seed is None:
+            seed = int(np.random.randint(0, np.iinfo(np.uint32).max, dtype=np.uint32))
+        self._seeds = [seed + i for i in range(self.num_envs)]
         return list(self._seeds)
 
     def set_options(self, options=None):
@@ -385,8 +392,23 @@ class DroneVecEnv(_VecEnvBase):
     def env_method(self, method_name, *args, indices=None, **kwargs):
         raise AttributeError(f"env_method({method_name!r}) is not available on the device-resident env")
 
+    # The wrappers make_env puts around every PBDroneEnv (PBDroneSimulator.py:181-196) are applied in-kernel, so the
+    # env answers "yes" for them: SB3's evaluate_policy asks env_is_wrapped(Monitor) and, on "yes", reads the episode
+    # statistics from info["episode"] (which step_wait fills from the in-kernel Monitor accounting) instead of warning
+    # and re-deriving them from raw rewards.  Classes are matched by name: neither SB3 nor gym is importable here.
+    def _wrappers(self):
+        w = {"Monitor"}
+        if self.cfg.normalize_obs:
+            w.add("NormalizeObservation")
+        if self.cfg.clip_rew:
+            w.add("TransformReward")
+        if self.cfg.norm_rew:
+            w.add("NormalizeReward")
+        return w
+
     def env_is_wrapped(self, wrapper_class, indices=None):
-        return [False for _ in self._indices(indices)]
+        name = wrapper_class if isinstance(wrapper_class, str) else getattr(wrapper_class, "__name__", "")
+        return [name in self._wrappers() for _ in self._indices(indices)]
 
     def get_images(self):
         return [None for _ in range(self.num_envs)]

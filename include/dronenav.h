@@ -65,7 +65,10 @@ typedef struct dn_config {
     int32_t include_distance;                   /* obs[12] = distance/max_target_dist (True in the driver) */
     int32_t normalize_actions;                  /* PBDroneEnv.rescale_action (True in the driver) */
     int32_t normalize_obs;                      /* per-drone normalize.NormalizeObservation (always on in make_env) */
-    int32_t ground_contact;                     /* approximate len(p.getContactPoints())>0 vs plane.urdf */
+    int32_t ground_contact;                     /* approximate len(p.getContactPoints())>0 vs plane.urdf (PBDroneEnv.py:699): lowest point of the
+                                                   collision cylinder within Bullet's contact margin of z = 0 -- the one term of the step that is
+                                                   neither pinned nor exact, so OFF by default; in the reference's configurations the corridor
+                                                   test ends the episode first (every waypoint sits >= 0.5 above the floor) */
     int32_t compute_f32;                        /* 0: float64 arithmetic in registers over the float32 state
                                                       (parity grade, default); 1: float32 arithmetic */
     float act_noise_sigma;                      /* sim-to-real: Gaussian action noise (0 = reference) */
@@ -121,7 +124,7 @@ const char *dn_last_error(void);
 int32_t dn_device_count(void);
 
 /* Fills *cfg with the driver's literals (threshold 0.3, max_steps 4096, cylinder, include_distance,
- * normalize_actions on; circle/normalize_obs/noise off) and an empty track. */
+ * normalize_actions on; circle/normalize_obs/ground_contact/noise off) and an empty track. */
 void dn_config_default(dn_config *cfg);
 
 /* Replaces N x PBDroneEnv.__init__ + the env.reset(seed=seed+rank) of make_env

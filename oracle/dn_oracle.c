@@ -640,7 +640,8 @@ void orc_normalize_obs(orc_env *e, const float obs_in[ORC_OBS_DIM], double obs_o
 
 /* ------------------------------------------------------------------------- */
 /* Noise (BASELINE config 5).  The reference has no noise code; sigma = 0 is the reference.   */
-/* Philox4x32-10, key = seed, counter = (env id lo, env id hi, step, stream); Box-Muller in    */
+/* Philox4x32-10, key = seed, counter = (env id lo, env id hi, step lo, stream | step hi << 8); */
+/* Box-Muller in                                                                               */
 /* float64, rounded to float32.                                                                */
 /* ------------------------------------------------------------------------- */
 void orc_philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
@@ -659,10 +660,11 @@ void orc_philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-void orc_noise4(uint64_t seed, uint64_t env_id, uint32_t step, uint32_t stream, float out[4])
+void orc_noise4(uint64_t seed, uint64_t env_id, uint64_t step, uint32_t stream, float out[4])
 {
     uint32_t r[4];
-    orc_philox4x32((uint32_t)env_id, (uint32_t)(env_id >> 32), step, stream,
+    /* counter = (env id lo, env id hi, step lo, stream | step hi << 8): the whole 64-bit vector-step counter, streams < 256 */
+    orc_philox4x32((uint32_t)env_id, (uint32_t)(env_id >> 32), (uint32_t)step, stream | ((uint32_t)(step >> 32) << 8),
                    (uint32_t)seed, (uint32_t)(seed >> 32), r);
     for (int h = 0; h < 2; ++h) {
         double u1 = ((double)r[2 * h] + 0.5) * (1.0 / 4294967296.0);
@@ -674,7 +676,7 @@ void orc_noise4(uint64_t seed, uint64_t env_id, uint32_t step, uint32_t stream, 
     }
 }
 
-static void add_obs_noise(const orc_config *c, uint64_t env_id, uint32_t step, uint32_t stream0, float obs[ORC_OBS_DIM])
+static void add_obs_noise(const orc_config *c, uint64_t env_id, uint64_t step, uint32_t stream0, float obs[ORC_OBS_DIM])
 {
     if (!(c->obs_noise_sigma > 0.0f)) return;
     for (int b = 0; b < 4; ++b) {

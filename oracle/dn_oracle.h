@@ -91,8 +91,8 @@ typedef struct orc_env {
     int32_t ep_len;
     /* normalize.RunningMeanStd, normalize.py:10-31 */
     double rms_mean[ORC_OBS_DIM], rms_var[ORC_OBS_DIM], rms_count;
-    /* noise counter */
-    uint32_t step_count;
+    /* noise counter (the vector-step counter, 64 bits: it enters the Philox counter whole) */
+    uint64_t step_count;
     /* NormalizeReward (normalize.py:100-147): discounted return and its RunningMeanStd(shape=()) */
     double rr_returns, rr_mean, rr_var, rr_count;
     /* BaseAviary.last_clipped_action (BaseAviary.py:442,545): the rpm of the previous control step, zeros after reset */
@@ -169,7 +169,7 @@ void orc_gae(const float *rewards, const float *values, const uint8_t *dones,
 /* ---- noise: Philox4x32-10 counter RNG -------------------------------------- */
 void orc_philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                     uint32_t k0, uint32_t k1, uint32_t out[4]);
-void orc_noise4(uint64_t seed, uint64_t env_id, uint32_t step, uint32_t stream, float out[4]);
+void orc_noise4(uint64_t seed, uint64_t env_id, uint64_t step, uint32_t stream, float out[4]);
 
 int32_t orc_sizeof_env(void);
 int32_t orc_sizeof_config(void);

@@ -53,7 +53,7 @@ class OrcEnv(C.Structure):
         ("idx", C.c_int32), ("just_found", C.c_int32), ("is_done", C.c_int32), ("steps", C.c_int32),
         ("ep_ret", C.c_double), ("ep_len", C.c_int32),
         ("rms_mean", C.c_double * OBS_DIM), ("rms_var", C.c_double * OBS_DIM), ("rms_count", C.c_double),
-        ("step_count", C.c_uint32),
+        ("step_count", C.c_uint64),
         ("rr_returns", C.c_double), ("rr_mean", C.c_double), ("rr_var", C.c_double), ("rr_count", C.c_double),
         ("last_clipped_action", C.c_double * 4),
     ]
@@ -72,7 +72,7 @@ ENV_DTYPE = np.dtype([
     ("idx", "i4"), ("just_found", "i4"), ("is_done", "i4"), ("steps", "i4"),
     ("ep_ret", "f8"), ("ep_len", "i4"),
     ("rms_mean", "f8", OBS_DIM), ("rms_var", "f8", OBS_DIM), ("rms_count", "f8"),
-    ("step_count", "u4"),
+    ("step_count", "u8"),
     ("rr_returns", "f8"), ("rr_mean", "f8"), ("rr_var", "f8"), ("rr_count", "f8"),
     ("last_clipped_action", "f8", 4),
 ], align=True)
@@ -130,7 +130,7 @@ def lib():
     L.orc_vec_step.argtypes = [cfgp, C.c_void_p, C.c_int64] + [C.c_void_p] * 10 + [C.c_int]
     L.orc_gae.argtypes = [C.c_void_p] * 5 + [C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
     L.orc_philox4x32.argtypes = [C.c_uint32] * 6 + [C.POINTER(C.c_uint32)]
-    L.orc_noise4.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, fp]
+    L.orc_noise4.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, fp]
     for name in ("orc_sizeof_env", "orc_sizeof_config", "orc_max_threads"):
         getattr(L, name).restype = C.c_int32
     assert L.orc_sizeof_env() == C.sizeof(OrcEnv) == ENV_DTYPE.itemsize, \
@@ -141,7 +141,7 @@ def lib():
 
 
 def make_config(waypoints, spawn, dim, *, threshold=0.3, max_steps=4096, circle=False, cylinder=True,
-                include_distance=True, normalize_actions=True, normalize_obs=False, ground_contact=True,
+                include_distance=True, normalize_actions=True, normalize_obs=False, ground_contact=False,
                 f32_state=False, act_noise_sigma=0.0, obs_noise_sigma=0.0, seed=0, env_id_offset=0, clip_rew=False,
                 norm_rew=False, physics=0, action_type=0):
     wp = np.asarray(waypoints, dtype=np.float64).reshape(-1, 3)

@@ -33,6 +33,7 @@ def make_pair(track, n, *, f32_state, max_steps=4096, **kw):
                                                 "act_noise_sigma", "obs_noise_sigma", "seed", "env_id_offset",
                                                 "ground_contact", "threshold", "cylinder", "clip_rew", "norm_rew")}
     okw.setdefault("normalize_obs", True)
+    okw.setdefault("ground_contact", False)        # DroneVecEnv's default: the contact approximation is opt-in
     cfg = O.make_config(track.targets(), track.initial_xyzs, track.aviary_dim, circle=track.is_circle,
                         max_steps=max_steps, f32_state=f32_state, **okw)
     return env, O.OracleVecEnv(cfg, n, threads=8)
@@ -308,6 +309,41 @@ def test_noise_streams_match_oracle():
         a = (0.0922 + 0.002 * rng.standard_normal((n, 4))).astype(np.float32)
         compare_step(env.step_tensor(torch.from_numpy(a).to(dev)), ora.step(a), f"noise t={t}", rew_atol=1e-4)
     env.close()
+
+
+def test_noise_streams_do_not_repeat_when_the_step_counter_wraps_32_bits():
+    """The Philox counter carries the whole 64-bit vector-step counter: across the 2^32 boundary (hours of fused
+    stepping) the device still matches the oracle, and the draws after the wrap are not the draws of step 0, 1, ..."""
+    track = _tracks().reaching()
+    n = 256
+    kw = dict(max_steps=50, normalize_obs=False, act_noise_sigma=0.002, obs_noise_sigma=0.01, seed=99)
+    env, ora = make_pair(track, n, f32_state=True, **kw)
+    low, _ = make_pair(track, n, f32_state=True, **kw)
+    env.reset_tensor(); ora.reset(); low.reset_tensor()
+    start = (1 << 32) - 3
+    env.step_count = start
+    ora.envs["step_count"] = start
+    assert env.step_count == start
+    dev = torch.device("cuda:0")
+    a = np.full((n, 4), 0.0922, np.float32)
+    at = torch.from_numpy(a).to(dev)
+    acts = at[None].repeat(8, 1, 1).contiguous()
+    for t in range(4):                                         # single steps across the boundary
+        compare_step(env.step_tensor(at), ora.step(a), f"wrap t={t}", rew_atol=1e-4)
+    out = env.rollout_tensor(acts)                             # and a fused launch beyond it
+    for t in range(8):
+        ref = ora.step(a)
+        np.testing.assert_allclose(out["obs"][t].cpu().numpy(), ref["obs"], rtol=0, atol=1e-5)
+    assert env.step_count == start + 12
+    # the same drones from step 0: the first observation after the wrap must differ from the one at step 0
+    o_low = low.step_tensor(at)[0].clone()
+    twin, _ = make_pair(track, n, f32_state=True, **kw)
+    twin.reset_tensor()
+    twin.step_count = 1 << 32
+    o_hi = twin.step_tensor(at)[0].clone()
+    assert not torch.equal(o_low, o_hi) and float((o_low - o_hi).abs().max()) > 1e-3
+    for e in (env, low, twin):
+        e.close()
 
 
 def test_float32_compute_mode_tolerance():
