@@ -814,30 +814,116 @@ DN_DEV void flight_entry(Flight<R> &fl, const float4 G0, const float4 G2, const 
 }
 
 // ---- A4: p.stepSimulation, one free rigid body [3P-recall of Bullet3 btMultiBody] -------------------------
+// No `fp contract` licence in the recurrence: every fused multiply-add is spelled out (F), in one order.  Left to the
+// compiler, WHICH product of a sum of products gets fused is picked per instantiation, and the picks differed between
+// the kernel shapes (found by a soak run: one float32 ulp in a component of 1e-6 rad/s, which then diverges) -- the
+// shapes, and with them every split of a fleet over ranks, are bit-identical only if the arithmetic is one sequence.
+//
+// The step is written as two halves that share nothing but their inputs, so that a kernel may run them on two waves:
+//   physics_linear   v += a dt (a = R[:,2] fz/M - (0,0,G) - v (c + c|v|)), clamp, x += v dt       needs quat, vel, pos, fz
+//   physics_angular  w += R I^-1 (tau - w_b x I w_b - I w_b (c + c|w_b|)) dt, clamp, q <- dq(w dt) q   needs quat, w, torques
+// Both start from the same btMatrix3x3::setRotation terms (written once, below): the same expressions give the same bits
+// on whichever wave evaluates them.  btMultiBody clamps every velocity coordinate at m_maxCoordinateVelocity; no reachable
+// state gets there (thrust/weight = 5.5, damping), so each half tests its three once per wave and clamps only then -- the
+// clamp is element-wise, so two tests over three values select the same results as one test over six.  NaN stays NaN.
+#define F(a, b, c) FM<R>::fma((a), (b), (c))
+template <typename R> struct QuatTerms {
+    R xs, ys, zs, wxs, wys, wzs, yy, zz;
+};
+template <typename R> DN_DEV QuatTerms<R> quat_terms(const R qx, const R qy, const R qz, const R qw)
+{   // btMatrix3x3::setRotation: s = 2 / |q|^2
+    QuatTerms<R> t;
+    const R s = R(2.0) * FM<R>::rcp(F(qw, qw, F(qz, qz, F(qy, qy, qx * qx))));
+    t.xs = qx * s; t.ys = qy * s; t.zs = qz * s;
+    t.wxs = qw * t.xs; t.wys = qw * t.ys; t.wzs = qw * t.zs;
+    t.yy = qy * t.ys; t.zz = qz * t.zs;
+    return t;
+}
+template <typename R> struct Lin {
+    R px, py, pz;          // new position
+    R vx, vy, vz;          // new velocity
+};
+template <typename R>
+DN_DEV Lin<R> physics_linear(const float4 G0, const float4 G1, const float4 G2, const R fz, const R dax, const R day, const R daz,
+                             const bool extra)
+{
+    Lin<R> o;
+    R px = G0.x, py = G0.y, pz = G0.z;
+    const R qx = G1.x, qy = G1.y, qz = G1.z, qw = G1.w;
+    R vx = G2.x, vy = G2.y, vz = G2.z;
+    const R dt = K<R>::DT;
+    const QuatTerms<R> t = quat_terms<R>(qx, qy, qz, qw);
+    const R r02 = F(qx, t.zs, t.wys), r12 = F(qy, t.zs, -t.wxs), r22 = R(1.0) - F(qx, t.xs, t.yy);
+    // linear: a = R[:,2] fz/M - (0,0,G) - v (c + c|v|)
+    // the damping norms enter the velocity update at dt * 0.04: a float32 root moves it by 1e-12 relative
+    const R kl = F(K<R>::LIN_DAMP, (R)__builtin_amdgcn_sqrtf((float)F(vz, vz, F(vy, vy, vx * vx))), K<R>::LIN_DAMP);
+    const R fm = fz * K<R>::INV_M;
+    R awx = F(r02, fm, -(vx * kl)), awy = F(r12, fm, -(vy * kl)), awz = F(-vz, kl, F(r22, fm, -K<R>::G));
+    if (extra) { awx += dax; awy += day; awz += daz; }
+    vx = F(awx, dt, vx); vy = F(awy, dt, vy); vz = F(awz, dt, vz);       // applyDeltaVeeMultiDof
+    const R mv = K<R>::MAX_COORD_VEL;
+    if (__builtin_expect(fmax(fmax(fabs(vx), fabs(vy)), fabs(vz)) > mv, 0)) {
+        vx = clipv(vx, -mv, mv); vy = clipv(vy, -mv, mv); vz = clipv(vz, -mv, mv);
+    }
+    o.px = F(dt, vx, px); o.py = F(dt, vy, py); o.pz = F(dt, vz, pz);    // stepPositionsMultiDof
+    o.vx = vx; o.vy = vy; o.vz = vz;
+    return o;
+}
+template <typename R> struct Ang {
+    R qx, qy, qz, qw;      // new attitude (unit quaternion)
+    R wx, wy, wz;          // new angular velocity
+};
+template <typename R>
+DN_DEV Ang<R> physics_angular(const float4 G1, const float4 G3, const R tx, const R ty, const R ztq)
+{
+    Ang<R> o;
+    const R qx = G1.x, qy = G1.y, qz = G1.z, qw = G1.w;
+    R wx = G3.x, wy = G3.y, wz = G3.z;
+    const R dt = K<R>::DT;
+    const QuatTerms<R> t = quat_terms<R>(qx, qy, qz, qw);
+    const R r00 = R(1.0) - F(qy, t.ys, t.zz), r01 = F(qx, t.ys, -t.wzs), r02 = F(qx, t.zs, t.wys);
+    const R r10 = F(qx, t.ys, t.wzs), r11 = R(1.0) - F(qx, t.xs, t.zz), r12 = F(qy, t.zs, -t.wxs);
+    const R r20 = F(qx, t.zs, -t.wys), r21 = F(qy, t.zs, t.wxs), r22 = R(1.0) - F(qx, t.xs, t.yy);
+    // angular, in the body frame: I dw = tau - w x (I w) - I w (c + c|w|)
+    const R wbx = F(r20, wz, F(r10, wy, r00 * wx)), wby = F(r21, wz, F(r11, wy, r01 * wx)), wbz = F(r22, wz, F(r12, wy, r02 * wx));
+    const R ka = F(K<R>::ANG_DAMP, (R)__builtin_amdgcn_sqrtf((float)F(wz, wz, F(wy, wy, wx * wx))), K<R>::ANG_DAMP);
+    const R Iwx = K<R>::IXX * wbx, Iwy = K<R>::IYY * wby, Iwz = K<R>::IZZ * wbz;
+    const R gx = F(wby, Iwz, -(wbz * Iwy)), gy = F(wbz, Iwx, -(wbx * Iwz)), gz = F(wbx, Iwy, -(wby * Iwx));
+    const R dbx = F(-Iwx, ka, tx - gx) * K<R>::INV_IXX, dby = F(-Iwy, ka, ty - gy) * K<R>::INV_IYY,
+            dbz = F(-Iwz, ka, ztq - gz) * K<R>::INV_IZZ;
+    const R dwx = F(r02, dbz, F(r01, dby, r00 * dbx)), dwy = F(r12, dbz, F(r11, dby, r10 * dbx)), dwz = F(r22, dbz, F(r21, dby, r20 * dbx));
+    wx = F(dwx, dt, wx); wy = F(dwy, dt, wy); wz = F(dwz, dt, wz);       // applyDeltaVeeMultiDof
+    const R mv = K<R>::MAX_COORD_VEL;
+    if (__builtin_expect(fmax(fmax(fabs(wx), fabs(wy)), fabs(wz)) > mv, 0)) {
+        wx = clipv(wx, -mv, mv); wy = clipv(wy, -mv, mv); wz = clipv(wz, -mv, mv);
+    }
+    // exponential map: Bullet clamps the angle rate, fAngle = min(|w|, (pi/4)/dt), and takes
+    // axis = w sin(h)/fAngle with h = fAngle dt/2, i.e. w (dt/2) sinc(h), and cos(h): both are even in h, so only
+    // h^2 = min(|w|^2 dt^2/4, (pi/8)^2) is needed and the sqrt of |w|^2 never is.  (Bullet's |w| < 1e-3 Taylor
+    // branch is the same function to 1e-24; and with |w_i| <= 100 the clamp itself cannot bind at dt = 1/240.)
+    R h2 = (R(0.25) * dt * dt) * F(wz, wz, F(wy, wy, wx * wx));
+    const R h2max = R(0.015625) * K<R>::PI * K<R>::PI;     // (pi/8)^2
+    h2 = h2 > h2max ? h2max : h2;
+    R sinc, aw;
+    sinc_cos_small<R>(h2, sinc, aw);
+    const R k = (R(0.5) * dt) * sinc;
+    const R ax = wx * k, ay = wy * k, az = wz * k;
+    const R nx = F(-az, qy, F(ay, qz, F(ax, qw, aw * qx)));
+    const R ny = F(-ax, qz, F(az, qx, F(ay, qw, aw * qy)));
+    const R nz = F(-ay, qx, F(ax, qy, F(az, qw, aw * qz)));
+    const R nw_ = F(-az, qz, F(-ay, qy, F(-ax, qx, aw * qw)));
+    const R inv = FM<R>::rsq(F(nw_, nw_, F(nz, nz, F(ny, ny, nx * nx))));
+    o.qx = nx * inv; o.qy = ny * inv; o.qz = nz * inv; o.qw = nw_ * inv;
+    o.wx = wx; o.wy = wy; o.wz = wz;
+    return o;
+}
+
 template <typename R, typename TH = Thrust, bool XOPT = false>
 DN_DEV Flight<R> physics_phase(const TH &th, const float4 G0, const float4 G1, const float4 G2, const float4 G3,
                                const int max_steps, const Extras *x = nullptr)
 {
-    // No `fp contract` licence in the recurrence: every fused multiply-add is spelled out (F), in one order.  Left to the
-    // compiler, WHICH product of a sum of products gets fused is picked per instantiation, and the picks differed between
-    // the kernel shapes (found by a soak run: one float32 ulp in a component of 1e-6 rad/s, which then diverges) -- the
-    // shapes, and with them every split of a fleet over ranks, are bit-identical only if the arithmetic is one sequence.
-#define F(a, b, c) FM<R>::fma((a), (b), (c))
     Flight<R> fl;
-    R px = G0.x, py = G0.y, pz = G0.z;
-    R qx = G1.x, qy = G1.y, qz = G1.z, qw = G1.w;
-    R vx = G2.x, vy = G2.y, vz = G2.z;
-    R wx = G3.x, wy = G3.y, wz = G3.z;
     flight_entry<R>(fl, G0, G2, G3, max_steps);
-    const R dt = K<R>::DT;
-    // btMatrix3x3::setRotation: s = 2 / |q|^2
-    const R s = R(2.0) * FM<R>::rcp(F(qw, qw, F(qz, qz, F(qy, qy, qx * qx))));
-    const R xs = qx * s, ys = qy * s, zs = qz * s;
-    const R wxs = qw * xs, wys = qw * ys, wzs = qw * zs;
-    const R yy = qy * ys, zz = qz * zs;
-    const R r00 = R(1.0) - F(qy, ys, zz), r01 = F(qx, ys, -wzs), r02 = F(qx, zs, wys);
-    const R r10 = F(qx, ys, wzs), r11 = R(1.0) - F(qx, xs, zz), r12 = F(qy, zs, -wxs);
-    const R r20 = F(qx, zs, -wys), r21 = F(qy, zs, wxs), r22 = R(1.0) - F(qx, xs, yy);
     // rotor thrusts along body z at the prop offsets (+,-) (-,-) (-,+) (+,+) * 0.028 (cf2x.urdf:42,54,66,78)
     R fz, tx, ty, ztq;
     R dax = R(0.0), day = R(0.0), daz = R(0.0);
@@ -846,6 +932,14 @@ DN_DEV Flight<R> physics_phase(const TH &th, const float4 G0, const float4 G1, c
     } else {
     R F0 = th.f[0], F1 = th.f[1], F2 = th.f[2], F3 = th.f[3];
     if (XOPT) {
+        const R px = G0.x, py = G0.y, pz = G0.z;
+        const R qx = G1.x, qy = G1.y, qz = G1.z, qw = G1.w;
+        const R vx = G2.x, vy = G2.y, vz = G2.z;
+        (void)px; (void)py;
+        const QuatTerms<R> t = quat_terms<R>(qx, qy, qz, qw);
+        const R r00 = R(1.0) - F(qy, t.ys, t.zz), r01 = F(qx, t.ys, -t.wzs), r02 = F(qx, t.zs, t.wys);
+        const R r10 = F(qx, t.ys, t.wzs), r11 = R(1.0) - F(qx, t.xs, t.zz), r12 = F(qy, t.zs, -t.wxs);
+        const R r20 = F(qx, t.zs, -t.wys), r21 = F(qy, t.zs, t.wxs), r22 = R(1.0) - F(qx, t.xs, t.yy);
         if (x->gnd) {   // BaseAviary._groundEffect (BaseAviary.py:800-832): a second +z force on each prop link
             // |roll| < pi/2 and |pitch| < pi/2 on the cached rpy (getEulerFromQuaternion [3P-recall]): roll =
             // atan2(., w^2-x^2-y^2+z^2) is inside (-pi/2, pi/2) iff its second argument = r22 |q|^2 is positive;
@@ -877,53 +971,15 @@ DN_DEV Flight<R> physics_phase(const TH &th, const float4 G0, const float4 G1, c
     ty = K<R>::ARM * ((F1 + F2) - (F0 + F3));
     ztq = (R)th.zt;
     }
-    // linear: a = R[:,2] fz/M - (0,0,G) - v (c + c|v|)
-    // the damping norms enter the velocity update at dt * 0.04: a float32 root moves it by 1e-12 relative
-    const R kl = F(K<R>::LIN_DAMP, (R)__builtin_amdgcn_sqrtf((float)F(vz, vz, F(vy, vy, vx * vx))), K<R>::LIN_DAMP);
-    const R fm = fz * K<R>::INV_M;
-    R awx = F(r02, fm, -(vx * kl)), awy = F(r12, fm, -(vy * kl)), awz = F(-vz, kl, F(r22, fm, -K<R>::G));
-    if (XOPT) { awx += dax; awy += day; awz += daz; }
-    // angular, in the body frame: I dw = tau - w x (I w) - I w (c + c|w|)
-    const R wbx = F(r20, wz, F(r10, wy, r00 * wx)), wby = F(r21, wz, F(r11, wy, r01 * wx)), wbz = F(r22, wz, F(r12, wy, r02 * wx));
-    const R ka = F(K<R>::ANG_DAMP, (R)__builtin_amdgcn_sqrtf((float)F(wz, wz, F(wy, wy, wx * wx))), K<R>::ANG_DAMP);
-    const R Iwx = K<R>::IXX * wbx, Iwy = K<R>::IYY * wby, Iwz = K<R>::IZZ * wbz;
-    const R gx = F(wby, Iwz, -(wbz * Iwy)), gy = F(wbz, Iwx, -(wbx * Iwz)), gz = F(wbx, Iwy, -(wby * Iwx));
-    const R dbx = F(-Iwx, ka, tx - gx) * K<R>::INV_IXX, dby = F(-Iwy, ka, ty - gy) * K<R>::INV_IYY,
-            dbz = F(-Iwz, ka, ztq - gz) * K<R>::INV_IZZ;
-    const R dwx = F(r02, dbz, F(r01, dby, r00 * dbx)), dwy = F(r12, dbz, F(r11, dby, r10 * dbx)), dwz = F(r22, dbz, F(r21, dby, r20 * dbx));
-    wx = F(dwx, dt, wx); wy = F(dwy, dt, wy); wz = F(dwz, dt, wz);       // applyDeltaVeeMultiDof
-    vx = F(awx, dt, vx); vy = F(awy, dt, vy); vz = F(awz, dt, vz);
-    // btMultiBody clamps every velocity coordinate at m_maxCoordinateVelocity; no reachable state gets there
-    // (thrust/weight = 5.5, damping), so test once per wave and clamp only then.  NaN stays NaN either way.
-    const R mv = K<R>::MAX_COORD_VEL;
-    const R big = fmax(fmax(fmax(fabs(wx), fabs(wy)), fmax(fabs(wz), fabs(vx))), fmax(fabs(vy), fabs(vz)));
-    if (__builtin_expect(big > mv, 0)) {
-        wx = clipv(wx, -mv, mv); wy = clipv(wy, -mv, mv); wz = clipv(wz, -mv, mv);
-        vx = clipv(vx, -mv, mv); vy = clipv(vy, -mv, mv); vz = clipv(vz, -mv, mv);
-    }
-    px = F(dt, vx, px); py = F(dt, vy, py); pz = F(dt, vz, pz);          // stepPositionsMultiDof
-    // exponential map: Bullet clamps the angle rate, fAngle = min(|w|, (pi/4)/dt), and takes
-    // axis = w sin(h)/fAngle with h = fAngle dt/2, i.e. w (dt/2) sinc(h), and cos(h): both are even in h, so only
-    // h^2 = min(|w|^2 dt^2/4, (pi/8)^2) is needed and the sqrt of |w|^2 never is.  (Bullet's |w| < 1e-3 Taylor
-    // branch is the same function to 1e-24.)
-    R h2 = (R(0.25) * dt * dt) * F(wz, wz, F(wy, wy, wx * wx));
-    const R h2max = R(0.015625) * K<R>::PI * K<R>::PI;     // (pi/8)^2
-    h2 = h2 > h2max ? h2max : h2;
-    R sinc, aw;
-    sinc_cos_small<R>(h2, sinc, aw);
-    const R k = (R(0.5) * dt) * sinc;
-    const R ax = wx * k, ay = wy * k, az = wz * k;
-    const R nx = F(-az, qy, F(ay, qz, F(ax, qw, aw * qx)));
-    const R ny = F(-ax, qz, F(az, qx, F(ay, qw, aw * qy)));
-    const R nz = F(-ay, qx, F(ax, qy, F(az, qw, aw * qz)));
-    const R nw_ = F(-az, qz, F(-ay, qy, F(-ax, qx, aw * qw)));
-    const R inv = FM<R>::rsq(F(nw_, nw_, F(nz, nz, F(ny, ny, nx * nx))));
-    fl.px = px; fl.py = py; fl.pz = pz;
-    fl.qx = nx * inv; fl.qy = ny * inv; fl.qz = nz * inv; fl.qw = nw_ * inv;
-    fl.vx = (float)vx; fl.vy = (float)vy; fl.vz = (float)vz; fl.wx = (float)wx; fl.wy = (float)wy; fl.wz = (float)wz;
+    const Lin<R> lin = physics_linear<R>(G0, G1, G2, fz, dax, day, daz, XOPT);
+    const Ang<R> ang = physics_angular<R>(G1, G3, tx, ty, ztq);
+    fl.px = lin.px; fl.py = lin.py; fl.pz = lin.pz;
+    fl.qx = ang.qx; fl.qy = ang.qy; fl.qz = ang.qz; fl.qw = ang.qw;
+    fl.vx = (float)lin.vx; fl.vy = (float)lin.vy; fl.vz = (float)lin.vz;
+    fl.wx = (float)ang.wx; fl.wy = (float)ang.wy; fl.wz = (float)ang.wz;
     return fl;
-#undef F
 }
+#undef F
 
 // ---- A8 + A9 on the flight wave: _computeTerminated (PBDroneEnv.py:456-473) as evaluated inside _computeReward
 // (:489) and again by BaseAviary.step (BaseAviary.py:448), the gate bookkeeping of _computeReward (:539-552),
@@ -931,16 +987,23 @@ DN_DEV Flight<R> physics_phase(const TH &th, const float4 G0, const float4 G1, c
 // SubprocVecEnv auto-reset -> PBDroneEnv.reset (:609-665; _current_position is NOT reset: quirk Q3).
 // Only the segment corridor depends on the waypoint index, so the common part of the collision test runs once
 // and the segment test once per index that is actually needed.
+// rules_verdict: everything the OTHER phases of the step wait for (collision / gate / termination flags and the distance
+// the reset observation shows); rules_commit: the state words that go back to HBM, with the auto-reset of the body.
+// rules_phase = the two back to back.
+template <typename R> struct RulesMid {
+    int idx, just_found, steps;
+    R d, d_prev;
+    bool terminated, done;
+};
 template <typename R>
-DN_DEV Verdict<R> rules_phase(const DnParams &p, const DnConsts<R> &c, const R *s_tab, const GateRow<R> &row_e, const R (&wp0)[3],
-                              const Flight<R> &fl, const float4 G0e, const float4 G3e, float4 *g6_blk, const unsigned li,
-                              const bool active, float4 &G0, float4 &G1, float4 &G2, float4 &G3)
+DN_DEV Verdict<R> rules_verdict(const DnParams &p, const DnConsts<R> &c, const R *s_tab, const GateRow<R> &row_e,
+                                const Flight<R> &fl, const float4 G3e, RulesMid<R> &m)
 {
-// (explicit fused multiply-adds, no contraction licence: see physics_phase)
+// (explicit fused multiply-adds, no contraction licence: see physics_linear)
     const Meta m_e = unpack_meta(G3e.w);
     const R px = fl.px, py = fl.py, pz = fl.pz;
     // rotation entry R[2][2] of the new (unit) attitude, for the ground-contact approximation only
-    const R r22n = FM<R>::fma(R(-2.0), FM<R>::fma(fl.qy, fl.qy, fl.qx * fl.qx), R(1.0));
+    const R r22n = p.ground_contact ? FM<R>::fma(R(-2.0), FM<R>::fma(fl.qy, fl.qy, fl.qx * fl.qx), R(1.0)) : R(1.0);
     int idx = m_e.idx, just_found = m_e.just_found;
     const bool seg_track = p.cylinder && !p.circle;
     const bool coll1 = collision_common<R>(p, c, px, py, pz, r22n) ||
@@ -960,8 +1023,6 @@ DN_DEV Verdict<R> rules_phase(const DnParams &p, const DnConsts<R> &c, const R *
         }
         d_prev = (R)fl.d_e;
     } else { just_found = 0; d_prev = (R)fl.d_e; terminated = false; }
-    const bool done = terminated || fl.truncated != 0;
-
     int steps = m_e.steps;
     R d = (R)fl.d_e;
     if (!terminated) {                                 // _update_state_post_step
@@ -976,7 +1037,20 @@ DN_DEV Verdict<R> rules_phase(const DnParams &p, const DnConsts<R> &c, const R *
     }
     Verdict<R> v;
     v.d_obs = d; v.coll1 = coll1; v.terminated = terminated;
-
+    m.idx = idx; m.just_found = just_found; m.steps = steps; m.d = d; m.d_prev = d_prev;
+    m.terminated = terminated; m.done = terminated || fl.truncated != 0;
+    return v;
+}
+template <typename R>
+DN_DEV void rules_commit(const DnConsts<R> &c, const R (&wp0)[3], const Flight<R> &fl, const RulesMid<R> &m, const float4 G0e,
+                         const float4 G3e, float4 *g6_blk, const unsigned li, const bool active,
+                         float4 &G0, float4 &G1, float4 &G2, float4 &G3)
+{
+    const Meta m_e = unpack_meta(G3e.w);
+    const R px = fl.px, py = fl.py, pz = fl.pz;
+    const bool terminated = m.terminated, done = m.done;
+    int idx = m.idx, just_found = m.just_found, steps = m.steps;
+    R d = m.d, d_prev = m.d_prev;
     // the advanced body state as the float32 words that go back to HBM
     float4 S0 = make_float4((float)px, (float)py, (float)pz, 0.0f);
     float4 S1 = make_float4((float)fl.qx, (float)fl.qy, (float)fl.qz, (float)fl.qw);
@@ -1001,6 +1075,15 @@ DN_DEV Verdict<R> rules_phase(const DnParams &p, const DnConsts<R> &c, const R *
     }
     S0.w = (float)d; S2.w = (float)d_prev; S3.w = pack_meta(steps, idx, just_found);
     G0 = S0; G1 = S1; G2 = S2; G3 = S3;
+}
+template <typename R>
+DN_DEV Verdict<R> rules_phase(const DnParams &p, const DnConsts<R> &c, const R *s_tab, const GateRow<R> &row_e, const R (&wp0)[3],
+                              const Flight<R> &fl, const float4 G0e, const float4 G3e, float4 *g6_blk, const unsigned li,
+                              const bool active, float4 &G0, float4 &G1, float4 &G2, float4 &G3)
+{
+    RulesMid<R> m;
+    const Verdict<R> v = rules_verdict<R>(p, c, s_tab, row_e, fl, G3e, m);
+    rules_commit<R>(c, wp0, fl, m, G0e, G3e, g6_blk, li, active, G0, G1, G2, G3);
     return v;
 }
 
@@ -1053,62 +1136,70 @@ template <typename R> struct Observed {
 };
 
 // ---- A5 + A6 + the value side of A7 on the report wave ---------------------------------------------------
+// observe_columns: the observation row; reward_candidates: both value branches of _computeReward.  The two read the
+// same Flight and share no intermediate, so a kernel may run them on two waves; observe_phase = both on one.
+template <typename R>
+DN_DEV void observe_columns(const DnParams &p, const DnConsts<R> &c, const Flight<R> &fl, float o[DN_OBS_DIM])
+{
+    const float roll32 = atan2_fast32(fl.roll_num32, fl.roll_den32), pitch32 = fl.pitch32, yaw32 = fl.yaw32;    // attitude_phase
+    // _computeObs (PBDroneEnv.py:296-336, :338-398), stale distance d_e (quirk Q1).  The reference clips position /
+    // yaw / distance columns to the float32 range before the cast (:326); positions are bounded by the aviary box
+    // plus one step at the velocity cap, so those clips can never bind and are not evaluated.  clip(v, -3, 3)/3 is
+    // monotone, so it equals clip(float32(v/3), -1, 1) exactly.
+    const float inv_pi32 = (float)K<R>::INV_PI;
+    o[0] = (float)(fl.px * c.inv_dim[0]);
+    o[1] = (float)(fl.py * c.inv_dim[1]);
+    o[2] = (float)(fl.pz * c.inv_dim[2]);
+    o[3] = roll32 * inv_pi32;
+    o[4] = pitch32 * inv_pi32;
+    o[5] = yaw32 * inv_pi32;
+    const float third32 = (float)K<R>::THIRD;
+    o[6] = clipv((float)((R)fl.vx * K<R>::THIRD), -1.0f, 1.0f);
+    o[7] = clipv((float)((R)fl.vy * K<R>::THIRD), -1.0f, 1.0f);
+    o[8] = clipv((float)((R)fl.vz * K<R>::THIRD), -third32, third32);
+    const R w2 = FM<R>::fma((R)fl.wz, (R)fl.wz, FM<R>::fma((R)fl.wy, (R)fl.wy, (R)fl.wx * (R)fl.wx));   // explicit order, see attitude_phase
+    if (w2 != R(0.0)) {                                   // ang_v / |ang_v|, zero stays zero (:383-384)
+        const R rw = FM<R>::rsq_f32grade(w2);
+        o[9] = (float)((R)fl.wx * rw); o[10] = (float)((R)fl.wy * rw); o[11] = (float)((R)fl.wz * rw);
+    } else { o[9] = fl.wx; o[10] = fl.wy; o[11] = fl.wz; }
+    o[12] = p.include_distance ? (float)((R)fl.d_e * c.inv_max_target_dist) : 0.0f;
+}
+template <typename R>
+DN_DEV void reward_candidates(const DnParams &p, const DnConsts<R> &c, const R *s_tab, const Flight<R> &fl, const float4 G4,
+                              const float4 G5, R &r_normal, float &r_found32)
+{
+    const R fwx = fl.fwx, fwy = fl.fwy, fwz = fl.fwz;
+    // _computeReward (PBDroneEnv.py:475-571): both value branches; report_phase selects once the verdict is in.
+    // The orientation term is evaluated once, against the waypoint the taken branch refers to.
+    const bool found_now = (R)fl.d_e <= c.threshold;
+    const bool last_gate = fl.idx_e + 1 == p.num_waypoints;
+    const int idx_ori = (found_now && !last_gate) ? fl.idx_e + 1 : fl.idx_e;
+    const int ori = orientation_reward<R>(fwx, fwy, fwz, fl.px, fl.py, fl.pz, s_tab + idx_ori * DN_T_STRIDE);
+    float r32 = 0.0f;
+    if (last_gate) r32 = r32 + 200.0f;                                        // :542-546
+    else { r32 = r32 + 75.0f; r32 = r32 + (float)(ori * 5); }                 // :548-552
+    r_found32 = r32;
+    // :555 3 e^{-2d} (v_exp_f32: 1e-7 rel, 1e-8 in the reward) + :556
+    const R gain = fl.just_found_e ? R(0.0) : ((R)fl.dprev_e - (R)fl.d_e) * R(3000.0);
+    R r = FM<R>::fma(R(3.0), (R)__builtin_amdgcn_exp2f((float)(R(-2.0 * 1.4426950408889634) * (R)fl.d_e)), gain);
+    r = r + (R)(ori * 3);                                                     // :557
+    // smoothness_reward (:599-607) on the stale post-step copies (quirk Q4): -|dv| if |dv| > 0.7, -|dw| if > 0.3
+    const R lx = (R)fl.vex - (R)G4.x, ly = (R)fl.vey - (R)G4.y, lz = (R)fl.vez - (R)G4.z;
+    const R ax_ = (R)fl.aex - (R)G5.x, ay_ = (R)fl.aey - (R)G5.y, az_ = (R)fl.aez - (R)G5.z;
+    const R la2 = FM<R>::fma(lz, lz, FM<R>::fma(ly, ly, lx * lx)), aa2 = FM<R>::fma(az_, az_, FM<R>::fma(ay_, ay_, ax_ * ax_));
+    // the penalties enter the reward at 1/25: a float32 root (1e-7 relative) is far inside the reward's 1e-5 bar
+    if (la2 > R(0.7) * R(0.7)) r = r - (R)__builtin_amdgcn_sqrtf((float)la2);     // needs > 160 m/s^2: rare
+    if (aa2 > R(0.3) * R(0.3)) r = r - (R)__builtin_amdgcn_sqrtf((float)aa2);
+    r_normal = r;
+}
 template <typename R, bool NORM, bool NOISE>
 DN_DEV Observed<R> observe_phase(const DnParams &p, const DnConsts<R> &c, const R *s_tab, const Flight<R> &fl,
                                  const float4 G4, const float4 G5, const unsigned long long gid, const unsigned long long step_count,
                                  Rms &rms)
 {
     Observed<R> ob;
-    const float roll32 = atan2_fast32(fl.roll_num32, fl.roll_den32), pitch32 = fl.pitch32, yaw32 = fl.yaw32;    // attitude_phase (flight wave)
-    const R fwx = fl.fwx, fwy = fl.fwy, fwz = fl.fwz;
-    // _computeObs (PBDroneEnv.py:296-336, :338-398), stale distance d_e (quirk Q1).  The reference clips position /
-    // yaw / distance columns to the float32 range before the cast (:326); positions are bounded by the aviary box
-    // plus one step at the velocity cap, so those clips can never bind and are not evaluated.  clip(v, -3, 3)/3 is
-    // monotone, so it equals clip(float32(v/3), -1, 1) exactly.
-    {
-        float *o = ob.o;
-        const float inv_pi32 = (float)K<R>::INV_PI;
-        o[0] = (float)(fl.px * c.inv_dim[0]);
-        o[1] = (float)(fl.py * c.inv_dim[1]);
-        o[2] = (float)(fl.pz * c.inv_dim[2]);
-        o[3] = roll32 * inv_pi32;
-        o[4] = pitch32 * inv_pi32;
-        o[5] = yaw32 * inv_pi32;
-        const float third32 = (float)K<R>::THIRD;
-        o[6] = clipv((float)((R)fl.vx * K<R>::THIRD), -1.0f, 1.0f);
-        o[7] = clipv((float)((R)fl.vy * K<R>::THIRD), -1.0f, 1.0f);
-        o[8] = clipv((float)((R)fl.vz * K<R>::THIRD), -third32, third32);
-        const R w2 = FM<R>::fma((R)fl.wz, (R)fl.wz, FM<R>::fma((R)fl.wy, (R)fl.wy, (R)fl.wx * (R)fl.wx));   // explicit order, see attitude_phase
-        if (w2 != R(0.0)) {                                   // ang_v / |ang_v|, zero stays zero (:383-384)
-            const R rw = FM<R>::rsq_f32grade(w2);
-            o[9] = (float)((R)fl.wx * rw); o[10] = (float)((R)fl.wy * rw); o[11] = (float)((R)fl.wz * rw);
-        } else { o[9] = fl.wx; o[10] = fl.wy; o[11] = fl.wz; }
-        o[12] = p.include_distance ? (float)((R)fl.d_e * c.inv_max_target_dist) : 0.0f;
-    }
-    // _computeReward (PBDroneEnv.py:475-571): both value branches; report_phase selects once the verdict is in.
-    // The orientation term is evaluated once, against the waypoint the taken branch refers to.
-    {
-        const bool found_now = (R)fl.d_e <= c.threshold;
-        const bool last_gate = fl.idx_e + 1 == p.num_waypoints;
-        const int idx_ori = (found_now && !last_gate) ? fl.idx_e + 1 : fl.idx_e;
-        const int ori = orientation_reward<R>(fwx, fwy, fwz, fl.px, fl.py, fl.pz, s_tab + idx_ori * DN_T_STRIDE);
-        float r32 = 0.0f;
-        if (last_gate) r32 = r32 + 200.0f;                                        // :542-546
-        else { r32 = r32 + 75.0f; r32 = r32 + (float)(ori * 5); }                 // :548-552
-        ob.r_found32 = r32;
-        // :555 3 e^{-2d} (v_exp_f32: 1e-7 rel, 1e-8 in the reward) + :556
-        const R gain = fl.just_found_e ? R(0.0) : ((R)fl.dprev_e - (R)fl.d_e) * R(3000.0);
-        R r = FM<R>::fma(R(3.0), (R)__builtin_amdgcn_exp2f((float)(R(-2.0 * 1.4426950408889634) * (R)fl.d_e)), gain);
-        r = r + (R)(ori * 3);                                                     // :557
-        // smoothness_reward (:599-607) on the stale post-step copies (quirk Q4): -|dv| if |dv| > 0.7, -|dw| if > 0.3
-        const R lx = (R)fl.vex - (R)G4.x, ly = (R)fl.vey - (R)G4.y, lz = (R)fl.vez - (R)G4.z;
-        const R ax_ = (R)fl.aex - (R)G5.x, ay_ = (R)fl.aey - (R)G5.y, az_ = (R)fl.aez - (R)G5.z;
-        const R la2 = FM<R>::fma(lz, lz, FM<R>::fma(ly, ly, lx * lx)), aa2 = FM<R>::fma(az_, az_, FM<R>::fma(ay_, ay_, ax_ * ax_));
-        // the penalties enter the reward at 1/25: a float32 root (1e-7 relative) is far inside the reward's 1e-5 bar
-        if (la2 > R(0.7) * R(0.7)) r = r - (R)__builtin_amdgcn_sqrtf((float)la2);     // needs > 160 m/s^2: rare
-        if (aa2 > R(0.3) * R(0.3)) r = r - (R)__builtin_amdgcn_sqrtf((float)aa2);
-        ob.r_normal = r;
-    }
+    observe_columns<R>(p, c, fl, ob.o);
+    reward_candidates<R>(p, c, s_tab, fl, G4, G5, ob.r_normal, ob.r_found32);
     // sensor noise / per-drone normaliser act on the step observation (which is also terminal_observation)
     if (NOISE && p.obs_noise_sigma > 0.0f) add_obs_noise(p, gid, step_count, 1u, ob.o);
     if (NORM) normalize_obs(rms, ob.o);
@@ -1190,11 +1281,13 @@ DN_DEV void store_obs_direct(float *row, const float o[DN_OBS_DIM])
     *reinterpret_cast<ObsQuad *>(row + 8) = ObsQuad{o[8], o[9], o[10], o[11]};
     row[12] = o[12];
 }
-template <typename R, bool NORM, bool NOISE, bool REW, int TILE = 0>
-DN_DEV void report_phase(const DnParams &p, const DnConsts<R> &c, float *s_tile, const StepOut &out, const Flight<R> &fl,
-                         const Verdict<R> &v, Observed<R> &ob, const unsigned long long gid, const unsigned long long step_count,
-                         const unsigned li, const unsigned lane, const unsigned rows, const bool active,
-                         float4 &G4, float4 &G5, StatAcc &acc, Rms &rms, RewNorm &rn)
+// report_scalars: A7 select + Monitor + episode statistics + the scalar outputs; report_obs: the observation row(s) of
+// the step -- terminal_observation and the reset observation of a finished drone (quirk Q2), sensor noise, normaliser.
+// The two share only the verdict, so a kernel may run them on two waves; report_phase = both on one.
+template <typename R, bool REW>
+DN_DEV void report_scalars(const DnParams &p, const DnConsts<R> &c, const StepOut &out, const Flight<R> &fl, const Verdict<R> &v,
+                           const R r_normal, const float r_found32, const unsigned li, const unsigned lane, const bool active,
+                           float4 &G4, float4 &G5, StatAcc &acc, RewNorm &rn)
 {
     const bool coll1 = v.coll1 != 0, terminated = v.terminated != 0, truncated = fl.truncated != 0;
     const bool found_now = !coll1 && (R)fl.d_e <= c.threshold;
@@ -1203,8 +1296,8 @@ DN_DEV void report_phase(const DnParams &p, const DnConsts<R> &c, float *s_tile,
     const bool done = terminated || truncated;
     R reward;
     if (coll1) reward = R(-10.0);                                                 // :489-490
-    else if (found_now) reward = (R)(ob.r_found32 / 25.0f);                       // :568-571
-    else reward = ob.r_normal * K<R>::INV_25;
+    else if (found_now) reward = (R)(r_found32 / 25.0f);                          // :568-571
+    else reward = r_normal * K<R>::INV_25;
     if (REW) reward = (R)reward_wrappers(p, rn, (double)reward, done);       // --clip_rew / --norm_rew (compiled out otherwise)
     const R epret_e = G4.w;
     const int eplen_e = __float_as_int(G5.w);
@@ -1216,22 +1309,14 @@ DN_DEV void report_phase(const DnParams &p, const DnConsts<R> &c, float *s_tile,
         S4 = make_float4(fl.vex, fl.vey, fl.vez, 0.0f);
         S5 = make_float4(fl.aex, fl.aey, fl.aez, 0.0f);
     }
-    float *o = ob.o;
     const unsigned long long done_ballot = __ballot(done && active);
     if (done_ballot != 0ull) {                         // wave-uniform: waves without a finished drone skip all of this
         const long long fix = fixed6((double)ep_ret);                             // Monitor 'r' in 1e-6 fixed point
         if (done) {
             if (active) {
-                if (out.terminal_obs) {
-#pragma unroll
-                    for (int k = 0; k < DN_OBS_DIM; ++k) out.terminal_obs[li * DN_OBS_DIM + k] = o[k];
-                }
                 if (out.ep_return) out.ep_return[li] = (float)ep_ret;
                 if (out.ep_length) out.ep_length[li] = ep_len;
             }
-            reset_obs<R>(p, c, v.d_obs, o);                               // BaseAviary.py:318 before :617-658 (Q2)
-            if (NOISE && p.obs_noise_sigma > 0.0f) add_obs_noise(p, gid, step_count, 5u, o);
-            if (NORM) normalize_obs(rms, o);
             S4 = S5 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             ep_ret = R(0.0); ep_len = 0;
         }
@@ -1262,9 +1347,36 @@ DN_DEV void report_phase(const DnParams &p, const DnConsts<R> &c, float *s_tile,
         out.found[li] = found;
     }
     if (out.done_word && lane == 0) *out.done_word = done_ballot;
+}
+template <typename R, bool NORM, bool NOISE, int TILE>
+DN_DEV void report_obs(const DnParams &p, const DnConsts<R> &c, float *s_tile, const StepOut &out, const bool truncated,
+                       const Verdict<R> &v, float *o, const unsigned long long gid, const unsigned long long step_count,
+                       const unsigned li, const unsigned lane, const unsigned rows, const bool active, Rms &rms)
+{
+    const bool done = v.terminated != 0 || truncated;
+    if (__ballot(done && active) != 0ull) {
+        if (done) {
+            if (active && out.terminal_obs) {
+#pragma unroll
+                for (int k = 0; k < DN_OBS_DIM; ++k) out.terminal_obs[li * DN_OBS_DIM + k] = o[k];
+            }
+            reset_obs<R>(p, c, v.d_obs, o);                               // BaseAviary.py:318 before :617-658 (Q2)
+            if (NOISE && p.obs_noise_sigma > 0.0f) add_obs_noise(p, gid, step_count, 5u, o);
+            if (NORM) normalize_obs(rms, o);
+        }
+    }
     if (TILE == 2) { if (active) store_obs_direct(out.obs + li * DN_OBS_DIM, o); }
     else if (TILE == 1) tile_park(s_tile, lane, o);        // streamed out by the caller one step later
     else store_obs_tile(s_tile, out.obs, rows, lane, o);
+}
+template <typename R, bool NORM, bool NOISE, bool REW, int TILE = 0>
+DN_DEV void report_phase(const DnParams &p, const DnConsts<R> &c, float *s_tile, const StepOut &out, const Flight<R> &fl,
+                         const Verdict<R> &v, Observed<R> &ob, const unsigned long long gid, const unsigned long long step_count,
+                         const unsigned li, const unsigned lane, const unsigned rows, const bool active,
+                         float4 &G4, float4 &G5, StatAcc &acc, Rms &rms, RewNorm &rn)
+{
+    report_scalars<R, REW>(p, c, out, fl, v, ob.r_normal, ob.r_found32, li, lane, active, G4, G5, acc, rn);
+    report_obs<R, NORM, NOISE, TILE>(p, c, s_tile, out, fl.truncated != 0, v, ob.o, gid, step_count, li, lane, rows, active, rms);
 }
 
 struct BlockState {

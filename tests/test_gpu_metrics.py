@@ -20,7 +20,7 @@ def test_device_rollout_through_the_metrics_writers(tmp_path):
         pytest.fail("-m gpu tests need a GPU")
     import drl_dronenavigation_amd as pkg
     from drl_dronenavigation_amd import metrics, tracks
-    n, K, max_steps = 2048, 96, 40
+    n, K, max_steps = 2048, 160, 110
     track = tracks.reaching()
     env = pkg.DroneVecEnv(track, n, max_steps=max_steps, normalize_obs=False, device="cuda:0")
     cfg = O.make_config(track.targets(), track.initial_xyzs, track.aviary_dim, circle=False, max_steps=max_steps,
@@ -40,7 +40,7 @@ def test_device_rollout_through_the_metrics_writers(tmp_path):
     got_n = log.add_step(out["done"], out["ep_return"], out["ep_length"], out["found_targets"], out["truncated"])
     for t in range(K):
         log_ref.add_step(ref[t]["done"], ref[t]["ep_ret"], ref[t]["ep_len"], ref[t]["found_targets"], ref[t]["truncated"])
-    assert got_n == len(log_ref.rows) > n          # every drone finished at least once (max_steps = 40 < K)
+    assert got_n == len(log_ref.rows) > n // 2     # bang-bang drones crash within ~100 steps, hovering ones hit max_steps = 110 < K
     key = lambda r: (r[1], r[3], r[4], r[5])       # noqa: E731  (l, found_targets, truncated, drone) -- exact
     assert [key(r) for r in log.rows] == [key(r) for r in log_ref.rows]
     np.testing.assert_allclose([r[0] for r in log.rows], [r[0] for r in log_ref.rows], rtol=1e-5, atol=2e-4)
