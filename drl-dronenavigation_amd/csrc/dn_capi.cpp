@@ -37,6 +37,7 @@ int32_t fail(dn_status st, const char *fmt, ...)
 inline double norm3d(const double v[3]) { return std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
 
 constexpr long long DN_TWO_WAVE_MAX_TILES = 1024;   // 65536 drones: one tile per SIMD
+constexpr long long DN_PQX_MAX_TILES = 1024;        // three-wave single step: while the tiles alone leave SIMDs idle
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -258,14 +259,26 @@ int32_t dn_create(const dn_config *cfg, dn_env **out)
     if (!plain && !cfg->normalize_obs) max_three = DN_TWO_WAVE_MAX_TILES * 3 / 4;
     else if (noisy) max_three = DN_TWO_WAVE_MAX_TILES / 4;
     e->waves_fused = e->blocks <= max_multi ? (e->blocks <= max_three ? 3 : 2) : 1;
-    e->waves_single = 1;
+    // dn_step (one control step per launch) is latency bound: ~2.9 us of launch-to-launch floor that an empty kernel
+    // already pays (profiles/r02_dispatch_floor.txt) plus the dependent instruction stream of the step.  Cutting the step
+    // by dependency over three waves (dn_step_pqx_kernel) shortens that stream while the chip has idle SIMDs; built for the
+    // plain configuration without the ground-contact term.  DN_WAVES_SINGLE=1|3 overrides the pick (sweeps).
+    // Measured (profiles/r02_sweep_single.txt, us per step, one wave / three waves): 32768 drones 6.4 / 4.7, 65536: 7.7 / 6.8,
+    // 98304: 9.5 / 9.8; with the normaliser 32768: 8.7 / 6.8, 49152: 9.5 / 10.9 -> three waves up to 1024 tiles, 512 with the
+    // normaliser's statistics (27 float64 per drone through one wave's loads and stores).
+    const bool pqx_ok = plain && !cfg->ground_contact;
+    e->waves_single = (pqx_ok && e->blocks <= (cfg->normalize_obs ? DN_PQX_MAX_TILES / 2 : DN_PQX_MAX_TILES)) ? 3 : 1;
     if (const char *w = getenv("DN_WAVES")) {
         if (w[0] == '1') e->waves_fused = e->waves_single = 1;
         else if (w[0] == '2') e->waves_fused = e->waves_single = 2;
         else if (w[0] == '3') {
             e->waves_fused = 3;
-            e->waves_single = 1;
+            e->waves_single = pqx_ok ? 3 : 1;
         }
+    }
+    if (const char *w = getenv("DN_WAVES_SINGLE")) {
+        if (w[0] == '1') e->waves_single = 1;
+        else if (w[0] == '3' && pqx_ok) e->waves_single = 3;
     }
     const int drag = cfg->physics == 2 || cfg->physics == 4;
     const Layout L = make_layout(n, cfg->normalize_obs, cfg->norm_rew, drag);
@@ -390,8 +403,8 @@ int32_t dn_step_sampled(dn_env *env, const float *mean, const float *log_std, ui
     io.mean = mean; io.act_out = actions_out; io.logp_out = log_prob_out;
     for (int j = 0; j < 4; ++j) io.log_std[j] = log_std[j];
     io.sample_seed = seed; io.sample_deterministic = deterministic != 0;
-    // the sampling lives in the one-wave single-step kernel
-    DN_HIP(dn_launch_step_many(env->p, io, 1, env->cfg.compute_f32 != 0, 1, (hipStream_t)stream));
+    // the sampling lives in the single-step kernels (one wave, or three waves cut by dependency)
+    DN_HIP(dn_launch_step_many(env->p, io, 1, env->cfg.compute_f32 != 0, env->waves_single == 3 ? 3 : 1, (hipStream_t)stream));
     return DN_OK;
 }
 

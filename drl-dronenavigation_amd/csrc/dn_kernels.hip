@@ -582,6 +582,13 @@ DN_DEV StepOut block_out(const DnStepIO &io, long long tile_base, long long step
     return o;
 }
 
+// "Evaluate this here": the compiler is free to sink pure arithmetic below a workgroup barrier (nothing orders ALU work
+// against s_barrier), which would move work a wave is meant to do WHILE it waits to after the wait.  An empty asm that
+// reads and writes the value pins it to this point of the program.
+DN_DEV void pin(double &x) { asm volatile("" : "+v"(x)); }
+DN_DEV void pin(float &x) { asm volatile("" : "+v"(x)); }
+DN_DEV void pin(bool &x) { int t = x; asm volatile("" : "+v"(t)); x = t != 0; }
+
 // LDS written by some lanes of a wave and read by other lanes of the SAME wave: order the accesses without a
 // workgroup barrier (the observation tile belongs to one wave).
 DN_DEV void wave_lds_sync()
@@ -651,6 +658,12 @@ DN_DEV void stage_table(const DnParams &p, R *s_tab)
 {   // all threads of the workgroup cooperate; the caller's next block barrier publishes the table
     const R *g = table_ptr<R>(p);
     for (unsigned j = threadIdx.x; j < (unsigned)(p.num_waypoints * DN_T_STRIDE); j += blockDim.x) s_tab[j] = g[j];
+}
+template <typename R>
+DN_DEV void stage_table_by(const DnParams &p, R *s_tab, const unsigned tid, const unsigned nthreads)
+{   // the first `nthreads` threads of the workgroup stage it
+    const R *g = table_ptr<R>(p);
+    for (unsigned j = tid; j < (unsigned)(p.num_waypoints * DN_T_STRIDE); j += nthreads) s_tab[j] = g[j];
 }
 
 // Observation of a body that has just been (re)loaded at the spawn pose (BaseAviary.reset -> _computeObs,
@@ -1088,7 +1101,7 @@ DN_DEV Verdict<R> rules_phase(const DnParams &p, const DnConsts<R> &c, const R *
 }
 
 // ---- A5 on the flight wave: the attitude of the post-physics pose as the observation and the reward read it -----
-template <typename R>
+template <typename R, bool EULER = true>      // EULER = false: the forward vector only (a wave that does not pack the observation)
 DN_DEV void attitude_phase(Flight<R> &fl)
 {
     const R qx = fl.qx, qy = fl.qy, qz = fl.qz, qw = fl.qw;
@@ -1114,6 +1127,7 @@ DN_DEV void attitude_phase(Flight<R> &fl)
             fwx = cos(yaw) * cpit; fwy = sin(yaw) * cpit; fwz = sin(pitch);
             pitch32 = (float)pitch; yaw32 = (float)yaw;
         } else {
+            if (EULER) {
             roll_num32 = (float)(R(2.0) * FM<R>::fma(qy, qz, qw * qx));
             roll_den32 = (float)FM<R>::fma(qw, qw, FM<R>::fma(qz, qz, -FM<R>::fma(qx, qx, qy * qy)));   // w^2 - x^2 - y^2 + z^2
             yaw32 = atan2_fast32((float)ys, (float)yc);
@@ -1121,6 +1135,7 @@ DN_DEV void attitude_phase(Flight<R> &fl)
             // of Flight, so pitch = atan2(s, cos pitch) is well conditioned everywhere (tumbling drones sit beyond
             // 72 deg often enough that a float64 asin tail would run on most wave-steps of a bang-bang workload)
             pitch32 = atan2_fast32((float)sarg, __builtin_amdgcn_sqrtf((float)FM<R>::fma(yc, yc, ys * ys)));
+            } else { roll_num32 = 0.0f; roll_den32 = 1.0f; yaw32 = pitch32 = 0.0f; }
             fwx = yc; fwy = ys; fwz = sarg;
         }
     }
@@ -1164,33 +1179,57 @@ DN_DEV void observe_columns(const DnParams &p, const DnConsts<R> &c, const Fligh
     } else { o[9] = fl.wx; o[10] = fl.wy; o[11] = fl.wz; }
     o[12] = p.include_distance ? (float)((R)fl.d_e * c.inv_max_target_dist) : 0.0f;
 }
+// _computeReward (PBDroneEnv.py:475-571), both value branches; report_scalars selects once the verdict is in.
+// reward_entry: the terms that read the ENTRY state only (distance gain, 3 e^{-2d}, smoothness penalties on the stale
+// velocity copies); reward_pose: the orientation term on the new pose and the assembly, in the reference's order of
+// additions.  reward_candidates = the two back to back (a kernel may evaluate the first while the pose is being computed).
+template <typename R> struct RewardPre {
+    R r0;                  // 3 e^{-2d} + 3000 (d_prev - d)                                   :555-556
+    R s_lin, s_ang;        // |dv|, |dw| where the smoothness penalty applies                  :599-607
+    bool pen_lin, pen_ang, found_now, last_gate;
+};
 template <typename R>
-DN_DEV void reward_candidates(const DnParams &p, const DnConsts<R> &c, const R *s_tab, const Flight<R> &fl, const float4 G4,
-                              const float4 G5, R &r_normal, float &r_found32)
+DN_DEV RewardPre<R> reward_entry(const DnParams &p, const DnConsts<R> &c, const Flight<R> &fl, const float4 G4, const float4 G5)
 {
-    const R fwx = fl.fwx, fwy = fl.fwy, fwz = fl.fwz;
-    // _computeReward (PBDroneEnv.py:475-571): both value branches; report_phase selects once the verdict is in.
-    // The orientation term is evaluated once, against the waypoint the taken branch refers to.
-    const bool found_now = (R)fl.d_e <= c.threshold;
-    const bool last_gate = fl.idx_e + 1 == p.num_waypoints;
-    const int idx_ori = (found_now && !last_gate) ? fl.idx_e + 1 : fl.idx_e;
-    const int ori = orientation_reward<R>(fwx, fwy, fwz, fl.px, fl.py, fl.pz, s_tab + idx_ori * DN_T_STRIDE);
-    float r32 = 0.0f;
-    if (last_gate) r32 = r32 + 200.0f;                                        // :542-546
-    else { r32 = r32 + 75.0f; r32 = r32 + (float)(ori * 5); }                 // :548-552
-    r_found32 = r32;
+    RewardPre<R> q;
+    q.found_now = (R)fl.d_e <= c.threshold;
+    q.last_gate = fl.idx_e + 1 == p.num_waypoints;
     // :555 3 e^{-2d} (v_exp_f32: 1e-7 rel, 1e-8 in the reward) + :556
     const R gain = fl.just_found_e ? R(0.0) : ((R)fl.dprev_e - (R)fl.d_e) * R(3000.0);
-    R r = FM<R>::fma(R(3.0), (R)__builtin_amdgcn_exp2f((float)(R(-2.0 * 1.4426950408889634) * (R)fl.d_e)), gain);
-    r = r + (R)(ori * 3);                                                     // :557
+    q.r0 = FM<R>::fma(R(3.0), (R)__builtin_amdgcn_exp2f((float)(R(-2.0 * 1.4426950408889634) * (R)fl.d_e)), gain);
     // smoothness_reward (:599-607) on the stale post-step copies (quirk Q4): -|dv| if |dv| > 0.7, -|dw| if > 0.3
     const R lx = (R)fl.vex - (R)G4.x, ly = (R)fl.vey - (R)G4.y, lz = (R)fl.vez - (R)G4.z;
     const R ax_ = (R)fl.aex - (R)G5.x, ay_ = (R)fl.aey - (R)G5.y, az_ = (R)fl.aez - (R)G5.z;
     const R la2 = FM<R>::fma(lz, lz, FM<R>::fma(ly, ly, lx * lx)), aa2 = FM<R>::fma(az_, az_, FM<R>::fma(ay_, ay_, ax_ * ax_));
     // the penalties enter the reward at 1/25: a float32 root (1e-7 relative) is far inside the reward's 1e-5 bar
-    if (la2 > R(0.7) * R(0.7)) r = r - (R)__builtin_amdgcn_sqrtf((float)la2);     // needs > 160 m/s^2: rare
-    if (aa2 > R(0.3) * R(0.3)) r = r - (R)__builtin_amdgcn_sqrtf((float)aa2);
+    q.pen_lin = la2 > R(0.7) * R(0.7);                                            // needs > 160 m/s^2: rare
+    q.pen_ang = aa2 > R(0.3) * R(0.3);
+    q.s_lin = q.s_ang = R(0.0);
+    if (q.pen_lin) q.s_lin = (R)__builtin_amdgcn_sqrtf((float)la2);
+    if (q.pen_ang) q.s_ang = (R)__builtin_amdgcn_sqrtf((float)aa2);
+    return q;
+}
+template <typename R>
+DN_DEV void reward_pose(const DnParams &p, const R *s_tab, const Flight<R> &fl, const RewardPre<R> &q, R &r_normal, float &r_found32)
+{
+    // The orientation term is evaluated once, against the waypoint the taken branch refers to.
+    const int idx_ori = (q.found_now && !q.last_gate) ? fl.idx_e + 1 : fl.idx_e;
+    const int ori = orientation_reward<R>(fl.fwx, fl.fwy, fl.fwz, fl.px, fl.py, fl.pz, s_tab + idx_ori * DN_T_STRIDE);
+    float r32 = 0.0f;
+    if (q.last_gate) r32 = r32 + 200.0f;                                      // :542-546
+    else { r32 = r32 + 75.0f; r32 = r32 + (float)(ori * 5); }                 // :548-552
+    r_found32 = r32;
+    R r = q.r0 + (R)(ori * 3);                                                // :557
+    if (q.pen_lin) r = r - q.s_lin;
+    if (q.pen_ang) r = r - q.s_ang;
     r_normal = r;
+}
+template <typename R>
+DN_DEV void reward_candidates(const DnParams &p, const DnConsts<R> &c, const R *s_tab, const Flight<R> &fl, const float4 G4,
+                              const float4 G5, R &r_normal, float &r_found32)
+{
+    const RewardPre<R> q = reward_entry<R>(p, c, fl, G4, G5);
+    reward_pose<R>(p, s_tab, fl, q, r_normal, r_found32);
 }
 template <typename R, bool NORM, bool NOISE>
 DN_DEV Observed<R> observe_phase(const DnParams &p, const DnConsts<R> &c, const R *s_tab, const Flight<R> &fl,
@@ -1260,6 +1299,17 @@ DN_DEV void flush_stats(const DnParams &p, const StatAcc &a, unsigned long long 
 {
     if (lane == 0) {
         DnStatSlot sl = p.st.stats[blockIdx.x];
+        sl.episodes += a.episodes; sl.truncated += a.truncated; sl.completed += a.completed;
+        sl.sum_len += a.sum_len; sl.sum_found += a.sum_found; sl.sum_ret_fix += a.sum_ret_fix;
+        sl.step_count = steps_after;
+        p.st.stats[blockIdx.x] = sl;
+    }
+}
+// The same with the slot read at the TOP of the kernel (the single-step launches: a read-modify-write at the end would put
+// a whole memory round trip, ~0.5 us, on the tail of a 5 us kernel; the slot belongs to this workgroup alone).
+DN_DEV void flush_stats_preloaded(const DnParams &p, DnStatSlot sl, const StatAcc &a, unsigned long long steps_after, unsigned lane)
+{
+    if (lane == 0) {
         sl.episodes += a.episodes; sl.truncated += a.truncated; sl.completed += a.completed;
         sl.sum_len += a.sum_len; sl.sum_found += a.sum_found; sl.sum_ret_fix += a.sum_ret_fix;
         sl.step_count = steps_after;
@@ -1464,7 +1514,9 @@ __global__ __launch_bounds__(DN_BLOCK) void dn_step_many_1w_kernel(const DnParam
     stage_table<R>(p, s_tab);
     block_lds_barrier();
     const long long n = p.n, words = (p.n + 63) / 64;
-    const unsigned long long sc0 = p.st.stats[blockIdx.x].step_count;      // this tile's vector-step counter
+    DnStatSlot slot0;
+    if (ONE) slot0 = p.st.stats[blockIdx.x];                               // single-step launch: the whole slot now (see flush_stats_preloaded)
+    const unsigned long long sc0 = ONE ? slot0.step_count : p.st.stats[blockIdx.x].step_count;      // this tile's vector-step counter
     if (sampled) A = sample_action(io0, gid, sc0, i, active);
     const R wp0[3] = {s_tab[DN_T_WP], s_tab[DN_T_WP + 1], s_tab[DN_T_WP + 2]};   // waypoint 0: every reset measures against it
     StatAcc acc;
@@ -1489,7 +1541,8 @@ __global__ __launch_bounds__(DN_BLOCK) void dn_step_many_1w_kernel(const DnParam
         report_phase<R, NORM, NOISE, XOPT>(p, c, s_tile, out, fl, v, ob, gid, sc, li, lane, rows, active, G4, G5, acc, rms, rn);
         A = A_next;
     }
-    flush_stats(p, acc, sc0 + (unsigned long long)k_steps, lane);
+    if (ONE) flush_stats_preloaded(p, slot0, acc, sc0 + 1ull, lane);
+    else flush_stats(p, acc, sc0 + (unsigned long long)k_steps, lane);
     if (NORM && active) store_rms(p, i, rms);
     if (XOPT && p.norm_rew && active) store_rewnorm(p, i, rn);
     if (active) {
@@ -1966,6 +2019,158 @@ __global__ __launch_bounds__(3 * DN_BLOCK, NORM ? 2 : 3) void dn_step_many_3w_ke
     }
 }
 
+// -----------------------------------------------------------------------------------------------------
+// Single-step kernel on three waves, cut by DEPENDENCY (dn_step / dn_step_sampled at small fleets).
+//
+// A lone control step has no "previous step" to overlap with, so the skewed pipelines above buy nothing for it; what
+// a step does have is three chains that only meet at three points.  192 threads = three waves over the same 64 drones:
+//
+//   X (thrust, rewards)   [sample] thrust A1-A3 -> tmail  |B1| entry-state reward terms           |B2| forward vector, orientation term
+//                                                                                  |B3| A7 select, Monitor, statistics, scalar outputs; g4 g5
+//   P (position, rules)   loads g0 g1 g2 g3, table        |B1| fz -> physics_linear -> pos, vel -> pmail  |B2| rules_verdict -> vmail
+//                                                                                  |B3| rules_commit; g0 g2 g3.w g6
+//   Q (attitude, obs)     loads g0 g1 g3 [statistics]     |B1| tx ty zt -> physics_angular -> quat -> qmail  |B2| attitude, observation
+//                                                              columns [noise, normaliser]    |B3| terminal / reset observation, obs rows; g1 g3.xyz
+//
+// The linear half of Bullet's step needs only the thrust direction (third column of R), the angular half only the
+// torques: they run side by side, and the collision / gate rules start as soon as the new position exists -- they do not
+// wait for the quaternion update.  Every value is computed by the same device function, with the same spelled-out
+// arithmetic, as in the one-wave kernel: the bits are the same (test_kernel_shapes_are_bit_identical under DN_WAVES=3).
+// Not built for the XOPT options or the ground-contact term (rules would need the new attitude): those keep one wave.
+// -----------------------------------------------------------------------------------------------------
+template <typename R> struct PosMail {
+    R p[3][DN_BLOCK];                     // new position
+    float4 v[DN_BLOCK];                   // new velocity as it goes back to HBM (float32)
+};
+template <typename R> struct VerdictMail {
+    R d_obs[DN_BLOCK];
+    int flags[DN_BLOCK];                  // coll1 | terminated << 1
+};
+template <typename R, bool NORM, bool NOISE, bool SAMPLE>
+__global__ __launch_bounds__(3 * DN_BLOCK) void dn_step_pqx_kernel(const DnParams p, const DnStepIO io0)
+{
+    __shared__ R s_tab[DN_MAX_WAYPOINTS * DN_T_STRIDE];
+    __shared__ __attribute__((aligned(16))) ThrustMail<R> tmail;
+    __shared__ __attribute__((aligned(16))) PosMail<R> pmail;
+    __shared__ R qmail[4][DN_BLOCK];
+    __shared__ VerdictMail<R> vmail;
+    const unsigned lane = threadIdx.x & (DN_BLOCK - 1);
+    const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);       // 0 = P, 1 = Q, 2 = X
+    const long long tile_base = (long long)blockIdx.x * DN_BLOCK;
+    const long long left = p.n - tile_base;
+    const unsigned rows = left < DN_BLOCK ? (unsigned)left : DN_BLOCK;
+    const bool active = lane < rows;
+    const unsigned li = active ? lane : rows - 1;
+    __builtin_assume(li < DN_BLOCK);
+    const long long i = tile_base + li;
+    const unsigned long long gid = (unsigned long long)(p.env_id_offset + i);
+    const BlockState b = block_state(p.st, tile_base);
+    const DnConsts<R> &c = consts<R>(p);
+    const StepOut out = block_out(io0, tile_base, 0, 0);
+    if (role == 2) {
+        // ---- X: the action chain first (nothing else can start without it), the value side of the step last
+        const float4 *act = reinterpret_cast<const float4 *>(io0.actions) + tile_base;
+        float4 A = SAMPLE ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : act[li];
+        const DnStatSlot slot0 = p.st.stats[blockIdx.x];                   // the whole slot now (see flush_stats_preloaded)
+        const unsigned long long sc0 = slot0.step_count;
+        if (SAMPLE) A = sample_action(io0, gid, sc0, i, active);
+        post_thrust<R>(tmail, lane, thrust_phase<NOISE>(p, gid, sc0, A));
+        // the entry state this wave reads is not needed before B2: requested only now, so that the action is the first
+        // word back from memory and nothing queues ahead of it
+        const float4 G0 = b.g0[li], G2 = b.g2[li], G3 = b.g3[li];
+        float4 G4 = b.g4[li], G5 = b.g5[li];
+        block_lds_barrier();                                               // B1: thrust and table published
+        Flight<R> fl;
+        flight_entry<R>(fl, G0, G2, G3, p.max_steps);
+        RewardPre<R> pre = reward_entry<R>(p, c, fl, G4, G5);              // while P and Q integrate
+        pin(pre.r0); pin(pre.s_lin); pin(pre.s_ang); pin(pre.pen_lin); pin(pre.pen_ang);
+        block_lds_barrier();                                               // B2: position and attitude published
+        fl.px = pmail.p[0][lane]; fl.py = pmail.p[1][lane]; fl.pz = pmail.p[2][lane];
+        fl.qx = qmail[0][lane]; fl.qy = qmail[1][lane]; fl.qz = qmail[2][lane]; fl.qw = qmail[3][lane];
+        attitude_phase<R, false>(fl);                                      // the forward vector of the new pose
+        R r_normal;
+        float r_found32;
+        reward_pose<R>(p, s_tab, fl, pre, r_normal, r_found32);
+        pin(r_normal); pin(r_found32);
+        block_lds_barrier();                                               // B3: verdict published
+        Verdict<R> v;
+        v.d_obs = vmail.d_obs[lane];
+        const int vf = vmail.flags[lane];
+        v.coll1 = vf & 1; v.terminated = (vf >> 1) & 1;
+        StatAcc acc;
+        RewNorm rn = {0.0, 0.0, 1.0, 1e-4};
+        report_scalars<R, false>(p, c, out, fl, v, r_normal, r_found32, li, lane, active, G4, G5, acc, rn);
+        flush_stats_preloaded(p, slot0, acc, sc0 + 1ull, lane);
+        if (active) { b.g4[li] = G4; b.g5[li] = G5; }
+    } else if (role == 0) {
+        // ---- P: the linear half of the rigid-body step, then the rules on the new position
+        const float4 G0 = b.g0[li], G1 = b.g1[li], G2 = b.g2[li], G3 = b.g3[li];
+        stage_table_by<R>(p, s_tab, threadIdx.x, 2 * DN_BLOCK);            // P and Q (threads 0..127) stage the table; X is busy with the thrust
+        block_lds_barrier();                                               // B1
+        const GateRow<R> row_e = load_gate_row<R>(s_tab, unpack_meta(G3.w).idx);
+        const R wp0[3] = {s_tab[DN_T_WP], s_tab[DN_T_WP + 1], s_tab[DN_T_WP + 2]};
+        const R fz = tmail.v[0][lane];
+        const Lin<R> lin = physics_linear<R>(G0, G1, G2, fz, R(0.0), R(0.0), R(0.0), false);
+        Flight<R> fl;
+        flight_entry<R>(fl, G0, G2, G3, p.max_steps);
+        fl.px = lin.px; fl.py = lin.py; fl.pz = lin.pz;
+        fl.vx = (float)lin.vx; fl.vy = (float)lin.vy; fl.vz = (float)lin.vz;
+        fl.qx = fl.qy = fl.qz = R(0.0); fl.qw = R(1.0);                    // the attitude belongs to Q (no ground-contact term here)
+        fl.wx = fl.wy = fl.wz = 0.0f;
+        pmail.p[0][lane] = fl.px; pmail.p[1][lane] = fl.py; pmail.p[2][lane] = fl.pz;
+        pmail.v[lane] = make_float4(fl.vx, fl.vy, fl.vz, 0.0f);
+        block_lds_barrier();                                               // B2
+        RulesMid<R> m;
+        const Verdict<R> v = rules_verdict<R>(p, c, s_tab, row_e, fl, G3, m);
+        vmail.d_obs[lane] = v.d_obs;
+        vmail.flags[lane] = v.coll1 | (v.terminated << 1);
+        block_lds_barrier();                                               // B3
+        float4 S0, S1, S2, S3;
+        rules_commit<R>(c, wp0, fl, m, G0, G3, b.g6, li, active, S0, S1, S2, S3);
+        if (active) {
+            b.g0[li] = S0; b.g2[li] = S2;
+            reinterpret_cast<float *>(b.g3 + li)[3] = S3.w;
+        }
+    } else {
+        // ---- Q: the angular half, then everything that reads the attitude
+        const float4 G0 = b.g0[li], G1 = b.g1[li], G3 = b.g3[li];
+        const unsigned long long sc0 = NOISE ? p.st.stats[blockIdx.x].step_count : 0ull;
+        stage_table_by<R>(p, s_tab, threadIdx.x, 2 * DN_BLOCK);            // before the statistics: memory returns in order, and B1 waits for the table
+        Rms rms;
+        if (NORM) load_rms(p, i, rms);
+        block_lds_barrier();                                               // B1
+        const R tx = tmail.v[1][lane], ty = tmail.v[2][lane], zt = tmail.v[3][lane];
+        const Ang<R> ang = physics_angular<R>(G1, G3, tx, ty, zt);
+        qmail[0][lane] = ang.qx; qmail[1][lane] = ang.qy; qmail[2][lane] = ang.qz; qmail[3][lane] = ang.qw;
+        block_lds_barrier();                                               // B2
+        Flight<R> fl;
+        flight_entry<R>(fl, G0, make_float4(0.0f, 0.0f, 0.0f, 0.0f), G3, p.max_steps);     // d_e, truncated: all this wave reads of it
+        fl.px = pmail.p[0][lane]; fl.py = pmail.p[1][lane]; fl.pz = pmail.p[2][lane];
+        const float4 nv = pmail.v[lane];
+        fl.vx = nv.x; fl.vy = nv.y; fl.vz = nv.z;
+        fl.qx = ang.qx; fl.qy = ang.qy; fl.qz = ang.qz; fl.qw = ang.qw;
+        fl.wx = (float)ang.wx; fl.wy = (float)ang.wy; fl.wz = (float)ang.wz;
+        attitude_phase<R>(fl);
+        float o[DN_OBS_DIM];
+        observe_columns<R>(p, c, fl, o);
+        if (NOISE && p.obs_noise_sigma > 0.0f) add_obs_noise(p, gid, sc0, 1u, o);
+        if (NORM) normalize_obs(rms, o);
+        block_lds_barrier();                                               // B3
+        Verdict<R> v;
+        v.d_obs = vmail.d_obs[lane];
+        const int vf = vmail.flags[lane];
+        v.coll1 = vf & 1; v.terminated = (vf >> 1) & 1;
+        report_obs<R, NORM, NOISE, 2>(p, c, nullptr, out, fl.truncated != 0, v, o, gid, sc0, li, lane, rows, active, rms);
+        if (NORM && active) store_rms(p, i, rms);
+        if (active) {
+            const bool done = v.terminated != 0 || fl.truncated != 0;      // the body is reloaded at rest, level (rules_commit's S1 / S3)
+            b.g1[li] = done ? make_float4(0.0f, 0.0f, 0.0f, 1.0f) : make_float4((float)ang.qx, (float)ang.qy, (float)ang.qz, (float)ang.qw);
+            float *g3 = reinterpret_cast<float *>(b.g3 + li);
+            g3[0] = done ? 0.0f : fl.wx; g3[1] = done ? 0.0f : fl.wy; g3[2] = done ? 0.0f : fl.wz;
+        }
+    }
+}
+
 // =====================================================================================================
 // VecEnv.reset(): every drone goes through Monitor.reset / NormalizeObservation.reset / PBDroneEnv.reset.
 // =====================================================================================================
@@ -2232,6 +2437,20 @@ hipError_t dn_launch_step_many_mw(const DnParams &p, const DnStepIO &io, int k, 
 hipError_t dn_launch_step_many(const DnParams &p, const DnStepIO &io, int k, bool f32, int waves, hipStream_t stream)
 {
     const bool norm = p.normalize_obs != 0;
+    if (io.mean && waves == 3) {            // dn_step_sampled on three waves
+        const unsigned grid = (unsigned)((p.n + DN_BLOCK - 1) / DN_BLOCK);
+        const bool noise = p.act_noise_sigma > 0.0f || p.obs_noise_sigma > 0.0f;
+#define DN_LPS(R, NORM, NOISE) hipLaunchKernelGGL((dn_step_pqx_kernel<R, NORM, NOISE, true>), dim3(grid), dim3(3 * DN_BLOCK), 0, stream, p, io)
+        if (f32) {
+            if (norm) { if (noise) DN_LPS(float, true, true); else DN_LPS(float, true, false); }
+            else { if (noise) DN_LPS(float, false, true); else DN_LPS(float, false, false); }
+        } else {
+            if (norm) { if (noise) DN_LPS(double, true, true); else DN_LPS(double, true, false); }
+            else { if (noise) DN_LPS(double, false, true); else DN_LPS(double, false, false); }
+        }
+#undef DN_LPS
+        return hipGetLastError();
+    }
     if (io.mean) {                          // dn_step_sampled: one-wave single-step kernels with the sampler compiled in
         const unsigned grid = (unsigned)((p.n + DN_BLOCK - 1) / DN_BLOCK);
         const bool noise = p.act_noise_sigma > 0.0f || p.obs_noise_sigma > 0.0f;
@@ -2244,6 +2463,20 @@ hipError_t dn_launch_step_many(const DnParams &p, const DnStepIO &io, int k, boo
             else { if (noise) DN_LS(double, false, true); else DN_LS(double, false, false); }
         }
 #undef DN_LS
+        return hipGetLastError();
+    }
+    if (waves == 3 && k == 1) {             // dn_step on three waves cut by dependency (plain configuration; the caller checked)
+        const unsigned grid = (unsigned)((p.n + DN_BLOCK - 1) / DN_BLOCK);
+        const bool noise = p.act_noise_sigma > 0.0f || p.obs_noise_sigma > 0.0f;
+#define DN_LP(R, NORM, NOISE) hipLaunchKernelGGL((dn_step_pqx_kernel<R, NORM, NOISE, false>), dim3(grid), dim3(3 * DN_BLOCK), 0, stream, p, io)
+        if (f32) {
+            if (norm) { if (noise) DN_LP(float, true, true); else DN_LP(float, true, false); }
+            else { if (noise) DN_LP(float, false, true); else DN_LP(float, false, false); }
+        } else {
+            if (norm) { if (noise) DN_LP(double, true, true); else DN_LP(double, true, false); }
+            else { if (noise) DN_LP(double, false, true); else DN_LP(double, false, false); }
+        }
+#undef DN_LP
         return hipGetLastError();
     }
     if ((waves >= 2 && !norm) || (waves == 3 && k > 1)) return dn_launch_step_many_mw(p, io, k, f32, waves, stream);

@@ -629,6 +629,45 @@ def test_kernel_shapes_are_bit_identical(norm, noise, monkeypatch):
         env.close()
 
 
+@pytest.mark.parametrize("norm,noise,n", [(False, 0.0, 1000), (True, 0.0, 4096), (True, 0.01, 200), (False, 0.02, 32768)])
+def test_three_wave_single_step_is_bit_identical(norm, noise, n, monkeypatch):
+    """dn_step on three waves cut by dependency (dn_step_pqx_kernel: thrust + rewards | position + rules | attitude +
+    observation) against the one-wave kernel: every output of every step and the final state, bit for bit, over 150
+    closed-loop steps with crashes, gate passes, truncations and resets, ragged last tile included."""
+    pkg = _gpu()
+    monkeypatch.delenv("DN_WAVES", raising=False)
+    track = _tracks().reaching()
+    kw = dict(normalize_obs=norm, max_steps=40, obs_noise_sigma=noise, act_noise_sigma=noise / 10, seed=11)
+    envs = {}
+    for shape in ("1", "3"):
+        monkeypatch.setenv("DN_WAVES_SINGLE", shape)
+        envs[shape] = pkg.DroneVecEnv(track, n, device="cuda:0", **kw)
+        assert envs[shape].kernel_waves(fused=False) == int(shape)
+    monkeypatch.delenv("DN_WAVES_SINGLE")
+    assert torch.equal(envs["1"].reset_tensor(), envs["3"].reset_tensor())
+    rng = np.random.default_rng(17)
+    dev = torch.device("cuda:0")
+    n_done = 0
+    for t in range(150):
+        a = torch.from_numpy(actions_mixed(rng, n)).to(dev)
+        o1, r1, d1, i1 = envs["1"].step_tensor(a)
+        o3, r3, d3, i3 = envs["3"].step_tensor(a)
+        assert torch.equal(o1, o3) and torch.equal(r1, r3) and torch.equal(d1, d3), t
+        dn = d1.bool()
+        for k in ("truncated", "found_targets", "done_mask"):
+            assert torch.equal(i1[k], i3[k]), (t, k)
+        for k in ("terminal_obs", "ep_return", "ep_length"):
+            assert torch.equal(i1[k][dn], i3[k][dn]), (t, k)
+        n_done += int(dn.sum())
+    assert n_done > n
+    s1, s3 = envs["1"].get_state(), envs["3"].get_state()
+    for k in s1.dtype.names:
+        assert np.ascontiguousarray(s1[k]).tobytes() == np.ascontiguousarray(s3[k]).tobytes(), k
+    assert envs["1"].stats() == envs["3"].stats() and envs["1"].step_count == envs["3"].step_count == 150
+    for e in envs.values():
+        e.close()
+
+
 def _assert_same_rollout(o1, o2, n):
     (f1, r1, s1, st1), (f2, r2, s2, st2) = o1, o2
     for a, b in zip(f1, f2):
