@@ -59,10 +59,10 @@ namespace {
 
 // Device arena: seven float4 groups, optional normaliser statistics, statistics slots, tables.
 struct Layout {
-    size_t off_g[7], off_g7, off_mean, off_var, off_count, off_rr, off_stats, off_tab64, off_tab32, total;
+    size_t off_g[7], off_g7, off_mean, off_var, off_count, off_rr, off_pid, off_stats, off_tab64, off_tab32, total;
 };
 
-Layout make_layout(long long n, int normalize_obs, int norm_rew = 0, int drag = 0)
+Layout make_layout(long long n, int normalize_obs, int norm_rew = 0, int drag = 0, int pid = 0)
 {
     Layout L;
     size_t o = 0;
@@ -72,6 +72,7 @@ Layout make_layout(long long n, int normalize_obs, int norm_rew = 0, int drag = 
     L.off_count = o; o = align_up(o + (normalize_obs ? (size_t)n * sizeof(double) : 0), 256);
     L.off_rr = o;    o = align_up(o + (norm_rew ? (size_t)n * 4 * sizeof(double) : 0), 256);
     L.off_g7 = o;    o = align_up(o + (drag ? (size_t)n * sizeof(float4) : 0), 256);
+    L.off_pid = o;   o = align_up(o + (pid ? (size_t)n * 9 * sizeof(double) : 0), 256);
     L.off_stats = o; o = align_up(o + (size_t)((n + DN_BLOCK - 1) / DN_BLOCK) * sizeof(DnStatSlot), 256);
     L.off_tab64 = o; o = align_up(o + DN_MAX_WAYPOINTS * DN_T_STRIDE * sizeof(double), 256);
     L.off_tab32 = o; o = align_up(o + DN_MAX_WAYPOINTS * DN_T_STRIDE * sizeof(float), 256);
@@ -145,7 +146,8 @@ int32_t validate(const dn_config *c)
         if (!(c->aviary_dim[3 + j] != 0.0)) return fail(DN_ERR_INVALID_ARGUMENT, "aviary_dim high bounds must be non-zero");
     if (c->act_noise_sigma < 0.0f || c->obs_noise_sigma < 0.0f) return fail(DN_ERR_INVALID_ARGUMENT, "noise sigma must be >= 0");
     if (c->physics < 0 || c->physics > 4) return fail(DN_ERR_INVALID_ARGUMENT, "physics must be 0..4 (PYB, PYB_GND, PYB_DRAG, PYB_DW, PYB_GND_DRAG_DW; got %d)", c->physics);
-    if (c->action_type < 0 || c->action_type > 1) return fail(DN_ERR_INVALID_ARGUMENT, "action_type must be 0 (THRUST) or 1 (RPM) (got %d)", c->action_type);
+    if (c->action_type < 0 || c->action_type > 5)
+        return fail(DN_ERR_INVALID_ARGUMENT, "action_type must be 0 THRUST | 1 RPM | 2 PID | 3 VEL | 4 ONE_D_RPM | 5 ONE_D_PID (got %d)", c->action_type);
     for (int j = 0; j < c->num_waypoints * 3; ++j)
         if (!std::isfinite(c->waypoints[j])) return fail(DN_ERR_INVALID_ARGUMENT, "waypoint %d is not finite", j / 3);
     return DN_OK;
@@ -177,6 +179,7 @@ int32_t init_state(dn_env *e, hipStream_t s)
         DN_HIP(dn_launch_filld(e->p.st.rr + 3 * n, 1e-4, n, s));       // .count
     }
     if (e->p.drag) DN_HIP(dn_launch_fill4(e->p.st.g7, make_float4(0.f, 0.f, 0.f, 0.f), n, s));   // BaseAviary.py:545
+    if (e->p.pid_mode) DN_HIP(dn_launch_filld(e->p.st.pid, 0.0, 9 * n, s));                       // DSLPIDControl.reset(), DSLPIDControl.py:63-76
     DN_HIP(hipMemsetAsync(e->p.st.stats, 0, (size_t)e->blocks * sizeof(DnStatSlot), s));
     return DN_OK;
 }
@@ -281,7 +284,9 @@ int32_t dn_create(const dn_config *cfg, dn_env **out)
         else if (w[0] == '3' && pqx_ok) e->waves_single = 3;
     }
     const int drag = cfg->physics == 2 || cfg->physics == 4;
-    const Layout L = make_layout(n, cfg->normalize_obs, cfg->norm_rew, drag);
+    const int pid_mode = (cfg->action_type == 2 || cfg->action_type == 3 || cfg->action_type == 5) ? cfg->action_type : 0;
+    if (pid_mode) e->waves_fused = e->waves_single = 1;      // the controller reads the step's entry state: one-wave kernels (dn_kernels.hip, PidCtx)
+    const Layout L = make_layout(n, cfg->normalize_obs, cfg->norm_rew, drag, pid_mode);
     hipError_t he = hipMalloc(&e->arena, L.total);
     if (he != hipSuccess) {
         delete e;
@@ -300,6 +305,7 @@ int32_t dn_create(const dn_config *cfg, dn_env **out)
     p.st.rms_var = (double *)(base + L.off_var);
     p.st.rms_count = (double *)(base + L.off_count);
     p.st.rr = (double *)(base + L.off_rr);
+    p.st.pid = pid_mode ? (double *)(base + L.off_pid) : nullptr;
     p.st.stats = (DnStatSlot *)(base + L.off_stats);
     e->tab64 = (double *)(base + L.off_tab64);
     e->tab32 = (float *)(base + L.off_tab32);
@@ -312,7 +318,8 @@ int32_t dn_create(const dn_config *cfg, dn_env **out)
     p.normalize_actions = cfg->normalize_actions != 0; p.normalize_obs = cfg->normalize_obs != 0;
     p.ground_contact = cfg->ground_contact != 0;
     p.clip_rew = cfg->clip_rew != 0; p.norm_rew = cfg->norm_rew != 0;
-    p.gnd = cfg->physics == 1 || cfg->physics == 4; p.drag = drag; p.rpm_actions = cfg->action_type == 1;
+    p.gnd = cfg->physics == 1 || cfg->physics == 4; p.drag = drag; p.rpm_actions = cfg->action_type == 1 ? 1 : (cfg->action_type == 4 ? 2 : 0);
+    p.pid_mode = pid_mode;
     p.act_noise_sigma = cfg->act_noise_sigma; p.obs_noise_sigma = cfg->obs_noise_sigma;
     p.seed = cfg->seed; p.env_id_offset = cfg->env_id_offset;
     build_consts<double>(*cfg, p.c64);
@@ -494,9 +501,15 @@ int32_t dn_get_state(dn_env *env, dn_env_state *states, int64_t count)
         g7.resize((size_t)n);
         DN_HIP(hipMemcpy(g7.data(), env->p.st.g7, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost));
     }
+    std::vector<double> pid;
+    if (env->p.pid_mode) {
+        pid.resize((size_t)n * 9);
+        DN_HIP(hipMemcpy(pid.data(), env->p.st.pid, pid.size() * sizeof(double), hipMemcpyDeviceToHost));
+    }
     for (long long i = 0; i < n; ++i) {
         dn_env_state &s = states[i];
         memset(&s, 0, sizeof s);
+        if (env->p.pid_mode) for (int k = 0; k < 9; ++k) s.pid[k] = pid[(size_t)k * n + i];
         if (env->p.drag) { s.last_rpm[0] = g7[(size_t)i].x; s.last_rpm[1] = g7[(size_t)i].y; s.last_rpm[2] = g7[(size_t)i].z; s.last_rpm[3] = g7[(size_t)i].w; }
         if (env->cfg.norm_rew) { s.rr_returns = rr[(size_t)i]; s.rr_mean = rr[(size_t)n + i]; s.rr_var = rr[(size_t)2 * n + i]; s.rr_count = rr[(size_t)3 * n + i]; }
         s.pos[0] = g[0][i].x; s.pos[1] = g[0][i].y; s.pos[2] = g[0][i].z; s.d = g[0][i].w;
@@ -533,8 +546,11 @@ int32_t dn_set_state(dn_env *env, const dn_env_state *states, int64_t count)
     if (env->cfg.norm_rew) rr.resize((size_t)n * 4);
     std::vector<float4> g7;
     if (env->p.drag) g7.resize((size_t)n);
+    std::vector<double> pid;
+    if (env->p.pid_mode) pid.resize((size_t)n * 9);
     for (long long i = 0; i < n; ++i) {
         const dn_env_state &s = states[i];
+        if (env->p.pid_mode) for (int k = 0; k < 9; ++k) pid[(size_t)k * n + i] = s.pid[k];
         if (env->p.drag) g7[(size_t)i] = make_float4(s.last_rpm[0], s.last_rpm[1], s.last_rpm[2], s.last_rpm[3]);
         if (env->cfg.norm_rew) { rr[(size_t)i] = s.rr_returns; rr[(size_t)n + i] = s.rr_mean; rr[(size_t)2 * n + i] = s.rr_var; rr[(size_t)3 * n + i] = s.rr_count; }
         if (s.idx < 0 || s.idx >= env->cfg.num_waypoints || s.steps < 0 || s.steps > (1 << 24) - 1)
@@ -568,6 +584,7 @@ int32_t dn_set_state(dn_env *env, const dn_env_state *states, int64_t count)
     }
     if (env->cfg.norm_rew) DN_HIP(hipMemcpy(env->p.st.rr, rr.data(), rr.size() * sizeof(double), hipMemcpyHostToDevice));
     if (env->p.drag) DN_HIP(hipMemcpy(env->p.st.g7, g7.data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice));
+    if (env->p.pid_mode) DN_HIP(hipMemcpy(env->p.st.pid, pid.data(), pid.size() * sizeof(double), hipMemcpyHostToDevice));
     return DN_OK;
 }
 

@@ -53,6 +53,7 @@ struct DnState {
     double *rms_var;    // [13][N]
     double *rms_count;  // [N]
     double *rr;         // [4][N]  NormalizeReward: returns, return_rms.mean, .var, .count (norm_rew only)
+    double *pid;        // [9][N]  DSLPIDControl: integral_pos_e, last_rpy, integral_rpy_e (action types PID / VEL / ONE_D_PID only)
     DnStatSlot *stats;  // [ceil(N/64)]
 };
 
@@ -96,7 +97,8 @@ struct DnParams {
     int num_waypoints;
     int max_steps;
     int circle, cylinder, include_distance, normalize_actions, normalize_obs, ground_contact, clip_rew, norm_rew;
-    int gnd, drag, rpm_actions;     // N4: Physics.PYB_GND / PYB_DRAG force terms, ActionType.RPM
+    int gnd, drag, rpm_actions;     // N4: Physics.PYB_GND / PYB_DRAG force terms, ActionType.RPM (1) / ONE_D_RPM (2)
+    int pid_mode;                   // N4: 0, or the dn_config.action_type of the DSLPIDControl family: 2 PID | 3 VEL | 5 ONE_D_PID
     float act_noise_sigma, obs_noise_sigma;
     unsigned long long seed;
     long long env_id_offset;

@@ -727,22 +727,155 @@ template <typename R> struct Verdict {
     int terminated;    // _computeTerminated of BaseAviary.step (advanced index, _is_done)
 };
 
+// ---- N4: ActionType.PID / VEL / ONE_D_PID -- BaseSingleAgentAviary._preprocessAction (BaseSingleAgentAviary.py:180-222)
+// around DSLPIDControl.computeControl (Sol/PyBullet/DSLPIDControl.py:78-262), float64 as numpy evaluates it, one controller per
+// drone.  st = integral_pos_e[3], last_rpy[3], integral_rpy_e[3]: resident in registers for the launch, never reset (the
+// reference calls ctrl.reset() only from DSLPIDControl.__init__).  The controller reads the ENTRY state of the step
+// (_getDroneStateVector before p.stepSimulation), so these action types run on the one-wave kernels, where the thrust is
+// computed in the step it belongs to.  Unreachable in the reference (PBDroneEnv overrides _preprocessAction); the libm
+// calls are left literal.
+struct PidCtx {
+    float4 G0, G1, G2;     // entry pos, quat, vel
+    double *st;            // 9 doubles, in registers
+};
+DN_DEV void euler_from_quat64(const double q[4], double rpy[3])
+{   // p.getEulerFromQuaternion [3P-recall of pybullet.c]
+    const double sqx = q[0] * q[0], sqy = q[1] * q[1], sqz = q[2] * q[2], squ = q[3] * q[3];
+    const double sarg = -2.0 * (q[0] * q[2] - q[3] * q[1]);
+    if (sarg <= -0.99999) { rpy[0] = 0.0; rpy[1] = -0.5 * 3.14159265358979323846; rpy[2] = 2.0 * atan2(q[0], -q[1]); }
+    else if (sarg >= 0.99999) { rpy[0] = 0.0; rpy[1] = 0.5 * 3.14159265358979323846; rpy[2] = 2.0 * atan2(-q[0], q[1]); }
+    else {
+        rpy[0] = atan2(2.0 * (q[1] * q[2] + q[3] * q[0]), squ - sqx - sqy + sqz);
+        rpy[1] = asin(sarg);
+        rpy[2] = atan2(2.0 * (q[0] * q[1] + q[3] * q[2]), squ + sqx - sqy - sqz);
+    }
+}
+DN_DEV void pid_control64(const int mode, const PidCtx &cx, const float cmd[4], double rpm[4])
+{
+    const double dt = 1.0 / 240.0;                             // CTRL_TIMESTEP
+    const double pos[3] = {cx.G0.x, cx.G0.y, cx.G0.z}, quat[4] = {cx.G1.x, cx.G1.y, cx.G1.z, cx.G1.w}, vel[3] = {cx.G2.x, cx.G2.y, cx.G2.z};
+    double *st = cx.st;
+    double target_pos[3], target_vel[3] = {0.0, 0.0, 0.0}, target_yaw = 0.0, rpy[3];
+    euler_from_quat64(quat, rpy);
+    if (mode == 2) {                                           // PID: _calculateNextStep(pos, action, 1), BaseAviary.py:1255-1298
+        const double dir[3] = {(double)cmd[0] - pos[0], (double)cmd[1] - pos[1], (double)cmd[2] - pos[2]};
+        const double dist = sqrt(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) target_pos[k] = dist <= 1.0 ? (double)cmd[k] : pos[k] + dir[k] / dist * 1.0;
+    } else if (mode == 3) {                                    // VEL (:195-210): float32 arithmetic on the action array
+        float n2 = cmd[0] * cmd[0];
+        n2 = n2 + cmd[1] * cmd[1];
+        n2 = n2 + cmd[2] * cmd[2];
+        const float n = sqrtf(n2);
+        const float lim = 0.25f * fabsf(cmd[3]);               // SPEED_LIMIT = 0.03 * MAX_SPEED_KMH * (1000 / 3600) = 0.25
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float u = n != 0.0f ? cmd[k] / n : 0.0f;
+            target_vel[k] = (double)(lim * u);
+            target_pos[k] = pos[k];
+        }
+        target_yaw = rpy[2];                                   // target_rpy = (0, 0, state[9])
+    } else {                                                   // ONE_D_PID (:213-221)
+        target_pos[0] = pos[0] + 0.1 * 0.0; target_pos[1] = pos[1] + 0.1 * 0.0;
+        target_pos[2] = pos[2] + 0.1 * (double)cmd[0];
+    }
+    // p.getMatrixFromQuaternion (btMatrix3x3::setRotation)
+    double R[9];
+    {
+        const double x = quat[0], y = quat[1], z = quat[2], w = quat[3];
+        const double d = x * x + y * y + z * z + w * w, sc = 2.0 / d;
+        const double xs = x * sc, ys = y * sc, zs = z * sc, wx = w * xs, wy = w * ys, wz = w * zs;
+        const double xx = x * xs, xy = x * ys, xz = x * zs, yy = y * ys, yz = y * zs, zz = z * zs;
+        R[0] = 1.0 - (yy + zz); R[1] = xy - wz; R[2] = xz + wy;
+        R[3] = xy + wz; R[4] = 1.0 - (xx + zz); R[5] = yz - wx;
+        R[6] = xz - wy; R[7] = yz + wx; R[8] = 1.0 - (xx + yy);
+    }
+    // _dslPIDPositionControl, DSLPIDControl.py:140-199
+    const double Pf[3] = {.4, .4, 1.25}, If[3] = {.05, .05, .05}, Df[3] = {.2, .2, .5};
+    double pos_e[3], vel_e[3], tt[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        pos_e[k] = target_pos[k] - pos[k];
+        vel_e[k] = target_vel[k] - vel[k];
+        st[k] = clipv(st[k] + pos_e[k] * dt, -2.0, 2.0);
+    }
+    st[2] = clipv(st[2], -0.15, 0.15);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) tt[k] = Pf[k] * pos_e[k] + If[k] * st[k] + Df[k] * vel_e[k] + (k == 2 ? 9.8 * 0.027 : 0.0);
+    const double dotz = tt[0] * R[2] + tt[1] * R[5] + tt[2] * R[8];
+    const double scalar_thrust = dotz > 0.0 ? dotz : 0.0;
+    const double thrust = (sqrt(scalar_thrust / (4 * 3.16e-10)) - 4070.3) / 0.2685;
+    const double nt = sqrt(tt[0] * tt[0] + tt[1] * tt[1] + tt[2] * tt[2]);
+    const double z_ax[3] = {tt[0] / nt, tt[1] / nt, tt[2] / nt};
+    const double x_c[3] = {cos(target_yaw), sin(target_yaw), 0.0};
+    double y_ax[3] = {z_ax[1] * x_c[2] - z_ax[2] * x_c[1], z_ax[2] * x_c[0] - z_ax[0] * x_c[2], z_ax[0] * x_c[1] - z_ax[1] * x_c[0]};
+    const double ny = sqrt(y_ax[0] * y_ax[0] + y_ax[1] * y_ax[1] + y_ax[2] * y_ax[2]);
+    y_ax[0] /= ny; y_ax[1] /= ny; y_ax[2] /= ny;
+    const double x_ax[3] = {y_ax[1] * z_ax[2] - y_ax[2] * z_ax[1], y_ax[2] * z_ax[0] - y_ax[0] * z_ax[2], y_ax[0] * z_ax[1] - y_ax[1] * z_ax[0]};
+    // target_rotation = [x_ax y_ax z_ax] (columns); the reference's scipy round trip (as_euler 'XYZ' -> from_euler -> as_quat ->
+    // from_quat -> as_matrix, :196, :236-238) returns the same rotation to rounding
+    const double Rt[9] = {x_ax[0], y_ax[0], z_ax[0], x_ax[1], y_ax[1], z_ax[1], x_ax[2], y_ax[2], z_ax[2]};
+    // _dslPIDAttitudeControl, :203-262: rot_matrix_e = Rt^T Rc - Rc^T Rt, rot_e = (e[2,1], e[0,2], e[1,0])
+    double A[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) A[3 * i + j] = Rt[i] * R[j] + Rt[3 + i] * R[3 + j] + Rt[6 + i] * R[6 + j];
+    const double rot_e[3] = {A[7] - A[5], A[2] - A[6], A[3] - A[1]};
+    const double Pt[3] = {70000., 70000., 60000.}, It[3] = {.0, .0, 500.}, Dt[3] = {20000., 20000., 12000.};
+    double tq[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double rate_e = 0.0 - (rpy[k] - st[3 + k]) / dt;
+        st[3 + k] = rpy[k];
+        st[6 + k] = clipv(st[6 + k] - rot_e[k] * dt, -1500.0, 1500.0);
+        if (k < 2) st[6 + k] = clipv(st[6 + k], -1.0, 1.0);
+        tq[k] = clipv(-(Pt[k] * rot_e[k]) + Dt[k] * rate_e + It[k] * st[6 + k], -3200.0, 3200.0);
+    }
+    const double MIX[4][3] = {{-.5, -.5, -1}, {-.5, .5, 1}, {.5, .5, -1}, {.5, -.5, 1}};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        double pwm = thrust + (MIX[i][0] * tq[0] + MIX[i][1] * tq[1] + MIX[i][2] * tq[2]);
+        pwm = clipv(pwm, 20000.0, 65535.0);
+        rpm[i] = 0.2685 * pwm + 4070.3;
+    }
+}
+
 struct ThrustX {       // XOPT kernels: float64 carriers (ActionType.RPM works in float64) + the rpm for the extra terms
     double f[4];
     double zt;
 };
 template <bool NOISE>
-DN_DEV ThrustX thrust_phase_x(const DnParams &p, unsigned long long gid, unsigned long long step_count, const float4 A, Extras &x)
+DN_DEV ThrustX thrust_phase_x(const DnParams &p, unsigned long long gid, unsigned long long step_count, const float4 A, Extras &x,
+                              const PidCtx *pid = nullptr)
 {
     float a[4] = {A.x, A.y, A.z, A.w};
     if (NOISE && p.act_noise_sigma > 0.0f) add_act_noise(p, gid, step_count, a);
     ThrustX t;
-    x.gnd = p.gnd; x.drag = p.drag; x.rpm_f32 = !p.rpm_actions;
-    if (p.rpm_actions) {   // BaseSingleAgentAviary._preprocessAction, ActionType.RPM (BaseSingleAgentAviary.py:176-179)
+    x.gnd = p.gnd; x.drag = p.drag; x.rpm_f32 = !p.rpm_actions && !p.pid_mode;
+    if (pid && p.pid_mode) {   // ActionType.PID / VEL / ONE_D_PID: the DSLPIDControl loop on the entry state
+        float cmd[4];
+        double rpm[4], tq[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cmd[j] = p.normalize_actions ? rescale_action32(a[j]) : a[j];   // PBDroneEnv.step, :173-176
+        pid_control64(p.pid_mode, *pid, cmd, rpm);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const double sq = rpm[j] * rpm[j];              // BaseAviary._physics on a float64 rpm array, BaseAviary.py:776-780
+            x.rpm[j] = rpm[j];
+            t.f[j] = sq * 3.16e-10;
+            tq[j] = sq * 7.94e-12;
+        }
+        double z = -tq[0];
+        z = z + tq[1];
+        z = z - tq[2];
+        t.zt = z + tq[3];
+    } else if (p.rpm_actions) {   // BaseSingleAgentAviary._preprocessAction, ActionType.RPM / ONE_D_RPM (BaseSingleAgentAviary.py:176-179, :211-212)
         double tq[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float cmd = p.normalize_actions ? rescale_action32(a[j]) : a[j];   // PBDroneEnv.step, :173-176
+            const float aj = p.rpm_actions == 2 ? a[0] : a[j];                       // ONE_D_RPM: np.repeat(.., 4)
+            const float cmd = p.normalize_actions ? rescale_action32(aj) : aj;       // PBDroneEnv.step, :173-176
             const float s = 0.05f * cmd;
             const float u = 1.0f + s;
             const double rpm = HOVER_RPM * (double)u;       // np.float64 scalar (x) float32 array
@@ -1444,12 +1577,14 @@ DN_DEV BlockState block_state(const DnState &st, long long tile_base)
 // thrust + physics of one step; the XOPT kernels take the float64 carriers and the optional force terms (N4)
 template <typename R, bool NOISE, bool XOPT>
 DN_DEV Flight<R> fly(const DnParams &p, unsigned long long gid, unsigned long long sc, const float4 A, const float4 G0, const float4 G1,
-                     const float4 G2, const float4 G3, const float4 G7, float4 &rpm_now)
+                     const float4 G2, const float4 G3, const float4 G7, float4 &rpm_now, double *pid_st = nullptr)
 {
     if (XOPT) {
         Extras x;
         x.last = G7;
-        const ThrustX th = thrust_phase_x<NOISE>(p, gid, sc, A, x);
+        PidCtx cx;
+        cx.G0 = G0; cx.G1 = G1; cx.G2 = G2; cx.st = pid_st;
+        const ThrustX th = thrust_phase_x<NOISE>(p, gid, sc, A, x, pid_st ? &cx : nullptr);
         rpm_now = make_float4((float)x.rpm[0], (float)x.rpm[1], (float)x.rpm[2], (float)x.rpm[3]);
         return physics_phase<R, ThrustX, true>(th, G0, G1, G2, G3, p.max_steps, &x);
     }
@@ -1524,6 +1659,11 @@ __global__ __launch_bounds__(DN_BLOCK) void dn_step_many_1w_kernel(const DnParam
     if (NORM) load_rms(p, i, rms);
     RewNorm rn = {0.0, 0.0, 1.0, 1e-4};
     if (XOPT && p.norm_rew) load_rewnorm(p, i, rn);
+    double pid_st[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (XOPT && p.pid_mode) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) pid_st[k] = p.st.pid[(long long)k * p.n + i];
+    }
 #pragma clang loop unroll(disable)
     for (int t = 0; t < k_steps; ++t) {
         // prefetch the next step's action while this step computes
@@ -1532,7 +1672,7 @@ __global__ __launch_bounds__(DN_BLOCK) void dn_step_many_1w_kernel(const DnParam
         const unsigned long long sc = sc0 + (unsigned long long)t;
         float4 rpm_now;
         const GateRow<R> row_e = load_gate_row<R>(s_tab, unpack_meta(G3.w).idx);
-        Flight<R> fl = fly<R, NOISE, XOPT>(p, gid, sc, A, G0, G1, G2, G3, G7, rpm_now);
+        Flight<R> fl = fly<R, NOISE, XOPT>(p, gid, sc, A, G0, G1, G2, G3, G7, rpm_now, XOPT ? pid_st : nullptr);
         const float4 G0e = G0, G3e = G3;
         const Verdict<R> v = rules_phase<R>(p, c, s_tab, row_e, wp0, fl, G0e, G3e, b.g6, li, active, G0, G1, G2, G3);
         if (XOPT && p.drag) G7 = (v.terminated || fl.truncated) ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : rpm_now;   // BaseAviary.py:442,545
@@ -1545,6 +1685,10 @@ __global__ __launch_bounds__(DN_BLOCK) void dn_step_many_1w_kernel(const DnParam
     else flush_stats(p, acc, sc0 + (unsigned long long)k_steps, lane);
     if (NORM && active) store_rms(p, i, rms);
     if (XOPT && p.norm_rew && active) store_rewnorm(p, i, rn);
+    if (XOPT && p.pid_mode && active) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) p.st.pid[(long long)k * p.n + i] = pid_st[k];
+    }
     if (active) {
         b.g0[li] = G0; b.g1[li] = G1; b.g2[li] = G2; b.g3[li] = G3; b.g4[li] = G4; b.g5[li] = G5;
         if (XOPT && p.drag) b.g7[li] = G7;
@@ -2410,7 +2554,7 @@ hipError_t dn_launch_step_many_mw(const DnParams &p, const DnStepIO &io, int k, 
     const unsigned grid = (unsigned)((p.n + DN_BLOCK - 1) / DN_BLOCK);
     const bool noise = p.act_noise_sigma > 0.0f || p.obs_noise_sigma > 0.0f;
     // the rarely used options share one set of instantiations (runtime switches inside): reward wrappers, N4 physics terms
-    const bool rew = p.clip_rew != 0 || p.norm_rew != 0 || p.gnd != 0 || p.drag != 0 || p.rpm_actions != 0;
+    const bool rew = p.clip_rew != 0 || p.norm_rew != 0 || p.gnd != 0 || p.drag != 0 || p.rpm_actions != 0 || p.pid_mode != 0;
     if (waves == 3 && k > 1) {                             // three waves per tile: fused launches
         const dim3 blk(3 * DN_BLOCK);
         const bool norm = p.normalize_obs != 0;
@@ -2483,7 +2627,7 @@ hipError_t dn_launch_step_many(const DnParams &p, const DnStepIO &io, int k, boo
     const bool two_wave = waves >= 2;       // with the normaliser: the two-wave kernels (there is no three-wave one)
     const unsigned grid = (unsigned)((p.n + DN_BLOCK - 1) / DN_BLOCK);
     const bool noise = p.act_noise_sigma > 0.0f || p.obs_noise_sigma > 0.0f;
-    const bool rew = p.clip_rew != 0 || p.norm_rew != 0 || p.gnd != 0 || p.drag != 0 || p.rpm_actions != 0;
+    const bool rew = p.clip_rew != 0 || p.norm_rew != 0 || p.gnd != 0 || p.drag != 0 || p.rpm_actions != 0 || p.pid_mode != 0;
     if (two_wave) {                         // normaliser on
         if (f32) { if (noise) DN_LAUNCH(float, true, true); else DN_LAUNCH(float, true, false); }
         else { if (noise) DN_LAUNCH(double, true, true); else DN_LAUNCH(double, true, false); }

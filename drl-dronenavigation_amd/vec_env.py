@@ -41,14 +41,14 @@ ACT_DIM = _capi.ACT_DIM
 # enums.Physics / enums.ActionType values of the reference (Sol/PyBullet/enums.py:12-21, :36-44) -> dn_config codes.
 # The reference only ever runs "pyb" + "thrust" (BaseAviary.py:411 pins the physics); the others are its dormant options.
 PHYSICS = {"pyb": 0, "pyb_gnd": 1, "pyb_drag": 2, "pyb_dw": 3, "pyb_gnd_drag_dw": 4}
-ACTION_TYPES = {"thrust": 0, "rpm": 1}
+ACTION_TYPES = {"thrust": 0, "rpm": 1, "pid": 2, "vel": 3, "one_d_rpm": 4, "one_d_pid": 5}
 
 
 def _enum_value(v):
     v = getattr(v, "value", v)              # accepts the reference's Enum members as well as their string values
     if not isinstance(v, str) or v.lower() not in {**PHYSICS, **ACTION_TYPES}:
         raise ValueError(f"unsupported physics / action type {v!r}: physics one of {sorted(PHYSICS)}, "
-                         f"act one of {sorted(ACTION_TYPES)} (pid / vel / one_d_* need the DSLPIDControl loop, not built)")
+                         f"act one of {sorted(ACTION_TYPES)}")
     return v.lower()
 
 
@@ -456,7 +456,7 @@ STATE_DTYPE = np.dtype([
     ("prev_ang_v", "f4", 3), ("cur_pos", "f4", 3), ("d", "f4"), ("d_prev", "f4"), ("idx", "i4"), ("steps", "i4"),
     ("just_found", "i4"), ("ep_ret", "f4"), ("ep_len", "i4"), ("rms_mean", "f8", OBS_DIM), ("rms_var", "f8", OBS_DIM),
     ("rms_count", "f8"), ("rr_returns", "f8"), ("rr_mean", "f8"), ("rr_var", "f8"), ("rr_count", "f8"),
-    ("last_rpm", "f4", 4)], align=True)
+    ("last_rpm", "f4", 4), ("pid", "f8", 9)], align=True)
 assert STATE_DTYPE.itemsize == C.sizeof(_capi.DnEnvState), (STATE_DTYPE.itemsize, C.sizeof(_capi.DnEnvState))
 
 

@@ -83,7 +83,10 @@ typedef struct dn_config {
                                                    | 2 PYB_DRAG (_drag, :836-862) | 3 PYB_DW (_downwash: other drones of the same world,
                                                    none here -> as PYB) | 4 PYB_GND_DRAG_DW */
     int32_t action_type;                        /* 0 ActionType.THRUST (PBDroneEnv._preprocessAction, PBDroneEnv.py:872-895)
-                                                   | 1 ActionType.RPM (BaseSingleAgentAviary.py:176-179: rpm = HOVER_RPM (1 + 0.05 a)) */
+                                                   | 1 ActionType.RPM (BaseSingleAgentAviary.py:176-179: rpm = HOVER_RPM (1 + 0.05 a))
+                                                   | 2 PID (a[0:3] = destination) | 3 VEL (a[0:3] direction, |a[3]| speed) | 4 ONE_D_RPM (a[0])
+                                                   | 5 ONE_D_PID (a[0]): BaseSingleAgentAviary._preprocessAction (:180-222) with the
+                                                   DSLPIDControl loop (Sol/PyBullet/DSLPIDControl.py) per drone; the action buffer stays [N, 4] */
 } dn_config;
 
 /* One drone's persistent state, host-side AoS view used by dn_get_state/dn_set_state (tests,
@@ -104,6 +107,7 @@ typedef struct dn_env_state {
     double rr_returns;                          /* NormalizeReward.returns (discounted return, norm_rew only)  */
     double rr_mean, rr_var, rr_count;           /* NormalizeReward.return_rms                                  */
     float last_rpm[4];                          /* BaseAviary.last_clipped_action (physics with drag only; zeros otherwise) */
+    double pid[9];                              /* DSLPIDControl.integral_pos_e, .last_rpy, .integral_rpy_e (action types PID / VEL / ONE_D_PID) */
 } dn_env_state;
 
 /* Wave-reduced episode statistics accumulated on the device since dn_create / dn_reset_stats. */

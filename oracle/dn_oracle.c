@@ -377,6 +377,100 @@ void orc_drag(const double quat[4], const double vel[3], const double last_rpm[4
     mat_vec(R, u, out);                                     /* np.dot(base_rot, ...) :853 */
 }
 
+/* ------------------------------------------------------------------------- */
+/* N4 -- ActionType.PID / VEL / ONE_D_RPM / ONE_D_PID: BaseSingleAgentAviary._preprocessAction  */
+/* (BaseSingleAgentAviary.py:180-222) around DSLPIDControl.computeControl                       */
+/* (Sol/PyBullet/DSLPIDControl.py:78-262).  Pinned by tests/golden/pid_control.npz (the          */
+/* reference's own methods; p.getMatrixFromQuaternion / getEulerFromQuaternion are [3P-recall]). */
+/* st = integral_pos_e[3], last_rpy[3], integral_rpy_e[3]; the reference never resets it after   */
+/* construction (ctrl.reset() is only called by DSLPIDControl.__init__).                          */
+/* ------------------------------------------------------------------------- */
+static void cross3(const double a[3], const double b[3], double o[3])
+{
+    o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
+}
+void orc_pid_control(int32_t action_type, const double pos[3], const double quat[4], const double vel[3],
+                     const float action[4], double st[9], double rpm[4])
+{
+    const double dt = ORC_DT;                                  /* CTRL_TIMESTEP = 1 / ctrl_freq */
+    if (action_type == 4) {                                    /* ONE_D_RPM: np.repeat(HOVER_RPM * (1 + 0.05 * action), 4), :211-212 */
+        float s = 0.05f * action[0];
+        float u = 1.0f + s;
+        double r = hover_rpm() * (double)u;
+        rpm[0] = rpm[1] = rpm[2] = rpm[3] = r;
+        return;
+    }
+    double target_pos[3], target_vel[3] = {0.0, 0.0, 0.0}, target_yaw = 0.0;
+    double rpy[3];
+    orc_euler_from_quat(quat, rpy);                            /* state[7:10] and cur_rpy */
+    if (action_type == 2) {                                    /* PID: _calculateNextStep(pos, action, 1), BaseAviary.py:1255-1298 */
+        double dir[3] = {(double)action[0] - pos[0], (double)action[1] - pos[1], (double)action[2] - pos[2]};
+        double dist = norm3(dir);
+        for (int k = 0; k < 3; ++k) target_pos[k] = dist <= 1.0 ? (double)action[k] : pos[k] + dir[k] / dist * 1.0;
+    } else if (action_type == 3) {                             /* VEL, :195-210: float32 arithmetic on the action array */
+        float n2 = action[0] * action[0];
+        n2 = n2 + action[1] * action[1];
+        n2 = n2 + action[2] * action[2];
+        float n = sqrtf(n2);
+        float lim = 0.25f * fabsf(action[3]);                  /* SPEED_LIMIT = 0.03 * MAX_SPEED_KMH * (1000/3600) = 0.25 */
+        for (int k = 0; k < 3; ++k) {
+            float u = n != 0.0f ? action[k] / n : 0.0f;
+            target_vel[k] = (double)(lim * u);
+            target_pos[k] = pos[k];
+        }
+        target_yaw = rpy[2];                                   /* target_rpy = (0, 0, state[9]) */
+    } else {                                                   /* ONE_D_PID, :213-221: state[0:3] + 0.1 * np.array([0, 0, action[0]]) */
+        target_pos[0] = pos[0] + 0.1 * 0.0; target_pos[1] = pos[1] + 0.1 * 0.0;
+        target_pos[2] = pos[2] + 0.1 * (double)action[0];
+    }
+    /* _dslPIDPositionControl, DSLPIDControl.py:140-199 */
+    double R[9];
+    quat_to_mat(quat, R);                                      /* p.getMatrixFromQuaternion */
+    const double Pf[3] = {.4, .4, 1.25}, If[3] = {.05, .05, .05}, Df[3] = {.2, .2, .5};
+    double pos_e[3], vel_e[3], tt[3];
+    for (int k = 0; k < 3; ++k) {
+        pos_e[k] = target_pos[k] - pos[k];
+        vel_e[k] = target_vel[k] - vel[k];
+        st[k] = clipd(st[k] + pos_e[k] * dt, -2.0, 2.0);
+    }
+    st[2] = clipd(st[2], -0.15, 0.15);
+    for (int k = 0; k < 3; ++k) tt[k] = Pf[k] * pos_e[k] + If[k] * st[k] + Df[k] * vel_e[k] + (k == 2 ? ORC_GRAVITY : 0.0);
+    double dotz = tt[0] * R[2] + tt[1] * R[5] + tt[2] * R[8];
+    double scalar_thrust = dotz > 0.0 ? dotz : 0.0;
+    double thrust = (sqrt(scalar_thrust / (4 * ORC_KF)) - ORC_PWM2RPM_CONST) / ORC_PWM2RPM_SCALE;
+    double nt = norm3(tt);
+    double z_ax[3] = {tt[0] / nt, tt[1] / nt, tt[2] / nt};
+    double x_c[3] = {cos(target_yaw), sin(target_yaw), 0.0};
+    double y_ax[3], x_ax[3];
+    cross3(z_ax, x_c, y_ax);
+    double ny = norm3(y_ax);
+    y_ax[0] /= ny; y_ax[1] /= ny; y_ax[2] /= ny;
+    cross3(y_ax, z_ax, x_ax);
+    /* target_rotation = [x_ax y_ax z_ax] (columns).  The reference sends it through scipy: as_euler('XYZ') -> from_euler ->
+     * as_quat -> from_quat -> as_matrix (:196, :236-238), a round trip that returns the same rotation to rounding. */
+    double Rt[9] = {x_ax[0], y_ax[0], z_ax[0], x_ax[1], y_ax[1], z_ax[1], x_ax[2], y_ax[2], z_ax[2]};
+    /* _dslPIDAttitudeControl, :203-262: rot_matrix_e = Rt^T Rc - Rc^T Rt, rot_e = (e[2,1], e[0,2], e[1,0]) */
+    double A[9];                                               /* A = Rt^T Rc; then e = A - A^T */
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) A[3 * i + j] = Rt[i] * R[j] + Rt[3 + i] * R[3 + j] + Rt[6 + i] * R[6 + j];
+    double rot_e[3] = {A[7] - A[5], A[2] - A[6], A[3] - A[1]};
+    const double Pt[3] = {70000., 70000., 60000.}, It[3] = {.0, .0, 500.}, Dt[3] = {20000., 20000., 12000.};
+    double tq[3];
+    for (int k = 0; k < 3; ++k) {
+        double rate_e = 0.0 - (rpy[k] - st[3 + k]) / dt;
+        st[3 + k] = rpy[k];
+        st[6 + k] = clipd(st[6 + k] - rot_e[k] * dt, -1500.0, 1500.0);
+        if (k < 2) st[6 + k] = clipd(st[6 + k], -1.0, 1.0);
+        tq[k] = clipd(-(Pt[k] * rot_e[k]) + Dt[k] * rate_e + It[k] * st[6 + k], -3200.0, 3200.0);
+    }
+    const double MIX[4][3] = {{-.5, -.5, -1}, {-.5, .5, 1}, {.5, .5, -1}, {.5, -.5, 1}};
+    for (int i = 0; i < 4; ++i) {
+        double pwm = thrust + (MIX[i][0] * tq[0] + MIX[i][1] * tq[1] + MIX[i][2] * tq[2]);
+        pwm = clipd(pwm, ORC_MIN_PWM, ORC_MAX_PWM);
+        rpm[i] = ORC_PWM2RPM_SCALE * pwm + ORC_PWM2RPM_CONST;
+    }
+}
+
 static double max_target_dist(const orc_config *c)
 {   /* PBDroneEnv.py:91 */
     double a = fabs(c->dim[0]) + c->dim[3], b = fabs(c->dim[1]) + c->dim[4], z = c->dim[5];
@@ -594,7 +688,19 @@ void orc_env_step(const orc_config *c, orc_env *e, const float action[4], orc_st
     else memcpy(cmd, action, sizeof cmd);
     const int rpm_is_f32 = c->action_type == 0;
     if (c->action_type == 1) orc_rpm_action(cmd, rpm, f, &zt);               /* ActionType.RPM (N4) */
-    else {
+    else if (c->action_type >= 2) {                                          /* PID / VEL / ONE_D_RPM / ONE_D_PID (N4) */
+        double tq[4];
+        orc_pid_control(c->action_type, e->pos, e->quat, e->vel, cmd, e->pid, rpm);
+        for (int i = 0; i < 4; ++i) {                                        /* BaseAviary._physics on a float64 rpm array, :776-780 */
+            double sq = rpm[i] * rpm[i];
+            f[i] = sq * ORC_KF;
+            tq[i] = sq * ORC_KM;
+        }
+        zt = -tq[0];
+        zt = zt + tq[1];
+        zt = zt - tq[2];
+        zt = zt + tq[3];
+    } else {
         orc_preprocess_action(cmd, rpm32);                                   /* BaseAviary.py:408 */
         orc_rotor_forces(rpm32, f32, &zt32);                                 /* :420-421 */
         for (int i = 0; i < 4; ++i) { rpm[i] = rpm32[i]; f[i] = f32[i]; }

@@ -67,7 +67,8 @@ typedef struct orc_config {
      * PBDroneEnv overrides _preprocessAction for ActionType.THRUST only):
      *   physics     0 PYB | 1 PYB_GND | 2 PYB_DRAG | 3 PYB_DW | 4 PYB_GND_DRAG_DW   (enums.py:12-21, BaseAviary.py:412-437;
      *               _downwash sums over OTHER drones of the same Bullet world, NUM_DRONES = 1 -> no force)
-     *   action_type 0 THRUST (PBDroneEnv._preprocessAction) | 1 RPM (BaseSingleAgentAviary.py:176-179) */
+     *   action_type 0 THRUST (PBDroneEnv._preprocessAction) | 1 RPM | 2 PID | 3 VEL | 4 ONE_D_RPM | 5 ONE_D_PID
+     *               (BaseSingleAgentAviary._preprocessAction, BaseSingleAgentAviary.py:176-222) */
     int32_t physics;
     int32_t action_type;
 } orc_config;
@@ -97,6 +98,8 @@ typedef struct orc_env {
     double rr_returns, rr_mean, rr_var, rr_count;
     /* BaseAviary.last_clipped_action (BaseAviary.py:442,545): the rpm of the previous control step, zeros after reset */
     double last_clipped_action[4];
+    /* DSLPIDControl state (ActionType.PID / VEL / ONE_D_PID): integral_pos_e, last_rpy, integral_rpy_e; never reset */
+    double pid[9];
 } orc_env;
 
 /* Result of one gym-level env.step (PBDroneEnv.step), before vectorisation. */
@@ -130,6 +133,10 @@ void orc_ground_effect(const double pos[3], const double quat[4], const double r
 /* BaseAviary._drag (:836-862): forceObj handed to link 4 */
 void orc_drag(const double quat[4], const double vel[3], const double last_rpm[4], int rpm_is_f32, double out[3]);
 void orc_euler_from_quat(const double q[4], double rpy[3]);
+/* ActionType.PID (2) / VEL (3) / ONE_D_RPM (4) / ONE_D_PID (5): BaseSingleAgentAviary._preprocessAction (:180-222) with
+ * DSLPIDControl.computeControl; st[9] = integral_pos_e, last_rpy, integral_rpy_e (python half pinned: pid_control.npz) */
+void orc_pid_control(int32_t action_type, const double pos[3], const double quat[4], const double vel[3],
+                     const float action[4], double st[9], double rpm[4]);
 
 /* ---- A6-A9: gym-level env -------------------------------------------------- */
 void orc_env_construct(const orc_config *cfg, orc_env *e);

@@ -56,6 +56,7 @@ class OrcEnv(C.Structure):
         ("step_count", C.c_uint64),
         ("rr_returns", C.c_double), ("rr_mean", C.c_double), ("rr_var", C.c_double), ("rr_count", C.c_double),
         ("last_clipped_action", C.c_double * 4),
+        ("pid", C.c_double * 9),
     ]
 
 
@@ -75,6 +76,7 @@ ENV_DTYPE = np.dtype([
     ("step_count", "u8"),
     ("rr_returns", "f8"), ("rr_mean", "f8"), ("rr_var", "f8"), ("rr_count", "f8"),
     ("last_clipped_action", "f8", 4),
+    ("pid", "f8", 9),
 ], align=True)
 
 
@@ -111,6 +113,7 @@ def lib():
     L.orc_ground_effect.argtypes = [dp, dp, dp, dp, C.c_int, dp]
     L.orc_drag.argtypes = [dp, dp, dp, C.c_int, dp]
     L.orc_euler_from_quat.argtypes = [dp, dp]
+    L.orc_pid_control.argtypes = [C.c_int32, dp, dp, dp, fp, dp, dp]
     L.orc_env_construct.argtypes = [cfgp, envp]
     L.orc_env_reset.argtypes = [cfgp, envp, fp]
     L.orc_env_step.argtypes = [cfgp, envp, fp, C.POINTER(OrcStepOut)]

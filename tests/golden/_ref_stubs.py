@@ -229,7 +229,15 @@ def install(oracle_lib):
     sys.modules["gym.core"] = core
     sys.modules["gym.spaces"] = spaces
 
-    sys.modules["pkg_resources"] = types.ModuleType("pkg_resources")
+    pkgr = types.ModuleType("pkg_resources")
+
+    def resource_filename(package, rel):
+        # BaseControl._getURDFParameter asks the (absent) gym_pybullet_drones package for assets/cf2x.urdf; the reference
+        # vendors that file as Sol/resources/cf2x.urdf (cwd is the reference root while fixtures are generated)
+        import os
+        return os.path.join("Sol", "resources", os.path.basename(rel))
+    pkgr.resource_filename = resource_filename
+    sys.modules["pkg_resources"] = pkgr
 
     sb3 = types.ModuleType("stable_baselines3")
     sb3c = types.ModuleType("stable_baselines3.common")

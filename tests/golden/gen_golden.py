@@ -458,6 +458,50 @@ def gen_extra_physics(out):
                                 GND_EFF_H_CLIP=np.float64(env.GND_EFF_H_CLIP), HOVER_RPM=np.float64(env.HOVER_RPM), **res)
 
 
+def gen_pid_control(out):
+    """N4: ActionType.PID / VEL / ONE_D_RPM / ONE_D_PID (BaseSingleAgentAviary._preprocessAction, BaseSingleAgentAviary.py:176-222)
+    with the DSLPIDControl loop (Sol/PyBullet/DSLPIDControl.py) -- the reference's own methods, called unbound on a
+    PBDroneEnv whose ACT_TYPE is switched (PBDroneEnv's own _preprocessAction override never reaches them).  One
+    controller per action type lives through the whole sequence (the reference never calls ctrl.reset() after
+    construction), fed a random walk of kinematic states through the fake Bullet getters."""
+    from Sol.PyBullet.BaseSingleAgentAviary import BaseSingleAgentAviary
+    from Sol.PyBullet.DSLPIDControl import DSLPIDControl
+    from Sol.PyBullet.enums import DroneModel
+    targets, spawn, dim, circle = track_circle(4)
+    env = make_ref_env(targets, spawn, dim, circle)
+    cl = pb._clients[env.CLIENT]
+    rng = np.random.default_rng(23)
+    T = 400
+    pos = np.array([1.0, 0.0, 1.0]) + np.cumsum(0.01 * rng.standard_normal((T, 3)), axis=0)
+    ang = np.cumsum(0.03 * rng.standard_normal((T, 3)), axis=0)
+    ang[T // 2:T // 2 + 20, 1] = np.pi / 2 - 1e-7             # a stretch inside getEulerFromQuaternion's gimbal-lock branch
+    quat = np.array([pb.getQuaternionFromEuler(a) for a in ang])
+    vel = 0.5 * rng.standard_normal((T, 3))
+    ang_v = rng.standard_normal((T, 3))
+    acts = rng.uniform(-1, 1, (T, 4)).astype(np.float32)
+    acts[::7, :3] = 0.0                                        # VEL: zero direction vector
+    acts[::11] *= 3.0                                          # PID: destinations farther than one step away
+    res = dict(pos=pos, quat=quat, vel=vel, ang_v=ang_v, actions=acts, SPEED_LIMIT=np.float64(0.03 * env.MAX_SPEED_KMH * (1000 / 3600)),
+               CTRL_TIMESTEP=np.float64(env.CTRL_TIMESTEP))
+    env.SPEED_LIMIT = float(res["SPEED_LIMIT"])
+    for name, at, adim in (("pid", ActionType.PID, 3), ("vel", ActionType.VEL, 4), ("one_d_rpm", ActionType.ONE_D_RPM, 1),
+                           ("one_d_pid", ActionType.ONE_D_PID, 1)):
+        env.ACT_TYPE = at
+        env.ctrl = quiet(DSLPIDControl, drone_model=DroneModel.CF2X)
+        rpm = np.zeros((T, 4))
+        ipos, lrpy, irpy = np.zeros((T, 3)), np.zeros((T, 3)), np.zeros((T, 3))
+        for t in range(T):
+            cl["pos"], cl["quat"], cl["vel"], cl["ang_v"] = pos[t].copy(), quat[t].copy(), vel[t].copy(), ang_v[t].copy()
+            quiet(env._updateAndStoreKinematicInformation)
+            r = quiet(BaseSingleAgentAviary._preprocessAction, env, acts[t, :adim].copy())
+            rpm[t] = np.asarray(r, dtype=np.float64).reshape(4)
+            if at != ActionType.ONE_D_RPM:
+                ipos[t], lrpy[t], irpy[t] = env.ctrl.integral_pos_e, env.ctrl.last_rpy, env.ctrl.integral_rpy_e
+        res.update({f"{name}_rpm": rpm, f"{name}_integral_pos_e": ipos, f"{name}_last_rpy": lrpy, f"{name}_integral_rpy_e": irpy})
+    env.ACT_TYPE = ActionType.THRUST
+    out["pid_control"] = res
+
+
 def gen_gae(out):
     """N1: execute the reference's GAE lines (cleanRLPPO.py:234-248) on random buffers."""
     import torch
@@ -517,7 +561,7 @@ def main():
     only = set(sys.argv[1:])
     gens = dict(actions=gen_constants_and_actions, tracks=gen_tracks, obs_pack=gen_obs_pack, closed_loop=gen_closed_loop,
                 scripted=gen_scripted, normalize=gen_normalize, gae=gen_gae, rollout_dump=gen_rollout_dump,
-                reward_wrappers=gen_reward_wrappers, extra_physics=gen_extra_physics)
+                reward_wrappers=gen_reward_wrappers, extra_physics=gen_extra_physics, pid_control=gen_pid_control)
     for key, fn in gens.items():          # `python gen_golden.py rollout_dump` regenerates only that group
         if not only or key in only:
             fn(out)

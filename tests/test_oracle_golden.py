@@ -270,3 +270,46 @@ def test_extra_physics_terms_match_reference(golden):
         elif act == 0:
             assert not np.array_equal(envs["pos"][0], base)         # the extra terms act
             np.testing.assert_allclose(envs["pos"][0], base, atol=1e-4)
+
+
+def test_pid_family_action_types_match_reference(golden):
+    """N4: ActionType.PID / VEL / ONE_D_RPM / ONE_D_PID -- BaseSingleAgentAviary._preprocessAction with the DSLPIDControl loop,
+    as the reference's own methods compute them over a 400-step sequence with one persistent controller per action type
+    (pid_control.npz, incl. a stretch inside getEulerFromQuaternion's gimbal-lock branch).  PID / ONE_D_PID agree to 1e-13,
+    ONE_D_RPM exactly, VEL to 1e-7 (numpy's float32 norm of the direction vector sums in BLAS order)."""
+    g = golden("pid_control")
+    L = O.lib()
+    assert float(g["SPEED_LIMIT"]) == 0.25 and abs(float(g["CTRL_TIMESTEP"]) - 1 / 240) < 1e-18
+    P = lambda a: np.ascontiguousarray(a, dtype=np.float64).ctypes.data_as(DP)   # noqa: E731
+    for name, code, tol in (("pid", 2, 1e-13), ("vel", 3, 1e-7), ("one_d_rpm", 4, 0.0), ("one_d_pid", 5, 1e-13)):
+        st = np.zeros(9)
+        unsat = 0
+        for t in range(len(g["pos"])):
+            rpm = np.zeros(4)
+            a = np.ascontiguousarray(g["actions"][t])
+            L.orc_pid_control(code, P(g["pos"][t]), P(g["quat"][t]), P(g["vel"][t]), a.ctypes.data_as(FP), st.ctypes.data_as(DP),
+                              rpm.ctypes.data_as(DP))
+            ref = g[name + "_rpm"][t]
+            np.testing.assert_allclose(rpm, ref, rtol=tol, atol=0, err_msg=f"{name} t={t}")
+            unsat += int(((ref > 9441) & (ref < 21666)).any())
+            if code != 4:
+                np.testing.assert_allclose(st[:3], g[name + "_integral_pos_e"][t], rtol=1e-12, atol=1e-15)
+                np.testing.assert_allclose(st[3:6], g[name + "_last_rpy"][t], rtol=1e-12, atol=1e-15)
+                np.testing.assert_allclose(st[6:], g[name + "_integral_rpy_e"][t], rtol=1e-6 if code == 3 else 1e-12, atol=1e-9 if code == 3 else 1e-12)
+        assert unsat > 30, (name, unsat)            # the mixer is not pinned at the PWM limits all the time
+    # the env step takes these action types: a hovering ONE_D_RPM drone, a PID drone flying towards a point
+    wp = np.array([[0.0, 1.0, 1.0], [-1.0, 0.0, 1.0]])
+    dim = np.array([-2.0, -2.0, 0.0, 2.0, 2.0, 2.0])
+    for act, a in ((4, [0.0, 9, 9, 9]), (2, [1.0, 0.0, 1.2, 0]), (3, [1, 0, 0, 0.5]), (5, [0.3, 0, 0, 0])):
+        cfg = O.make_config(wp, np.array([1.0, 0.0, 1.0]), dim, circle=False, cylinder=False, action_type=act, normalize_actions=False)
+        ve = O.OracleVecEnv(cfg, 1)
+        ve.reset()
+        for _ in range(120):
+            out = ve.step(np.array([a], np.float32))
+            assert not out["done"][0]
+        p = ve.envs["pos"][0]
+        assert np.all(np.abs(p - [1.0, 0.0, 1.0]) < 0.5), (act, p)       # controlled flight, no run-away
+        if act == 2:
+            assert p[2] > 1.0                                            # climbing towards z = 1.2
+        if act != 4:
+            assert np.any(ve.envs["pid"][0] != 0.0)
