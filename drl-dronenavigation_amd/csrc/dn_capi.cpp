@@ -153,6 +153,15 @@ int32_t validate(const dn_config *c)
     return DN_OK;
 }
 
+int32_t init_state_rms(dn_env *e, hipStream_t s)
+{   // normalize.RunningMeanStd.__init__, normalize.py:14-18
+    const long long n = e->cfg.num_envs;
+    DN_HIP(dn_launch_filld(e->p.st.rms_mean, 0.0, n * DN_OBS_DIM, s));
+    DN_HIP(dn_launch_filld(e->p.st.rms_var, 1.0, n * DN_OBS_DIM, s));
+    DN_HIP(dn_launch_filld(e->p.st.rms_count, 1e-4, n, s));
+    return DN_OK;
+}
+
 int32_t init_state(dn_env *e, hipStream_t s)
 {
     const dn_config &c = e->cfg;
@@ -168,11 +177,7 @@ int32_t init_state(dn_env *e, hipStream_t s)
     DN_HIP(dn_launch_fill4(e->p.st.g4, make_float4(0.f, 0.f, 0.f, 0.f), n, s));
     DN_HIP(dn_launch_fill4(e->p.st.g5, make_float4(0.f, 0.f, 0.f, 0.f), n, s));
     DN_HIP(dn_launch_fill4(e->p.st.g6, make_float4(sx, sy, sz, 0.f), n, s));
-    if (c.normalize_obs) {                         // normalize.RunningMeanStd.__init__, normalize.py:14-18
-        DN_HIP(dn_launch_filld(e->p.st.rms_mean, 0.0, n * DN_OBS_DIM, s));
-        DN_HIP(dn_launch_filld(e->p.st.rms_var, 1.0, n * DN_OBS_DIM, s));
-        DN_HIP(dn_launch_filld(e->p.st.rms_count, 1e-4, n, s));
-    }
+    if (c.normalize_obs) { int32_t rc = init_state_rms(e, s); if (rc != DN_OK) return rc; }
     if (c.norm_rew) {                              // NormalizeReward.__init__, normalize.py:124-128
         DN_HIP(dn_launch_filld(e->p.st.rr, 0.0, 2 * n, s));            // returns, return_rms.mean
         DN_HIP(dn_launch_filld(e->p.st.rr + 2 * n, 1.0, n, s));        // .var
@@ -255,7 +260,7 @@ int32_t dn_create(const dn_config *cfg, dn_env **out)
     //   noise (Philox + Box-Muller per observation column): 16384 drones 3.51 / 4.63 / 5.86; 32768: 4.86 / 4.78 / 6.02;
     //     49152: 5.36 / 4.88 / 6.04 -> three waves up to 256 tiles, two beyond (same with the normaliser, up to 512);
     //     noise + XOPT without the normaliser follows the XOPT row (49152: 5.75 / 6.23 / 6.99).
-    const bool plain = !cfg->clip_rew && !cfg->norm_rew && cfg->physics == 0 && cfg->action_type == 0;
+    const bool plain = !cfg->clip_rew && !cfg->norm_rew && cfg->physics == 0 && cfg->action_type == 0 && !cfg->random_spawn;
     const bool noisy = cfg->act_noise_sigma > 0.0f || cfg->obs_noise_sigma > 0.0f;
     const long long max_multi = cfg->normalize_obs ? DN_TWO_WAVE_MAX_TILES / 2 : DN_TWO_WAVE_MAX_TILES;
     long long max_three = max_multi;
@@ -286,6 +291,7 @@ int32_t dn_create(const dn_config *cfg, dn_env **out)
     const int drag = cfg->physics == 2 || cfg->physics == 4;
     const int pid_mode = (cfg->action_type == 2 || cfg->action_type == 3 || cfg->action_type == 5) ? cfg->action_type : 0;
     if (pid_mode) e->waves_fused = e->waves_single = 1;      // the controller reads the step's entry state: one-wave kernels (dn_kernels.hip, PidCtx)
+    if (cfg->random_spawn) e->waves_fused = e->waves_single = 1;   // the spawn draw lives in the one-wave option kernels only
     const Layout L = make_layout(n, cfg->normalize_obs, cfg->norm_rew, drag, pid_mode);
     hipError_t he = hipMalloc(&e->arena, L.total);
     if (he != hipSuccess) {
@@ -320,6 +326,7 @@ int32_t dn_create(const dn_config *cfg, dn_env **out)
     p.clip_rew = cfg->clip_rew != 0; p.norm_rew = cfg->norm_rew != 0;
     p.gnd = cfg->physics == 1 || cfg->physics == 4; p.drag = drag; p.rpm_actions = cfg->action_type == 1 ? 1 : (cfg->action_type == 4 ? 2 : 0);
     p.pid_mode = pid_mode;
+    p.random_spawn = cfg->random_spawn != 0;
     p.act_noise_sigma = cfg->act_noise_sigma; p.obs_noise_sigma = cfg->obs_noise_sigma;
     p.seed = cfg->seed; p.env_id_offset = cfg->env_id_offset;
     build_consts<double>(*cfg, p.c64);
@@ -338,6 +345,17 @@ int32_t dn_create(const dn_config *cfg, dn_env **out)
         }
         st = init_state(e, nullptr);
         if (st != DN_OK) break;
+        if (cfg->random_spawn) {                // make_env's env.reset(seed=...) (PBDroneSimulator.py:173) already draws a spawn point
+            float *scratch = nullptr;
+            if (hipMalloc(&scratch, (size_t)n * DN_OBS_DIM * sizeof(float)) != hipSuccess) { st = fail(DN_ERR_OUT_OF_MEMORY, "scratch observation buffer"); break; }
+            const bool launched = dn_launch_reset(e->p, scratch, cfg->compute_f32 != 0, nullptr) == hipSuccess && hipStreamSynchronize(nullptr) == hipSuccess;
+            (void)hipFree(scratch);
+            if (!launched) { st = fail(DN_ERR_HIP, "initial random spawn failed"); break; }
+            if (cfg->normalize_obs) {           // that reset happens BEFORE the NormalizeObservation wrapper exists: statistics stay pristine
+                st = init_state_rms(e, nullptr);
+                if (st != DN_OK) break;
+            }
+        }
         if (hipStreamSynchronize(nullptr) != hipSuccess) { st = fail(DN_ERR_HIP, "state initialisation failed"); break; }
     } while (0);
     if (st != DN_OK) {

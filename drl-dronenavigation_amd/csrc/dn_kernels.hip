@@ -1133,6 +1133,39 @@ DN_DEV Flight<R> physics_phase(const TH &th, const float4 G0, const float4 G1, c
 // SubprocVecEnv auto-reset -> PBDroneEnv.reset (:609-665; _current_position is NOT reset: quirk Q3).
 // Only the segment corridor depends on the waypoint index, so the common part of the collision test runs once
 // and the segment test once per index that is actually needed.
+// ---- N4: random spawn (PBDroneEnv(random_spawn=True), dormant in the reference: PBDroneEnv.py:622-627) --------------
+// PositionGenerator.generate_random_point_around_line (position_generator.py:121-152, max_distance 0.1, bounds = aviary_dim)
+// between two distinct target points drawn at random.  The reference draws from `random` / `np.random`; here Philox words
+// keyed by (seed; global drone id, vector step, streams 11 / 12).  float64 whatever R is (a rare path).
+DN_DEV void spawn_point(const DnParams &p, const unsigned long long gid, const unsigned long long step, double out[3])
+{
+    const int W = p.num_waypoints;
+    if (W < 2) { out[0] = p.c64.spawn[0]; out[1] = p.c64.spawn[1]; out[2] = p.c64.spawn[2]; return; }
+    unsigned r[4];
+    philox4x32((unsigned)gid, (unsigned)(gid >> 32), (unsigned)step, 11u | ((unsigned)(step >> 32) << 8), (unsigned)p.seed,
+               (unsigned)(p.seed >> 32), r);
+    const int i = (int)(r[0] % (unsigned)W);
+    int j = (int)(r[1] % (unsigned)(W - 1));                   // np.random.choice(W, size=2, replace=False)
+    if (j >= i) j += 1;
+    const double t = ((double)r[2] + 0.5) * (1.0 / 4294967296.0);
+    const double u = ((double)r[3] + 0.5) * (1.0 / 4294967296.0);
+    const double offset = -0.1 + (0.1 - -0.1) * u;             // random.uniform(-max_distance, max_distance)
+    float z[4];
+    noise4(p.seed, gid, step, 12u, z);                         // np.random.randn(3)
+    const double *f = p.tab64 + i * DN_T_STRIDE + DN_T_WP, *g = p.tab64 + j * DN_T_STRIDE + DN_T_WP;     // global table: rare path
+    const double dir[3] = {g[0] - f[0], g[1] - f[1], g[2] - f[2]};
+    const double rv[3] = {(double)z[0], (double)z[1], (double)z[2]};
+    const double perp[3] = {dir[1] * rv[2] - dir[2] * rv[1], dir[2] * rv[0] - dir[0] * rv[2], dir[0] * rv[1] - dir[1] * rv[0]};
+    const double n = sqrt(perp[0] * perp[0] + perp[1] * perp[1] + perp[2] * perp[2]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        double x = f[k] + t * (g[k] - f[k]);
+        x += offset * (perp[k] / n);
+        const double hi = x < p.c64.dim[3 + k] ? x : p.c64.dim[3 + k];      // max(lo, min(hi, x)), :113-118
+        out[k] = p.c64.dim[k] > hi ? p.c64.dim[k] : hi;
+    }
+}
+
 // rules_verdict: everything the OTHER phases of the step wait for (collision / gate / termination flags and the distance
 // the reset observation shows); rules_commit: the state words that go back to HBM, with the auto-reset of the body.
 // rules_phase = the two back to back.
@@ -1187,10 +1220,11 @@ DN_DEV Verdict<R> rules_verdict(const DnParams &p, const DnConsts<R> &c, const R
     m.terminated = terminated; m.done = terminated || fl.truncated != 0;
     return v;
 }
-template <typename R>
+template <typename R, bool SPAWN = false>
 DN_DEV void rules_commit(const DnConsts<R> &c, const R (&wp0)[3], const Flight<R> &fl, const RulesMid<R> &m, const float4 G0e,
                          const float4 G3e, float4 *g6_blk, const unsigned li, const bool active,
-                         float4 &G0, float4 &G1, float4 &G2, float4 &G3)
+                         float4 &G0, float4 &G1, float4 &G2, float4 &G3, const DnParams *sp = nullptr,
+                         const unsigned long long gid = 0ull, const unsigned long long step = 0ull)
 {
     const Meta m_e = unpack_meta(G3e.w);
     const R px = fl.px, py = fl.py, pz = fl.pz;
@@ -1211,6 +1245,13 @@ DN_DEV void rules_commit(const DnConsts<R> &c, const R (&wp0)[3], const Flight<R
             if (active && !(terminated && m_e.steps == 0)) g6_blk[li] = make_float4((float)cpx, (float)cpy, (float)cpz, 0.0f);
             // freshly loaded body at the spawn pose, at rest
             S0 = make_float4((float)c.spawn[0], (float)c.spawn[1], (float)c.spawn[2], 0.0f);
+            if (SPAWN && sp->random_spawn) {           // this episode's INIT_XYZS[0]; _current_position follows it (PBDroneEnv.py:624-626)
+                double q[3];
+                spawn_point(*sp, gid, step, q);
+                S0 = make_float4((float)q[0], (float)q[1], (float)q[2], 0.0f);
+                cpx = (R)S0.x; cpy = (R)S0.y; cpz = (R)S0.z;
+                if (active) g6_blk[li] = make_float4(S0.x, S0.y, S0.z, 0.0f);
+            }
             S1 = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
             S2 = S3 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             const R ex = cpx - wp0[0], ey = cpy - wp0[1], ez = cpz - wp0[2];
@@ -1222,14 +1263,15 @@ DN_DEV void rules_commit(const DnConsts<R> &c, const R (&wp0)[3], const Flight<R
     S0.w = (float)d; S2.w = (float)d_prev; S3.w = pack_meta(steps, idx, just_found);
     G0 = S0; G1 = S1; G2 = S2; G3 = S3;
 }
-template <typename R>
+template <typename R, bool SPAWN = false>
 DN_DEV Verdict<R> rules_phase(const DnParams &p, const DnConsts<R> &c, const R *s_tab, const GateRow<R> &row_e, const R (&wp0)[3],
                               const Flight<R> &fl, const float4 G0e, const float4 G3e, float4 *g6_blk, const unsigned li,
-                              const bool active, float4 &G0, float4 &G1, float4 &G2, float4 &G3)
+                              const bool active, float4 &G0, float4 &G1, float4 &G2, float4 &G3,
+                              const unsigned long long gid = 0ull, const unsigned long long step = 0ull)
 {
     RulesMid<R> m;
     const Verdict<R> v = rules_verdict<R>(p, c, s_tab, row_e, fl, G3e, m);
-    rules_commit<R>(c, wp0, fl, m, G0e, G3e, g6_blk, li, active, G0, G1, G2, G3);
+    rules_commit<R, SPAWN>(c, wp0, fl, m, G0e, G3e, g6_blk, li, active, G0, G1, G2, G3, &p, gid, step);
     return v;
 }
 
@@ -1531,7 +1573,7 @@ DN_DEV void report_scalars(const DnParams &p, const DnConsts<R> &c, const StepOu
     }
     if (out.done_word && lane == 0) *out.done_word = done_ballot;
 }
-template <typename R, bool NORM, bool NOISE, int TILE>
+template <typename R, bool NORM, bool NOISE, int TILE, bool SPAWN = false>
 DN_DEV void report_obs(const DnParams &p, const DnConsts<R> &c, float *s_tile, const StepOut &out, const bool truncated,
                        const Verdict<R> &v, float *o, const unsigned long long gid, const unsigned long long step_count,
                        const unsigned li, const unsigned lane, const unsigned rows, const bool active, Rms &rms)
@@ -1544,6 +1586,12 @@ DN_DEV void report_obs(const DnParams &p, const DnConsts<R> &c, float *s_tile, c
                 for (int k = 0; k < DN_OBS_DIM; ++k) out.terminal_obs[li * DN_OBS_DIM + k] = o[k];
             }
             reset_obs<R>(p, c, v.d_obs, o);                               // BaseAviary.py:318 before :617-658 (Q2)
+            if (SPAWN && p.random_spawn) {                                // the body was loaded at this episode's spawn point
+                double q[3];
+                spawn_point(p, gid, step_count, q);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) o[k] = (float)((R)(float)q[k] * c.inv_dim[k]);
+            }
             if (NOISE && p.obs_noise_sigma > 0.0f) add_obs_noise(p, gid, step_count, 5u, o);
             if (NORM) normalize_obs(rms, o);
         }
@@ -1552,14 +1600,14 @@ DN_DEV void report_obs(const DnParams &p, const DnConsts<R> &c, float *s_tile, c
     else if (TILE == 1) tile_park(s_tile, lane, o);        // streamed out by the caller one step later
     else store_obs_tile(s_tile, out.obs, rows, lane, o);
 }
-template <typename R, bool NORM, bool NOISE, bool REW, int TILE = 0>
+template <typename R, bool NORM, bool NOISE, bool REW, int TILE = 0, bool SPAWN = false>
 DN_DEV void report_phase(const DnParams &p, const DnConsts<R> &c, float *s_tile, const StepOut &out, const Flight<R> &fl,
                          const Verdict<R> &v, Observed<R> &ob, const unsigned long long gid, const unsigned long long step_count,
                          const unsigned li, const unsigned lane, const unsigned rows, const bool active,
                          float4 &G4, float4 &G5, StatAcc &acc, Rms &rms, RewNorm &rn)
 {
     report_scalars<R, REW>(p, c, out, fl, v, ob.r_normal, ob.r_found32, li, lane, active, G4, G5, acc, rn);
-    report_obs<R, NORM, NOISE, TILE>(p, c, s_tile, out, fl.truncated != 0, v, ob.o, gid, step_count, li, lane, rows, active, rms);
+    report_obs<R, NORM, NOISE, TILE, SPAWN>(p, c, s_tile, out, fl.truncated != 0, v, ob.o, gid, step_count, li, lane, rows, active, rms);
 }
 
 struct BlockState {
@@ -1674,11 +1722,11 @@ __global__ __launch_bounds__(DN_BLOCK) void dn_step_many_1w_kernel(const DnParam
         const GateRow<R> row_e = load_gate_row<R>(s_tab, unpack_meta(G3.w).idx);
         Flight<R> fl = fly<R, NOISE, XOPT>(p, gid, sc, A, G0, G1, G2, G3, G7, rpm_now, XOPT ? pid_st : nullptr);
         const float4 G0e = G0, G3e = G3;
-        const Verdict<R> v = rules_phase<R>(p, c, s_tab, row_e, wp0, fl, G0e, G3e, b.g6, li, active, G0, G1, G2, G3);
+        const Verdict<R> v = rules_phase<R, XOPT>(p, c, s_tab, row_e, wp0, fl, G0e, G3e, b.g6, li, active, G0, G1, G2, G3, gid, sc);
         if (XOPT && p.drag) G7 = (v.terminated || fl.truncated) ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : rpm_now;   // BaseAviary.py:442,545
         attitude_phase<R>(fl);
         Observed<R> ob = observe_phase<R, NORM, NOISE>(p, c, s_tab, fl, G4, G5, gid, sc, rms);
-        report_phase<R, NORM, NOISE, XOPT>(p, c, s_tile, out, fl, v, ob, gid, sc, li, lane, rows, active, G4, G5, acc, rms, rn);
+        report_phase<R, NORM, NOISE, XOPT, 0, XOPT>(p, c, s_tile, out, fl, v, ob, gid, sc, li, lane, rows, active, G4, G5, acc, rms, rn);
         A = A_next;
     }
     if (ONE) flush_stats_preloaded(p, slot0, acc, sc0 + 1ull, lane);
@@ -2342,6 +2390,14 @@ __global__ __launch_bounds__(DN_BLOCK) void dn_reset_kernel(const DnParams p, fl
     float o[DN_OBS_DIM];
     reset_obs<R>(p, c, (R)G0.w, o);
     const unsigned long long gid = (unsigned long long)(p.env_id_offset + i);
+    float sx = (float)c.spawn[0], sy = (float)c.spawn[1], sz = (float)c.spawn[2];
+    if (p.random_spawn) {                  // this episode's INIT_XYZS[0]; _current_position follows it (PBDroneEnv.py:624-626)
+        double q[3];
+        spawn_point(p, gid, p.st.stats[blockIdx.x].step_count, q);
+        sx = (float)q[0]; sy = (float)q[1]; sz = (float)q[2];
+        cpx = (R)sx; cpy = (R)sy; cpz = (R)sz;
+        o[0] = (float)((R)sx * c.inv_dim[0]); o[1] = (float)((R)sy * c.inv_dim[1]); o[2] = (float)((R)sz * c.inv_dim[2]);
+    }
     if (p.obs_noise_sigma > 0.0f) add_obs_noise(p, gid, p.st.stats[blockIdx.x].step_count, 5u, o);
     if (p.normalize_obs) {
         Rms rms;
@@ -2352,7 +2408,7 @@ __global__ __launch_bounds__(DN_BLOCK) void dn_reset_kernel(const DnParams p, fl
     const R ex = cpx - s_tab[0], ey = cpy - s_tab[1], ez = cpz - s_tab[2];
     const R d = FM<R>::sqrt0(FM<R>::fma(ez, ez, FM<R>::fma(ey, ey, ex * ex)));
     if (active) {
-        b.g0[li] = make_float4((float)c.spawn[0], (float)c.spawn[1], (float)c.spawn[2], (float)d);
+        b.g0[li] = make_float4(sx, sy, sz, (float)d);
         b.g1[li] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
         b.g2[li] = make_float4(0.0f, 0.0f, 0.0f, (float)d);
         b.g3[li] = make_float4(0.0f, 0.0f, 0.0f, pack_meta(0, 0, 0));
@@ -2554,7 +2610,7 @@ hipError_t dn_launch_step_many_mw(const DnParams &p, const DnStepIO &io, int k, 
     const unsigned grid = (unsigned)((p.n + DN_BLOCK - 1) / DN_BLOCK);
     const bool noise = p.act_noise_sigma > 0.0f || p.obs_noise_sigma > 0.0f;
     // the rarely used options share one set of instantiations (runtime switches inside): reward wrappers, N4 physics terms
-    const bool rew = p.clip_rew != 0 || p.norm_rew != 0 || p.gnd != 0 || p.drag != 0 || p.rpm_actions != 0 || p.pid_mode != 0;
+    const bool rew = p.clip_rew != 0 || p.norm_rew != 0 || p.gnd != 0 || p.drag != 0 || p.rpm_actions != 0 || p.pid_mode != 0 || p.random_spawn != 0;
     if (waves == 3 && k > 1) {                             // three waves per tile: fused launches
         const dim3 blk(3 * DN_BLOCK);
         const bool norm = p.normalize_obs != 0;
@@ -2627,7 +2683,7 @@ hipError_t dn_launch_step_many(const DnParams &p, const DnStepIO &io, int k, boo
     const bool two_wave = waves >= 2;       // with the normaliser: the two-wave kernels (there is no three-wave one)
     const unsigned grid = (unsigned)((p.n + DN_BLOCK - 1) / DN_BLOCK);
     const bool noise = p.act_noise_sigma > 0.0f || p.obs_noise_sigma > 0.0f;
-    const bool rew = p.clip_rew != 0 || p.norm_rew != 0 || p.gnd != 0 || p.drag != 0 || p.rpm_actions != 0 || p.pid_mode != 0;
+    const bool rew = p.clip_rew != 0 || p.norm_rew != 0 || p.gnd != 0 || p.drag != 0 || p.rpm_actions != 0 || p.pid_mode != 0 || p.random_spawn != 0;
     if (two_wave) {                         // normaliser on
         if (f32) { if (noise) DN_LAUNCH(float, true, true); else DN_LAUNCH(float, true, false); }
         else { if (noise) DN_LAUNCH(double, true, true); else DN_LAUNCH(double, true, false); }

@@ -87,6 +87,10 @@ typedef struct dn_config {
                                                    | 2 PID (a[0:3] = destination) | 3 VEL (a[0:3] direction, |a[3]| speed) | 4 ONE_D_RPM (a[0])
                                                    | 5 ONE_D_PID (a[0]): BaseSingleAgentAviary._preprocessAction (:180-222) with the
                                                    DSLPIDControl loop (Sol/PyBullet/DSLPIDControl.py) per drone; the action buffer stays [N, 4] */
+    int32_t random_spawn;                       /* PBDroneEnv(random_spawn=True): every episode starts at a random point around a random track line
+                                                   (PositionGenerator.generate_random_point_around_line, position_generator.py:121-152, max_distance
+                                                   0.1, fed by the dormant block PBDroneEnv.py:622-627); draws are Philox words keyed by `seed`, the
+                                                   global drone id and the vector step, so sharding does not move them.  0 = the reference as it runs */
 } dn_config;
 
 /* One drone's persistent state, host-side AoS view used by dn_get_state/dn_set_state (tests,

@@ -471,6 +471,46 @@ void orc_pid_control(int32_t action_type, const double pos[3], const double quat
     }
 }
 
+/* ------------------------------------------------------------------------- */
+/* N4 -- random spawn around a track line: PositionGenerator.generate_random_point_around_line        */
+/* (Sol/Utilities/position_generator.py:121-152; geometry pinned by tests/golden/random_spawn.npz) fed   */
+/* by the dormant block of PBDroneEnv.reset (PBDroneEnv.py:622-627: two distinct target points at        */
+/* random, max_distance 0.1, bounds = aviary_dim, :168-169).  The reference draws from `random` /         */
+/* `np.random`; here the draws are Philox words keyed by (seed; global env id, vector step, streams       */
+/* 11 / 12) so that a sharded fleet spawns where the unsharded one does.                                   */
+/* ------------------------------------------------------------------------- */
+void orc_point_around_line(const double frm[3], const double to[3], double t, const double rv[3], double offset,
+                           const double bounds[6], double out[3])
+{
+    double dir[3] = {to[0] - frm[0], to[1] - frm[1], to[2] - frm[2]};
+    double pt[3] = {frm[0] + t * (to[0] - frm[0]), frm[1] + t * (to[1] - frm[1]), frm[2] + t * (to[2] - frm[2])};
+    double perp[3];
+    cross3(dir, rv, perp);
+    double n = norm3(perp);
+    for (int k = 0; k < 3; ++k) {
+        pt[k] += offset * (perp[k] / n);
+        double hi = pt[k] < bounds[3 + k] ? pt[k] : bounds[3 + k];          /* max(lo, min(hi, x)), :113-118 */
+        out[k] = bounds[k] > hi ? bounds[k] : hi;
+    }
+}
+void orc_random_spawn(const orc_config *c, uint64_t env_id, uint64_t step, double out[3])
+{
+    const int W = c->num_waypoints;
+    if (W < 2) { out[0] = c->spawn[0]; out[1] = c->spawn[1]; out[2] = c->spawn[2]; return; }   /* no line to spawn around */
+    uint32_t r[4];
+    orc_philox4x32((uint32_t)env_id, (uint32_t)(env_id >> 32), (uint32_t)step, 11u | ((uint32_t)(step >> 32) << 8),
+                   (uint32_t)c->seed, (uint32_t)(c->seed >> 32), r);
+    int i = (int)(r[0] % (uint32_t)W), j = (int)(r[1] % (uint32_t)(W - 1));     /* np.random.choice(W, size=2, replace=False) */
+    if (j >= i) j += 1;
+    double t = ((double)r[2] + 0.5) * (1.0 / 4294967296.0);
+    double u = ((double)r[3] + 0.5) * (1.0 / 4294967296.0);
+    double offset = -0.1 + (0.1 - -0.1) * u;                                    /* random.uniform(-max_distance, max_distance) */
+    float z[4];
+    orc_noise4(c->seed, env_id, step, 12u, z);                                  /* np.random.randn(3) */
+    double rv[3] = {z[0], z[1], z[2]};
+    orc_point_around_line(&c->waypoints[3 * i], &c->waypoints[3 * j], t, rv, offset, c->dim, out);
+}
+
 static double max_target_dist(const orc_config *c)
 {   /* PBDroneEnv.py:91 */
     double a = fabs(c->dim[0]) + c->dim[3], b = fabs(c->dim[1]) + c->dim[4], z = c->dim[5];
@@ -648,6 +688,7 @@ void orc_post_step(const orc_config *c, orc_env *e)
 static void bullet_reset(const orc_config *c, orc_env *e)
 {   /* p.resetSimulation + _housekeeping: body reloaded at INIT_XYZS / INIT_RPYS = 0, at rest */
     memcpy(e->pos, c->spawn, sizeof e->pos);
+    if (c->random_spawn && e->spawn_ready) memcpy(e->pos, e->spawn_pt, sizeof e->pos);   /* INIT_XYZS[0] of this episode */
     e->quat[0] = e->quat[1] = e->quat[2] = 0.0; e->quat[3] = 1.0;
     memset(e->vel, 0, sizeof e->vel);
     memset(e->ang_v, 0, sizeof e->ang_v);
@@ -668,7 +709,13 @@ void orc_env_construct(const orc_config *c, orc_env *e)
 
 void orc_env_reset(const orc_config *c, orc_env *e, float obs[ORC_OBS_DIM])
 {
+    if (c->random_spawn) {           /* the dormant block of PBDroneEnv.reset (:622-627), built as what it evidently intends: the
+                                      * episode's spawn point is drawn, the body is loaded there and _current_position follows */
+        orc_random_spawn(c, e->gid, e->step_count, e->spawn_pt);
+        e->spawn_ready = 1;
+    }
     bullet_reset(c, e);
+    if (c->random_spawn) memcpy(e->cur_pos, e->spawn_pt, sizeof e->cur_pos);
     orc_compute_obs(c, e, obs);              /* BaseAviary.py:318 -- BEFORE the bookkeeping below (Q2) */
     e->is_done = 0; e->idx = 0; e->steps = 0;                                /* :617-619 */
     double df[3] = {e->cur_pos[0] - c->waypoints[0], e->cur_pos[1] - c->waypoints[1], e->cur_pos[2] - c->waypoints[2]};
@@ -846,6 +893,7 @@ void orc_vec_create(const orc_config *c, orc_env *envs, int64_t n)
     for (int64_t i = 0; i < n; ++i) {
         float obs[ORC_OBS_DIM];
         orc_env_construct(c, &envs[i]);
+        envs[i].gid = (uint64_t)(c->env_id_offset + i);
         envs[i].rr_returns = 0.0; envs[i].rr_mean = 0.0; envs[i].rr_var = 1.0; envs[i].rr_count = 1e-4;   /* normalize.py:14-18, :127-128 */
         orc_env_reset(c, &envs[i], obs);         /* make_env: env.reset(seed=seed+rank) before wrapping, PBDroneSimulator.py:173 */
         if (c->f32_state) round_state_f32(&envs[i]);

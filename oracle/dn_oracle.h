@@ -71,6 +71,8 @@ typedef struct orc_config {
      *               (BaseSingleAgentAviary._preprocessAction, BaseSingleAgentAviary.py:176-222) */
     int32_t physics;
     int32_t action_type;
+    /* N4: spawn every episode at a random point around a random track line (PBDroneEnv.py:622-627, dormant in the reference) */
+    int32_t random_spawn;
 } orc_config;
 
 /* Every per-env variable the reference keeps, under the reference's names. */
@@ -100,6 +102,10 @@ typedef struct orc_env {
     double last_clipped_action[4];
     /* DSLPIDControl state (ActionType.PID / VEL / ONE_D_PID): integral_pos_e, last_rpy, integral_rpy_e; never reset */
     double pid[9];
+    /* random spawn: global env id (Philox counter word), this episode's INIT_XYZS[0] */
+    uint64_t gid;
+    double spawn_pt[3];
+    int32_t spawn_ready;
 } orc_env;
 
 /* Result of one gym-level env.step (PBDroneEnv.step), before vectorisation. */
@@ -135,6 +141,10 @@ void orc_drag(const double quat[4], const double vel[3], const double last_rpm[4
 void orc_euler_from_quat(const double q[4], double rpy[3]);
 /* ActionType.PID (2) / VEL (3) / ONE_D_RPM (4) / ONE_D_PID (5): BaseSingleAgentAviary._preprocessAction (:180-222) with
  * DSLPIDControl.computeControl; st[9] = integral_pos_e, last_rpy, integral_rpy_e (python half pinned: pid_control.npz) */
+/* position_generator.py:121-152 with the draws supplied; and the Philox-keyed draw of one episode's spawn point */
+void orc_point_around_line(const double frm[3], const double to[3], double t, const double rv[3], double offset,
+                           const double bounds[6], double out[3]);
+void orc_random_spawn(const orc_config *cfg, uint64_t env_id, uint64_t step, double out[3]);
 void orc_pid_control(int32_t action_type, const double pos[3], const double quat[4], const double vel[3],
                      const float action[4], double st[9], double rpm[4]);
 

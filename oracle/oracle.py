@@ -39,6 +39,7 @@ class OrcConfig(C.Structure):
         ("norm_rew", C.c_int32),
         ("physics", C.c_int32),
         ("action_type", C.c_int32),
+        ("random_spawn", C.c_int32),
     ]
 
 
@@ -57,6 +58,7 @@ class OrcEnv(C.Structure):
         ("rr_returns", C.c_double), ("rr_mean", C.c_double), ("rr_var", C.c_double), ("rr_count", C.c_double),
         ("last_clipped_action", C.c_double * 4),
         ("pid", C.c_double * 9),
+        ("gid", C.c_uint64), ("spawn_pt", C.c_double * 3), ("spawn_ready", C.c_int32),
     ]
 
 
@@ -77,6 +79,7 @@ ENV_DTYPE = np.dtype([
     ("rr_returns", "f8"), ("rr_mean", "f8"), ("rr_var", "f8"), ("rr_count", "f8"),
     ("last_clipped_action", "f8", 4),
     ("pid", "f8", 9),
+    ("gid", "u8"), ("spawn_pt", "f8", 3), ("spawn_ready", "i4"),
 ], align=True)
 
 
@@ -114,6 +117,8 @@ def lib():
     L.orc_drag.argtypes = [dp, dp, dp, C.c_int, dp]
     L.orc_euler_from_quat.argtypes = [dp, dp]
     L.orc_pid_control.argtypes = [C.c_int32, dp, dp, dp, fp, dp, dp]
+    L.orc_point_around_line.argtypes = [dp, dp, C.c_double, dp, C.c_double, dp, dp]
+    L.orc_random_spawn.argtypes = [cfgp, C.c_uint64, C.c_uint64, dp]
     L.orc_env_construct.argtypes = [cfgp, envp]
     L.orc_env_reset.argtypes = [cfgp, envp, fp]
     L.orc_env_step.argtypes = [cfgp, envp, fp, C.POINTER(OrcStepOut)]
@@ -146,7 +151,7 @@ def lib():
 def make_config(waypoints, spawn, dim, *, threshold=0.3, max_steps=4096, circle=False, cylinder=True,
                 include_distance=True, normalize_actions=True, normalize_obs=False, ground_contact=False,
                 f32_state=False, act_noise_sigma=0.0, obs_noise_sigma=0.0, seed=0, env_id_offset=0, clip_rew=False,
-                norm_rew=False, physics=0, action_type=0):
+                norm_rew=False, physics=0, action_type=0, random_spawn=False):
     wp = np.asarray(waypoints, dtype=np.float64).reshape(-1, 3)
     assert 1 <= len(wp) <= MAX_WAYPOINTS
     cfg = OrcConfig()
@@ -166,6 +171,7 @@ def make_config(waypoints, spawn, dim, *, threshold=0.3, max_steps=4096, circle=
     cfg.seed, cfg.env_id_offset = int(seed), int(env_id_offset)
     cfg.clip_rew, cfg.norm_rew = int(clip_rew), int(norm_rew)
     cfg.physics, cfg.action_type = int(physics), int(action_type)
+    cfg.random_spawn = int(random_spawn)
     return cfg
 
 

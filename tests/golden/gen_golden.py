@@ -502,6 +502,33 @@ def gen_pid_control(out):
     out["pid_control"] = res
 
 
+def gen_random_spawn(out):
+    """N4: PositionGenerator.generate_random_point_around_line (Sol/Utilities/position_generator.py:121-152), the geometry of the
+    dormant random-spawn block (PBDroneEnv.py:622-627).  Its draws come from `random` / `np.random`; here they are supplied
+    (the two modules' functions are patched for the duration of the call), so the fixture pins the arithmetic: interpolation,
+    the perpendicular through a cross product, the offset, the clip to the aviary bounds."""
+    import random
+    from unittest import mock
+    from Sol.Utilities.position_generator import PositionGenerator
+    rng = np.random.default_rng(31)
+    n = 400
+    bounds = np.array([-2.0, -2.0, 0.0, 2.0, 2.0, 2.0])
+    gen = PositionGenerator(bounds, 0.1)                      # PBDroneEnv.py:168-169
+    frm = rng.uniform([-2, -2, 0], [2, 2, 2], (n, 3))
+    to = rng.uniform([-2, -2, 0], [2, 2, 2], (n, 3))
+    frm[:40] = np.clip(frm[:40] * 1.2, bounds[:3], bounds[3:])   # some on the faces of the box: the clip binds
+    t = rng.uniform(0, 1, n)
+    rv = rng.standard_normal((n, 3))
+    u = rng.uniform(0, 1, n)                                  # random.uniform(a, b) = a + (b - a) * random()
+    pts = np.zeros((n, 3))
+    for k in range(n):
+        draws = iter([t[k], -0.1 + (0.1 - -0.1) * u[k]])
+        with mock.patch.object(random, "uniform", lambda a, b: next(draws)), \
+                mock.patch.object(np.random, "randn", lambda *shape: rv[k].copy()):
+            pts[k] = gen.generate_random_point_around_line(frm[k], to[k])
+    out["random_spawn"] = dict(frm=frm, to=to, t=t, rv=rv, u=u, bounds=bounds, max_distance=np.float64(0.1), points=pts)
+
+
 def gen_gae(out):
     """N1: execute the reference's GAE lines (cleanRLPPO.py:234-248) on random buffers."""
     import torch
@@ -561,7 +588,7 @@ def main():
     only = set(sys.argv[1:])
     gens = dict(actions=gen_constants_and_actions, tracks=gen_tracks, obs_pack=gen_obs_pack, closed_loop=gen_closed_loop,
                 scripted=gen_scripted, normalize=gen_normalize, gae=gen_gae, rollout_dump=gen_rollout_dump,
-                reward_wrappers=gen_reward_wrappers, extra_physics=gen_extra_physics, pid_control=gen_pid_control)
+                reward_wrappers=gen_reward_wrappers, extra_physics=gen_extra_physics, pid_control=gen_pid_control, random_spawn=gen_random_spawn)
     for key, fn in gens.items():          # `python gen_golden.py rollout_dump` regenerates only that group
         if not only or key in only:
             fn(out)

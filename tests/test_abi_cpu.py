@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol(pkg):
 
 def test_struct_layouts_match_header(pkg):
     # sizes computed by hand from include/dronenav.h (natural alignment) ...
-    assert C.sizeof(pkg._capi.DnConfig) == 8 + 4 + 4 + 64 * 3 * 8 + 3 * 8 + 6 * 8 + 8 + 8 * 4 + 2 * 4 + 8 + 8 + 4 * 4
+    assert C.sizeof(pkg._capi.DnConfig) == 8 + 4 + 4 + 64 * 3 * 8 + 3 * 8 + 6 * 8 + 8 + 8 * 4 + 2 * 4 + 8 + 8 + 4 * 4 + 2 * 4   # ... + random_spawn + tail padding
     assert C.sizeof(pkg._capi.DnStats) == 7 * 8
     # ... and by the C compiler from the header itself: sizes and the offsets of the trailing fields
     import subprocess
@@ -52,7 +52,7 @@ def test_struct_layouts_match_header(pkg):
 #include "dronenav.h"
 int main(void) {
     printf("%zu %zu %zu %zu %zu %zu %zu %zu %d\n", sizeof(dn_config), sizeof(dn_env_state), sizeof(dn_stats), sizeof(dn_mlp_net),
-           offsetof(dn_config, action_type), offsetof(dn_config, seed), offsetof(dn_env_state, last_rpm),
+           offsetof(dn_config, random_spawn), offsetof(dn_config, seed), offsetof(dn_env_state, pid),
            offsetof(dn_env_state, rms_mean), DN_ABI_VERSION);
     return 0;
 }
@@ -65,7 +65,7 @@ int main(void) {
         got = [int(v) for v in subprocess.check_output([exe]).split()]
     K = pkg._capi
     assert got == [C.sizeof(K.DnConfig), C.sizeof(K.DnEnvState), C.sizeof(K.DnStats), C.sizeof(K.DnMlpNet),
-                   K.DnConfig.action_type.offset, K.DnConfig.seed.offset, K.DnEnvState.last_rpm.offset,
+                   K.DnConfig.random_spawn.offset, K.DnConfig.seed.offset, K.DnEnvState.pid.offset,
                    K.DnEnvState.rms_mean.offset, K.ABI_VERSION], got
     assert pkg._capi.load().dn_abi_version() == pkg._capi.ABI_VERSION == 4
 

@@ -31,7 +31,7 @@ def make_pair(track, n, *, f32_state, max_steps=4096, **kw):
     env = pkg.DroneVecEnv(track, n, max_steps=max_steps, device="cuda:0", **kw)
     okw = {k: v for k, v in kw.items() if k in ("normalize_obs", "include_distance", "normalize_actions",
                                                 "act_noise_sigma", "obs_noise_sigma", "seed", "env_id_offset",
-                                                "ground_contact", "threshold", "cylinder", "clip_rew", "norm_rew")}
+                                                "ground_contact", "threshold", "cylinder", "clip_rew", "norm_rew", "random_spawn")}
     okw.setdefault("normalize_obs", True)
     okw.setdefault("ground_contact", False)        # DroneVecEnv's default: the contact approximation is opt-in
     cfg = O.make_config(track.targets(), track.initial_xyzs, track.aviary_dim, circle=track.is_circle,
@@ -1133,6 +1133,46 @@ def test_physics_options_match_oracle(physics, act):
     for k in sa.dtype.names:
         assert np.array_equal(sa[k], sb[k]), k
     env.close(); twin.close()
+
+
+def test_random_spawn_matches_oracle_and_sharding():
+    """N4: PBDroneEnv(random_spawn=True) -- every episode starts at a Philox-drawn point around a random track line
+    (position_generator.py:121-152; the geometry is pinned to the reference by random_spawn.npz through the oracle).  The HIP
+    path against the oracle free-running over many resets, and a fleet split in two against the whole fleet bit for bit."""
+    pkg = _gpu()
+    track = _tracks().REGISTRY["circle6"]()               # distinct gates (the race track repeats its first gate: a zero-length
+    n = 512                                               # line, on which the reference's own formula divides 0 by 0)
+    kw = dict(max_steps=25, normalize_obs=False, random_spawn=True, seed=21, cylinder=False)
+    env = pkg.DroneVecEnv(track, n, device="cuda:0", **kw)
+    assert env.kernel_waves(fused=True) == 1 and env.kernel_waves(fused=False) == 1
+    cfg = O.make_config(track.targets(), track.initial_xyzs, track.aviary_dim, circle=track.is_circle, f32_state=True, **kw)
+    ora = O.OracleVecEnv(cfg, n, threads=4)
+    st0 = env.get_state()
+    np.testing.assert_allclose(st0["pos"], ora.envs["pos"], rtol=0, atol=1e-6)       # make_env's env.reset() already drew
+    assert len({tuple(p) for p in st0["pos"]}) == n and np.isfinite(st0["pos"]).all()
+    np.testing.assert_allclose(env.reset(), ora.reset(), rtol=0, atol=1e-6)
+    rng = np.random.default_rng(2)
+    dev = torch.device("cuda:0")
+    n_done = 0
+    for t in range(80):
+        a = actions_mixed(rng, n)
+        n_done += compare_step(env.step_tensor(torch.from_numpy(a).to(dev)), ora.step(a), f"random spawn t={t}", rew_atol=1e-4)
+    assert n_done > 2 * n
+    st = env.get_state()
+    np.testing.assert_allclose(st["pos"], ora.envs["pos"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(st["cur_pos"], ora.envs["cur_pos"], rtol=0, atol=1e-5)
+    # sharding: halves with env_id_offset against the whole fleet, fused launches
+    whole = pkg.DroneVecEnv(track, n, device="cuda:0", **kw)
+    parts = [pkg.DroneVecEnv(track, n // 2, device="cuda:0", env_id_offset=r * (n // 2), **kw) for r in range(2)]
+    assert torch.equal(whole.reset_tensor(), torch.cat([p.reset_tensor() for p in parts]))
+    acts = torch.from_numpy(np.stack([actions_mixed(rng, n) for _ in range(60)])).to(dev)
+    a_ = whole.rollout_tensor(acts)
+    bs = [p.rollout_tensor(acts[:, r * (n // 2):(r + 1) * (n // 2)].contiguous()) for r, p in enumerate(parts)]
+    for k in ("obs", "reward", "done", "truncated", "found_targets"):
+        assert torch.equal(a_[k], torch.cat([b[k] for b in bs], dim=1)), k
+    assert int(a_["done"].sum()) > n
+    for e in [env, whole] + parts:
+        e.close()
 
 
 def test_nan_actions_propagate_like_numpy():

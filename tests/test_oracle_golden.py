@@ -313,3 +313,33 @@ def test_pid_family_action_types_match_reference(golden):
             assert p[2] > 1.0                                            # climbing towards z = 1.2
         if act != 4:
             assert np.any(ve.envs["pid"][0] != 0.0)
+
+
+def test_random_spawn_geometry_matches_reference(golden):
+    """N4: PositionGenerator.generate_random_point_around_line (position_generator.py:121-152) with the draws supplied
+    (random_spawn.npz): interpolation along the line, perpendicular offset through the cross product, clip to the aviary."""
+    g = golden("random_spawn")
+    L = O.lib()
+    P = lambda a: np.ascontiguousarray(a, dtype=np.float64).ctypes.data_as(DP)   # noqa: E731
+    assert float(g["max_distance"]) == 0.1
+    clipped = 0
+    for k in range(len(g["t"])):
+        out = np.zeros(3)
+        L.orc_point_around_line(P(g["frm"][k]), P(g["to"][k]), float(g["t"][k]), P(g["rv"][k]), -0.1 + (0.1 - -0.1) * float(g["u"][k]),
+                                P(g["bounds"]), out.ctypes.data_as(DP))
+        np.testing.assert_allclose(out, g["points"][k], rtol=1e-13, atol=1e-15)
+        clipped += bool(((out == g["bounds"][:3]) | (out == g["bounds"][3:])).any())
+    assert clipped >= 1
+    # the Philox-keyed draw: inside the aviary, within max_distance of the line through two DISTINCT gates, reproducible
+    wp = np.array([[0.0, 1.0, 1.0], [-1.0, 0.0, 1.0], [0.0, -1.0, 1.2], [1.0, 0.0, 0.8]])
+    cfg = O.make_config(wp, np.array([1.0, 0.0, 1.0]), g["bounds"], circle=False, random_spawn=True, seed=7)
+    seen = set()
+    for env_id in range(300):
+        a, b = np.zeros(3), np.zeros(3)
+        L.orc_random_spawn(C.byref(cfg), env_id, 5, a.ctypes.data_as(DP))
+        L.orc_random_spawn(C.byref(cfg), env_id, 5, b.ctypes.data_as(DP))
+        assert np.array_equal(a, b) and np.all(a >= g["bounds"][:3]) and np.all(a <= g["bounds"][3:])
+        dist = min(np.linalg.norm(np.cross(q - p_, a - p_)) / np.linalg.norm(q - p_) for i, p_ in enumerate(wp) for j, q in enumerate(wp) if i != j)
+        assert dist <= 0.1 + 1e-12
+        seen.add(tuple(np.round(a, 6)))
+    assert len(seen) == 300
