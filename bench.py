@@ -56,7 +56,7 @@ def kernel_name(waves, dtype, norm, fused):
     if waves >= 3 and fused:
         return f"dn_step_many_3w_kernel<{r}, {nm}, false, false>"
     if waves >= 3:
-        return f"dn_step_{waves}w_kernel<{r}, {nm}, false>"
+        return f"dn_step_pqx_kernel<{r}, {nm}, false, false>"
     return f"dn_step_many_{waves}w_kernel<{r}, {nm}, false, {'false' if fused else 'true'}, false, false>"
 
 
@@ -100,6 +100,9 @@ def parse():
                     help="BASELINE configs[3]: also time the policy-in-the-loop rollout on every rank with the per-rollout RCCL "
                          "all-gather of advantages/returns (opt-in: a collective inside the bench line is not worth risking "
                          "the scaling run for)")
+    ap.add_argument("--profile-lite", action="store_true",
+                    help="for rocprofv3 --pmc passes (every dispatch costs tens of ms there): no pre-roll, a few launches per leg, "
+                         "no NumPy-surface legs; timings of such a run mean nothing, only the counters do")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the RCCL process group even for one rank (exercises the N > 1 code path on a 1-GPU box)")
     return ap.parse_args()
@@ -159,12 +162,16 @@ def ppo_rollout(pkg, track, n, max_steps, dev, rank):
     net = pkg.MlpActorCritic().to(dev)
     res = {}
     fused = pkg.FusedMlpPolicy(net, n, dev)
+    fused32 = pkg.FusedMlpPolicy(net, n, dev, grade="fp32")
     for label, use_graph, trunk in (("eager", False, None), ("graph", True, None), ("graph_bf16", True, torch.bfloat16),
                                     ("graph_mfma", True, "mfma"), ("eager_mfma", False, "mfma"),
-                                    ("fused_eager", False, "fused"), ("fused_graph", True, "fused")):
-        net.trunk_dtype = trunk if trunk not in ("mfma", "fused") else None
+                                    ("fused_eager", False, "fused"), ("fused_graph", True, "fused"),
+                                    ("fused_graph_fp32", True, "fused32")):
+        net.trunk_dtype = trunk if trunk not in ("mfma", "fused", "fused32") else None
         env = pkg.DroneVecEnv(track, n, max_steps=max_steps, normalize_obs=True, env_id_offset=rank * n, device=dev)
-        if trunk == "fused":
+        if trunk == "fused32":
+            col = FusedRolloutCollector(env, fused32, n_steps, use_graph=use_graph, seed=1 + rank)
+        elif trunk == "fused":
             col = FusedRolloutCollector(env, fused, n_steps, use_graph=use_graph, seed=1 + rank)
         elif trunk == "mfma":
             col = RolloutCollector(env, fused, n_steps, value_fn=fused.predict_values, use_graph=use_graph)
@@ -184,12 +191,16 @@ def ppo_rollout(pkg, track, n, max_steps, dev, rank):
     return {"value": round(res["fused_graph"], 1), "unit": "env-steps/s",
             "policy": "fused MFMA MLP (dn_mlp_forward, bf16 weights/activations, float32 accumulate) + dn_step_sampled "
                       "(Gaussian sample + step): two launches per step, the truncation bootstrap as one masked critic pass per rollout, hipGraph replay",
+            "value_fp32_grade": round(res["fused_graph_fp32"], 1),
+            "policy_fp32_grade": "the same loop with the networks at the reference's float32 precision (dn_mlp_forward grade 1: split-bf16 "
+                                 "operands, three MFMAs per product; <= 1e-4 on the action mean against the float32 torch network)",
             "variants": {"torch fp32 eager": round(res["eager"], 1), "torch fp32 hipGraph": round(res["graph"], 1),
                          "torch bf16 trunks hipGraph": round(res["graph_bf16"], 1),
                          "fused MFMA policy, torch glue, eager": round(res["eager_mfma"], 1),
                          "fused MFMA policy, torch glue, hipGraph": round(res["graph_mfma"], 1),
                          "fused collector eager": round(res["fused_eager"], 1),
-                         "fused collector hipGraph": round(res["fused_graph"], 1)},
+                         "fused collector hipGraph": round(res["fused_graph"], 1),
+                         "fused collector hipGraph, fp32-grade networks": round(res["fused_graph_fp32"], 1)},
             "n_steps": n_steps, "num_envs": n,
             "what": "policy-in-the-loop rollout: MLP 13-512-512-256 (pi, vf; Tanh) + Gaussian sample + dn_step + "
                     "V(terminal_obs) bootstrap per step, dn_gae per rollout, per-drone obs normaliser on"}
@@ -339,7 +350,7 @@ def main():
     # driver's default (--steps 20 --warmup 5) is a 40 us timed region
     t_pre = time.perf_counter()
     pre_steps = 0
-    while time.perf_counter() - t_pre < PREROLL_SECONDS:
+    while time.perf_counter() - t_pre < (0.0 if args.profile_lite else PREROLL_SECONDS):
         run_many(64 * A)
         torch.cuda.synchronize(dev)
         pre_steps += 64 * A
@@ -384,7 +395,8 @@ def main():
     # the other launch shapes, outside the timed region: "single" = one dn_step launch per step from Python (what a
     # policy-in-the-loop VecEnv.step_tensor() costs incl. host launch gaps), "graph" = the same launches replayed from a
     # hipGraph (GPU timeline only), "many" = the fused K-step kernel
-    k_single = 8192 // A * A if A <= 8192 else A
+    k_single = (8192 if not args.profile_lite else 2 * A) // A * A if A <= 8192 else A
+    k_many = max(A, (32768 if not args.profile_lite else 4 * A) // A * A)
     others = {}
     for m_ in ("many", "single", "graph"):
         if world > 1 and m_ == "graph":
@@ -392,7 +404,7 @@ def main():
         fn = {"many": run_many, "single": run_single, "graph": run_graph}[m_]
         spl = A if m_ == "many" else 1
         wv = env.kernel_waves(fused=m_ == "many")
-        d = leg(m_, fn, k_single if m_ != "many" else max(A, 32768 // A * A), spl, args.normalize_obs, wv)
+        d = leg(m_, fn, k_single if m_ != "many" else k_many, spl, args.normalize_obs, wv)
         others[m_] = d
     single_step = dict(others["graph"] if "graph" in others else others["single"])
     single_step["launched_from"] = "hipGraph replay of dn_step launches" if "graph" in others else "python loop of dn_step calls"
@@ -423,7 +435,7 @@ def main():
                     if rc:
                         pkg._capi.check(rc)
 
-            norm_on = {"fused": leg("many", many_n, max(A, 32768 // A * A), A, True, env_n.kernel_waves(fused=True)),
+            norm_on = {"fused": leg("many", many_n, k_many, A, True, env_n.kernel_waves(fused=True)),
                        "single_step": leg("single", single_n, k_single, 1, True, env_n.kernel_waves(fused=False)),
                        "what": "same workload with the per-drone NormalizeObservation fused in (the reference always wraps it, "
                                "PBDroneSimulator.py:181): +432 B of statistics per drone and launch"}
@@ -433,7 +445,7 @@ def main():
 
     # the SB3 NumPy surface (PCIe-inclusive: H2D actions, D2H obs/reward/done/found, N info dicts built in Python);
     # host bound, reported for the record only
-    if world == 1:
+    if world == 1 and not args.profile_lite:
         import numpy as np
         a_np = acts[0].cpu().numpy()
         for mode_ in ("full", "sparse"):

@@ -56,7 +56,7 @@ class DnEnvState(C.Structure):
 class DnMlpNet(C.Structure):
     _fields_ = [("w1", C.c_void_p), ("w2", C.c_void_p), ("w3", C.c_void_p), ("wh", C.c_void_p),
                 ("b1", C.c_void_p), ("b2", C.c_void_p), ("b3", C.c_void_p), ("bh", C.c_void_p),
-                ("out", C.c_void_p), ("out_dim", C.c_int32)]
+                ("out", C.c_void_p), ("out_dim", C.c_int32), ("grade", C.c_int32)]
 
 
 class DnStats(C.Structure):

@@ -42,6 +42,7 @@ struct MlpNetDev {
     float *out;
     int out_dim;
 };
+// (fp32-grade networks, dn_mlp_net.grade = 1: the w* streams hold, per M-tile, the KS hi fragments then the KS lo fragments)
 struct MlpArgs {
     MlpNetDev net[2];
     const float *obs;
@@ -560,6 +561,225 @@ __global__ __launch_bounds__(64 * PWAVES) void dn_mlp_pair_kernel(const MlpArgs 
     else mlp_pair_body<1>(a, net, wbuf, xb, lbias, wave, lane, row0, live, row, tile_wanted);
 }
 
+// -----------------------------------------------------------------------------------------------------
+// fp32-grade shape ("x3"): the same network at the reference's precision.
+//
+// The reference's policy runs in float32 (SB3 ActorCriticPolicy, PBDroneSimulator.py:251-286), and PBDroneEnv.rescale_action
+// leaves a band only 0.0073 wide in which an action is not saturated (PBDroneEnv.py:949-971): bf16 activations and weights
+// (8 mantissa bits) move the action mean by ~1e-3, a seventh of that band.  gfx950 has no fast float32 matrix path (the
+// float32 MFMA runs at 1/16 of the bf16 rate), so float32 grade is reached by splitting both operands into two bf16 words,
+// w = w_hi + w_lo, x = x_hi + x_lo (16 mantissa bits each), and forming  w_hi x_hi + w_hi x_lo + w_lo x_hi  with three
+// MFMAs into ONE float32 accumulator (the dropped w_lo x_lo term is 2^-16 of a product whose error budget is 2^-16).
+// Measured against the torch float32 network: ~3e-5 on the action mean (tests: <= 1e-4).
+//
+// Registers decide the shape: activations now cost two words per value, 128 KB per 32-drone tile for a layer's input plus
+// output -- a whole SIMD's register file.  So a tile is shared by TWO waves that split K exactly as in the pair shape, but
+// on two SIMDs (one wave per SIMD: 512 registers each), four waves = two tiles = 64 drones per workgroup.  Weights stream
+// through LDS as before, one chunk = the 32 hi + 32 lo fragments of an M-tile (64 KB, double-buffered: 128 KB of the 160).
+// -----------------------------------------------------------------------------------------------------
+constexpr int XWAVES = 4;
+constexpr int CH3 = 2 * CHUNK;                               // fragments per chunk: hi then lo
+constexpr int XB3_U4 = 2 * 2 * 4 * 64;                       // exchange: 2 pairs x 2 parities x 4 uint4 x 64 lanes
+constexpr int LDS_X3_U4 = 2 * CH3 * 64 + XB3_U4 + (NBIAS + 3) / 4 + 1;
+
+template <int NF>
+MLP_DEV void dma_x3(const uint4 *__restrict__ src, uint4 *lds, const int wave, const int lane)
+{   // NF fragments (64 or 32) shared by 4 waves: 16 or 8 consecutive fragments each, four per asm group
+    constexpr int per = NF / XWAVES;
+#pragma unroll
+    for (int j0 = 0; j0 < per; j0 += 4) {
+        const int f = wave * per + j0;
+        const uint4 *gsrc = src + f * 64 + lane;
+        const unsigned lds_dst = (unsigned)(uintptr_t)(lds + f * 64);
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, off\n\t"
+                     "global_load_lds_dwordx4 %1, off offset:1024\n\t"
+                     "global_load_lds_dwordx4 %1, off offset:2048\n\t"
+                     "global_load_lds_dwordx4 %1, off offset:3072\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    }
+}
+MLP_DEV float bf16_hi_as_float(const unsigned packed, const int which)      // element 0 / 1 of a packed bf16 pair, widened
+{
+    return __uint_as_float(which ? (packed & 0xFFFF0000u) : (packed << 16));
+}
+// two float32 values -> one dword of the hi operand and one of the lo operand (v = hi + lo to 16 mantissa bits)
+MLP_DEV void split2(const float a, const float b, unsigned &hi, unsigned &lo)
+{
+    hi = pack2(a, b);
+    lo = pack2(a - bf16_hi_as_float(hi, 0), b - bf16_hi_as_float(hi, 1));
+}
+MLP_DEV void epilogue3_pair(const f32x16 &acc, const int q, u32x4 &hlo, u32x4 &hhi, u32x4 &llo, u32x4 &lhi)
+{   // accumulator elements 2q, 2q+1 -> tanh -> dword q of the hi and of the lo operand
+    unsigned h, l;
+    split2(tanh_fast(acc[2 * q]), tanh_fast(acc[2 * q + 1]), h, l);
+    if (q < 4) { hlo[q] = h; llo[q] = l; } else { hhi[q - 4] = h; lhi[q - 4] = l; }
+}
+MLP_DEV void epilogue3(const f32x16 &acc, u32x4 &hlo, u32x4 &hhi, u32x4 &llo, u32x4 &lhi)
+{
+#pragma unroll
+    for (int q = 0; q < 8; ++q) epilogue3_pair(acc, q, hlo, hhi, llo, lhi);
+}
+MLP_DEV f32x16 mfma3(const uint4 whi, const uint4 wlo, const u32x4 xhi, const u32x4 xlo, f32x16 acc)
+{   // small terms first
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wlo), __builtin_bit_cast(bf16x8, xhi), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, whi), __builtin_bit_cast(bf16x8, xlo), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, whi), __builtin_bit_cast(bf16x8, xhi), acc, 0, 0, 0);
+    return acc;
+}
+
+// A 512-input layer for wave-half HALF in the x3 shape (see layer_pair): K-steps [16 HALF, 16 HALF + 16) of every M-tile,
+// owner of tiles [HALF MT/2, (HALF + 1) MT/2).  A chunk holds fragments [0, 32) = hi, [32, 64) = lo of one M-tile.
+template <int HALF, int MT, int PAR, int NEXT_FR>
+MLP_DEV void layer_x3(const uint4 *__restrict__ w, const float *lbias, const uint4 *__restrict__ next, const u32x4 (&inh)[16],
+                      const u32x4 (&inl)[16], u32x4 (&outh)[MT], u32x4 (&outl)[MT], uint4 *wbuf, float4 *xb, const int wave, const int lane)
+{
+    const int g = lane >> 5;
+    f32x16 prev;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        uint4 *cur = wbuf + ((PAR + m) & 1) * (CH3 * 64);
+        uint4 *nxt = wbuf + ((PAR + m + 1) & 1) * (CH3 * 64);
+        if (m + 1 < MT) dma_x3<CH3>(w + (size_t)(m + 1) * CH3 * 64, nxt, wave, lane);
+        else dma_x3<NEXT_FR>(next, nxt, wave, lane);
+        const bool fin = m > 0 && (((m - 1) >= MT / 2) == (HALF == 1));      // I own tile m-1: finish it under this tile's MFMAs
+        if (fin) merge_partial(xb, (m - 1) & 1, lane, prev);
+        f32x16 acc;
+        if ((m >= MT / 2) == (HALF == 1)) bias_init(lbias, m, g, acc);       // mine: start from the bias
+        else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        }
+        constexpr int RG = 4;                                                // ring depth (fragment PAIRS in flight)
+        uint4 rh[RG], rl[RG];
+#pragma unroll
+        for (int kk = 0; kk < RG; ++kk) {
+            rh[kk] = cur[(HALF * 16 + kk) * 64 + lane];
+            rl[kk] = cur[(CHUNK + HALF * 16 + kk) * 64 + lane];
+        }
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const uint4 ah = rh[kk % RG], al = rl[kk % RG];
+            if (kk + RG < 16) {
+                rh[kk % RG] = cur[(HALF * 16 + kk + RG) * 64 + lane];
+                rl[kk % RG] = cur[(CHUNK + HALF * 16 + kk + RG) * 64 + lane];
+            }
+            acc = mfma3(ah, al, inh[kk], inl[kk], acc);
+            if (fin && (kk & 1)) {
+                const int ml = (m - 1) - HALF * (MT / 2);
+                epilogue3_pair(prev, kk >> 1, outh[2 * ml], outh[2 * ml + 1], outl[2 * ml], outl[2 * ml + 1]);
+            }
+        }
+        if ((m >= MT / 2) == (HALF == 1)) prev = acc;                         // mine: keep, finish next round
+        else park_partial(xb, m & 1, lane, acc);                             // partner's: hand over through LDS
+        chunk_barrier();
+    }
+    if (HALF == 1) {                                                         // the last tile belongs to half 1
+        merge_partial(xb, (MT - 1) & 1, lane, prev);
+        epilogue3(prev, outh[MT - 2], outh[MT - 1], outl[MT - 2], outl[MT - 1]);
+    }
+}
+
+template <int HALF>
+MLP_DEV void mlp_x3_body(const MlpArgs &a, const MlpNetDev &net, uint4 *wbuf, float4 *xb, const float *lbias, const int wave,
+                         const int lane, const long long row0, const bool live, const long long row, const bool tile_wanted)
+{
+    const int g = lane >> 5, col = lane & 31;
+    u32x4 x0h, x0l;
+    {
+        const float *o = a.obs + row * a.obs_dim;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = 8 * g + 2 * q;
+            unsigned h, l;
+            split2(k < a.obs_dim ? o[k] : 0.0f, k + 1 < a.obs_dim ? o[k + 1] : 0.0f, h, l);
+            x0h[q] = h; x0l[q] = l;
+        }
+    }
+    // layer 1 (K = 16: one K-step, no split): this half computes its own 8 tiles outright.  Its 16 (hi, lo) fragment pairs are in
+    // buffer 0, stored per M-tile as hi then lo.
+    u32x4 h1h[16], h1l[16];
+    dma_x3<CH3>(net.w2, wbuf + CH3 * 64, wave, lane);                        // layer 2, chunk 0 -> buffer 1
+#pragma unroll
+    for (int ml = 0; ml < 8; ++ml) {
+        const int m = HALF * 8 + ml;
+        f32x16 acc;
+        bias_init(lbias, m, g, acc);
+        const uint4 wh = wbuf[(2 * m) * 64 + lane], wl = wbuf[(2 * m + 1) * 64 + lane];
+        acc = mfma3(wh, wl, x0h, x0l, acc);
+        epilogue3(acc, h1h[2 * ml], h1h[2 * ml + 1], h1l[2 * ml], h1l[2 * ml + 1]);
+    }
+    chunk_barrier();
+    u32x4 h2h[16], h2l[16];
+    layer_x3<HALF, H2 / 32, 1, CH3>(net.w2, lbias + H1, net.w3, h1h, h1l, h2h, h2l, wbuf, xb, wave, lane);
+    u32x4 h3h[8], h3l[8];
+    layer_x3<HALF, H3 / 32, 1, 2 * (H3 / 16)>(net.w3, lbias + H1 + H2, net.wh, h2h, h2l, h3h, h3l, wbuf, xb, wave, lane);
+    // head: one tile, K = 256 = 16 K-steps, 8 per half; chunk in buffer 1 as [16 hi][16 lo]
+    f32x16 acc;
+    if (HALF == 0) bias_init(lbias + H1 + H2 + H3, 0, g, acc);
+    else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    }
+    const uint4 *cur = wbuf + CH3 * 64;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+        const uint4 wh = cur[(HALF * 8 + kk) * 64 + lane], wl = cur[(H3 / 16 + HALF * 8 + kk) * 64 + lane];
+        acc = mfma3(wh, wl, h3h[kk], h3l[kk], acc);
+    }
+    if (HALF == 1) park_partial(xb, 0, lane, acc);
+    chunk_barrier();
+    if (HALF == 0) {
+        merge_partial(xb, 0, lane, acc);
+        if (live) {
+            float *o = net.out + (row0 + col) * net.out_dim;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = acc_row(0, g, r);
+                if (j < net.out_dim) o[j] = tile_wanted ? acc[r] : 0.0f;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(64 * XWAVES) __attribute__((amdgpu_waves_per_eu(1, 1))) void dn_mlp_x3_kernel(const MlpArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint4 lds[LDS_X3_U4];           // ONE __shared__ object (see dn_mlp_lds_kernel)
+    uint4 *wbuf = lds;
+    float *lbias = reinterpret_cast<float *>(lds + 2 * CH3 * 64 + XB3_U4);
+    int *s_any = reinterpret_cast<int *>(lds + LDS_X3_U4 - 1);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pair = wave & 1, half = wave >> 1;                              // waves p and p + 2 share a tile, on two SIMDs
+    float4 *xb = reinterpret_cast<float4 *>(lds + 2 * CH3 * 64) + pair * (2 * 4 * 64);
+    const int col = lane & 31;
+    const MlpNetDev &net = a.net[blockIdx.y];
+    const long long row0 = ((long long)blockIdx.x * 2 + pair) * TILE;
+    const bool live = row0 + col < a.n;
+    const long long row = live ? row0 + col : a.n - 1;
+    bool tile_wanted = true;
+    if (a.row_mask) {
+        const bool wanted = live && a.row_mask[row0 + col] != 0;
+        tile_wanted = __ballot(wanted) != 0ull;
+        if (lane == 0 && half == 0) s_any[pair] = tile_wanted;
+        __syncthreads();
+        if ((s_any[0] | s_any[1]) == 0) {
+            if (half == 0 && (lane >> 5) == 0 && live)
+                for (int j = 0; j < net.out_dim; ++j) net.out[(row0 + col) * net.out_dim + j] = 0.0f;
+            return;
+        }
+    }
+    // biases -> LDS (once), layer-1 fragments (16 hi/lo pairs) -> buffer 0
+    for (int i = threadIdx.x; i < NBIAS; i += 64 * XWAVES)
+        lbias[i] = i < H1 ? net.b1[i] : i < H1 + H2 ? net.b2[i - H1] : i < H1 + H2 + H3 ? net.b3[i - H1 - H2] : net.bh[i - H1 - H2 - H3];
+    dma_x3<2 * (H1 / 32)>(net.w1, wbuf, wave, lane);
+    chunk_barrier();
+    if (half == 0) mlp_x3_body<0>(a, net, wbuf, xb, lbias, wave, lane, row0, live, row, tile_wanted);
+    else mlp_x3_body<1>(a, net, wbuf, xb, lbias, wave, lane, row0, live, row, tile_wanted);
+}
+
 }  // namespace
 
 hipError_t dn_launch_mlp(const dn_mlp_net *nets, int num_nets, const float *obs, const uint8_t *row_mask, long long n, int obs_dim,
@@ -575,6 +795,10 @@ hipError_t dn_launch_mlp(const dn_mlp_net *nets, int num_nets, const float *obs,
     }
     a.obs = obs; a.row_mask = row_mask; a.n = n; a.obs_dim = obs_dim;
     const unsigned tiles = (unsigned)((n + TILE - 1) / TILE);
+    if (nets[0].grade == 1) {                                // fp32-grade networks (split-bf16 x3): their own kernel and packing
+        hipLaunchKernelGGL(dn_mlp_x3_kernel, dim3((tiles + 1) / 2, num_nets), dim3(64 * XWAVES), 0, stream, a);
+        return hipGetLastError();
+    }
     const char *e = getenv("DN_MLP_SHAPE");                  // 1 | 4 | 8 waves per workgroup (A/B measurements, tests)
     const int shape = e ? atoi(e) : DN_MLP_DEFAULT_SHAPE;
     if (shape == 1) hipLaunchKernelGGL(dn_mlp_kernel, dim3(tiles, num_nets), dim3(64), 0, stream, a);

@@ -33,9 +33,11 @@ def _k_order(in_features, first):
 TANH_PRESCALE = 2.0 / math.log(2.0)          # 2 log2(e): the kernel's tanh is 1 - 2 / (1 + 2^x) on pre-scaled x
 
 
-def pack_layer(weight, bias, first, scale=1.0):
+def pack_layer(weight, bias, first, scale=1.0, grade="bf16"):
     """weight [out, in] float32, bias [out] -> (packed bf16 [MT, KS, 64, 8] as a torch tensor, bias padded to 32*MT).
-    `scale` multiplies both before the bf16 rounding (TANH_PRESCALE for the layers that feed a tanh)."""
+    `scale` multiplies both before the bf16 rounding (TANH_PRESCALE for the layers that feed a tanh).
+    grade="fp32": the weights are split into two bf16 words, w = w_hi + w_lo (16 mantissa bits), and packed per M-tile as
+    the KS hi fragments followed by the KS lo fragments, [MT, 2, KS, 64, 8] -- the stream of dn_mlp_x3_kernel."""
     w = np.asarray(weight.detach().cpu().float().numpy() if hasattr(weight, "detach") else weight, dtype=np.float32)
     b = np.asarray(bias.detach().cpu().float().numpy() if hasattr(bias, "detach") else bias, dtype=np.float32)
     w, b = (w * np.float32(scale)).astype(np.float32), (b * np.float32(scale)).astype(np.float32)
@@ -54,18 +56,31 @@ def pack_layer(weight, bias, first, scale=1.0):
     packed = wp[lane_row[:, None, :, None], cols[None, :, :, :]]             # [MT, KS, 64, 8]
     bp = np.zeros(mt * 32, np.float32)
     bp[:out_f] = b
-    return torch.from_numpy(packed).to(torch.bfloat16).contiguous(), torch.from_numpy(bp)
+    pt = torch.from_numpy(packed)
+    if grade == "fp32":
+        hi = pt.to(torch.bfloat16)
+        lo = (pt - hi.float()).to(torch.bfloat16)
+        return torch.stack((hi, lo), dim=1).contiguous(), torch.from_numpy(bp)          # [MT, 2, KS, 64, 8]
+    return pt.to(torch.bfloat16).contiguous(), torch.from_numpy(bp)
 
 
-def pack_mlp(layers, device):
-    """layers: [(W1, b1), (W2, b2), (W3, b3), (Wh, bh)] of one network -> dict of device tensors for dn_mlp_net."""
+GRADES = {"bf16": 0, "fp32": 1}
+
+
+def pack_mlp(layers, device, grade="bf16"):
+    """layers: [(W1, b1), (W2, b2), (W3, b3), (Wh, bh)] of one network -> dict of device tensors for dn_mlp_net.
+    grade: "bf16" (speed: bf16 operands, ~1e-3 on the outputs) or "fp32" (the reference's precision through split-bf16
+    operands and three MFMAs per product, <= 1e-4; about 2.5x the time)."""
+    if grade not in GRADES:
+        raise ValueError(f"grade must be one of {sorted(GRADES)}")
     if [tuple(w.shape) for w, _ in layers[1:3]] != [(HIDDEN[1], HIDDEN[0]), (HIDDEN[2], HIDDEN[1])] or \
             layers[0][0].shape[0] != HIDDEN[0] or layers[3][0].shape[1] != HIDDEN[2]:
         raise ValueError("the fused kernel is built for obs -> 512 -> 512 -> 256 -> out (PBDroneSimulator.py:251-258)")
     out = {}
     for name, (w, b), first in zip(("1", "2", "3", "h"), layers, (True, False, False, False)):
-        pw, pb = pack_layer(w, b, first, scale=1.0 if name == "h" else TANH_PRESCALE)
+        pw, pb = pack_layer(w, b, first, scale=1.0 if name == "h" else TANH_PRESCALE, grade=grade)
         out["w" + name], out["b" + name] = pw.to(device), pb.to(device)
+    out["grade"] = GRADES[grade]
     out["out_dim"] = int(layers[3][0].shape[0])
     out["obs_dim"] = int(layers[0][0].shape[1])
     return out
@@ -75,7 +90,7 @@ def _net_struct(pk, out_tensor):
     n = _capi.DnMlpNet()
     for k in ("w1", "w2", "w3", "wh", "b1", "b2", "b3", "bh"):
         setattr(n, k, pk[k].data_ptr())
-    n.out, n.out_dim = out_tensor.data_ptr(), pk["out_dim"]
+    n.out, n.out_dim, n.grade = out_tensor.data_ptr(), pk["out_dim"], pk.get("grade", 0)
     return n
 
 
@@ -101,8 +116,8 @@ class FusedMlpPolicy:
     """policy(obs) -> (actions, values, log_probs) for RolloutCollector on the fused kernel, from an MlpActorCritic's
     weights (re-pack with `refresh()` after every optimiser step).  Static output buffers: hipGraph-capture safe."""
 
-    def __init__(self, module, num_envs, device):
-        self.module, self.device = module, torch.device(device)
+    def __init__(self, module, num_envs, device, grade="bf16"):
+        self.module, self.device, self.grade = module, torch.device(device), grade
         self._mean = torch.empty((num_envs, module.action_net.out_features), dtype=torch.float32, device=self.device)
         self._value = torch.empty((num_envs, 1), dtype=torch.float32, device=self.device)
         self.refresh()
@@ -112,7 +127,7 @@ class FusedMlpPolicy:
         lin = lambda seq: [l for l in seq if isinstance(l, torch.nn.Linear)]           # noqa: E731
         pi = [(l.weight, l.bias) for l in lin(m.pi)] + [(m.action_net.weight, m.action_net.bias)]
         vf = [(l.weight, l.bias) for l in lin(m.vf)] + [(m.value_net.weight, m.value_net.bias)]
-        self.pi, self.vf = pack_mlp(pi, self.device), pack_mlp(vf, self.device)
+        self.pi, self.vf = pack_mlp(pi, self.device, self.grade), pack_mlp(vf, self.device, self.grade)
         self.log_std = m.log_std.detach().to(self.device).float()
         self.log_std_host = [float(x) for x in m.log_std.detach().cpu().float()]     # dn_policy_sample takes it by value
 

@@ -236,6 +236,10 @@ typedef struct dn_mlp_net {
     const float *b1, *b2, *b3, *bh;             /* biases */
     float *out;                                 /* float[num_envs * out_dim] */
     int32_t out_dim;                            /* 1..32 (4 action means / 1 value) */
+    int32_t grade;                              /* 0: bf16 weights and activations, float32 accumulate (the speed option, ~1e-3 on the action mean)
+                                                   1: float32 grade -- both operands split into two bf16 words, three MFMAs per product
+                                                      (policy_mfma.pack_mlp(..., grade="fp32") packs the hi / lo fragment streams); matches the
+                                                      reference's float32 networks to <= 1e-4.  All networks of one call share the grade. */
 } dn_mlp_net;
 
 /* Forward pass of one or two such networks over the same observations in one launch (replaces the mlp_extractor +

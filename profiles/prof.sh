@@ -10,6 +10,8 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats -- python3 $ROOT/bench.py --no-cpu-baseline "$@" > $OUT/bench_stats.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o fetch -- python3 $ROOT/bench.py --no-cpu-baseline "$@" > $OUT/bench_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o write -- python3 $ROOT/bench.py --no-cpu-baseline "$@" > $OUT/bench_write.log 2>&1
+# the counter passes run the bench with --profile-lite: under --pmc every dispatch costs tens of milliseconds, and the counters of a
+# kernel do not depend on how many times it is launched
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o fetch -- python3 $ROOT/bench.py --no-cpu-baseline --profile-lite "$@" > $OUT/bench_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o write -- python3 $ROOT/bench.py --no-cpu-baseline --profile-lite "$@" > $OUT/bench_write.log 2>&1
 ls $OUT/*/ | head -20

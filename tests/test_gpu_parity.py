@@ -786,6 +786,60 @@ def test_fused_mfma_mlp_matches_torch(n, shape, monkeypatch):
     assert torch.equal(mv[tile_has], value.squeeze(-1)[tile_has]) and float(mv[~tile_has].abs().sum()) == 0.0
 
 
+@pytest.mark.parametrize("n", [32, 1000, 32768])
+def test_fp32_grade_mlp_matches_the_float32_torch_network(n):
+    """dn_mlp_forward with grade = 1 (split-bf16 operands, three MFMAs per product, dn_mlp_x3_kernel) against the network
+    the reference actually runs: SB3's float32 ActorCriticPolicy MLPs (PBDroneSimulator.py:251-286).  Bar: 1e-4 on the
+    action mean and the value (the band of non-saturated actions is 0.0073 wide, PBDroneEnv.py:949-971); the bf16 speed
+    grade sits around 1e-3 on the same inputs."""
+    pkg = _gpu()
+    from drl_dronenavigation_amd import policy_mfma as pm
+    dev = torch.device("cuda:0")
+    torch.manual_seed(n + 1)
+    net = pkg.MlpActorCritic().to(dev)
+    with torch.no_grad():
+        for p_ in net.parameters():
+            p_.add_(0.05 * torch.randn_like(p_))
+    obs = (torch.rand(n, 13, device=dev) * 2 - 1) * torch.tensor([1, 1, 1, 1, 1, 1, 1, 1, 0.33, 1, 1, 1, 1], device=dev)
+    obs[: min(n, 8)] *= 30.0                                   # a few far outside the unit box (un-normalised early observations)
+    lin = lambda seq: [l for l in seq if isinstance(l, torch.nn.Linear)]      # noqa: E731
+    pi = [(l.weight.detach(), l.bias.detach()) for l in lin(net.pi)] + [(net.action_net.weight.detach(), net.action_net.bias.detach())]
+    vf = [(l.weight.detach(), l.bias.detach()) for l in lin(net.vf)] + [(net.value_net.weight.detach(), net.value_net.bias.detach())]
+
+    def f64(layers, x):                                       # the float32 network's exact value, evaluated in float64
+        h = x.double()
+        for k, (w, b) in enumerate(layers):
+            h = h @ w.double().t() + b.double()
+            if k < len(layers) - 1:
+                h = torch.tanh(h)
+        return h
+
+    want_pi, want_vf = f64(pi, obs), f64(vf, obs)
+    with torch.no_grad():
+        t_pi = net.action_net(net.pi(obs))                    # torch float32 itself (rocBLAS), for scale
+    errs = {}
+    for grade in ("fp32", "bf16"):
+        got_pi, got_vf = pm.mlp_forward([pm.pack_mlp(pi, dev, grade), pm.pack_mlp(vf, dev, grade)], obs)
+        torch.cuda.synchronize()
+        errs[grade] = (float((got_pi.double() - want_pi).abs().max()), float((got_vf.double() - want_vf).abs().max()))
+    e32 = float((t_pi.double() - want_pi).abs().max())
+    print(f"n={n}: max |err| vs float64 -- fp32 grade pi {errs['fp32'][0]:.2e} vf {errs['fp32'][1]:.2e}; bf16 grade pi {errs['bf16'][0]:.2e} "
+          f"vf {errs['bf16'][1]:.2e}; torch float32 pi {e32:.2e}")
+    assert errs["fp32"][0] <= 1e-4 and errs["fp32"][1] <= 1e-4, errs
+    assert errs["bf16"][0] > 3 * errs["fp32"][0]              # the grade buys what it costs
+    # masked forward and a single network go through the same kernel
+    mask = torch.zeros(n, dtype=torch.uint8, device=dev)
+    mask[::97] = 1
+    (mv,) = pm.mlp_forward([pm.pack_mlp(vf, dev, "fp32")], obs, row_mask=mask)
+    torch.cuda.synchronize()
+    sel = mask.bool()
+    assert float((mv[sel].double() - want_vf[sel]).abs().max()) <= 1e-4
+    tile_has = mask.bool().cpu().numpy()
+    for t0 in range(0, n, 32):                                # a 32-drone tile without a flagged drone reads zeros
+        if not tile_has[t0:t0 + 32].any():
+            assert float(mv[t0:t0 + 32].abs().max()) == 0.0
+
+
 def test_off_policy_collector_fills_replay_buffer_like_sb3():
     """BASELINE config 5: SAC-style collection with Philox action/observation noise on; every stored transition is
     checked against an oracle replay of the actions taken: next_obs is the terminal observation where the episode
