@@ -49,7 +49,7 @@ class DnEnvState(C.Structure):
         ("ep_ret", C.c_float), ("ep_len", C.c_int32),
         ("rms_mean", C.c_double * OBS_DIM), ("rms_var", C.c_double * OBS_DIM), ("rms_count", C.c_double),
         ("rr_returns", C.c_double), ("rr_mean", C.c_double), ("rr_var", C.c_double), ("rr_count", C.c_double),
-        ("last_rpm", C.c_float * 4), ("pid", C.c_double * 9),
+        ("last_rpm", C.c_float * 4), ("pid", C.c_double * 9), ("ep_ret_lo", C.c_float),
     ]
 
 

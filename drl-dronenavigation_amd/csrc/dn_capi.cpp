@@ -538,6 +538,7 @@ int32_t dn_get_state(dn_env *env, dn_env_state *states, int64_t count)
         memcpy(&meta, &g[3][i].w, 4);
         s.steps = (int32_t)(meta & 0xFFFFFFu); s.idx = (int32_t)((meta >> 24) & 0x7Fu); s.just_found = (int32_t)(meta >> 31);
         s.prev_vel[0] = g[4][i].x; s.prev_vel[1] = g[4][i].y; s.prev_vel[2] = g[4][i].z; s.ep_ret = g[4][i].w;
+        s.ep_ret_lo = g[6][i].w;
         s.prev_ang_v[0] = g[5][i].x; s.prev_ang_v[1] = g[5][i].y; s.prev_ang_v[2] = g[5][i].z;
         memcpy(&s.ep_len, &g[5][i].w, 4);
         // _current_position equals pos once a post-step has run (steps > 0); the stored copy is the stale one
@@ -585,7 +586,7 @@ int32_t dn_set_state(dn_env *env, const dn_env_state *states, int64_t count)
         g[3][i] = make_float4(s.ang_v[0], s.ang_v[1], s.ang_v[2], fmeta);
         g[4][i] = make_float4(s.prev_vel[0], s.prev_vel[1], s.prev_vel[2], s.ep_ret);
         g[5][i] = make_float4(s.prev_ang_v[0], s.prev_ang_v[1], s.prev_ang_v[2], flen);
-        g[6][i] = make_float4(s.cur_pos[0], s.cur_pos[1], s.cur_pos[2], 0.0f);
+        g[6][i] = make_float4(s.cur_pos[0], s.cur_pos[1], s.cur_pos[2], s.ep_ret_lo);
         if (env->cfg.normalize_obs) {
             for (int k = 0; k < DN_OBS_DIM; ++k) { mean[(size_t)k * n + i] = s.rms_mean[k]; var[(size_t)k * n + i] = s.rms_var[k]; }
             cnt[(size_t)i] = s.rms_count;

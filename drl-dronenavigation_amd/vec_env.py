@@ -457,7 +457,7 @@ STATE_DTYPE = np.dtype([
     ("prev_ang_v", "f4", 3), ("cur_pos", "f4", 3), ("d", "f4"), ("d_prev", "f4"), ("idx", "i4"), ("steps", "i4"),
     ("just_found", "i4"), ("ep_ret", "f4"), ("ep_len", "i4"), ("rms_mean", "f8", OBS_DIM), ("rms_var", "f8", OBS_DIM),
     ("rms_count", "f8"), ("rr_returns", "f8"), ("rr_mean", "f8"), ("rr_var", "f8"), ("rr_count", "f8"),
-    ("last_rpm", "f4", 4), ("pid", "f8", 9)], align=True)
+    ("last_rpm", "f4", 4), ("pid", "f8", 9), ("ep_ret_lo", "f4")], align=True)
 assert STATE_DTYPE.itemsize == C.sizeof(_capi.DnEnvState), (STATE_DTYPE.itemsize, C.sizeof(_capi.DnEnvState))
 
 

@@ -103,7 +103,7 @@ typedef struct dn_env_state {
     int32_t idx;                                /* _current_target_index */
     int32_t steps;                              /* _steps */
     int32_t just_found;                         /* just_found */
-    float ep_ret;                               /* Monitor: running episode return */
+    float ep_ret;                               /* Monitor: running episode return (high word, see ep_ret_lo) */
     int32_t ep_len;                             /* Monitor: running episode length */
     double rms_mean[DN_OBS_DIM];                /* normalize.RunningMeanStd.mean  (normalize_obs only) */
     double rms_var[DN_OBS_DIM];                 /*                         .var                       */
@@ -112,6 +112,8 @@ typedef struct dn_env_state {
     double rr_mean, rr_var, rr_count;           /* NormalizeReward.return_rms                                  */
     float last_rpm[4];                          /* BaseAviary.last_clipped_action (physics with drag only; zeros otherwise) */
     double pid[9];                              /* DSLPIDControl.integral_pos_e, .last_rpy, .integral_rpy_e (action types PID / VEL / ONE_D_PID) */
+    float ep_ret_lo;                            /* Monitor: low word of the running return -- the return is ep_ret + ep_ret_lo (a float32 pair, so that
+                                                   the float64 sum SB3's Monitor keeps is not re-rounded to float32 every step) */
 } dn_env_state;
 
 /* Wave-reduced episode statistics accumulated on the device since dn_create / dn_reset_stats. */

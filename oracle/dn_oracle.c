@@ -857,7 +857,7 @@ static void round_state_f32(orc_env *e)
     for (int i = 0; i < 3; ++i) { RF(e->pos[i]); RF(e->vel[i]); RF(e->ang_v[i]); RF(e->cur_pos[i]);
                                   RF(e->cur_vel[i]); RF(e->cur_ang_v[i]); RF(e->prev_vel[i]); RF(e->prev_ang_v[i]); }
     for (int i = 0; i < 4; ++i) { RF(e->quat[i]); RF(e->last_clipped_action[i]); }
-    RF(e->d); RF(e->d_prev); RF(e->ep_ret);
+    RF(e->d); RF(e->d_prev);                    /* not ep_ret: Monitor's sum is a Python float, and the device carries it as a float32 pair */
 #undef RF
 }
 

@@ -1,5 +1,6 @@
-"""Soak run: random fleet sizes, rollout lengths, tracks and options; the kernel shape the library picks against the
-one-wave kernels, bit for bit (outputs, state, statistics).  python profiles/soak_shapes.py <seconds>   (GPU)"""
+"""Soak run: random fleet sizes, rollout lengths, tracks and options; the kernel shapes the library picks (fused launches AND
+single-step launches: three waves cut by dependency where it applies) against the one-wave kernels, bit for bit (outputs,
+state, statistics).  python profiles/soak_shapes.py <seconds>   (GPU)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # repo root (this file lives in profiles/)
 sys.path.insert(0, ROOT)
@@ -24,7 +25,9 @@ while time.time() < t_end:
     if rng.integers(0, 4) == 0:
         kw.update(physics=str(rng.choice(["pyb_gnd", "pyb_drag", "pyb_gnd_drag_dw"])))
     if rng.integers(0, 6) == 0:
-        kw.update(act="rpm", normalize_actions=False)
+        kw.update(act=str(rng.choice(["rpm", "one_d_rpm", "pid", "vel", "one_d_pid"])), normalize_actions=False)
+    if rng.integers(0, 8) == 0 and trk != "reaching":
+        kw.update(random_spawn=True)
     if rng.integers(0, 5) == 0:
         kw.update(clip_rew=bool(rng.integers(0, 2)), norm_rew=True)
     os.environ["DN_WAVES"] = "1"
@@ -37,9 +40,21 @@ while time.time() < t_end:
     os.environ.pop("DN_WAVES", None)
     w = env.kernel_waves(fused=True)
     shapes[w] = shapes.get(w, 0) + 1
+    ws = env.kernel_waves(fused=False)
+    shapes["single%d" % ws] = shapes.get("single%d" % ws, 0) + 1
     ref.reset(); env.reset()
     torch.manual_seed(it)
     for rep in range(2):
+        for _ in range(int(rng.integers(0, 7))):           # a few closed-loop single steps between the fused launches
+            a1 = torch.rand((n, 4), device=dev) * 2 - 1
+            x, y = ref.step_tensor(a1), env.step_tensor(a1)
+            d = x[2].bool()
+            for k, (xx, yy) in {"obs": (x[0], y[0]), "reward": (x[1], y[1]), "done": (x[2], y[2]), "truncated": (x[3]["truncated"], y[3]["truncated"]),
+                                "found": (x[3]["found_targets"], y[3]["found_targets"]), "terminal_obs": (x[3]["terminal_obs"][d], y[3]["terminal_obs"][d]),
+                                "ep_return": (x[3]["ep_return"][d], y[3]["ep_return"][d]), "ep_length": (x[3]["ep_length"][d], y[3]["ep_length"][d])}.items():
+                if not torch.equal(xx, yy):
+                    print("MISMATCH single step it", it, "n", n, "track", trk, "kw", kw, "waves single", ws, "key", k, flush=True)
+                    raise SystemExit(1)
         u = torch.rand((K, n, 4), device=dev)
         acts = (u * 2 - 1) if rng.integers(0, 2) else (0.0922 + 0.01 * (u - 0.5))
         a, b = ref.rollout_tensor(acts, want_terminal=True), env.rollout_tensor(acts, want_terminal=True)
