@@ -30,8 +30,10 @@ while time.time() < t_end:
     phys = act = None
     if rng.integers(0, 4) == 0:
         phys = str(rng.choice(["pyb_gnd", "pyb_drag", "pyb_gnd_drag_dw"]))
-    if rng.integers(0, 6) == 0:
-        act = "rpm"; kw["normalize_actions"] = okw["normalize_actions"] = False
+    if rng.integers(0, 5) == 0:
+        act = str(rng.choice(["rpm", "one_d_rpm", "pid", "vel", "one_d_pid"])); kw["normalize_actions"] = okw["normalize_actions"] = False
+    if rng.integers(0, 8) == 0 and trk != "reaching":      # random spawn (the race track repeats a gate: a zero-length line)
+        kw["random_spawn"] = okw["random_spawn"] = True
     env = pkg.DroneVecEnv(track, n, device=dev, **kw, **({"physics": phys} if phys else {}), **({"act": act} if act else {}))
     cfg = O.make_config(track.targets(), track.initial_xyzs, track.aviary_dim, circle=track.is_circle, f32_state=False,
                         physics=pkg.vec_env.PHYSICS[phys or "pyb"], action_type=pkg.vec_env.ACTION_TYPES[act or "thrust"], **okw)
