@@ -19,7 +19,11 @@
  *              functions restate Bullet's published algorithm from memory
  *              (btMultiBody::computeAccelerationsArticulatedBodyAlgorithmMultiDof,
  *              btMultiBody::stepPositionsMultiDof, pybullet.c getEulerFromQuaternion) and
- *              are "parity unpinned"; they are covered by analytic invariants only.
+ *              are "parity unpinned".  Stand-in evidence (tests/test_bullet_invariants.py): closed-form one-step
+ *              results, an independent world-frame integrator (1e-12), and through it the reference's own
+ *              dead explicit model BaseAviary._dynamics (BaseAviary.py:899-973, fixture dead_dynamics.npz,
+ *              1e-13 with the damping switched off) -- the structure of the step is tied to a statement the
+ *              reference owns; Bullet's damping law and velocity clamp are recall.
  *
  * All arithmetic follows the reference's dtypes: float32 for the action chain
  * (A1-A3, numpy float32 arrays), float64 for everything else.

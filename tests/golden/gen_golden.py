@@ -529,6 +529,45 @@ def gen_random_spawn(out):
     out["random_spawn"] = dict(frm=frm, to=to, t=t, rv=rv, u=u, bounds=bounds, max_distance=np.float64(0.1), points=pts)
 
 
+def gen_dead_dynamics(out):
+    """Row A4, structure only: the reference's own explicit rigid-body model, BaseAviary._dynamics + _integrateQ
+    (BaseAviary.py:899-973).  It is dead code (Physics.DYN is never selected and `self.TIMESTEP` is undefined, :944), differs
+    from what Bullet simulates in three declared ways (no damping; arm L / sqrt(2) instead of the loaded URDF's 0.028; the y
+    signs of the safegym URDF's prop layout) and is NOT Bullet -- but it is the one statement of the
+    semi-implicit step, the thrust direction, the yaw-torque convention and the gyroscopic term that the reference itself
+    owns.  Called unbound on a PBDroneEnv with TIMESTEP set; the fake Bullet records what it hands to
+    resetBasePositionAndOrientation / resetBaseVelocity."""
+    from Sol.PyBullet.BaseAviary import BaseAviary
+    targets, spawn, dim, circle = track_circle(4)
+    env = make_ref_env(targets, spawn, dim, circle)
+    env.TIMESTEP = env.PYB_TIMESTEP
+    env.rpy_rates = np.zeros((1, 3))                           # _housekeeping creates it only for Physics.DYN (BaseAviary.py:547-548)
+    rng = np.random.default_rng(41)
+    n = 300
+    pos = rng.uniform(-2, 2, (n, 3)) + [0, 0, 3]
+    quat = rng.standard_normal((n, 4))
+    quat /= np.linalg.norm(quat, axis=1, keepdims=True)
+    vel = rng.normal(0, 2.0, (n, 3))
+    rates = rng.normal(0, 8.0, (n, 3))                        # body-frame angular velocity (rpy_rates)
+    rates[:3] = 0.0                                           # _integrateQ's |omega| = 0 branch
+    rpm = rng.uniform(9440.3, 21666.4, (n, 4))
+    got = {k: np.zeros((n, d)) for k, d in (("pos", 3), ("quat", 4), ("vel", 3), ("ang_v_world", 3), ("rates", 3))}
+    captured = {}
+    orig_pose, orig_vel = pb.resetBasePositionAndOrientation, pb.resetBaseVelocity
+    pb.resetBasePositionAndOrientation = lambda bid, p_, q_, **kw: captured.update(pos=np.array(p_, float), quat=np.array(q_, float))
+    pb.resetBaseVelocity = lambda bid, v_, w_, **kw: captured.update(vel=np.array(v_, float), ang=np.array(w_, float))
+    try:
+        for k in range(n):
+            env.pos[0], env.quat[0], env.vel[0], env.rpy_rates[0] = pos[k], quat[k], vel[k], rates[k]
+            BaseAviary._dynamics(env, rpm[k].copy(), 0)
+            got["pos"][k], got["quat"][k], got["vel"][k], got["ang_v_world"][k] = captured["pos"], captured["quat"], captured["vel"], captured["ang"]
+            got["rates"][k] = env.rpy_rates[0]
+    finally:
+        pb.resetBasePositionAndOrientation, pb.resetBaseVelocity = orig_pose, orig_vel
+    out["dead_dynamics"] = dict(pos=pos, quat=quat, vel=vel, rates=rates, rpm=rpm, L=np.float64(env.L), KF=np.float64(env.KF),
+                                KM=np.float64(env.KM), **{"out_" + k: v for k, v in got.items()})
+
+
 def gen_gae(out):
     """N1: execute the reference's GAE lines (cleanRLPPO.py:234-248) on random buffers."""
     import torch
@@ -588,7 +627,8 @@ def main():
     only = set(sys.argv[1:])
     gens = dict(actions=gen_constants_and_actions, tracks=gen_tracks, obs_pack=gen_obs_pack, closed_loop=gen_closed_loop,
                 scripted=gen_scripted, normalize=gen_normalize, gae=gen_gae, rollout_dump=gen_rollout_dump,
-                reward_wrappers=gen_reward_wrappers, extra_physics=gen_extra_physics, pid_control=gen_pid_control, random_spawn=gen_random_spawn)
+                reward_wrappers=gen_reward_wrappers, extra_physics=gen_extra_physics, pid_control=gen_pid_control, random_spawn=gen_random_spawn,
+                dead_dynamics=gen_dead_dynamics)
     for key, fn in gens.items():          # `python gen_golden.py rollout_dump` regenerates only that group
         if not only or key in only:
             fn(out)

@@ -31,30 +31,37 @@ PROP_XY = np.array([[0.028, -0.028], [-0.028, -0.028], [-0.028, 0.028], [0.028, 
 YAW_SIGN = np.array([-1.0, 1.0, -1.0, 1.0])          # z_torque = -t0 + t1 - t2 + t3, BaseAviary.py:780
 
 
-def body_wrench(forces, z_torque):
+# the layout of the reference's own (dead) explicit model, BaseAviary._dynamics (BaseAviary.py:927-931): arm L / sqrt(2) and
+# the y signs of Sol/resources/safegym/cf2x.urdf -- x_torque = (F0 + F1 - F2 - F3) l, y_torque = (-F0 + F1 + F2 - F3) l
+L_DEAD = 0.0397 / np.sqrt(2.0)
+PROP_XY_DEAD = np.array([[L_DEAD, L_DEAD], [-L_DEAD, L_DEAD], [-L_DEAD, -L_DEAD], [L_DEAD, -L_DEAD]])
+
+
+def body_wrench(forces, z_torque, prop_xy=None):
     """Resultant of four +z forces at the prop offsets and the yaw torque, body frame."""
     f = np.asarray(forces, dtype=np.float64)
     force = np.array([0.0, 0.0, f.sum()])
     tau = np.zeros(3)
-    for (x, y), fi in zip(PROP_XY, f):
+    for (x, y), fi in zip(PROP_XY if prop_xy is None else prop_xy, f):
         tau += np.cross([x, y, 0.0], [0.0, 0.0, fi])
     tau[2] += z_torque
     return force, tau
 
 
-def step(pos, quat, vel, ang_v, forces, z_torque, extra_world_force=None):
-    """One 1/240 s step.  quat is (x, y, z, w), base -> world.  Returns new (pos, quat, vel, ang_v)."""
+def step(pos, quat, vel, ang_v, forces, z_torque, extra_world_force=None, damping=C_DAMP, prop_xy=None):
+    """One 1/240 s step.  quat is (x, y, z, w), base -> world.  Returns new (pos, quat, vel, ang_v).
+    damping / prop_xy: Bullet's default damping and the loaded URDF's prop layout unless overridden."""
     pos, vel, w = (np.asarray(a, dtype=np.float64).copy() for a in (pos, vel, ang_v))
     rot = Rotation.from_quat(np.asarray(quat, dtype=np.float64))
     R = rot.as_matrix()
-    f_b, tau_b = body_wrench(forces, z_torque)
-    f_w = R @ f_b + np.array([0.0, 0.0, -M * G]) - M * vel * (C_DAMP + C_DAMP * np.linalg.norm(vel))
+    f_b, tau_b = body_wrench(forces, z_torque, prop_xy)
+    f_w = R @ f_b + np.array([0.0, 0.0, -M * G]) - M * vel * (damping + damping * np.linalg.norm(vel))
     if extra_world_force is not None:
         f_w = f_w + np.asarray(extra_world_force, dtype=np.float64)
     a = f_w / M
     I_w = R @ np.diag(J) @ R.T
     L = I_w @ w
-    rhs = R @ tau_b - np.cross(w, L) - L * (C_DAMP + C_DAMP * np.linalg.norm(w))
+    rhs = R @ tau_b - np.cross(w, L) - L * (damping + damping * np.linalg.norm(w))
     w_dot = np.linalg.solve(I_w, rhs)
     w = np.clip(w + w_dot * DT, -MAX_COORD_VEL, MAX_COORD_VEL)
     vel = np.clip(vel + a * DT, -MAX_COORD_VEL, MAX_COORD_VEL)

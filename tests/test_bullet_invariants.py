@@ -200,6 +200,33 @@ def test_bullet_multi_step_trajectory_matches_independent_integrator():
         np.testing.assert_allclose(a, b, rtol=0, atol=1e-9)
 
 
+def test_independent_integrator_reproduces_the_references_own_explicit_dynamics(golden):
+    """The one statement of a rigid-body step the reference itself owns: BaseAviary._dynamics + _integrateQ
+    (BaseAviary.py:899-973; dead code -- Physics.DYN is never selected -- executed for the fixture dead_dynamics.npz with
+    TIMESTEP set).  With its three declared differences from what Bullet simulates switched in (no damping, arm
+    L / sqrt(2), the safegym URDF's prop y signs) the independent world-frame integrator reproduces it to 1e-13:
+    semi-implicit order (v, w first, then x with the NEW v), thrust along body z, yaw torque -t0 + t1 - t2 + t3, the
+    gyroscopic term's sign, the exponential-map attitude update.  Chain of evidence for row A4's structure:
+    reference _dynamics == rigid_body_ref(damping 0, dead layout) here; rigid_body_ref(Bullet damping, loaded URDF layout)
+    == oracle to 1e-12 (above) == HIP path to 2e-6 (tests/test_gpu_bullet.py).  What stays unpinned is Bullet-specific: the
+    damping law and the velocity clamp."""
+    g = golden("dead_dynamics")
+    assert abs(float(g["L"]) / np.sqrt(2.0) - RB.L_DEAD) < 1e-18 and float(g["KF"]) == RB.KF and float(g["KM"]) == RB.KM
+    assert (np.abs(g["rates"]).sum(1) == 0).sum() >= 3                  # _integrateQ's |omega| = 0 branch is in the fixture
+    for k in range(len(g["pos"])):
+        q = g["quat"][k]
+        R = Rotation.from_quat(q).as_matrix()
+        f, tq = g["rpm"][k] ** 2 * RB.KF, g["rpm"][k] ** 2 * RB.KM
+        zt = -tq[0] + tq[1] - tq[2] + tq[3]
+        pos, quat, vel, w = RB.step(g["pos"][k], q, g["vel"][k], R @ g["rates"][k], f, zt, damping=0.0, prop_xy=RB.PROP_XY_DEAD)
+        np.testing.assert_allclose(pos, g["out_pos"][k], rtol=0, atol=1e-13)
+        np.testing.assert_allclose(vel, g["out_vel"][k], rtol=0, atol=1e-13)
+        qq = g["out_quat"][k] / np.linalg.norm(g["out_quat"][k])
+        np.testing.assert_allclose(quat, qq if np.dot(qq, quat) > 0 else -qq, rtol=0, atol=1e-13)
+        np.testing.assert_allclose(R.T @ w, g["out_rates"][k], rtol=0, atol=1e-12)      # new body rates: w' = R w_b' to first order
+        np.testing.assert_allclose(R @ g["out_rates"][k], g["out_ang_v_world"][k], rtol=0, atol=1e-12)
+
+
 def test_euler_matches_scipy_zyx_away_from_gimbal_lock():
     """p.getEulerFromQuaternion = intrinsic yaw-pitch-roll (Z-Y-X); scipy is the independent statement."""
     quats = Rotation.random(5000, random_state=7).as_quat()
