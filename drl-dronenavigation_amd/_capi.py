@@ -37,7 +37,7 @@ class DnConfig(C.Structure):
         ("ground_contact", C.c_int32), ("compute_f32", C.c_int32), ("act_noise_sigma", C.c_float),
         ("obs_noise_sigma", C.c_float), ("seed", C.c_uint64), ("env_id_offset", C.c_int64),
         ("clip_rew", C.c_int32), ("norm_rew", C.c_int32), ("physics", C.c_int32), ("action_type", C.c_int32),
-        ("random_spawn", C.c_int32),
+        ("random_spawn", C.c_int32), ("zero_damping", C.c_int32),
     ]
 
 

@@ -260,7 +260,7 @@ int32_t dn_create(const dn_config *cfg, dn_env **out)
     //   noise (Philox + Box-Muller per observation column): 16384 drones 3.51 / 4.63 / 5.86; 32768: 4.86 / 4.78 / 6.02;
     //     49152: 5.36 / 4.88 / 6.04 -> three waves up to 256 tiles, two beyond (same with the normaliser, up to 512);
     //     noise + XOPT without the normaliser follows the XOPT row (49152: 5.75 / 6.23 / 6.99).
-    const bool plain = !cfg->clip_rew && !cfg->norm_rew && cfg->physics == 0 && cfg->action_type == 0 && !cfg->random_spawn;
+    const bool plain = !cfg->clip_rew && !cfg->norm_rew && cfg->physics == 0 && cfg->action_type == 0 && !cfg->random_spawn && !cfg->zero_damping;
     const bool noisy = cfg->act_noise_sigma > 0.0f || cfg->obs_noise_sigma > 0.0f;
     const long long max_multi = cfg->normalize_obs ? DN_TWO_WAVE_MAX_TILES / 2 : DN_TWO_WAVE_MAX_TILES;
     long long max_three = max_multi;
@@ -327,6 +327,7 @@ int32_t dn_create(const dn_config *cfg, dn_env **out)
     p.gnd = cfg->physics == 1 || cfg->physics == 4; p.drag = drag; p.rpm_actions = cfg->action_type == 1 ? 1 : (cfg->action_type == 4 ? 2 : 0);
     p.pid_mode = pid_mode;
     p.random_spawn = cfg->random_spawn != 0;
+    p.zero_damping = cfg->zero_damping != 0;
     p.act_noise_sigma = cfg->act_noise_sigma; p.obs_noise_sigma = cfg->obs_noise_sigma;
     p.seed = cfg->seed; p.env_id_offset = cfg->env_id_offset;
     build_consts<double>(*cfg, p.c64);

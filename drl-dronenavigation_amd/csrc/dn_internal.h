@@ -100,6 +100,7 @@ struct DnParams {
     int gnd, drag, rpm_actions;     // N4: Physics.PYB_GND / PYB_DRAG force terms, ActionType.RPM (1) / ONE_D_RPM (2)
     int pid_mode;                   // N4: 0, or the dn_config.action_type of the DSLPIDControl family: 2 PID | 3 VEL | 5 ONE_D_PID
     int random_spawn;               // N4: episodes start at a Philox-drawn point around a random track line
+    int zero_damping;               // N4: changeDynamics(linearDamping=0, angularDamping=0), BaseAviary.py:571-573 (commented out there)
     float act_noise_sigma, obs_noise_sigma;
     unsigned long long seed;
     long long env_id_offset;

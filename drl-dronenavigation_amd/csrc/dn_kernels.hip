@@ -142,6 +142,7 @@ struct Extras {
     int gnd, drag, rpm_f32;     // Physics.PYB_GND / PYB_DRAG terms on; the rpm array is float32 (ActionType.THRUST chain)
     double rpm[4];              // this step's clipped_action (rpm)
     float4 last;                // BaseAviary.last_clipped_action: the previous step's rpm, zeros after a reset
+    double damp;                // btMultiBody m_linearDamping = m_angularDamping: 0.04, or 0 with dn_config.zero_damping
 };
 DN_DEV double gnd_effect_rotor(double rpm, bool rpm_f32)
 {   // np.array(rpm**2) * KF * GND_EFF_COEFF, BaseAviary.py:822 -- float32 while the rpm array is
@@ -853,6 +854,7 @@ DN_DEV ThrustX thrust_phase_x(const DnParams &p, unsigned long long gid, unsigne
     if (NOISE && p.act_noise_sigma > 0.0f) add_act_noise(p, gid, step_count, a);
     ThrustX t;
     x.gnd = p.gnd; x.drag = p.drag; x.rpm_f32 = !p.rpm_actions && !p.pid_mode;
+    x.damp = p.zero_damping ? 0.0 : 0.04;
     if (pid && p.pid_mode) {   // ActionType.PID / VEL / ONE_D_PID: the DSLPIDControl loop on the entry state
         float cmd[4];
         double rpm[4], tq[4];
@@ -991,7 +993,7 @@ template <typename R> struct Lin {
 };
 template <typename R>
 DN_DEV Lin<R> physics_linear(const float4 G0, const float4 G1, const float4 G2, const R fz, const R dax, const R day, const R daz,
-                             const bool extra)
+                             const bool extra, const R damp = K<R>::LIN_DAMP)
 {
     Lin<R> o;
     R px = G0.x, py = G0.y, pz = G0.z;
@@ -1002,7 +1004,7 @@ DN_DEV Lin<R> physics_linear(const float4 G0, const float4 G1, const float4 G2, 
     const R r02 = F(qx, t.zs, t.wys), r12 = F(qy, t.zs, -t.wxs), r22 = R(1.0) - F(qx, t.xs, t.yy);
     // linear: a = R[:,2] fz/M - (0,0,G) - v (c + c|v|)
     // the damping norms enter the velocity update at dt * 0.04: a float32 root moves it by 1e-12 relative
-    const R kl = F(K<R>::LIN_DAMP, (R)__builtin_amdgcn_sqrtf((float)F(vz, vz, F(vy, vy, vx * vx))), K<R>::LIN_DAMP);
+    const R kl = F(damp, (R)__builtin_amdgcn_sqrtf((float)F(vz, vz, F(vy, vy, vx * vx))), damp);
     const R fm = fz * K<R>::INV_M;
     R awx = F(r02, fm, -(vx * kl)), awy = F(r12, fm, -(vy * kl)), awz = F(-vz, kl, F(r22, fm, -K<R>::G));
     if (extra) { awx += dax; awy += day; awz += daz; }
@@ -1020,7 +1022,7 @@ template <typename R> struct Ang {
     R wx, wy, wz;          // new angular velocity
 };
 template <typename R>
-DN_DEV Ang<R> physics_angular(const float4 G1, const float4 G3, const R tx, const R ty, const R ztq)
+DN_DEV Ang<R> physics_angular(const float4 G1, const float4 G3, const R tx, const R ty, const R ztq, const R damp = K<R>::ANG_DAMP)
 {
     Ang<R> o;
     const R qx = G1.x, qy = G1.y, qz = G1.z, qw = G1.w;
@@ -1032,7 +1034,7 @@ DN_DEV Ang<R> physics_angular(const float4 G1, const float4 G3, const R tx, cons
     const R r20 = F(qx, t.zs, -t.wys), r21 = F(qy, t.zs, t.wxs), r22 = R(1.0) - F(qx, t.xs, t.yy);
     // angular, in the body frame: I dw = tau - w x (I w) - I w (c + c|w|)
     const R wbx = F(r20, wz, F(r10, wy, r00 * wx)), wby = F(r21, wz, F(r11, wy, r01 * wx)), wbz = F(r22, wz, F(r12, wy, r02 * wx));
-    const R ka = F(K<R>::ANG_DAMP, (R)__builtin_amdgcn_sqrtf((float)F(wz, wz, F(wy, wy, wx * wx))), K<R>::ANG_DAMP);
+    const R ka = F(damp, (R)__builtin_amdgcn_sqrtf((float)F(wz, wz, F(wy, wy, wx * wx))), damp);
     const R Iwx = K<R>::IXX * wbx, Iwy = K<R>::IYY * wby, Iwz = K<R>::IZZ * wbz;
     const R gx = F(wby, Iwz, -(wbz * Iwy)), gy = F(wbz, Iwx, -(wbx * Iwz)), gz = F(wbx, Iwy, -(wby * Iwx));
     const R dbx = F(-Iwx, ka, tx - gx) * K<R>::INV_IXX, dby = F(-Iwy, ka, ty - gy) * K<R>::INV_IYY,
@@ -1117,8 +1119,9 @@ DN_DEV Flight<R> physics_phase(const TH &th, const float4 G0, const float4 G1, c
     ty = K<R>::ARM * ((F1 + F2) - (F0 + F3));
     ztq = (R)th.zt;
     }
-    const Lin<R> lin = physics_linear<R>(G0, G1, G2, fz, dax, day, daz, XOPT);
-    const Ang<R> ang = physics_angular<R>(G1, G3, tx, ty, ztq);
+    const R damp = XOPT ? (R)x->damp : K<R>::LIN_DAMP;        // the option kernels take it at run time (dn_config.zero_damping)
+    const Lin<R> lin = physics_linear<R>(G0, G1, G2, fz, dax, day, daz, XOPT, damp);
+    const Ang<R> ang = physics_angular<R>(G1, G3, tx, ty, ztq, damp);
     fl.px = lin.px; fl.py = lin.py; fl.pz = lin.pz;
     fl.qx = ang.qx; fl.qy = ang.qy; fl.qz = ang.qz; fl.qw = ang.qw;
     fl.vx = (float)lin.vx; fl.vy = (float)lin.vy; fl.vz = (float)lin.vz;
@@ -2127,6 +2130,7 @@ __global__ __launch_bounds__(3 * DN_BLOCK, NORM ? 2 : 3) void dn_step_many_3w_ke
                     ThrustX th;
                     take_thrust_x(tmx[t & 1], lane, th, x);
                     x.gnd = p.gnd; x.drag = p.drag; x.rpm_f32 = !p.rpm_actions;
+                    x.damp = p.zero_damping ? 0.0 : 0.04;
                     x.last = G7;
                     rpm_now = make_float4((float)x.rpm[0], (float)x.rpm[1], (float)x.rpm[2], (float)x.rpm[3]);
                     fl = physics_phase<R, ThrustX, true>(th, G0, G1, G2, G3, p.max_steps, &x);
@@ -2626,7 +2630,7 @@ hipError_t dn_launch_step_many_mw(const DnParams &p, const DnStepIO &io, int k, 
     const unsigned grid = (unsigned)((p.n + DN_BLOCK - 1) / DN_BLOCK);
     const bool noise = p.act_noise_sigma > 0.0f || p.obs_noise_sigma > 0.0f;
     // the rarely used options share one set of instantiations (runtime switches inside): reward wrappers, N4 physics terms
-    const bool rew = p.clip_rew != 0 || p.norm_rew != 0 || p.gnd != 0 || p.drag != 0 || p.rpm_actions != 0 || p.pid_mode != 0 || p.random_spawn != 0;
+    const bool rew = p.clip_rew != 0 || p.norm_rew != 0 || p.gnd != 0 || p.drag != 0 || p.rpm_actions != 0 || p.pid_mode != 0 || p.random_spawn != 0 || p.zero_damping != 0;
     if (waves == 3 && k > 1) {                             // three waves per tile: fused launches
         const dim3 blk(3 * DN_BLOCK);
         const bool norm = p.normalize_obs != 0;
@@ -2699,7 +2703,7 @@ hipError_t dn_launch_step_many(const DnParams &p, const DnStepIO &io, int k, boo
     const bool two_wave = waves >= 2;       // with the normaliser: the two-wave kernels (there is no three-wave one)
     const unsigned grid = (unsigned)((p.n + DN_BLOCK - 1) / DN_BLOCK);
     const bool noise = p.act_noise_sigma > 0.0f || p.obs_noise_sigma > 0.0f;
-    const bool rew = p.clip_rew != 0 || p.norm_rew != 0 || p.gnd != 0 || p.drag != 0 || p.rpm_actions != 0 || p.pid_mode != 0 || p.random_spawn != 0;
+    const bool rew = p.clip_rew != 0 || p.norm_rew != 0 || p.gnd != 0 || p.drag != 0 || p.rpm_actions != 0 || p.pid_mode != 0 || p.random_spawn != 0 || p.zero_damping != 0;
     if (two_wave) {                         // normaliser on
         if (f32) { if (noise) DN_LAUNCH(float, true, true); else DN_LAUNCH(float, true, false); }
         else { if (noise) DN_LAUNCH(double, true, true); else DN_LAUNCH(double, true, false); }

@@ -91,6 +91,8 @@ typedef struct dn_config {
                                                    (PositionGenerator.generate_random_point_around_line, position_generator.py:121-152, max_distance
                                                    0.1, fed by the dormant block PBDroneEnv.py:622-627); draws are Philox words keyed by `seed`, the
                                                    global drone id and the vector step, so sharding does not move them.  0 = the reference as it runs */
+    int32_t zero_damping;                       /* p.changeDynamics(linearDamping=0, angularDamping=0): the line the reference keeps commented out
+                                                   (BaseAviary.py:571-573).  0 = Bullet's default damping 0.04 (1 + |v|), what the reference simulates */
 } dn_config;
 
 /* One drone's persistent state, host-side AoS view used by dn_get_state/dn_set_state (tests,

@@ -200,6 +200,14 @@ void orc_bullet_step(double pos[3], double quat[4], double vel[3], double ang_v[
 void orc_bullet_step_ex(double pos[3], double quat[4], double vel[3], double ang_v[3],
                         const double forces[4], double z_torque, const double body_force[3])
 {
+    orc_bullet_step_damp(pos, quat, vel, ang_v, forces, z_torque, body_force, ORC_LIN_DAMP);
+}
+
+/* damp: btMultiBody's m_linearDamping = m_angularDamping (0.04 by default; 0 is what the reference's commented-out
+ * p.changeDynamics(..., linearDamping=0, angularDamping=0) would set, BaseAviary.py:571-573) */
+void orc_bullet_step_damp(double pos[3], double quat[4], double vel[3], double ang_v[3],
+                          const double forces[4], double z_torque, const double body_force[3], double damp)
+{
     const double dt = ORC_DT;
     double R[9];
     quat_to_mat(quat, R);                       /* base -> world */
@@ -220,8 +228,8 @@ void orc_bullet_step_ex(double pos[3], double quat[4], double vel[3], double ang
     matT_vec(R, gw, gb);
 
     double nv = norm3(vb), nw = norm3(wb);
-    double kl = ORC_LIN_DAMP + ORC_LIN_DAMP * nv;
-    double ka = ORC_ANG_DAMP + ORC_ANG_DAMP * nw;
+    double kl = damp + damp * nv;
+    double ka = damp + damp * nw;
     /* body_force: LINK_FRAME force on link 4, whose frame coincides with the base frame (cf2x.urdf:88-98) */
     double Fb[3] = { body_force[0] + gb[0] - ORC_M * vb[0] * kl,
                      body_force[1] + gb[1] - ORC_M * vb[1] * kl,
@@ -760,7 +768,7 @@ void orc_env_step(const orc_config *c, orc_env *e, const float action[4], orc_st
     }
     if (c->physics == 2 || c->physics == 4)                                  /* _drag(last_clipped_action), :425-427,435 */
         orc_drag(e->quat, e->vel, e->last_clipped_action, rpm_is_f32, body_force);
-    orc_bullet_step_ex(e->pos, e->quat, e->vel, e->ang_v, f, zt, body_force);   /* :439-440 */
+    orc_bullet_step_damp(e->pos, e->quat, e->vel, e->ang_v, f, zt, body_force, c->zero_damping ? 0.0 : ORC_LIN_DAMP);   /* :439-440 */
     memcpy(e->last_clipped_action, rpm, sizeof rpm);                         /* :442 */
     orc_euler_from_quat(e->quat, e->rpy);                                    /* :444 */
     orc_compute_obs(c, e, out->obs);                                         /* :446 */

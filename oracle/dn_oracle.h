@@ -77,6 +77,8 @@ typedef struct orc_config {
     int32_t action_type;
     /* N4: spawn every episode at a random point around a random track line (PBDroneEnv.py:622-627, dormant in the reference) */
     int32_t random_spawn;
+    /* N4: p.changeDynamics(linearDamping=0, angularDamping=0), the line the reference keeps commented out (BaseAviary.py:571-573) */
+    int32_t zero_damping;
 } orc_config;
 
 /* Every per-env variable the reference keeps, under the reference's names. */
@@ -142,6 +144,8 @@ void orc_ground_effect(const double pos[3], const double quat[4], const double r
                        double out[4]);
 /* BaseAviary._drag (:836-862): forceObj handed to link 4 */
 void orc_drag(const double quat[4], const double vel[3], const double last_rpm[4], int rpm_is_f32, double out[3]);
+void orc_bullet_step_damp(double pos[3], double quat[4], double vel[3], double ang_v[3],
+                          const double forces[4], double z_torque, const double body_force[3], double damp);
 void orc_euler_from_quat(const double q[4], double rpy[3]);
 /* ActionType.PID (2) / VEL (3) / ONE_D_RPM (4) / ONE_D_PID (5): BaseSingleAgentAviary._preprocessAction (:180-222) with
  * DSLPIDControl.computeControl; st[9] = integral_pos_e, last_rpy, integral_rpy_e (python half pinned: pid_control.npz) */

@@ -40,6 +40,7 @@ class OrcConfig(C.Structure):
         ("physics", C.c_int32),
         ("action_type", C.c_int32),
         ("random_spawn", C.c_int32),
+        ("zero_damping", C.c_int32),
     ]
 
 
@@ -112,6 +113,7 @@ def lib():
     L.orc_rotor_forces.argtypes = [fp, fp, fp]
     L.orc_bullet_step.argtypes = [dp, dp, dp, dp, dp, C.c_double]
     L.orc_bullet_step_ex.argtypes = [dp, dp, dp, dp, dp, C.c_double, dp]
+    L.orc_bullet_step_damp.argtypes = [dp, dp, dp, dp, dp, C.c_double, dp, C.c_double]
     L.orc_rpm_action.argtypes = [fp, dp, dp, dp]
     L.orc_ground_effect.argtypes = [dp, dp, dp, dp, C.c_int, dp]
     L.orc_drag.argtypes = [dp, dp, dp, C.c_int, dp]
@@ -151,7 +153,7 @@ def lib():
 def make_config(waypoints, spawn, dim, *, threshold=0.3, max_steps=4096, circle=False, cylinder=True,
                 include_distance=True, normalize_actions=True, normalize_obs=False, ground_contact=False,
                 f32_state=False, act_noise_sigma=0.0, obs_noise_sigma=0.0, seed=0, env_id_offset=0, clip_rew=False,
-                norm_rew=False, physics=0, action_type=0, random_spawn=False):
+                norm_rew=False, physics=0, action_type=0, random_spawn=False, zero_damping=False):
     wp = np.asarray(waypoints, dtype=np.float64).reshape(-1, 3)
     assert 1 <= len(wp) <= MAX_WAYPOINTS
     cfg = OrcConfig()
@@ -172,6 +174,7 @@ def make_config(waypoints, spawn, dim, *, threshold=0.3, max_steps=4096, circle=
     cfg.clip_rew, cfg.norm_rew = int(clip_rew), int(norm_rew)
     cfg.physics, cfg.action_type = int(physics), int(action_type)
     cfg.random_spawn = int(random_spawn)
+    cfg.zero_damping = int(zero_damping)
     return cfg
 
 

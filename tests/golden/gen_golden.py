@@ -562,10 +562,36 @@ def gen_dead_dynamics(out):
             BaseAviary._dynamics(env, rpm[k].copy(), 0)
             got["pos"][k], got["quat"][k], got["vel"][k], got["ang_v_world"][k] = captured["pos"], captured["quat"], captured["vel"], captured["ang"]
             got["rates"][k] = env.rpy_rates[0]
+        # second set: thrust COMMANDS through the reference's own action chain (PBDroneEnv._preprocessAction -> float32 rpm ->
+        # _dynamics), in the pattern (a, b, a, b): no roll / pitch torque in either prop layout, so this model and the body
+        # Bullet simulates coincide once the damping is off -- a direct target for the oracle and the HIP step with
+        # dn_config.zero_damping (the changeDynamics line the reference keeps commented out, BaseAviary.py:571-573).
+        # Inputs are float32-representable (the HIP state's type).
+        m = 256
+        f32 = lambda a: np.asarray(a, np.float32).astype(np.float64)      # noqa: E731
+        pos2 = f32(rng.uniform(-2, 2, (m, 3)) + [0, 0, 3])
+        q2 = rng.standard_normal((m, 4)); q2 /= np.linalg.norm(q2, axis=1, keepdims=True); q2 = f32(q2)
+        vel2, rates2 = f32(rng.normal(0, 2.0, (m, 3))), rng.normal(0, 6.0, (m, 3))
+        ab = rng.uniform(0.03, 0.14, (m, 2)).astype(np.float32)
+        thrust = np.stack([ab[:, 0], ab[:, 1], ab[:, 0], ab[:, 1]], axis=1)
+        rpm2 = np.zeros((m, 4), np.float32)
+        got2 = {k: np.zeros((m, d)) for k, d in (("pos", 3), ("quat", 4), ("vel", 3), ("ang_v_world", 3))}
+        w_in = np.zeros((m, 3))
+        for k in range(m):
+            R = np.array(pb.getMatrixFromQuaternion(q2[k])).reshape(3, 3)
+            w_in[k] = f32(R @ rates2[k])                          # world angular velocity as the float32 state holds it
+            rates2[k] = R.T @ w_in[k]
+            rpm2[k] = env._preprocessAction(thrust[k].copy())
+            assert rpm2[k].dtype == np.float32
+            env.pos[0], env.quat[0], env.vel[0], env.rpy_rates[0] = pos2[k], q2[k], vel2[k], rates2[k]
+            BaseAviary._dynamics(env, rpm2[k].copy(), 0)
+            got2["pos"][k], got2["quat"][k], got2["vel"][k], got2["ang_v_world"][k] = captured["pos"], captured["quat"], captured["vel"], captured["ang"]
     finally:
         pb.resetBasePositionAndOrientation, pb.resetBaseVelocity = orig_pose, orig_vel
     out["dead_dynamics"] = dict(pos=pos, quat=quat, vel=vel, rates=rates, rpm=rpm, L=np.float64(env.L), KF=np.float64(env.KF),
-                                KM=np.float64(env.KM), **{"out_" + k: v for k, v in got.items()})
+                                KM=np.float64(env.KM), **{"out_" + k: v for k, v in got.items()},
+                                chain_pos=pos2, chain_quat=q2, chain_vel=vel2, chain_ang_v=w_in, chain_thrust=thrust, chain_rpm=rpm2,
+                                **{"chain_out_" + k: v for k, v in got2.items()})
 
 
 def gen_gae(out):

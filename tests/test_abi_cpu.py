@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol(pkg):
 
 def test_struct_layouts_match_header(pkg):
     # sizes computed by hand from include/dronenav.h (natural alignment) ...
-    assert C.sizeof(pkg._capi.DnConfig) == 8 + 4 + 4 + 64 * 3 * 8 + 3 * 8 + 6 * 8 + 8 + 8 * 4 + 2 * 4 + 8 + 8 + 4 * 4 + 2 * 4   # ... + random_spawn + tail padding
+    assert C.sizeof(pkg._capi.DnConfig) == 8 + 4 + 4 + 64 * 3 * 8 + 3 * 8 + 6 * 8 + 8 + 8 * 4 + 2 * 4 + 8 + 8 + 4 * 4 + 2 * 4   # ... + random_spawn + zero_damping
     assert C.sizeof(pkg._capi.DnStats) == 7 * 8
     # ... and by the C compiler from the header itself: sizes and the offsets of the trailing fields
     import subprocess

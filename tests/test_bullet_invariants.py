@@ -227,6 +227,34 @@ def test_independent_integrator_reproduces_the_references_own_explicit_dynamics(
         np.testing.assert_allclose(R @ g["out_rates"][k], g["out_ang_v_world"][k], rtol=0, atol=1e-12)
 
 
+def test_oracle_without_damping_matches_the_references_explicit_dynamics_through_its_action_chain(golden):
+    """A DIRECT reference-generated target for the rigid-body step: thrust commands (a, b, a, b) through the reference's own
+    PBDroneEnv._preprocessAction (float32 rpm) into its own BaseAviary._dynamics (dead_dynamics.npz, chain_* arrays).  That
+    pattern has no roll / pitch torque in either prop layout, so the reference's explicit model and the body Bullet
+    simulates coincide once Bullet's damping is switched off -- which is the changeDynamics line the reference keeps
+    commented out (BaseAviary.py:571-573) and dn_config.zero_damping here.  The oracle step with damp = 0 against it:
+    tumbling states, gyroscopic coupling, yaw torque, semi-implicit order, attitude update.  (1e-7: _dynamics sums the
+    four float32 rotor forces in float32, Bullet in double.)"""
+    g = golden("dead_dynamics")
+    L = O.lib()
+    n = len(g["chain_pos"])
+    assert n >= 200 and np.abs(g["chain_ang_v"]).max() > 10.0
+    for k in range(n):
+        rpm = g["chain_rpm"][k]
+        assert rpm.dtype == np.float32
+        f = np.zeros(4, np.float32)
+        z = C.c_float()
+        L.orc_rotor_forces(rpm.ctypes.data_as(C.POINTER(C.c_float)), f.ctypes.data_as(C.POINTER(C.c_float)), C.byref(z))
+        p, q, v, w = (np.array(g["chain_" + name][k], dtype=np.float64) for name in ("pos", "quat", "vel", "ang_v"))
+        fd, none = f.astype(np.float64), np.zeros(3)
+        L.orc_bullet_step_damp(_dp(p), _dp(q), _dp(v), _dp(w), _dp(fd), float(z.value), _dp(none), 0.0)
+        qq = g["chain_out_quat"][k] / np.linalg.norm(g["chain_out_quat"][k])
+        np.testing.assert_allclose(p, g["chain_out_pos"][k], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(v, g["chain_out_vel"][k], rtol=0, atol=1e-7)
+        np.testing.assert_allclose(q, qq if np.dot(qq, q) > 0 else -qq, rtol=0, atol=1e-8)
+        np.testing.assert_allclose(w, g["chain_out_ang_v_world"][k], rtol=0, atol=1e-6)
+
+
 def test_euler_matches_scipy_zyx_away_from_gimbal_lock():
     """p.getEulerFromQuaternion = intrinsic yaw-pitch-roll (Z-Y-X); scipy is the independent statement."""
     quats = Rotation.random(5000, random_state=7).as_quat()

@@ -215,3 +215,27 @@ def test_euler_gimbal_lock_branches_fire_on_gpu(sign):
         elif abs(abs(rpy[1]) - np.pi / 2) > 5e-3:                          # away from the branch edge (float32 quaternion)
             np.testing.assert_allclose(obs[k, 3:6], np.array(rpy) / np.pi, atol=2e-5)
     assert locked >= 15, locked
+
+
+def test_hip_step_without_damping_matches_the_references_own_explicit_dynamics(golden):
+    """The HIP step against numbers the REFERENCE produced: thrust commands (a, b, a, b) through the reference's own
+    PBDroneEnv._preprocessAction into its own BaseAviary._dynamics (BaseAviary.py:899-973; dead_dynamics.npz chain_* arrays,
+    tests/golden/gen_golden.py::gen_dead_dynamics).  For that pattern the reference's explicit model and the body Bullet
+    simulates coincide once Bullet's damping is off (dn_config.zero_damping = the changeDynamics line commented out at
+    BaseAviary.py:571-573): 256 tumbling states, float32 state bar 1e-5.  No oracle, no recalled formula in between."""
+    g = golden("dead_dynamics")
+    n = len(g["chain_pos"])
+    st, _ = one_step(g["chain_pos"], g["chain_quat"], g["chain_vel"], g["chain_ang_v"], g["chain_thrust"], zero_damping=True)
+    worst = {}
+    for k in range(n):
+        qq = g["chain_out_quat"][k] / np.linalg.norm(g["chain_out_quat"][k])
+        got_q = st["quat"][k].astype(np.float64)
+        for name, got, want in (("pos", st["pos"][k], g["chain_out_pos"][k]), ("vel", st["vel"][k], g["chain_out_vel"][k]),
+                                ("quat", got_q, qq if np.dot(qq, got_q) > 0 else -qq), ("ang_v", st["ang_v"][k], g["chain_out_ang_v_world"][k])):
+            err = np.abs(np.asarray(got, np.float64) - want)
+            worst[name] = max(worst.get(name, 0.0), float(err.max()))
+            assert np.all(err <= 1e-5 + 1e-6 * np.abs(want)), f"state {k}: {name} {got} vs {want}"
+    # and the damping matters: the same step with Bullet's default damping is visibly different
+    st_d, _ = one_step(g["chain_pos"], g["chain_quat"], g["chain_vel"], g["chain_ang_v"], g["chain_thrust"])
+    assert np.abs(st_d["vel"].astype(np.float64) - g["chain_out_vel"]).max() > 1e-4
+    print("HIP step (zero damping) vs the reference's _dynamics: max |err|", {k: f"{v:.2e}" for k, v in worst.items()})
