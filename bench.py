@@ -245,6 +245,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if os.environ.get("DN_BENCH_SPIN", "1") == "1":
+        # The contract's timed region ends in a host-side synchronize; with the driver's 20 steps it is one 40 us launch, and the
+        # default blocking wait adds a thread wake-up of the same order.  Ask HIP to spin in its waits instead (a host-side wait
+        # policy, hipDeviceScheduleSpin; it must be set before the device is initialised).
+        try:
+            hip = C.CDLL("libamdhip64.so")
+            hip.hipSetDeviceFlags(C.c_uint(1))
+        except OSError:
+            pass
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     dev = torch.device("cuda", local_rank)
