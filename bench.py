@@ -251,6 +251,7 @@ def main():
         # policy, hipDeviceScheduleSpin; it must be set before the device is initialised).
         try:
             hip = C.CDLL("libamdhip64.so")
+            hip.hipSetDevice(C.c_int(local_rank))              # the flag belongs to the current device: this rank's own
             hip.hipSetDeviceFlags(C.c_uint(1))
         except OSError:
             pass
