@@ -453,6 +453,38 @@ def main():
         except Exception as exc:  # noqa: BLE001
             norm_on = {"error": f"{type(exc).__name__}: {exc}"}
 
+    # where HBM IS the bound: the same step kernel over a fleet that fills the chip many times over (one wave per 64 drones,
+    # 32768 workgroups), one control step per launch -- the regime the byte model of SURVEY 8(d) describes
+    large = None
+    if world == 1 and not args.profile_lite:
+        try:
+            nl = 2097152
+            env_l = pkg.DroneVecEnv(track, nl, max_steps=max_steps, normalize_obs=False, compute_dtype=args.compute_dtype, device=dev)
+            env_l.reset_tensor()
+            gl = torch.Generator(device="cpu").manual_seed(7)
+            acts_l = (torch.rand((2, nl, 4), generator=gl, dtype=torch.float32) * 2 - 1).to(dev)
+            for t in range(20):
+                env_l.step_tensor(acts_l[t & 1])
+            e0_, e1_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize(dev)
+            e0_.record(stream)
+            reps_l = 200
+            for t in range(reps_l):
+                env_l.step_tensor(acts_l[t & 1])
+            e1_.record(stream)
+            torch.cuda.synchronize(dev)
+            us_l = e0_.elapsed_time(e1_) * 1e3 / reps_l
+            bytes_l = ALGO_BYTES_PER_ENV_STEP * nl
+            large = {"num_envs": nl, "kernel": kernel_name(env_l.kernel_waves(fused=False), args.compute_dtype, False, False),
+                     "us_per_vector_step": round(us_l, 3), "value": round(nl / (us_l * 1e-6), 1), "unit": "env-steps/s",
+                     "algorithmic_bytes_per_launch": bytes_l, "achieved_GBps": round(bytes_l / (us_l * 1e-6) / 1e9, 1),
+                     "frac": round(bytes_l / (us_l * 1e-6) / 1e9 / HBM_PEAK_GBPS, 5),
+                     "what": "2 097 152 drones, one control step per launch: the fleet size at which the step IS bandwidth bound"}
+            env_l.close()
+            del acts_l
+        except Exception as exc:  # noqa: BLE001
+            large = {"error": f"{type(exc).__name__}: {exc}"}
+
     # the SB3 NumPy surface (PCIe-inclusive: H2D actions, D2H obs/reward/done/found, N info dicts built in Python);
     # host bound, reported for the record only
     if world == 1 and not args.profile_lite:
@@ -509,6 +541,7 @@ def main():
                                  "instruction stream of the flight wave, the single-step launch by load + launch latency (DESIGN.md 4.3)"},
             "single_step": single_step,
             "normalize_obs_on": norm_on,
+            "hbm_bound_fleet": large,
             "other_launch_shapes": others,
         }
         if sharded is not None:
