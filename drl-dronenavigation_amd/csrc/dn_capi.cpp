@@ -490,6 +490,25 @@ int32_t dn_compact_done(const uint64_t *done_mask, int64_t num_envs, int32_t *in
     return DN_OK;
 }
 
+// Monitor's running return is held as the float32 hi (g4.w) + k * ulp(hi) / 256 with k the signed top byte of the length
+// word (dn_kernels.hip report_scalars); dn_env_state shows the low part as a float.
+static float ret_lo_decode(float hi, int k)
+{
+    uint32_t bits;
+    memcpy(&bits, &hi, 4);
+    const int eb = (int)((bits >> 23) & 0xFFu);
+    return eb > 31 ? (float)ldexp((double)k, eb - 127 - 31) : 0.0f;
+}
+static int ret_lo_encode(float hi, float lo)
+{
+    uint32_t bits;
+    memcpy(&bits, &hi, 4);
+    const int eb = (int)((bits >> 23) & 0xFFu);
+    if (eb <= 31 || eb == 255) return 0;
+    const double q = nearbyint(ldexp((double)lo, 127 + 31 - eb));
+    return (int)fmin(fmax(q, -128.0), 127.0) & 0xFF;
+}
+
 int32_t dn_get_state(dn_env *env, dn_env_state *states, int64_t count)
 {
     if (!env || !states) return fail(DN_ERR_INVALID_ARGUMENT, "env and states are required");
@@ -539,9 +558,11 @@ int32_t dn_get_state(dn_env *env, dn_env_state *states, int64_t count)
         memcpy(&meta, &g[3][i].w, 4);
         s.steps = (int32_t)(meta & 0xFFFFFFu); s.idx = (int32_t)((meta >> 24) & 0x7Fu); s.just_found = (int32_t)(meta >> 31);
         s.prev_vel[0] = g[4][i].x; s.prev_vel[1] = g[4][i].y; s.prev_vel[2] = g[4][i].z; s.ep_ret = g[4][i].w;
-        s.ep_ret_lo = g[6][i].w;
         s.prev_ang_v[0] = g[5][i].x; s.prev_ang_v[1] = g[5][i].y; s.prev_ang_v[2] = g[5][i].z;
-        memcpy(&s.ep_len, &g[5][i].w, 4);
+        int32_t lenword;
+        memcpy(&lenword, &g[5][i].w, 4);
+        s.ep_len = lenword & 0xFFFFFF;
+        s.ep_ret_lo = ret_lo_decode(s.ep_ret, lenword >> 24);
         // _current_position equals pos once a post-step has run (steps > 0); the stored copy is the stale one
         if (s.steps > 0) { s.cur_pos[0] = s.pos[0]; s.cur_pos[1] = s.pos[1]; s.cur_pos[2] = s.pos[2]; }
         else { s.cur_pos[0] = g[6][i].x; s.cur_pos[1] = g[6][i].y; s.cur_pos[2] = g[6][i].z; }
@@ -580,14 +601,16 @@ int32_t dn_set_state(dn_env *env, const dn_env_state *states, int64_t count)
         uint32_t meta = ((uint32_t)s.steps & 0xFFFFFFu) | (((uint32_t)s.idx & 0x7Fu) << 24) | ((uint32_t)(s.just_found != 0) << 31);
         float fmeta, flen;
         memcpy(&fmeta, &meta, 4);
-        memcpy(&flen, &s.ep_len, 4);
+        if (s.ep_len < 0 || s.ep_len > 0xFFFFFF) return fail(DN_ERR_INVALID_ARGUMENT, "state %lld: ep_len out of range", i);
+        const int32_t lenword = s.ep_len | (int32_t)((uint32_t)ret_lo_encode(s.ep_ret, s.ep_ret_lo) << 24);
+        memcpy(&flen, &lenword, 4);
         g[0][i] = make_float4(s.pos[0], s.pos[1], s.pos[2], s.d);
         g[1][i] = make_float4(s.quat[0], s.quat[1], s.quat[2], s.quat[3]);
         g[2][i] = make_float4(s.vel[0], s.vel[1], s.vel[2], s.d_prev);
         g[3][i] = make_float4(s.ang_v[0], s.ang_v[1], s.ang_v[2], fmeta);
         g[4][i] = make_float4(s.prev_vel[0], s.prev_vel[1], s.prev_vel[2], s.ep_ret);
         g[5][i] = make_float4(s.prev_ang_v[0], s.prev_ang_v[1], s.prev_ang_v[2], flen);
-        g[6][i] = make_float4(s.cur_pos[0], s.cur_pos[1], s.cur_pos[2], s.ep_ret_lo);
+        g[6][i] = make_float4(s.cur_pos[0], s.cur_pos[1], s.cur_pos[2], 0.0f);
         if (env->cfg.normalize_obs) {
             for (int k = 0; k < DN_OBS_DIM; ++k) { mean[(size_t)k * n + i] = s.rms_mean[k]; var[(size_t)k * n + i] = s.rms_var[k]; }
             cnt[(size_t)i] = s.rms_count;

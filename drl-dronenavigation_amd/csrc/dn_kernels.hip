@@ -1245,7 +1245,7 @@ DN_DEV void rules_commit(const DnConsts<R> &c, const R (&wp0)[3], const Flight<R
             if (!terminated) { cpx = px; cpy = py; cpz = pz; }            // post-step ran: it is the new position
             else if (__builtin_expect(m_e.steps > 0, 1)) { cpx = G0e.x; cpy = G0e.y; cpz = G0e.z; }
             else { const float4 G6 = g6_blk[li]; cpx = G6.x; cpy = G6.y; cpz = G6.z; }
-            if (active && !(terminated && m_e.steps == 0)) {       // .xyz only: .w belongs to the wave that keeps Monitor's return (its low word)
+            if (active && !(terminated && m_e.steps == 0)) {       // .w is unused
                 float *g6f = reinterpret_cast<float *>(g6_blk + li);
                 g6f[0] = (float)cpx; g6f[1] = (float)cpy; g6f[2] = (float)cpz;
             }
@@ -1512,13 +1512,28 @@ DN_DEV void store_obs_direct(float *row, const float o[DN_OBS_DIM])
     *reinterpret_cast<ObsQuad *>(row + 8) = ObsQuad{o[8], o[9], o[10], o[11]};
     row[12] = o[12];
 }
+// The low byte of Monitor's running return (see report_scalars): k * 2^(e - 31) for hi = 1.m * 2^e, zero below 2^-95.
+DN_DEV float ret_lo(const float hi, const int lenword)
+{
+    const int eb = (__float_as_int(hi) >> 23) & 0xFF;
+    return (float)(lenword >> 24) * __int_as_float((eb > 31 ? eb - 31 : 0) << 23);
+}
+DN_DEV int ret_lo_byte(const double ep_ret, const float hi)
+{
+    const int eb = (__float_as_int(hi) >> 23) & 0xFF;
+    const bool ok = eb > 31 && eb < 255;
+    const float inv = __int_as_float((ok ? 285 - eb : 127) << 23);
+    const double q = __builtin_rint((ep_ret - (double)hi) * (double)inv);
+    const int k = (int)fmin(fmax(q, -128.0), 127.0);
+    return ok ? (k & 0xFF) : 0;
+}
 // report_scalars: A7 select + Monitor + episode statistics + the scalar outputs; report_obs: the observation row(s) of
 // the step -- terminal_observation and the reset observation of a finished drone (quirk Q2), sensor noise, normaliser.
 // The two share only the verdict, so a kernel may run them on two waves; report_phase = both on one.
 template <typename R, bool REW>
 DN_DEV void report_scalars(const DnParams &p, const DnConsts<R> &c, const StepOut &out, const Flight<R> &fl, const Verdict<R> &v,
                            const R r_normal, const float r_found32, const unsigned li, const unsigned lane, const bool active,
-                           float4 &G4, float4 &G5, float &ep_lo, StatAcc &acc, RewNorm &rn)
+                           float4 &G4, float4 &G5, StatAcc &acc, RewNorm &rn)
 {
     const bool coll1 = v.coll1 != 0, terminated = v.terminated != 0, truncated = fl.truncated != 0;
     const bool found_now = !coll1 && (R)fl.d_e <= c.threshold;
@@ -1530,11 +1545,13 @@ DN_DEV void report_scalars(const DnParams &p, const DnConsts<R> &c, const StepOu
     else if (found_now) reward = (R)(r_found32 / 25.0f);                          // :568-571
     else reward = r_normal * K<R>::INV_25;
     if (REW) reward = (R)reward_wrappers(p, rn, (double)reward, done);       // --clip_rew / --norm_rew (compiled out otherwise)
-    // Monitor sums the episode's rewards in float64 (a Python float); the state keeps the running return as a float32 pair
-    // hi (g4.w) + lo (g6.w), lo = the part of the sum that hi's rounding dropped, so that re-rounding it every step does not
-    // drift over a 4096-step episode (with R = double the pair carries ~48 bits)
-    const int eplen_e = __float_as_int(G5.w);
-    R ep_ret = ((R)G4.w + (R)ep_lo) + reward;
+    // Monitor sums the episode's rewards in float64 (a Python float); the state keeps the running return as the float32
+    // hi (g4.w) plus a signed byte k in the top of the length word (g5.w), return = hi + k * ulp(hi) / 256: the part of
+    // the sum that hi's rounding dropped, so that re-rounding it every step does not drift over a 4096-step episode
+    // (32 mantissa bits; a fifth 16-byte group for a full low word cost 11 % of the bandwidth-bound 2 M-drone step)
+    const int lenword = __float_as_int(G5.w);
+    const int eplen_e = lenword & 0xFFFFFF;
+    R ep_ret = ((R)G4.w + (R)ret_lo(G4.w, lenword)) + reward;
     int ep_len = eplen_e + 1;
     // prev_vel / prev_ang_v shift in _update_state_post_step (skipped on a terminated step, quirk Q5)
     float4 S4 = G4, S5 = G5;
@@ -1571,8 +1588,7 @@ DN_DEV void report_scalars(const DnParams &p, const DnConsts<R> &c, const StepOu
         acc.episodes += __popcll(done_ballot); acc.truncated += n_trunc; acc.completed += n_compl;
         acc.sum_len += s_len; acc.sum_found += s_fd; acc.sum_ret_fix += s_ret;
     }
-    S4.w = (float)ep_ret; S5.w = __int_as_float(ep_len);
-    ep_lo = (float)(ep_ret - (R)S4.w);
+    S4.w = (float)ep_ret; S5.w = __int_as_float(ep_len | (ret_lo_byte((double)ep_ret, S4.w) << 24));
     G4 = S4; G5 = S5;
     if (active) {
         out.reward[li] = (float)reward;
@@ -1613,9 +1629,9 @@ template <typename R, bool NORM, bool NOISE, bool REW, int TILE = 0, bool SPAWN 
 DN_DEV void report_phase(const DnParams &p, const DnConsts<R> &c, float *s_tile, const StepOut &out, const Flight<R> &fl,
                          const Verdict<R> &v, Observed<R> &ob, const unsigned long long gid, const unsigned long long step_count,
                          const unsigned li, const unsigned lane, const unsigned rows, const bool active,
-                         float4 &G4, float4 &G5, float &ep_lo, StatAcc &acc, Rms &rms, RewNorm &rn)
+                         float4 &G4, float4 &G5, StatAcc &acc, Rms &rms, RewNorm &rn)
 {
-    report_scalars<R, REW>(p, c, out, fl, v, ob.r_normal, ob.r_found32, li, lane, active, G4, G5, ep_lo, acc, rn);
+    report_scalars<R, REW>(p, c, out, fl, v, ob.r_normal, ob.r_found32, li, lane, active, G4, G5, acc, rn);
     report_obs<R, NORM, NOISE, TILE, SPAWN>(p, c, s_tile, out, fl.truncated != 0, v, ob.o, gid, step_count, li, lane, rows, active, rms);
 }
 
@@ -1701,7 +1717,6 @@ __global__ __launch_bounds__(DN_BLOCK) void dn_step_many_1w_kernel(const DnParam
                                                           // the sampler's Box-Muller code costs the plain single step 9 % if it is merely linked in)
     float4 A = sampled ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : act[li];
     float4 G0 = b.g0[li], G1 = b.g1[li], G2 = b.g2[li], G3 = b.g3[li], G4 = b.g4[li], G5 = b.g5[li];
-    float EL = reinterpret_cast<const float *>(b.g6 + li)[3];             // low word of Monitor's running return
     float4 G7 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (XOPT && p.drag) G7 = b.g7[li];
     stage_table<R>(p, s_tab);
@@ -1736,7 +1751,7 @@ __global__ __launch_bounds__(DN_BLOCK) void dn_step_many_1w_kernel(const DnParam
         if (XOPT && p.drag) G7 = (v.terminated || fl.truncated) ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : rpm_now;   // BaseAviary.py:442,545
         attitude_phase<R>(fl);
         Observed<R> ob = observe_phase<R, NORM, NOISE>(p, c, s_tab, fl, G4, G5, gid, sc, rms);
-        report_phase<R, NORM, NOISE, XOPT, 0, XOPT>(p, c, s_tile, out, fl, v, ob, gid, sc, li, lane, rows, active, G4, G5, EL, acc, rms, rn);
+        report_phase<R, NORM, NOISE, XOPT, 0, XOPT>(p, c, s_tile, out, fl, v, ob, gid, sc, li, lane, rows, active, G4, G5, acc, rms, rn);
         A = A_next;
     }
     if (ONE) flush_stats_preloaded(p, slot0, acc, sc0 + 1ull, lane);
@@ -1749,7 +1764,6 @@ __global__ __launch_bounds__(DN_BLOCK) void dn_step_many_1w_kernel(const DnParam
     }
     if (active) {
         b.g0[li] = G0; b.g1[li] = G1; b.g2[li] = G2; b.g3[li] = G3; b.g4[li] = G4; b.g5[li] = G5;
-        reinterpret_cast<float *>(b.g6 + li)[3] = EL;
         if (XOPT && p.drag) b.g7[li] = G7;
     }
 }
@@ -1780,7 +1794,6 @@ __global__ __launch_bounds__(DN_BLOCK) void dn_eval_kinematics_kernel(const DnPa
     const BlockState b = block_state(p.st, tile_base);
     const DnConsts<R> &c = consts<R>(p);
     float4 G0 = b.g0[li], G1 = b.g1[li], G2 = b.g2[li], G3 = b.g3[li], G4 = b.g4[li], G5 = b.g5[li];
-    float EL = reinterpret_cast<const float *>(b.g6 + li)[3];
     const double *kr = kin + i * 13;
     double kv[13];
 #pragma unroll
@@ -1805,12 +1818,11 @@ __global__ __launch_bounds__(DN_BLOCK) void dn_eval_kinematics_kernel(const DnPa
     const Verdict<R> v = rules_phase<R>(p, c, s_tab, row_e, wp0, fl, G0e, G3e, b.g6, li, active, G0, G1, G2, G3);
     attitude_phase<R>(fl);
     Observed<R> ob = observe_phase<R, NORM, false>(p, c, s_tab, fl, G4, G5, gid, sc0, rms);
-    report_phase<R, NORM, false, false>(p, c, s_tile, out, fl, v, ob, gid, sc0, li, lane, rows, active, G4, G5, EL, acc, rms, rn);
+    report_phase<R, NORM, false, false>(p, c, s_tile, out, fl, v, ob, gid, sc0, li, lane, rows, active, G4, G5, acc, rms, rn);
     flush_stats(p, acc, sc0 + 1ull, lane);
     if (NORM && active) store_rms(p, i, rms);
     if (active) {
         b.g0[li] = G0; b.g1[li] = G1; b.g2[li] = G2; b.g3[li] = G3; b.g4[li] = G4; b.g5[li] = G5;
-        reinterpret_cast<float *>(b.g6 + li)[3] = EL;
     }
 }
 
@@ -1908,7 +1920,6 @@ __global__ __launch_bounds__(2 * DN_BLOCK) void dn_step_many_2w_kernel(const DnP
     stage_table<R>(p, s_tab);
     if (report_wave) {
         float4 G4 = b.g4[li], G5 = b.g5[li];
-        float EL = reinterpret_cast<const float *>(b.g6 + li)[3];
         StatAcc acc;
         Rms rms;
         if (NORM) load_rms(p, i, rms);
@@ -1943,7 +1954,7 @@ __global__ __launch_bounds__(2 * DN_BLOCK) void dn_step_many_2w_kernel(const DnP
                 Observed<R> ob = observe_phase<R, NORM, NOISE>(p, c, s_tab, fl, G4, G5, gid, sc, rms);
                 if (u > 0) tile_stream(tile, s_tile, io0.obs + ((long long)(u - 1) * n + tile_base) * DN_OBS_DIM, rows, lane);
                 const StepOut out = block_out(io0, tile_base, (long long)u * n, (long long)u * words);
-                report_phase<R, NORM, NOISE, XOPT, 1>(p, c, s_tile, out, fl, v, ob, gid, sc, li, lane, rows, active, G4, G5, EL, acc, rms, rn);
+                report_phase<R, NORM, NOISE, XOPT, 1>(p, c, s_tile, out, fl, v, ob, gid, sc, li, lane, rows, active, G4, G5, acc, rms, rn);
             }
             if (t < k_steps) block_lds_barrier();                          // barrier t
         }
@@ -1954,7 +1965,7 @@ __global__ __launch_bounds__(2 * DN_BLOCK) void dn_step_many_2w_kernel(const DnP
         flush_stats(p, acc, sc0 + (unsigned long long)k_steps, lane);
         if (NORM && active) store_rms(p, i, rms);
         if (XOPT && p.norm_rew && active) store_rewnorm(p, i, rn);
-        if (active) { b.g4[li] = G4; b.g5[li] = G5; reinterpret_cast<float *>(b.g6 + li)[3] = EL; }
+        if (active) { b.g4[li] = G4; b.g5[li] = G5; }
     } else {
         const float4 *act = reinterpret_cast<const float4 *>(io0.actions) + tile_base;
         float4 A = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -2197,7 +2208,6 @@ __global__ __launch_bounds__(3 * DN_BLOCK, NORM ? 2 : 3) void dn_step_many_3w_ke
         }
     } else {
         float4 G4 = b.g4[li], G5 = b.g5[li];                               // .w: Monitor return / length
-        float EL = reinterpret_cast<const float *>(b.g6 + li)[3];          // and the return's low word
         StatAcc acc;
         Rms rms;
         if (NORM) load_rms(p, i, rms);
@@ -2215,7 +2225,7 @@ __global__ __launch_bounds__(3 * DN_BLOCK, NORM ? 2 : 3) void dn_step_many_3w_ke
                 take_maila<R>(maila[u & 1], lane, fl, v, ob);
                 if (NORM) normalize_obs(rms, ob.o);                            // the step observation (= terminal_observation)
                 const StepOut out = block_out(io0, tile_base, (long long)u * n, (long long)u * words);
-                report_phase<R, NORM, NOISE, XOPT, 2>(p, c, s_tile, out, fl, v, ob, gid, sc, li, lane, rows, active, G4, G5, EL, acc, rms, rn);
+                report_phase<R, NORM, NOISE, XOPT, 2>(p, c, s_tile, out, fl, v, ob, gid, sc, li, lane, rows, active, G4, G5, acc, rms, rn);
             }
             if (t <= k_steps) block_lds_barrier();                         // barrier t
         }
@@ -2225,8 +2235,7 @@ __global__ __launch_bounds__(3 * DN_BLOCK, NORM ? 2 : 3) void dn_step_many_3w_ke
         if (active) {
             reinterpret_cast<float *>(b.g4 + li)[3] = G4.w;
             reinterpret_cast<float *>(b.g5 + li)[3] = G5.w;
-            reinterpret_cast<float *>(b.g6 + li)[3] = EL;
-        }
+            }
     }
 }
 
@@ -2290,7 +2299,6 @@ __global__ __launch_bounds__(3 * DN_BLOCK) void dn_step_pqx_kernel(const DnParam
         // word back from memory and nothing queues ahead of it
         const float4 G0 = b.g0[li], G2 = b.g2[li], G3 = b.g3[li];
         float4 G4 = b.g4[li], G5 = b.g5[li];
-        float EL = reinterpret_cast<const float *>(b.g6 + li)[3];
         block_lds_barrier();                                               // B1: thrust and table published
         Flight<R> fl;
         flight_entry<R>(fl, G0, G2, G3, p.max_steps);
@@ -2311,9 +2319,9 @@ __global__ __launch_bounds__(3 * DN_BLOCK) void dn_step_pqx_kernel(const DnParam
         v.coll1 = vf & 1; v.terminated = (vf >> 1) & 1;
         StatAcc acc;
         RewNorm rn = {0.0, 0.0, 1.0, 1e-4};
-        report_scalars<R, false>(p, c, out, fl, v, r_normal, r_found32, li, lane, active, G4, G5, EL, acc, rn);
+        report_scalars<R, false>(p, c, out, fl, v, r_normal, r_found32, li, lane, active, G4, G5, acc, rn);
         flush_stats_preloaded(p, slot0, acc, sc0 + 1ull, lane);
-        if (active) { b.g4[li] = G4; b.g5[li] = G5; reinterpret_cast<float *>(b.g6 + li)[3] = EL; }
+        if (active) { b.g4[li] = G4; b.g5[li] = G5; }
     } else if (role == 0) {
         // ---- P: the linear half of the rigid-body step, then the rules on the new position
         const float4 G0 = b.g0[li], G1 = b.g1[li], G2 = b.g2[li], G3 = b.g3[li];

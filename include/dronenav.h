@@ -114,8 +114,9 @@ typedef struct dn_env_state {
     double rr_mean, rr_var, rr_count;           /* NormalizeReward.return_rms                                  */
     float last_rpm[4];                          /* BaseAviary.last_clipped_action (physics with drag only; zeros otherwise) */
     double pid[9];                              /* DSLPIDControl.integral_pos_e, .last_rpy, .integral_rpy_e (action types PID / VEL / ONE_D_PID) */
-    float ep_ret_lo;                            /* Monitor: low word of the running return -- the return is ep_ret + ep_ret_lo (a float32 pair, so that
-                                                   the float64 sum SB3's Monitor keeps is not re-rounded to float32 every step) */
+    float ep_ret_lo;                            /* Monitor: low part of the running return -- the return is ep_ret + ep_ret_lo, ep_ret_lo a multiple k/256
+                                                   (k a signed byte) of ep_ret's ulp, so that the float64 sum SB3's Monitor keeps is not re-rounded to
+                                                   24 bits every step; dn_set_state rounds what it is given to that grid */
 } dn_env_state;
 
 /* Wave-reduced episode statistics accumulated on the device since dn_create / dn_reset_stats. */
