@@ -2478,19 +2478,26 @@ __global__ __launch_bounds__(256) void dn_gae_kernel(const float *__restrict__ r
 
 // =====================================================================================================
 // Episode-done compaction: ballot words -> ordered index list (popcount + block-wide exclusive scan).
-// Single workgroup of 1024 lanes, each lane walks ceil(words/1024) consecutive words.
+// One workgroup of 1024 lanes per 1024 words (65 536 drones), one word per lane.  A workgroup's place in the list is the
+// number of set bits in all earlier words, which it counts itself (coalesced popcount sweep + reduction: at 2 M drones the
+// last of 32 workgroups re-reads 256 KB out of L2) -- no second launch, no scratch buffer, no atomics, and the list stays in
+// ascending order whatever order the workgroups run in.
 // =====================================================================================================
 __global__ __launch_bounds__(1024) void dn_compact_kernel(const unsigned long long *__restrict__ mask, long long n,
                                                           int32_t *__restrict__ indices, int32_t *__restrict__ count)
 {
-    __shared__ int s_wave[16];
+    __shared__ int s_wave[16], s_before[16];
     const long long words = (n + 63) / 64;
-    const long long per = (words + 1023) / 1024;
-    const long long w0 = (long long)threadIdx.x * per;
-    int mine = 0;
-    for (long long w = w0; w < w0 + per && w < words; ++w) mine += __popcll(mask[w]);
-    // exclusive scan: within the wave by shuffles, across the 16 waves through LDS
+    const long long w_base = (long long)blockIdx.x * 1024;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int before = 0;
+    for (long long w = threadIdx.x; w < w_base; w += 1024) before += __popcll(mask[w]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) before += __shfl_xor(before, off);
+    const long long w = w_base + threadIdx.x;
+    unsigned long long mword = w < words ? mask[w] : 0ull;
+    const int mine = __popcll(mword);
+    // exclusive scan: within the wave by shuffles, across the 16 waves through LDS
     int incl = mine;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -2498,19 +2505,18 @@ __global__ __launch_bounds__(1024) void dn_compact_kernel(const unsigned long lo
         if (lane >= off) incl += v;
     }
     if (lane == 63) s_wave[wave] = incl;
+    if (lane == 0) s_before[wave] = before;
     __syncthreads();
     int base = 0;
+    for (int k = 0; k < 16; ++k) base += s_before[k];
     for (int k = 0; k < wave; ++k) base += s_wave[k];
     int pos = base + incl - mine;
-    for (long long w = w0; w < w0 + per && w < words; ++w) {
-        unsigned long long mword = mask[w];
-        while (mword) {
-            int b = __ffsll((long long)mword) - 1;
-            indices[pos++] = (int32_t)(w * 64 + b);
-            mword &= mword - 1;
-        }
+    while (mword) {
+        int b = __ffsll((long long)mword) - 1;
+        indices[pos++] = (int32_t)(w * 64 + b);
+        mword &= mword - 1;
     }
-    if (threadIdx.x == 1023) *count = base + incl;
+    if (threadIdx.x == 1023 && blockIdx.x == gridDim.x - 1) *count = base + incl;
 }
 
 // A1-A3 on their own (dn_preprocess_action): N x PBDroneEnv._preprocessAction + the force/torque lines of
@@ -2801,7 +2807,8 @@ hipError_t dn_launch_set_step_count(DnStatSlot *slots, long long blocks, unsigne
 hipError_t dn_launch_compact(const unsigned long long *mask, long long n, int32_t *indices, int32_t *count,
                              hipStream_t stream)
 {
-    hipLaunchKernelGGL(dn_compact_kernel, dim3(1), dim3(1024), 0, stream, mask, n, indices, count);
+    const unsigned blocks = (unsigned)(((n + 63) / 64 + 1023) / 1024);
+    hipLaunchKernelGGL(dn_compact_kernel, dim3(blocks), dim3(1024), 0, stream, mask, n, indices, count);
     return hipGetLastError();
 }
 #endif  // DN_TU == 1

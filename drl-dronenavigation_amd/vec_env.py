@@ -391,7 +391,17 @@ class DroneVecEnv(_VecEnvBase):
         raise AttributeError(f"DroneVecEnv has no per-env attribute {attr_name!r}")
 
     def set_attr(self, attr_name, value, indices=None):
-        raise AttributeError(f"cannot set {attr_name!r}: per-drone attributes live on the device; use set_state()")
+        """SB3's set_attr for the per-drone state the reference keeps as attributes (`_current_target_index`, `_steps`,
+        ...): a dn_get_state / dn_set_state round trip over the selected drones (dn_set_state validates the result).
+        Configuration (`_threshold`, track, ...) is fixed at dn_create."""
+        if attr_name not in self._STATE_ATTRS:
+            raise AttributeError(f"cannot set {attr_name!r}: only the per-drone state {sorted(self._STATE_ATTRS)} is "
+                                 "settable; configuration is fixed when the env is created")
+        st = self.get_state()
+        col = st[self._STATE_ATTRS[attr_name]]
+        for i in self._indices(indices):
+            col[i] = value
+        self.set_state(st)
 
     def env_method(self, method_name, *args, indices=None, **kwargs):
         raise AttributeError(f"env_method({method_name!r}) is not available on the device-resident env")

@@ -1529,3 +1529,30 @@ def test_step_sampled_equals_policy_sample_then_step(deterministic):
     for k in sa.dtype.names:
         assert np.ascontiguousarray(sa[k]).tobytes() == np.ascontiguousarray(sb[k]).tobytes(), k
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 65535, 65536, 65537, 200001, 2097152])
+def test_done_compaction_is_ordered_at_every_size(n):
+    """dn_compact_done on random ballot words: the index list equals numpy's nonzero (ascending, bit-exact) from one drone
+    to 2 M (32 workgroups; sizes straddle the 64-drone word and the 65 536-drone workgroup boundaries), dense and sparse."""
+    _gpu()
+    import ctypes as C
+    from drl_dronenavigation_amd import _capi
+    lib = _capi.load()
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(n)
+    words = (n + 63) // 64
+    for density in (0.5, 0.003, 0.0):
+        bits = rng.random(words * 64) < density
+        bits[n:] = False                                   # the step kernels never set bits beyond the fleet
+        packed = np.packbits(bits.astype(np.uint8), bitorder="little").view(np.uint64)
+        mask = torch.from_numpy(packed.view(np.int64)).to(dev)
+        idx = torch.full((n,), -1, dtype=torch.int32, device=dev)
+        cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+        _capi.check(lib.dn_compact_done(mask.data_ptr(), n, idx.data_ptr(), cnt.data_ptr(), 0,
+                                        C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        torch.cuda.synchronize()
+        want = np.nonzero(bits[:n])[0].astype(np.int32)
+        assert int(cnt.item()) == want.size
+        assert np.array_equal(idx[:want.size].cpu().numpy(), want)
+        assert bool((idx[want.size:] == -1).all())         # nothing written past the count

@@ -151,5 +151,15 @@ def test_drone_vec_env_under_the_sb3_base_on_gpu(vec_env_module):
     assert seen_done > n
     with pytest.raises(RuntimeError):
         env.step_wait()                                                # without step_async
+    # set_attr / get_attr on the per-drone state the reference keeps as attributes
+    env.reset()
+    env.set_attr("_current_target_index", 3, indices=[5, 7])
+    assert env.get_attr("_current_target_index", indices=[4, 5, 7]) == [0, 3, 3]
+    env.set_attr("_distance_to_target", 0.25)
+    assert env.get_attr("_distance_to_target", indices=[0, n - 1]) == [0.25, 0.25]
+    with pytest.raises(AttributeError):
+        env.set_attr("_threshold", 0.5)                                # configuration is fixed at dn_create
+    with pytest.raises(AttributeError):
+        env.env_method("getDroneStateVector")
     env.close()
     env.close()                                                        # idempotent
