@@ -369,14 +369,23 @@ def main():
     barrier()
     torch.cuda.synchronize(dev)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)                                     # a torch event creates its hipEvent on first use (~30 us, measured):
+    e1.record(stream)                                     # not inside a timed region that is one 31 us launch
+    torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     e0.record(stream)
+    ta = time.perf_counter()
     run(K)
+    tb = time.perf_counter()
     e1.record(stream)
+    tc = time.perf_counter()
     torch.cuda.synchronize(dev)
+    td = time.perf_counter()
     barrier()
     torch.cuda.synchronize(dev)
     wall = time.perf_counter() - t0
+    if os.environ.get("DN_BENCH_DEBUG"):
+        print(f"timed region: rec0 {(ta - t0) * 1e6:.1f} run {(tb - ta) * 1e6:.1f} rec1 {(tc - tb) * 1e6:.1f} sync {(td - tc) * 1e6:.1f} tail {(wall - (td - t0)) * 1e6:.1f} us", file=sys.stderr)
     gpu_ms = e0.elapsed_time(e1)                          # HIP events on the launch stream, timed region only
     if dist is not None:
         tw = torch.tensor([wall, gpu_ms], dtype=torch.float64, device=dev)
