@@ -206,6 +206,56 @@ def ppo_rollout(pkg, track, n, max_steps, dev, rank):
                     "V(terminal_obs) bootstrap per step, dn_gae per rollout, per-drone obs normaliser on"}
 
 
+def sac_collect(pkg, track, n, max_steps, dev, rank):
+    """BASELINE configs[4] per GPU as the reference's SAC agent collects (PBDroneSimulator.py:297-338): actor network
+    13-256-256 -> (mu, log_std) in the loop, squashed-Gaussian sample, dn_step with action / observation noise, every
+    transition into a device-resident replay buffer.  Reported beside the headline, never as `value`."""
+    import torch
+    from drl_dronenavigation_amd.collector import OffPolicyCollector
+    torch.manual_seed(7 + rank)
+    actor = pkg.SacActor().to(dev)
+    res = {}
+    steps = 64
+    for label, grade, graph in (("torch fp32 actor, eager", None, False), ("torch fp32 actor, hipGraph", None, True),
+                                ("fused MFMA actor bf16 grade, hipGraph", "bf16", True), ("fused MFMA actor fp32 grade, eager", "fp32", False),
+                                ("fused MFMA actor fp32 grade, hipGraph", "fp32", True)):
+        env = pkg.DroneVecEnv(track, n, max_steps=max_steps, normalize_obs=True, act_noise_sigma=0.002, obs_noise_sigma=0.01,
+                              seed=1, env_id_offset=rank * n, device=dev)
+        pol = actor if grade is None else pkg.FusedSacActor(actor, n, dev, grade=grade)
+        col = OffPolicyCollector(env, pol, buffer_size=steps)
+        run = col.collect_cycle if graph else (lambda: col.collect(steps))      # noqa: B023
+        for _ in range(3):
+            run()
+        torch.cuda.synchronize(dev)
+        reps = 5
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            run()
+        torch.cuda.synchronize(dev)
+        res[label] = round(n * steps * reps / (time.perf_counter() - t0), 1)
+        env.close()
+    fused = pkg.FusedSacActor(actor, n, dev, grade="fp32")
+    obs = torch.rand(n, 13, device=dev)
+    kern = {}
+    for grade in ("bf16", "fp32"):
+        fused.grade = grade
+        fused.refresh()
+        for _ in range(5):
+            fused.mean_log_std(obs)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(50):
+            fused.mean_log_std(obs)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        kern[grade] = round(e0.elapsed_time(e1) * 1e3 / 50, 2)
+    return {"value": res["fused MFMA actor fp32 grade, hipGraph"], "unit": "env-steps/s", "variants": res, "num_envs": n, "steps": steps,
+            "actor_forward_us_python_loop": kern,
+            "what": "SAC collection loop of config 5 on one shard: actor MLP 13-256-256 (ReLU) -> mu, log_std -> tanh(mu + sigma eps) -> "
+                    "dn_step (Philox action + observation noise, per-drone obs normaliser) -> ReplayBuffer.add; `value` = float32-grade actor, the "
+                    "whole ring-buffer cycle replayed from a hipGraph"}
+
+
 def ppo_rollout_sharded(pkg, track, n, max_steps, dev, rank, world, dist):
     """BASELINE configs[3] (131072 drones over 4 GPUs): FusedRolloutCollector per rank on its shard + one all-gather of
     the packed advantages/returns per rollout over RCCL; aggregate env-steps/s with the collective inside the timed
@@ -561,6 +611,10 @@ def main():
                 line["ppo_rollout"] = ppo_rollout(pkg, track, n, max_steps, dev, rank)
             except Exception as exc:  # noqa: BLE001
                 line["ppo_rollout"] = {"error": f"{type(exc).__name__}: {exc}"}
+            try:
+                line["sac_collect"] = sac_collect(pkg, track, n, max_steps, dev, rank)
+            except Exception as exc:  # noqa: BLE001
+                line["sac_collect"] = {"error": f"{type(exc).__name__}: {exc}"}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(track, n, max_steps, args.cpu_baseline_seconds)

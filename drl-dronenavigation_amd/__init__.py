@@ -11,7 +11,7 @@ from ._capi import DroneNavError, DroneNavLibraryError  # noqa: F401
 from .tracks import Track  # noqa: F401
 
 __all__ = ["DroneVecEnv", "Track", "tracks", "gae", "DroneNavError", "DroneNavLibraryError", "make_config",
-           "RolloutCollector", "ShardPlan", "all_gather_rollout", "preprocess_action", "MlpActorCritic"]
+           "RolloutCollector", "ShardPlan", "all_gather_rollout", "preprocess_action", "MlpActorCritic", "SacActor", "FusedSacActor"]
 
 
 def __getattr__(name):
@@ -24,12 +24,12 @@ def __getattr__(name):
                 "FusedRolloutCollector"):
         collector = importlib.import_module(__name__ + ".collector")
         return collector if name == "collector" else getattr(collector, name)
-    if name in ("policy_mfma", "FusedMlpPolicy"):
+    if name in ("policy_mfma", "FusedMlpPolicy", "FusedSacActor"):
         pm = importlib.import_module(__name__ + ".policy_mfma")
         return pm if name == "policy_mfma" else getattr(pm, name)
     if name == "metrics":
         return importlib.import_module(__name__ + ".metrics")
-    if name in ("policy", "MlpActorCritic"):
+    if name in ("policy", "MlpActorCritic", "SacActor"):
         policy = importlib.import_module(__name__ + ".policy")
         return policy if name == "policy" else getattr(policy, name)
     raise AttributeError(name)

@@ -11,7 +11,7 @@ from . import build as _build
 MAX_WAYPOINTS = 64
 OBS_DIM = 13
 ACT_DIM = 4
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 DN_OK = 0
 STATUS_NAMES = {0: "DN_OK", -1: "DN_ERR_INVALID_ARGUMENT", -2: "DN_ERR_HIP", -3: "DN_ERR_OUT_OF_MEMORY",
@@ -56,7 +56,8 @@ class DnEnvState(C.Structure):
 class DnMlpNet(C.Structure):
     _fields_ = [("w1", C.c_void_p), ("w2", C.c_void_p), ("w3", C.c_void_p), ("wh", C.c_void_p),
                 ("b1", C.c_void_p), ("b2", C.c_void_p), ("b3", C.c_void_p), ("bh", C.c_void_p),
-                ("out", C.c_void_p), ("out_dim", C.c_int32), ("grade", C.c_int32)]
+                ("out", C.c_void_p), ("out_dim", C.c_int32), ("grade", C.c_int32), ("arch", C.c_int32),
+                ("reserved_", C.c_int32)]
 
 
 class DnStats(C.Structure):

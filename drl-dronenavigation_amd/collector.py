@@ -226,7 +226,12 @@ class ReplayBuffer:
 class OffPolicyCollector:
     """BASELINE config 5's collection loop (SAC: one environment step per policy step, every transition into the
     replay buffer): actor(obs) -> actions in [-1, 1] -> dn_step -> ReplayBuffer.add with SB3's terminal-observation
-    handling.  Sharded like the on-policy collector: a rank's drones feed the rank's buffer, no collective."""
+    handling.  Sharded like the on-policy collector: a rank's drones feed the rank's buffer, no collective.
+
+    `collect_cycle()`: one whole pass over the ring buffer (buffer_size steps, slot 0 .. buffer_size - 1) captured into
+    a hipGraph on its second call and replayed afterwards -- every tensor of the loop is static and the ring position is
+    back where it started, so the host leaves the loop as it does for RolloutCollector(use_graph=True).  The actor must
+    be capture-safe (policy_mfma.FusedSacActor and a plain torch module are)."""
 
     def __init__(self, env, actor, buffer_size):
         from .vec_env import ACT_DIM, DroneVecEnv
@@ -236,9 +241,9 @@ class OffPolicyCollector:
         self.buffer = ReplayBuffer(buffer_size, env.num_envs, env.obs_dim, ACT_DIM, env.device)
         self._obs = env.reset_tensor().clone()
         self.num_timesteps = 0
+        self._graph, self._cycles = None, 0
 
-    @torch.no_grad()
-    def collect(self, n_steps=1):
+    def _steps(self, n_steps):
         env = self.env
         for _ in range(int(n_steps)):
             actions = self.actor(self._obs).clamp(-1.0, 1.0)
@@ -247,7 +252,32 @@ class OffPolicyCollector:
             self.buffer.add(self._obs, torch.where(d, info["terminal_obs"], next_obs), actions, reward, done.float(),
                             info["truncated"].float())
             self._obs.copy_(next_obs)
-            self.num_timesteps += env.num_envs
+
+    @torch.no_grad()
+    def collect(self, n_steps=1):
+        self._steps(n_steps)
+        self.num_timesteps += int(n_steps) * self.env.num_envs
+        return self.buffer
+
+    @torch.no_grad()
+    def collect_cycle(self):
+        if self.buffer.pos != 0:
+            raise RuntimeError("collect_cycle() fills slots 0 .. buffer_size - 1: call it with the ring at position 0")
+        T = self.buffer.buffer_size
+        with torch.cuda.device(self.env.device):
+            if self._cycles >= 1:
+                if self._graph is None:
+                    torch.cuda.synchronize(self.env.device)
+                    self._graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(self._graph):
+                        self._steps(T)
+                    self.buffer.pos = 0                     # the capture pass advanced the host-side ring position only
+                self._graph.replay()
+                self.buffer.full = True
+            else:
+                self._steps(T)
+        self._cycles += 1
+        self.num_timesteps += T * self.env.num_envs
         return self.buffer
 
 

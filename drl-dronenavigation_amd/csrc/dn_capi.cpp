@@ -726,12 +726,16 @@ int32_t dn_mlp_forward(const dn_mlp_net *nets, int32_t num_nets, const float *ob
     if (obs_dim < 1 || obs_dim > 16) return fail(DN_ERR_INVALID_ARGUMENT, "obs_dim must be in 1..16 (got %d)", obs_dim);
     for (int k = 0; k < num_nets; ++k) {
         const dn_mlp_net &n = nets[k];
-        if (!n.w1 || !n.w2 || !n.w3 || !n.wh || !n.b1 || !n.b2 || !n.b3 || !n.bh || !n.out)
+        if (n.arch != DN_MLP_ARCH_PPO && n.arch != DN_MLP_ARCH_SAC)
+            return fail(DN_ERR_INVALID_ARGUMENT, "net %d: arch must be 0 (PPO 512-512-256 Tanh) or 1 (SAC actor 256-256 ReLU)", k);
+        const bool three = n.arch == DN_MLP_ARCH_PPO;
+        if (!n.w1 || !n.w2 || (three && !n.w3) || !n.wh || !n.b1 || !n.b2 || (three && !n.b3) || !n.bh || !n.out)
             return fail(DN_ERR_INVALID_ARGUMENT, "net %d: every weight, bias and output pointer is required", k);
         if (n.out_dim < 1 || n.out_dim > 32) return fail(DN_ERR_INVALID_ARGUMENT, "net %d: out_dim must be in 1..32", k);
         if (n.grade != 0 && n.grade != 1) return fail(DN_ERR_INVALID_ARGUMENT, "net %d: grade must be 0 (bf16) or 1 (fp32 grade)", k);
-        if (n.grade != nets[0].grade) return fail(DN_ERR_INVALID_ARGUMENT, "all networks of one call must share the grade");
-        if (((uintptr_t)n.w1 | (uintptr_t)n.w2 | (uintptr_t)n.w3 | (uintptr_t)n.wh) & 15u)
+        if (n.grade != nets[0].grade || n.arch != nets[0].arch)
+            return fail(DN_ERR_INVALID_ARGUMENT, "all networks of one call must share grade and arch");
+        if (((uintptr_t)n.w1 | (uintptr_t)n.w2 | (three ? (uintptr_t)n.w3 : 0) | (uintptr_t)n.wh) & 15u)
             return fail(DN_ERR_INVALID_ARGUMENT, "net %d: packed weights must be 16-byte aligned", k);
     }
     DN_HIP(hipSetDevice(device_id));

@@ -30,6 +30,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));     // a B operand as the four dwords it occupies
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define MLP_DEV __device__ __forceinline__
 
@@ -780,6 +781,144 @@ __global__ __launch_bounds__(64 * XWAVES) __attribute__((amdgpu_waves_per_eu(1, 
     else mlp_x3_body<1>(a, net, wbuf, xb, lbias, wave, lane, row0, live, row, tile_wanted);
 }
 
+
+// -----------------------------------------------------------------------------------------------------
+// The SAC actor (dn_mlp_net.arch = DN_MLP_ARCH_SAC): obs -> 256 -> 256 -> {mu[4] | log_std[4]}, ReLU.
+//
+// SB3's SAC Actor with policy_kwargs net_arch = dict(pi=[256, 256]), activation_fn = ReLU (PBDroneSimulator.py:297-303):
+// latent_pi = ReLU(W2 ReLU(W1 obs + b1) + b2), mu = Wm latent + bm, log_std = Ws latent + bs; the two heads are stacked
+// into one [8, 256] matrix by the host, so the whole actor is three layers of the same transposed product as above and a
+// 32-drone tile needs 71 k multiply-adds per drone against the PPO pair's 2 x 400 k.  It is far too small to be worth the
+// LDS machinery: one wavefront per tile, the 142 KB of weights (284 KB in the fp32 grade) straight from L2 through an
+// 8-deep register ring, activations in registers (64 per layer, 128 with the hi / lo split).  Both grades in one body:
+// X3 = the split-bf16 float32 grade of dn_mlp_x3_kernel (three MFMAs per fragment pair, w_lo x_hi + w_hi x_lo + w_hi x_hi).
+// -----------------------------------------------------------------------------------------------------
+constexpr int S1 = 256, S2 = 256;
+constexpr int SAC_RING = 8;
+
+// This lane's eight layer-1 inputs k = 8g .. 8g + 7 of drone `row` (zero beyond obs_dim): eight independent loads at a
+// clamped index, selected afterwards (a load under `if (k < obs_dim)` compiles to a branch with its own s_waitcnt).
+MLP_DEV void load_obs8(const MlpArgs &a, const long long row, const int g, float (&v)[8])
+{
+    const float *o = a.obs + row * a.obs_dim;
+    const int last = a.obs_dim - 1;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = 8 * g + j;
+        const float x = o[k < last ? k : last];
+        v[j] = k <= last ? x : 0.0f;
+    }
+}
+MLP_DEV void split_pair(const float a, const float b, unsigned &hi, unsigned &lo)
+{   // two float32 values -> one dword of the hi operand and one of the lo operand (v = hi + lo to 16 mantissa bits)
+    bf16x2 h, l;
+    h[0] = (__bf16)a; h[1] = (__bf16)b;
+    l[0] = (__bf16)(a - (float)h[0]); l[1] = (__bf16)(b - (float)h[1]);
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, l);
+}
+// One Linear(+ReLU) layer of the SAC actor for this wave's 32 drones.  Weight stream per M-tile: KS fragments (bf16
+// grade) or KS hi fragments then KS lo fragments (X3), consumed in storage order through a ring.
+template <int KS, int MT, bool X3>
+MLP_DEV void sac_layer(const uint4 *__restrict__ w, const float *__restrict__ bias, const u32x4 (&inh)[KS], const u32x4 (&inl)[KS],
+                       u32x4 (&outh)[2 * MT], u32x4 (&outl)[2 * MT], const int lane)
+{
+    const int g = lane >> 5;
+    constexpr int PER = X3 ? 2 : 1;
+    constexpr int T = KS * MT;                              // K-steps in the layer; step t = (m, kk) reads PER fragments
+    constexpr int P = SAC_RING < T ? SAC_RING : T;
+    const uint4 *wl = w + lane;
+    uint4 rh[P], rl[P];
+    auto frag = [&](const int t, const int part) { return wl[(size_t)(((t / KS) * PER + part) * KS + t % KS) * 64]; };
+#pragma unroll
+    for (int t = 0; t < P; ++t) {
+        rh[t] = frag(t, 0);
+        if (X3) rl[t] = frag(t, 1);
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = bias[acc_row(m, g, r)];
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            const int t = m * KS + kk;
+            const uint4 ah = rh[t % P], al = rl[t % P];
+            if (t + P < T) {
+                rh[t % P] = frag(t + P, 0);
+                if (X3) rl[t % P] = frag(t + P, 1);
+            }
+            if (X3) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al), __builtin_bit_cast(bf16x8, inh[kk]), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, inl[kk]), acc, 0, 0, 0);
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, inh[kk]), acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {                       // ReLU, pack (and split) into the next layer's K-steps 2m, 2m + 1
+            const float v0 = fmaxf(acc[2 * q], 0.0f), v1 = fmaxf(acc[2 * q + 1], 0.0f);
+            unsigned hi, lo = 0u;
+            if (X3) split_pair(v0, v1, hi, lo); else hi = pack2(v0, v1);
+            if (q < 4) { outh[2 * m][q] = hi; if (X3) outl[2 * m][q] = lo; }
+            else { outh[2 * m + 1][q - 4] = hi; if (X3) outl[2 * m + 1][q - 4] = lo; }
+        }
+    }
+}
+
+template <bool X3>
+__global__ __launch_bounds__(64) void dn_mlp_sac_kernel(const MlpArgs a)
+{
+    const int lane = threadIdx.x;
+    const int g = lane >> 5, col = lane & 31;
+    const MlpNetDev &net = a.net[blockIdx.y];
+    const long long row0 = (long long)blockIdx.x * TILE;
+    const bool live = row0 + col < a.n;
+    const long long row = live ? row0 + col : a.n - 1;      // ragged last tile: shadow the last drone
+    if (a.row_mask) {
+        const bool wanted = live && a.row_mask[row0 + col] != 0;
+        if (__ballot(wanted) == 0ull) {
+            if (g == 0 && live)
+                for (int j = 0; j < net.out_dim; ++j) net.out[(row0 + col) * net.out_dim + j] = 0.0f;
+            return;
+        }
+    }
+    float ob[8];
+    load_obs8(a, row, g, ob);
+    u32x4 x0h[1], x0l[1];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        unsigned hi, lo = 0u;
+        if (X3) split_pair(ob[2 * q], ob[2 * q + 1], hi, lo); else hi = pack2(ob[2 * q], ob[2 * q + 1]);
+        x0h[0][q] = hi; x0l[0][q] = lo;
+    }
+    u32x4 h1h[S1 / 16], h1l[S1 / 16];
+    sac_layer<1, S1 / 32, X3>(net.w1, net.b1, x0h, x0l, h1h, h1l, lane);
+    u32x4 h2h[S2 / 16], h2l[S2 / 16];
+    sac_layer<S1 / 16, S2 / 32, X3>(net.w2, net.b2, h1h, h1l, h2h, h2l, lane);
+    // heads: one M-tile (8 rows used), float32 straight from the accumulator
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = net.bh[acc_row(0, g, r)];
+#pragma unroll
+    for (int kk = 0; kk < S2 / 16; ++kk) {
+        const uint4 wh = net.wh[kk * 64 + lane];
+        if (X3) {
+            const uint4 wlo = net.wh[(S2 / 16 + kk) * 64 + lane];
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wlo), __builtin_bit_cast(bf16x8, h2h[kk]), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wh), __builtin_bit_cast(bf16x8, h2l[kk]), acc, 0, 0, 0);
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wh), __builtin_bit_cast(bf16x8, h2h[kk]), acc, 0, 0, 0);
+    }
+    if (live) {
+        float *o = net.out + (row0 + col) * net.out_dim;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = acc_row(0, g, r);
+            if (j < net.out_dim) o[j] = acc[r];
+        }
+    }
+}
+
 }  // namespace
 
 hipError_t dn_launch_mlp(const dn_mlp_net *nets, int num_nets, const float *obs, const uint8_t *row_mask, long long n, int obs_dim,
@@ -795,6 +934,11 @@ hipError_t dn_launch_mlp(const dn_mlp_net *nets, int num_nets, const float *obs,
     }
     a.obs = obs; a.row_mask = row_mask; a.n = n; a.obs_dim = obs_dim;
     const unsigned tiles = (unsigned)((n + TILE - 1) / TILE);
+    if (nets[0].arch == DN_MLP_ARCH_SAC) {
+        if (nets[0].grade == 1) hipLaunchKernelGGL(dn_mlp_sac_kernel<true>, dim3(tiles, num_nets), dim3(64), 0, stream, a);
+        else hipLaunchKernelGGL(dn_mlp_sac_kernel<false>, dim3(tiles, num_nets), dim3(64), 0, stream, a);
+        return hipGetLastError();
+    }
     if (nets[0].grade == 1) {                                // fp32-grade networks (split-bf16 x3): their own kernel and packing
         hipLaunchKernelGGL(dn_mlp_x3_kernel, dim3((tiles + 1) / 2, num_nets), dim3(64 * XWAVES), 0, stream, a);
         return hipGetLastError();

@@ -67,3 +67,38 @@ class MlpActorCritic(nn.Module):
         mean, log_std = self._dist(obs)
         entropy = (0.5 + 0.5 * math.log(2 * math.pi) + log_std).sum(-1)
         return self.predict_values(obs), self._log_prob(actions, mean, log_std), entropy
+
+
+LOG_STD_MIN, LOG_STD_MAX = -20.0, 2.0          # SB3 sac/policies.py [3P-recall]
+
+
+class SacActor(nn.Module):
+    """The actor of the reference's SAC agent: SB3 `SAC("MlpPolicy", policy_kwargs=dict(activation_fn=ReLU,
+    net_arch=dict(qf=[256, 256, 128], pi=[256, 256]), share_features_extractor=False), use_sde=False)`
+    (Sol/Model/PBDroneSimulator.py:297-338).  SB3's Actor [3P-recall]: latent_pi = MLP(obs -> 256 -> 256, ReLU), two linear
+    heads `mu` and `log_std` (clamped to [-20, 2]), action = tanh(mu + exp(log_std) eps): a squashed Gaussian in (-1, 1);
+    default torch initialisation (SAC does not use SB3's orthogonal init).  Only the actor takes part in collection
+    (BASELINE config 5); the critics belong to the learner."""
+
+    def __init__(self, obs_dim=13, act_dim=4, pi=(256, 256)):
+        super().__init__()
+        self.latent_pi = _mlp((obs_dim,) + tuple(pi), nn.ReLU)
+        self.mu = nn.Linear(pi[-1], act_dim)
+        self.log_std = nn.Linear(pi[-1], act_dim)
+
+    def mean_log_std(self, obs):
+        z = self.latent_pi(obs)
+        return self.mu(z), torch.clamp(self.log_std(z), LOG_STD_MIN, LOG_STD_MAX)
+
+    @staticmethod
+    def squash(mean, log_std, eps=None):
+        """actions in (-1, 1) and their log-probability (SquashedDiagGaussianDistribution, epsilon = 1e-6)."""
+        pre = mean if eps is None else mean + torch.exp(log_std) * eps
+        act = torch.tanh(pre)
+        z = (pre - mean) * torch.exp(-log_std)
+        logp = (-0.5 * z * z - log_std - 0.5 * math.log(2 * math.pi)).sum(-1) - torch.log(1.0 - act * act + 1e-6).sum(-1)
+        return act, logp
+
+    def forward(self, obs, deterministic=False):
+        mean, log_std = self.mean_log_std(obs)
+        return self.squash(mean, log_std, None if deterministic else torch.randn_like(mean))[0]

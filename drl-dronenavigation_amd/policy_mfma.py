@@ -1,4 +1,5 @@
-"""The reference's policy/value networks on the fused MFMA kernel (csrc/dn_mlp.hip, dn_mlp_forward).
+"""The reference's policy/value networks (PPO actor + critic, SAC actor) on the fused MFMA kernels (csrc/dn_mlp.hip,
+dn_mlp_forward).
 
 `pack_mlp` turns the float32 [out, in] matrices of one 13-512-512-256-out network into the bfloat16 fragment order
 the kernel loads (see dn_mlp.hip for why the K index of every layer but the first is permuted), `FusedMlpPolicy`
@@ -86,11 +87,37 @@ def pack_mlp(layers, device, grade="bf16"):
     return out
 
 
+ARCH_PPO, ARCH_SAC = 0, 1
+SAC_HIDDEN = (256, 256)
+
+
+def pack_sac_actor(layers, device, grade="bf16"):
+    """layers: [(W1, b1), (W2, b2), (Wmu, bmu), (Wls, bls)] of the reference's SAC actor (obs -> 256 -> 256 -> mu | log_std,
+    ReLU; PBDroneSimulator.py:297-303) -> dict of device tensors for dn_mlp_net with arch = DN_MLP_ARCH_SAC: the two heads
+    are stacked into one [2 act_dim, 256] matrix (rows [0, act_dim) mu, [act_dim, 2 act_dim) log_std)."""
+    if grade not in GRADES:
+        raise ValueError(f"grade must be one of {sorted(GRADES)}")
+    (w1, b1), (w2, b2), (wm, bm), (ws, bs) = layers
+    if w1.shape[0] != SAC_HIDDEN[0] or tuple(w2.shape) != (SAC_HIDDEN[1], SAC_HIDDEN[0]) or wm.shape[1] != SAC_HIDDEN[1] \
+            or tuple(ws.shape) != tuple(wm.shape):
+        raise ValueError("the SAC actor kernel is built for obs -> 256 -> 256 -> (mu, log_std) (PBDroneSimulator.py:297-303)")
+    f = lambda t: t.detach().cpu().float()          # noqa: E731
+    wh, bh = torch.cat((f(wm), f(ws)), 0), torch.cat((f(bm), f(bs)), 0)
+    out = {}
+    for name, (w, b), first in zip(("1", "2", "h"), ((w1, b1), (w2, b2), (wh, bh)), (True, False, False)):
+        pw, pb = pack_layer(w, b, first, scale=1.0, grade=grade)
+        out["w" + name], out["b" + name] = pw.to(device), pb.to(device)
+    out["grade"], out["arch"] = GRADES[grade], ARCH_SAC
+    out["out_dim"], out["obs_dim"] = int(wh.shape[0]), int(w1.shape[1])
+    return out
+
+
 def _net_struct(pk, out_tensor):
     n = _capi.DnMlpNet()
     for k in ("w1", "w2", "w3", "wh", "b1", "b2", "b3", "bh"):
-        setattr(n, k, pk[k].data_ptr())
-    n.out, n.out_dim, n.grade = out_tensor.data_ptr(), pk["out_dim"], pk.get("grade", 0)
+        if k in pk:
+            setattr(n, k, pk[k].data_ptr())
+    n.out, n.out_dim, n.grade, n.arch = out_tensor.data_ptr(), pk["out_dim"], pk.get("grade", 0), pk.get("arch", ARCH_PPO)
     return n
 
 
@@ -145,3 +172,31 @@ class FusedMlpPolicy:
         out = self._value if out is None else out
         mlp_forward([self.vf], obs, [out], row_mask=row_mask)
         return out.squeeze(-1)
+
+
+class FusedSacActor:
+    """actor(obs) -> actions in (-1, 1) for OffPolicyCollector (BASELINE config 5) on the fused kernel, from a policy.SacActor's
+    weights (re-pack with `refresh()` after optimiser steps): ONE launch gives mu and log_std of every drone; the clamp, the
+    Gaussian draw and the tanh squash (a few element-wise ops on [N, 4]) stay in torch, float32."""
+
+    def __init__(self, module, num_envs, device, grade="bf16"):
+        self.module, self.device, self.grade = module, torch.device(device), grade
+        self.act_dim = module.mu.out_features
+        self._out = torch.empty((num_envs, 2 * self.act_dim), dtype=torch.float32, device=self.device)
+        self.refresh()
+
+    def refresh(self):
+        m = self.module
+        lin = [l for l in m.latent_pi if isinstance(l, torch.nn.Linear)]
+        layers = [(l.weight, l.bias) for l in lin] + [(m.mu.weight, m.mu.bias), (m.log_std.weight, m.log_std.bias)]
+        self.pack = pack_sac_actor(layers, self.device, self.grade)
+
+    def mean_log_std(self, obs):
+        from .policy import LOG_STD_MAX, LOG_STD_MIN
+        mlp_forward([self.pack], obs, [self._out])
+        return self._out[:, :self.act_dim], torch.clamp(self._out[:, self.act_dim:], LOG_STD_MIN, LOG_STD_MAX)
+
+    def __call__(self, obs, deterministic=False):
+        mean, log_std = self.mean_log_std(obs)
+        pre = mean if deterministic else mean + torch.exp(log_std) * torch.randn_like(mean)
+        return torch.tanh(pre)

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define DN_ABI_VERSION 4
+#define DN_ABI_VERSION 5
 #define DN_MAX_WAYPOINTS 64
 #define DN_OBS_DIM 13      /* 12 kinematic + distance, PBDroneEnv._computeObs, PBDroneEnv.py:296-336 */
 #define DN_ACT_DIM 4       /* four rotor thrust commands, PBDroneEnv._actionSpace, PBDroneEnv.py:225-243 */
@@ -232,19 +232,28 @@ int32_t dn_gae(const float *rewards, const float *values, const uint8_t *dones,
                double gamma, double gae_lambda, float *advantages, float *returns,
                int32_t device_id, void *stream);
 
-/* One actor or critic network of the reference's policy (SB3 ActorCriticPolicy with net_arch pi = vf = [512, 512,
- * 256], Tanh, built at Sol/Model/PBDroneSimulator.py:251-286): obs -> 512 -> 512 -> 256 -> out_dim.  Weights are
- * bfloat16 in the fragment order of the kernel (drl-dronenavigation_amd/policy_mfma.py::pack_mlp produces it from
- * the [out, in] float32 matrices), biases float32 padded to 512 / 512 / 256 / 32.  All pointers are device pointers. */
+/* One network of the reference's agents, by `arch`:
+ *   DN_MLP_ARCH_PPO (0)  actor or critic of SB3's ActorCriticPolicy with net_arch pi = vf = [512, 512, 256], Tanh
+ *                        (Sol/Model/PBDroneSimulator.py:251-286): obs -> 512 -> 512 -> 256 -> out_dim;
+ *   DN_MLP_ARCH_SAC (1)  latent_pi + heads of SB3's SAC Actor with net_arch pi = [256, 256], ReLU
+ *                        (Sol/Model/PBDroneSimulator.py:297-303): obs -> 256 -> 256 -> out_dim, the mu and log_std heads stacked
+ *                        into one [8, 256] matrix (rows 0..3 mu, 4..7 log_std); w3 / b3 are unused and may be NULL.
+ * Weights are bfloat16 in the fragment order of the kernel (drl-dronenavigation_amd/policy_mfma.py::pack_mlp / pack_sac_actor
+ * produce it from the [out, in] float32 matrices), biases float32 padded to a multiple of 32 (the head's to 32).  All pointers
+ * are device pointers. */
+#define DN_MLP_ARCH_PPO 0
+#define DN_MLP_ARCH_SAC 1
 typedef struct dn_mlp_net {
-    const void *w1, *w2, *w3, *wh;              /* packed bf16 weights of the three hidden layers and the head */
+    const void *w1, *w2, *w3, *wh;              /* packed bf16 weights of the hidden layers and the head */
     const float *b1, *b2, *b3, *bh;             /* biases */
     float *out;                                 /* float[num_envs * out_dim] */
-    int32_t out_dim;                            /* 1..32 (4 action means / 1 value) */
+    int32_t out_dim;                            /* 1..32 (4 action means / 1 value / 8 = mu | log_std) */
     int32_t grade;                              /* 0: bf16 weights and activations, float32 accumulate (the speed option, ~1e-3 on the action mean)
                                                    1: float32 grade -- both operands split into two bf16 words, three MFMAs per product
-                                                      (policy_mfma.pack_mlp(..., grade="fp32") packs the hi / lo fragment streams); matches the
-                                                      reference's float32 networks to <= 1e-4.  All networks of one call share the grade. */
+                                                      (pack_mlp / pack_sac_actor(..., grade="fp32") pack the hi / lo fragment streams); matches the
+                                                      reference's float32 networks to <= 1e-4.  All networks of one call share grade and arch. */
+    int32_t arch;                               /* DN_MLP_ARCH_* (appended in ABI 5) */
+    int32_t reserved_;                          /* 0 */
 } dn_mlp_net;
 
 /* Forward pass of one or two such networks over the same observations in one launch (replaces the mlp_extractor +

@@ -144,3 +144,78 @@ def test_bench_rccl_path_with_one_rank():
     assert line["roofline"]["traffic"] and 0 < line["roofline"]["traffic_frac"] <= 1.0
     sh = line["ppo_rollout_sharded"]
     assert sh["global_num_envs"] == 32768 and sh["value"] > 1e7 and sh["all_gather_bytes_sent_per_rank_per_rollout"] == 2 * 32 * 32768 * 4
+
+
+def test_config5_collection_with_the_fused_sac_actor():
+    """BASELINE config 5's loop as the reference's SAC agent runs it -- actor network in the loop (PBDroneSimulator.py:297-338):
+    FusedSacActor (MFMA kernel, fp32 grade) -> tanh-squashed actions -> dn_step with action / observation noise ->
+    ReplayBuffer.  The transitions are replayed through the oracle from the stored actions on a sampled range of drones."""
+    pkg = _pkg()
+    from drl_dronenavigation_amd import tracks
+    from drl_dronenavigation_amd.collector import OffPolicyCollector
+    track = tracks.reaching()
+    n, T, rank = 32768, 24, 5
+    kw = dict(max_steps=20, normalize_obs=False, act_noise_sigma=0.002, obs_noise_sigma=0.01, seed=3)
+    env = pkg.DroneVecEnv(track, n, device="cuda:0", env_id_offset=rank * n, **kw)
+    torch.manual_seed(0)
+    actor = pkg.SacActor().to(env.device)
+    fused = pkg.FusedSacActor(actor, n, env.device, grade="fp32")
+    col = OffPolicyCollector(env, fused, buffer_size=T)
+    buf = col.collect(T)
+    assert len(buf) == T * n and buf.full
+    assert float(buf.actions.abs().max()) <= 1.0 and float(buf.actions.std()) > 0.3      # squashed Gaussian, not a constant
+    # the stored action of a deterministic call is tanh(mu) of the float32 actor on the stored observation
+    with torch.no_grad():
+        mu, _ = actor.mean_log_std(buf.obs[T - 1])
+    assert float((fused(buf.obs[T - 1], deterministic=True) - torch.tanh(mu)).abs().max()) <= 2e-4
+    lo = 7777
+    sl = slice(lo, lo + 128)
+    cfg = O.make_config(track.targets(), track.initial_xyzs, track.aviary_dim, circle=False, f32_state=True,
+                        env_id_offset=rank * n + lo, **kw)
+    ora = O.OracleVecEnv(cfg, 128, threads=4)
+    obs_ref = ora.reset()
+    done_seen = 0
+    for t in range(T):
+        np.testing.assert_allclose(buf.obs[t, sl].cpu().numpy(), obs_ref, rtol=0, atol=1e-5, err_msg=f"obs t={t}")
+        ref = ora.step(buf.actions[t, sl].cpu().numpy())
+        dn = ref["done"].astype(bool)
+        np.testing.assert_allclose(buf.next_obs[t, sl].cpu().numpy(), np.where(dn[:, None], ref["terminal_obs"], ref["obs"]), rtol=0, atol=1e-5)
+        np.testing.assert_allclose(buf.rewards[t, sl].cpu().numpy(), ref["reward"], rtol=1e-5, atol=1e-4)
+        assert np.array_equal(buf.dones[t, sl].cpu().numpy().astype(bool), dn)
+        done_seen += int(dn.sum())
+        obs_ref = ref["obs"]
+    assert done_seen > 0
+    env.close()
+
+
+def test_off_policy_cycle_under_hipgraph_equals_the_eager_loop():
+    """OffPolicyCollector.collect_cycle(): the third pass (a hipGraph replay) leaves the replay buffer bit-identical to three
+    eager passes of the same loop -- actor kernel, dn_step with Philox action / observation noise (device-side step counter),
+    terminal-observation select, ring-buffer writes."""
+    pkg = _pkg()
+    from drl_dronenavigation_amd import tracks
+    from drl_dronenavigation_amd.collector import OffPolicyCollector
+    track = tracks.reaching()
+    n, T = 4096, 16
+    kw = dict(max_steps=12, normalize_obs=True, act_noise_sigma=0.002, obs_noise_sigma=0.01, seed=4)
+    torch.manual_seed(2)
+    actor = pkg.SacActor().to("cuda:0")
+    bufs = []
+    for mode in ("eager", "graph"):
+        env = pkg.DroneVecEnv(track, n, device="cuda:0", **kw)
+        fused = pkg.FusedSacActor(actor, n, env.device, grade="fp32")
+        col = OffPolicyCollector(env, lambda o: fused(o, deterministic=True), buffer_size=T)   # noqa: B023
+        for _ in range(3):
+            if mode == "eager":
+                col.collect(T)
+            else:
+                col.collect_cycle()
+        torch.cuda.synchronize()
+        assert col.num_timesteps == 3 * T * n and col.buffer.full and col.buffer.pos == 0
+        bufs.append({k: getattr(col.buffer, k).clone() for k in ("obs", "next_obs", "actions", "rewards", "dones", "timeouts")})
+        if mode == "graph":
+            assert col._graph is not None
+        env.close()
+    for k in bufs[0]:
+        assert torch.equal(bufs[0][k], bufs[1][k]), k
+    assert float(bufs[0]["dones"].sum()) >= n                                  # episodes ended and restarted inside the cycle

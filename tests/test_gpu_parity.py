@@ -1556,3 +1556,61 @@ def test_done_compaction_is_ordered_at_every_size(n):
         assert int(cnt.item()) == want.size
         assert np.array_equal(idx[:want.size].cpu().numpy(), want)
         assert bool((idx[want.size:] == -1).all())         # nothing written past the count
+
+
+@pytest.mark.parametrize("n", [1, 33, 4096 + 5])
+def test_sac_actor_kernel_matches_the_float32_torch_actor(n):
+    """dn_mlp_forward with arch = DN_MLP_ARCH_SAC (obs -> 256 -> 256 -> mu | log_std, ReLU; PBDroneSimulator.py:297-303)
+    against the float64 evaluation of the float32 SacActor: fp32 grade <= 1e-4 on mu and log_std, the bf16 grade an order
+    coarser; ragged tile sizes; masked forward; and FusedSacActor's deterministic action = tanh(mu)."""
+    pkg = _gpu()
+    from drl_dronenavigation_amd import policy_mfma as pm
+    dev = torch.device("cuda:0")
+    torch.manual_seed(n + 11)
+    actor = pkg.SacActor().to(dev)
+    with torch.no_grad():
+        for p_ in actor.parameters():
+            p_.add_(0.03 * torch.randn_like(p_))
+    obs = (torch.rand(n, 13, device=dev) * 2 - 1) * torch.tensor([1, 1, 1, 1, 1, 1, 1, 1, 0.33, 1, 1, 1, 1], device=dev)
+    obs[: min(n, 8)] *= 10.0
+    lin = [l for l in actor.latent_pi if isinstance(l, torch.nn.Linear)]
+    with torch.no_grad():
+        h = obs.double()
+        for l in lin:
+            h = torch.relu(h @ l.weight.double().t() + l.bias.double())
+        want = torch.cat((h @ actor.mu.weight.double().t() + actor.mu.bias.double(),
+                          h @ actor.log_std.weight.double().t() + actor.log_std.bias.double()), 1)
+    layers = [(l.weight, l.bias) for l in lin] + [(actor.mu.weight, actor.mu.bias), (actor.log_std.weight, actor.log_std.bias)]
+    errs = {}
+    for grade in ("fp32", "bf16"):
+        (got,) = pm.mlp_forward([pm.pack_sac_actor(layers, dev, grade)], obs)
+        torch.cuda.synchronize()
+        assert got.shape == (n, 8)
+        errs[grade] = float((got.double() - want).abs().max())
+    print(f"n={n}: SAC actor max |err| vs float64 -- fp32 grade {errs['fp32']:.2e}, bf16 grade {errs['bf16']:.2e}")
+    assert errs["fp32"] <= 1e-4, errs
+    assert errs["bf16"] <= 5e-2 and errs["bf16"] > 3 * errs["fp32"], errs
+    fused = pkg.FusedSacActor(actor, n, dev, grade="fp32")
+    mean, log_std = fused.mean_log_std(obs)
+    assert float((mean.double() - want[:, :4]).abs().max()) <= 1e-4
+    assert float(log_std.max()) <= 2.0 and float(log_std.min()) >= -20.0
+    act = fused(obs, deterministic=True)
+    assert float((act.double() - torch.tanh(want[:, :4])).abs().max()) <= 1e-4
+    smp = fused(obs)
+    assert smp.shape == (n, 4) and float(smp.abs().max()) <= 1.0
+    mask = torch.zeros(n, dtype=torch.uint8, device=dev)
+    mask[::61] = 1
+    (mv,) = pm.mlp_forward([pm.pack_sac_actor(layers, dev, "fp32")], obs, row_mask=mask)
+    torch.cuda.synchronize()
+    sel = mask.bool()
+    assert float((mv[sel].double() - want[sel]).abs().max()) <= 1e-4
+    host = mask.bool().cpu().numpy()
+    for t0 in range(0, n, 32):
+        if not host[t0:t0 + 32].any():
+            assert float(mv[t0:t0 + 32].abs().max()) == 0.0
+    # the ABI refuses a mixed call
+    with pytest.raises(pkg.DroneNavError):
+        net = pkg.MlpActorCritic().to(dev)
+        lin2 = [l for l in net.vf if isinstance(l, torch.nn.Linear)]
+        vf = pm.pack_mlp([(l.weight, l.bias) for l in lin2] + [(net.value_net.weight, net.value_net.bias)], dev)
+        pm.mlp_forward([pm.pack_sac_actor(layers, dev, "bf16"), vf], obs)
