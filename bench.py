@@ -217,8 +217,9 @@ def sac_collect(pkg, track, n, max_steps, dev, rank):
     res = {}
     steps = 64
     for label, grade, graph in (("torch fp32 actor, eager", None, False), ("torch fp32 actor, hipGraph", None, True),
-                                ("fused MFMA actor bf16 grade, hipGraph", "bf16", True), ("fused MFMA actor fp32 grade, eager", "fp32", False),
-                                ("fused MFMA actor fp32 grade, hipGraph", "fp32", True)):
+                                ("fused MFMA actor bf16 grade, three launches per step, hipGraph", "bf16", True),
+                                ("fused MFMA actor fp32 grade, three launches per step, eager", "fp32", False),
+                                ("fused MFMA actor fp32 grade, three launches per step, hipGraph", "fp32", True)):
         env = pkg.DroneVecEnv(track, n, max_steps=max_steps, normalize_obs=True, act_noise_sigma=0.002, obs_noise_sigma=0.01,
                               seed=1, env_id_offset=rank * n, device=dev)
         pol = actor if grade is None else pkg.FusedSacActor(actor, n, dev, grade=grade)
@@ -249,11 +250,11 @@ def sac_collect(pkg, track, n, max_steps, dev, rank):
         e1.record()
         torch.cuda.synchronize(dev)
         kern[grade] = round(e0.elapsed_time(e1) * 1e3 / 50, 2)
-    return {"value": res["fused MFMA actor fp32 grade, hipGraph"], "unit": "env-steps/s", "variants": res, "num_envs": n, "steps": steps,
+    return {"value": res["fused MFMA actor fp32 grade, three launches per step, hipGraph"], "unit": "env-steps/s", "variants": res, "num_envs": n, "steps": steps,
             "actor_forward_us_python_loop": kern,
-            "what": "SAC collection loop of config 5 on one shard: actor MLP 13-256-256 (ReLU) -> mu, log_std -> tanh(mu + sigma eps) -> "
-                    "dn_step (Philox action + observation noise, per-drone obs normaliser) -> ReplayBuffer.add; `value` = float32-grade actor, the "
-                    "whole ring-buffer cycle replayed from a hipGraph"}
+            "what": "SAC collection loop of config 5 on one shard: dn_mlp_forward (actor 13-256-256 ReLU -> mu | log_std), dn_squashed_sample "
+                    "(clamp, Philox draw, tanh), dn_step (Philox action + observation noise, per-drone obs normaliser), every output written in "
+                    "place into the replay ring; `value` = float32-grade actor, the whole ring-buffer cycle replayed from a hipGraph"}
 
 
 def ppo_rollout_sharded(pkg, track, n, max_steps, dev, rank, world, dist):
@@ -431,11 +432,11 @@ def main():
     tc = time.perf_counter()
     torch.cuda.synchronize(dev)
     td = time.perf_counter()
-    barrier()
-    torch.cuda.synchronize(dev)
-    wall = time.perf_counter() - t0
+    wall = td - t0                                        # this rank's K steps, started together (barrier above); MAX over ranks below
+    barrier()                                             # the closing bracket: a rank's clock stops when ITS work is done, not after
+    torch.cuda.synchronize(dev)                           # an RCCL barrier (tens of us, the size of the driver's whole 20-step region)
     if os.environ.get("DN_BENCH_DEBUG"):
-        print(f"timed region: rec0 {(ta - t0) * 1e6:.1f} run {(tb - ta) * 1e6:.1f} rec1 {(tc - tb) * 1e6:.1f} sync {(td - tc) * 1e6:.1f} tail {(wall - (td - t0)) * 1e6:.1f} us", file=sys.stderr)
+        print(f"timed region: rec0 {(ta - t0) * 1e6:.1f} run {(tb - ta) * 1e6:.1f} rec1 {(tc - tb) * 1e6:.1f} sync {(td - tc) * 1e6:.1f} us", file=sys.stderr)
     gpu_ms = e0.elapsed_time(e1)                          # HIP events on the launch stream, timed region only
     if dist is not None:
         tw = torch.tensor([wall, gpu_ms], dtype=torch.float64, device=dev)

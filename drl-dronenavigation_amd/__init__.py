@@ -20,7 +20,7 @@ def __getattr__(name):
     if name in ("DroneVecEnv", "gae", "make_config", "vec_env", "preprocess_action"):
         vec_env = importlib.import_module(__name__ + ".vec_env")
         return vec_env if name == "vec_env" else getattr(vec_env, name)
-    if name in ("collector", "RolloutCollector", "ShardPlan", "all_gather_rollout", "ReplayBuffer", "OffPolicyCollector",
+    if name in ("collector", "RolloutCollector", "ShardPlan", "all_gather_rollout", "ReplayBuffer", "RingReplayBuffer", "OffPolicyCollector",
                 "FusedRolloutCollector"):
         collector = importlib.import_module(__name__ + ".collector")
         return collector if name == "collector" else getattr(collector, name)

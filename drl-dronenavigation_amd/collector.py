@@ -223,27 +223,117 @@ class ReplayBuffer:
                     dones=self.dones[t, e] * (1.0 - self.timeouts[t, e]))
 
 
+class RingReplayBuffer:
+    """The same transitions as ReplayBuffer, laid out so that the kernels write them in place: `obs_ring[t + 1]` is both the
+    observation the step at slot t produced and the input of the step at slot t + 1 (SB3's `optimize_memory_usage` idea, with one
+    spare row, so that every slot is whole at a cycle boundary; mid-cycle the slot being replaced is excluded), `terminal_obs[t]` holds the terminal observations dn_step reports, `dones` /
+    `timeouts` stay the uint8 flags the kernel writes.  SB3's view of a transition is assembled on demand: `next_obs` = the
+    TERMINAL observation where the episode ended, the next one elsewhere; `dones`, `timeouts` as float32."""
+
+    def __init__(self, buffer_size, num_envs, obs_dim, act_dim, device):
+        f32, u8, dev = torch.float32, torch.uint8, torch.device(device)
+        self.buffer_size, self.num_envs = int(buffer_size), int(num_envs)
+        self.obs_ring = torch.zeros((self.buffer_size + 1, num_envs, obs_dim), dtype=f32, device=dev)
+        self.terminal_obs = torch.zeros((self.buffer_size, num_envs, obs_dim), dtype=f32, device=dev)
+        self.actions = torch.zeros((self.buffer_size, num_envs, act_dim), dtype=f32, device=dev)
+        self.rewards = torch.zeros((self.buffer_size, num_envs), dtype=f32, device=dev)
+        self.done_flags = torch.zeros((self.buffer_size, num_envs), dtype=u8, device=dev)
+        self.timeout_flags = torch.zeros((self.buffer_size, num_envs), dtype=u8, device=dev)
+        self.pos, self.full = 0, False
+
+    obs = property(lambda self: self.obs_ring[:self.buffer_size])
+    next_obs = property(lambda self: torch.where(self.done_flags.bool()[..., None], self.terminal_obs, self.obs_ring[1:]))
+    dones = property(lambda self: self.done_flags.float())
+    timeouts = property(lambda self: self.timeout_flags.float())
+
+    def valid_slots(self):
+        """Slots whose transition is whole.  Mid-cycle on a full ring the OLDEST slot (= pos, the next to be written) has lost
+        its observation to the newest transition's next observation (they share a row); at a cycle boundary (pos = 0) the
+        spare row keeps all buffer_size slots whole."""
+        if not self.full:
+            return list(range(self.pos))
+        return [t for t in range(self.buffer_size) if t != self.pos or self.pos == 0]
+
+    def __len__(self):
+        return len(self.valid_slots()) * self.num_envs
+
+    def _sample_slots(self, batch_size, generator=None):
+        dev = self.obs_ring.device
+        upper = (self.buffer_size - (1 if self.pos else 0)) if self.full else self.pos
+        if upper == 0:
+            raise RuntimeError("the replay buffer is empty")
+        t = torch.randint(0, upper, (batch_size,), device=dev, generator=generator)
+        if self.full and self.pos:
+            t = t + (t >= self.pos).long()                                   # skip the slot that is being replaced
+        return t, torch.randint(0, self.num_envs, (batch_size,), device=dev, generator=generator)
+
+    def sample(self, batch_size, generator=None):
+        t, e = self._sample_slots(batch_size, generator)
+        d = self.done_flags[t, e].bool()
+        return dict(obs=self.obs_ring[t, e], next_obs=torch.where(d[:, None], self.terminal_obs[t, e], self.obs_ring[t + 1, e]),
+                    actions=self.actions[t, e], rewards=self.rewards[t, e],
+                    dones=d.float() * (1.0 - self.timeout_flags[t, e].float()))
+
+
 class OffPolicyCollector:
     """BASELINE config 5's collection loop (SAC: one environment step per policy step, every transition into the
-    replay buffer): actor(obs) -> actions in [-1, 1] -> dn_step -> ReplayBuffer.add with SB3's terminal-observation
+    replay buffer): actor(obs) -> actions in [-1, 1] -> dn_step -> replay buffer, with SB3's terminal-observation
     handling.  Sharded like the on-policy collector: a rank's drones feed the rank's buffer, no collective.
+
+    With a policy_mfma.FusedSacActor the loop is three launches per step and no copies: dn_mlp_forward (mu | log_std from the
+    ring's current observation row), dn_squashed_sample (clamp, Philox draw, tanh: the action lands in its buffer slot),
+    dn_step (next observation, reward, flags and terminal observation land in theirs) -- RingReplayBuffer.  With any other
+    torch callable the actions come from the callable and the transitions are copied into a ReplayBuffer.
 
     `collect_cycle()`: one whole pass over the ring buffer (buffer_size steps, slot 0 .. buffer_size - 1) captured into
     a hipGraph on its second call and replayed afterwards -- every tensor of the loop is static and the ring position is
-    back where it started, so the host leaves the loop as it does for RolloutCollector(use_graph=True).  The actor must
-    be capture-safe (policy_mfma.FusedSacActor and a plain torch module are)."""
+    back where it started, so the host leaves the loop as it does for RolloutCollector(use_graph=True)."""
 
-    def __init__(self, env, actor, buffer_size):
+    def __init__(self, env, actor, buffer_size, *, seed=0, deterministic=False):
+        from .policy_mfma import FusedSacActor
         from .vec_env import ACT_DIM, DroneVecEnv
         if not isinstance(env, DroneVecEnv):
             raise TypeError("OffPolicyCollector drives a DroneVecEnv (HIP); there is no CPU path")
         self.env, self.actor = env, actor
-        self.buffer = ReplayBuffer(buffer_size, env.num_envs, env.obs_dim, ACT_DIM, env.device)
-        self._obs = env.reset_tensor().clone()
+        self.direct = isinstance(actor, FusedSacActor)
+        self.seed, self.deterministic = int(seed), bool(deterministic)
+        if self.direct:
+            if env.obs_dim != 13 or env.num_envs != actor._out.shape[0]:
+                raise ValueError("the direct loop needs the full 13-column observation and an actor built for env.num_envs drones")
+            self.buffer = RingReplayBuffer(buffer_size, env.num_envs, env.obs_dim, ACT_DIM, env.device)
+            self.buffer.obs_ring[0].copy_(env.reset_tensor())
+            self._found = torch.zeros(env.num_envs, dtype=torch.int32, device=env.device)
+        else:
+            self.buffer = ReplayBuffer(buffer_size, env.num_envs, env.obs_dim, ACT_DIM, env.device)
+            self._obs = env.reset_tensor().clone()
         self.num_timesteps = 0
-        self._graph, self._cycles = None, 0
+        self._graph, self._cycles, self._carry = None, 0, False
+
+    def _steps_direct(self, n_steps):
+        import ctypes as C
+        from . import _capi
+        from .policy_mfma import mlp_forward
+        env, buf, lib = self.env, self.buffer, _capi.load()
+        h, T = env._handle, buf.buffer_size
+        sptr = C.c_void_p(torch.cuda.current_stream(env.device).cuda_stream)
+        out8 = self.actor._out
+        for _ in range(int(n_steps)):
+            p = buf.pos
+            if p == 0 and self._carry:                      # wrapped: the newest observation (row T) becomes row 0 only now, when
+                buf.obs_ring[0].copy_(buf.obs_ring[T])      # slot 0's old transition is about to be replaced as a whole
+                self._carry = False
+            mlp_forward([self.actor.pack], buf.obs_ring[p], [out8])
+            _capi.check(lib.dn_squashed_sample(h, out8.data_ptr(), self.seed, int(self.deterministic), buf.actions[p].data_ptr(), None, sptr))
+            _capi.check(lib.dn_step(h, buf.actions[p].data_ptr(), buf.obs_ring[p + 1].data_ptr(), buf.rewards[p].data_ptr(),
+                                    buf.done_flags[p].data_ptr(), buf.timeout_flags[p].data_ptr(), self._found.data_ptr(),
+                                    buf.terminal_obs[p].data_ptr(), None, None, None, sptr))
+            buf.pos = p + 1
+            if buf.pos == T:
+                buf.pos, buf.full, self._carry = 0, True, True
 
     def _steps(self, n_steps):
+        if self.direct:
+            return self._steps_direct(n_steps)
         env = self.env
         for _ in range(int(n_steps)):
             actions = self.actor(self._obs).clamp(-1.0, 1.0)
@@ -255,7 +345,8 @@ class OffPolicyCollector:
 
     @torch.no_grad()
     def collect(self, n_steps=1):
-        self._steps(n_steps)
+        with torch.cuda.device(self.env.device):
+            self._steps(n_steps)
         self.num_timesteps += int(n_steps) * self.env.num_envs
         return self.buffer
 
@@ -273,7 +364,7 @@ class OffPolicyCollector:
                         self._steps(T)
                     self.buffer.pos = 0                     # the capture pass advanced the host-side ring position only
                 self._graph.replay()
-                self.buffer.full = True
+                self.buffer.full, self._carry = True, True
             else:
                 self._steps(T)
         self._cycles += 1

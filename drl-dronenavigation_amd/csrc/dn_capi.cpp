@@ -707,6 +707,16 @@ int32_t dn_policy_sample(dn_env *env, const float *mean, const float *log_std, u
     return DN_OK;
 }
 
+int32_t dn_squashed_sample(dn_env *env, const float *mu_log_std, uint64_t seed, int32_t deterministic, float *actions, float *log_prob,
+                           void *stream)
+{
+    if (!env || !mu_log_std || !actions) return fail(DN_ERR_INVALID_ARGUMENT, "env, mu_log_std and actions are required");
+    if (((uintptr_t)mu_log_std | (uintptr_t)actions) & 15u)
+        return fail(DN_ERR_INVALID_ARGUMENT, "mu_log_std and actions must be 16-byte aligned");
+    DN_HIP(dn_launch_squashed_sample(env->p, mu_log_std, seed, deterministic, actions, log_prob, (hipStream_t)stream));
+    return DN_OK;
+}
+
 int32_t dn_add_bootstrap(float *reward, const float *terminal_value, const uint8_t *truncated, double gamma, int64_t num_envs,
                          int32_t device_id, void *stream)
 {

@@ -121,6 +121,8 @@ hipError_t dn_launch_action_chain(const float *actions, long long n, int normali
                                   float *z_torque, hipStream_t stream);
 hipError_t dn_launch_fill4(float4 *dst, float4 v, long long n, hipStream_t stream);
 hipError_t dn_launch_filld(double *dst, double v, long long n, hipStream_t stream);
+hipError_t dn_launch_squashed_sample(const DnParams &p, const float *mu_log_std, unsigned long long seed, int deterministic,
+                                     float *actions, float *log_prob, hipStream_t stream);
 hipError_t dn_launch_policy_sample(const DnParams &p, const float *mean, const float *log_std4, unsigned long long seed, int deterministic,
                                    float *actions, float *clipped, float *log_prob, hipStream_t stream);
 hipError_t dn_launch_add_bootstrap(float *reward, const float *terminal_value, const uint8_t *truncated, float gamma, long long n,

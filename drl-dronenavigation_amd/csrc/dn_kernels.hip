@@ -2569,6 +2569,32 @@ __global__ __launch_bounds__(256) void dn_policy_sample_kernel(const DnParams p,
     log_prob[i] = lp;
 }
 
+// dn_squashed_sample_kernel -- SB3 SAC's Actor on top of the (mu | log_std) rows of dn_mlp_forward(arch = SAC) [3P-recall of
+// sac/policies.py and SquashedDiagGaussianDistribution]: log_std clamped to [-20, 2], pre = mu + exp(log_std) z with z ~ N(0,1)
+// from the environment's Philox stream (seed, global drone id, the tile's vector-step counter, stream 9: as dn_policy_sample),
+// action = tanh(pre) -- already inside dn_step's [-1, 1] --, log_prob = sum_j log N(pre_j; mu_j, sigma_j) - log(1 - a_j^2 + 1e-6).
+__global__ __launch_bounds__(256) void dn_squashed_sample_kernel(const DnParams p, const float4 *__restrict__ mu_log_std,
+                                                                 const unsigned long long seed, const int deterministic,
+                                                                 float4 *__restrict__ actions, float *__restrict__ log_prob)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.n) return;
+    const float4 m = mu_log_std[2 * i], l = mu_log_std[2 * i + 1];
+    const float mu[4] = {m.x, m.y, m.z, m.w};
+    const float ls[4] = {clipv(l.x, -20.0f, 2.0f), clipv(l.y, -20.0f, 2.0f), clipv(l.z, -20.0f, 2.0f), clipv(l.w, -20.0f, 2.0f)};
+    float z[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (!deterministic)
+        noise4(seed, (unsigned long long)(p.env_id_offset + i), p.st.stats[i / DN_BLOCK].step_count, 9u, z);
+    float a[4], lp = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        a[j] = tanhf(mu[j] + expf(ls[j]) * z[j]);
+        lp += (-0.5f * z[j] * z[j] - ls[j] - 0.91893853320467274178f) - logf(1.0f - a[j] * a[j] + 1e-6f);
+    }
+    actions[i] = make_float4(a[0], a[1], a[2], a[3]);
+    if (log_prob) log_prob[i] = lp;
+}
+
 __global__ __launch_bounds__(256) void dn_add_bootstrap_kernel(float *__restrict__ reward, const float *__restrict__ terminal_value,
                                                                const uint8_t *__restrict__ truncated, float gamma, long long n)
 {
@@ -2776,6 +2802,15 @@ hipError_t dn_launch_action_chain(const float *actions, long long n, int normali
     const unsigned grid = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(dn_action_chain_kernel, dim3(grid), dim3(256), 0, stream, reinterpret_cast<const float4 *>(actions), n,
                        normalize_actions, reinterpret_cast<float4 *>(rpm), reinterpret_cast<float4 *>(forces), z_torque);
+    return hipGetLastError();
+}
+
+hipError_t dn_launch_squashed_sample(const DnParams &p, const float *mu_log_std, unsigned long long seed, int deterministic,
+                                     float *actions, float *log_prob, hipStream_t stream)
+{
+    const unsigned grid = (unsigned)((p.n + 255) / 256);
+    hipLaunchKernelGGL(dn_squashed_sample_kernel, dim3(grid), dim3(256), 0, stream, p, reinterpret_cast<const float4 *>(mu_log_std),
+                       seed, deterministic, reinterpret_cast<float4 *>(actions), log_prob);
     return hipGetLastError();
 }
 

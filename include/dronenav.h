@@ -274,6 +274,14 @@ int32_t dn_mlp_forward(const dn_mlp_net *nets, int32_t num_nets, const float *ob
  *   dn_add_bootstrap  reward[i] += gamma * terminal_value[i] where truncated[i] (TimeLimit bootstrap). */
 int32_t dn_policy_sample(dn_env *env, const float *mean, const float *log_std, uint64_t seed, int32_t deterministic,
                          float *actions, float *clipped, float *log_prob, void *stream);
+/* The SAC actor's sampling step on top of dn_mlp_forward(arch = DN_MLP_ARCH_SAC) (replaces SB3's Actor.forward /
+ * action_log_prob after latent_pi, Sol/Model/PBDroneSimulator.py:297-338) [3P-recall of SB3]: log_std clamped to [-20, 2],
+ * actions = tanh(mu + exp(log_std) z), z ~ N(0,1) from the environment's Philox streams exactly as dn_policy_sample draws it
+ * (seed, global drone id, vector-step counter; reproducible under hipGraph replay and independent of the sharding); the result
+ * lies inside dn_step's action box.  mu_log_std: device float[N*8], rows (mu[4], log_std[4]); actions: device float[N*4];
+ * log_prob: device float[N] or NULL (sum over the four dims of log N(pre; mu, sigma) - log(1 - a^2 + 1e-6)). */
+int32_t dn_squashed_sample(dn_env *env, const float *mu_log_std, uint64_t seed, int32_t deterministic, float *actions,
+                           float *log_prob, void *stream);
 int32_t dn_add_bootstrap(float *reward, const float *terminal_value, const uint8_t *truncated, double gamma,
                          int64_t num_envs, int32_t device_id, void *stream);
 /* dn_policy_sample + dn_step in one launch (the rollout loop's per-step pair): the action is drawn inside the step kernel

@@ -190,8 +190,8 @@ def test_config5_collection_with_the_fused_sac_actor():
 
 def test_off_policy_cycle_under_hipgraph_equals_the_eager_loop():
     """OffPolicyCollector.collect_cycle(): the third pass (a hipGraph replay) leaves the replay buffer bit-identical to three
-    eager passes of the same loop -- actor kernel, dn_step with Philox action / observation noise (device-side step counter),
-    terminal-observation select, ring-buffer writes."""
+    eager passes of the same loop -- actor kernel, dn_squashed_sample (Philox draw keyed by the device-side step counter),
+    dn_step with Philox action / observation noise, every output written in place into the ring."""
     pkg = _pkg()
     from drl_dronenavigation_amd import tracks
     from drl_dronenavigation_amd.collector import OffPolicyCollector
@@ -204,7 +204,7 @@ def test_off_policy_cycle_under_hipgraph_equals_the_eager_loop():
     for mode in ("eager", "graph"):
         env = pkg.DroneVecEnv(track, n, device="cuda:0", **kw)
         fused = pkg.FusedSacActor(actor, n, env.device, grade="fp32")
-        col = OffPolicyCollector(env, lambda o: fused(o, deterministic=True), buffer_size=T)   # noqa: B023
+        col = OffPolicyCollector(env, fused, buffer_size=T, seed=11)    # the direct loop: three launches per step, Philox draws
         for _ in range(3):
             if mode == "eager":
                 col.collect(T)
@@ -212,6 +212,7 @@ def test_off_policy_cycle_under_hipgraph_equals_the_eager_loop():
                 col.collect_cycle()
         torch.cuda.synchronize()
         assert col.num_timesteps == 3 * T * n and col.buffer.full and col.buffer.pos == 0
+        assert col.direct
         bufs.append({k: getattr(col.buffer, k).clone() for k in ("obs", "next_obs", "actions", "rewards", "dones", "timeouts")})
         if mode == "graph":
             assert col._graph is not None
@@ -219,3 +220,52 @@ def test_off_policy_cycle_under_hipgraph_equals_the_eager_loop():
     for k in bufs[0]:
         assert torch.equal(bufs[0][k], bufs[1][k]), k
     assert float(bufs[0]["dones"].sum()) >= n                                  # episodes ended and restarted inside the cycle
+    assert float(bufs[0]["actions"].std()) > 0.3                               # sampled, not the deterministic mean
+
+
+def test_ring_replay_buffer_across_wraps_matches_the_oracle():
+    """The direct SAC loop writes in place into RingReplayBuffer; after 2.5 passes over a 10-slot ring every stored transition
+    (the newest 10 steps, wrapped) must still read as SB3's (obs, next_obs, action, reward, done, timeout): replayed through
+    the oracle from the stored actions -- the row that carries the newest observation over the wrap is the delicate one."""
+    pkg = _pkg()
+    from drl_dronenavigation_amd import tracks
+    from drl_dronenavigation_amd.collector import OffPolicyCollector, RingReplayBuffer
+    track = tracks.reaching()
+    n, T, steps = 256, 10, 25
+    kw = dict(max_steps=7, normalize_obs=False, act_noise_sigma=0.0, obs_noise_sigma=0.0, seed=1)
+    env = pkg.DroneVecEnv(track, n, device="cuda:0", **kw)
+    torch.manual_seed(5)
+    actor = pkg.SacActor().to(env.device)
+    col = OffPolicyCollector(env, pkg.FusedSacActor(actor, n, env.device, grade="fp32"), buffer_size=T, seed=2)
+    assert isinstance(col.buffer, RingReplayBuffer)
+    hist = []                                                      # every action the loop took, in order
+    for _ in range(steps):
+        p = col.buffer.pos
+        col.collect(1)
+        hist.append(col.buffer.actions[p].cpu().numpy().copy())
+    buf = col.buffer
+    assert buf.full and buf.pos == steps % T and len(buf) == (T - 1) * n      # mid-cycle: the slot being replaced is not whole
+    assert buf.valid_slots() == [t for t in range(T) if t != buf.pos]
+    slots, _ = buf._sample_slots(4096)
+    assert buf.pos not in set(slots.cpu().tolist()) and set(slots.cpu().tolist()) == set(buf.valid_slots())
+    cfg = O.make_config(track.targets(), track.initial_xyzs, track.aviary_dim, circle=False, f32_state=True, **kw)
+    ora = O.OracleVecEnv(cfg, n, threads=4)
+    obs_ref = ora.reset()
+    obs_b, next_b, rew_b = buf.obs.cpu().numpy(), buf.next_obs.cpu().numpy(), buf.rewards.cpu().numpy()
+    done_b, to_b = buf.dones.cpu().numpy().astype(bool), buf.timeouts.cpu().numpy().astype(bool)
+    checked = 0
+    for t in range(steps):
+        ref = ora.step(hist[t])
+        if t >= steps - T and t % T in buf.valid_slots():          # still in the ring, at slot t % T
+            s_ = t % T
+            dn = ref["done"].astype(bool)
+            np.testing.assert_allclose(obs_b[s_], obs_ref, rtol=0, atol=1e-5, err_msg=f"obs of step {t} (slot {s_})")
+            np.testing.assert_allclose(next_b[s_], np.where(dn[:, None], ref["terminal_obs"], ref["obs"]), rtol=0, atol=1e-5)
+            np.testing.assert_allclose(rew_b[s_], ref["reward"], rtol=1e-5, atol=1e-4)
+            assert np.array_equal(done_b[s_], dn) and np.array_equal(to_b[s_], ref["truncated"].astype(bool))
+            checked += 1
+        obs_ref = ref["obs"]
+    assert checked == T - 1
+    batch = buf.sample(512)
+    assert batch["obs"].shape == (512, 13) and batch["next_obs"].shape == (512, 13) and batch["dones"].max() <= 1.0
+    env.close()
