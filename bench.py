@@ -217,9 +217,9 @@ def sac_collect(pkg, track, n, max_steps, dev, rank):
     res = {}
     steps = 64
     for label, grade, graph in (("torch fp32 actor, eager", None, False), ("torch fp32 actor, hipGraph", None, True),
-                                ("fused MFMA actor bf16 grade, three launches per step, hipGraph", "bf16", True),
-                                ("fused MFMA actor fp32 grade, three launches per step, eager", "fp32", False),
-                                ("fused MFMA actor fp32 grade, three launches per step, hipGraph", "fp32", True)):
+                                ("fused MFMA actor bf16 grade, two launches per step, hipGraph", "bf16", True),
+                                ("fused MFMA actor fp32 grade, two launches per step, eager", "fp32", False),
+                                ("fused MFMA actor fp32 grade, two launches per step, hipGraph", "fp32", True)):
         env = pkg.DroneVecEnv(track, n, max_steps=max_steps, normalize_obs=True, act_noise_sigma=0.002, obs_noise_sigma=0.01,
                               seed=1, env_id_offset=rank * n, device=dev)
         pol = actor if grade is None else pkg.FusedSacActor(actor, n, dev, grade=grade)
@@ -250,11 +250,11 @@ def sac_collect(pkg, track, n, max_steps, dev, rank):
         e1.record()
         torch.cuda.synchronize(dev)
         kern[grade] = round(e0.elapsed_time(e1) * 1e3 / 50, 2)
-    return {"value": res["fused MFMA actor fp32 grade, three launches per step, hipGraph"], "unit": "env-steps/s", "variants": res, "num_envs": n, "steps": steps,
+    return {"value": res["fused MFMA actor fp32 grade, two launches per step, hipGraph"], "unit": "env-steps/s", "variants": res, "num_envs": n, "steps": steps,
             "actor_forward_us_python_loop": kern,
-            "what": "SAC collection loop of config 5 on one shard: dn_mlp_forward (actor 13-256-256 ReLU -> mu | log_std), dn_squashed_sample "
-                    "(clamp, Philox draw, tanh), dn_step (Philox action + observation noise, per-drone obs normaliser), every output written in "
-                    "place into the replay ring; `value` = float32-grade actor, the whole ring-buffer cycle replayed from a hipGraph"}
+            "what": "SAC collection loop of config 5 on one shard: dn_mlp_forward (actor 13-256-256 ReLU -> mu | log_std) and dn_step_squashed "
+                    "(clamp, Philox draw, tanh inside the step kernel; Philox action + observation noise, per-drone obs normaliser), every output "
+                    "written in place into the replay ring; `value` = float32-grade actor, the whole ring-buffer cycle replayed from a hipGraph"}
 
 
 def ppo_rollout_sharded(pkg, track, n, max_steps, dev, rank, world, dist):

@@ -90,6 +90,7 @@ PROTOTYPES = {
     "dn_preprocess_action": (_I32, [_VP, _I64, _I32, _VP, _VP, _VP, _I32, _VP]),
     "dn_policy_sample": (_I32, [_VP, _VP, C.POINTER(C.c_float), C.c_uint64, _I32, _VP, _VP, _VP, _VP]),
     "dn_squashed_sample": (_I32, [_VP, _VP, C.c_uint64, _I32, _VP, _VP, _VP]),
+    "dn_step_squashed": (_I32, [_VP, _VP, C.c_uint64, _I32] + [_VP] * 12),
     "dn_add_bootstrap": (_I32, [_VP, _VP, _VP, C.c_double, _I64, _I32, _VP]),
     "dn_step_sampled": (_I32, [_VP, _VP, C.POINTER(C.c_float), C.c_uint64, _I32] + [_VP] * 12),
     "dn_mlp_forward": (_I32, [_VP, _I32, _VP, _VP, _I64, _I32, _I32, _VP]),

@@ -280,16 +280,17 @@ class OffPolicyCollector:
     replay buffer): actor(obs) -> actions in [-1, 1] -> dn_step -> replay buffer, with SB3's terminal-observation
     handling.  Sharded like the on-policy collector: a rank's drones feed the rank's buffer, no collective.
 
-    With a policy_mfma.FusedSacActor the loop is three launches per step and no copies: dn_mlp_forward (mu | log_std from the
-    ring's current observation row), dn_squashed_sample (clamp, Philox draw, tanh: the action lands in its buffer slot),
-    dn_step (next observation, reward, flags and terminal observation land in theirs) -- RingReplayBuffer.  With any other
+    With a policy_mfma.FusedSacActor the loop is two launches per step and no copies: dn_mlp_forward (mu | log_std from the
+    ring's current observation row) and dn_step_squashed (clamp, Philox draw, tanh inside the step kernel: the action, the next
+    observation, reward, flags and terminal observation land in their buffer slots) -- RingReplayBuffer; three launches
+    (dn_squashed_sample + dn_step, the same bits) with `fused_sample=False` or with the options dn_step_squashed is not built for.  With any other
     torch callable the actions come from the callable and the transitions are copied into a ReplayBuffer.
 
     `collect_cycle()`: one whole pass over the ring buffer (buffer_size steps, slot 0 .. buffer_size - 1) captured into
     a hipGraph on its second call and replayed afterwards -- every tensor of the loop is static and the ring position is
     back where it started, so the host leaves the loop as it does for RolloutCollector(use_graph=True)."""
 
-    def __init__(self, env, actor, buffer_size, *, seed=0, deterministic=False):
+    def __init__(self, env, actor, buffer_size, *, seed=0, deterministic=False, fused_sample=True):
         from .policy_mfma import FusedSacActor
         from .vec_env import ACT_DIM, DroneVecEnv
         if not isinstance(env, DroneVecEnv):
@@ -303,6 +304,8 @@ class OffPolicyCollector:
             self.buffer = RingReplayBuffer(buffer_size, env.num_envs, env.obs_dim, ACT_DIM, env.device)
             self.buffer.obs_ring[0].copy_(env.reset_tensor())
             self._found = torch.zeros(env.num_envs, dtype=torch.int32, device=env.device)
+            cfg = env.cfg
+            self._fused_sample = fused_sample and not (cfg.clip_rew or cfg.norm_rew or cfg.physics or cfg.action_type)   # dn_step_squashed's scope
         else:
             self.buffer = ReplayBuffer(buffer_size, env.num_envs, env.obs_dim, ACT_DIM, env.device)
             self._obs = env.reset_tensor().clone()
@@ -323,10 +326,13 @@ class OffPolicyCollector:
                 buf.obs_ring[0].copy_(buf.obs_ring[T])      # slot 0's old transition is about to be replaced as a whole
                 self._carry = False
             mlp_forward([self.actor.pack], buf.obs_ring[p], [out8])
-            _capi.check(lib.dn_squashed_sample(h, out8.data_ptr(), self.seed, int(self.deterministic), buf.actions[p].data_ptr(), None, sptr))
-            _capi.check(lib.dn_step(h, buf.actions[p].data_ptr(), buf.obs_ring[p + 1].data_ptr(), buf.rewards[p].data_ptr(),
-                                    buf.done_flags[p].data_ptr(), buf.timeout_flags[p].data_ptr(), self._found.data_ptr(),
-                                    buf.terminal_obs[p].data_ptr(), None, None, None, sptr))
+            outs = (buf.obs_ring[p + 1].data_ptr(), buf.rewards[p].data_ptr(), buf.done_flags[p].data_ptr(), buf.timeout_flags[p].data_ptr(),
+                    self._found.data_ptr(), buf.terminal_obs[p].data_ptr(), None, None, None, sptr)
+            if self._fused_sample:                          # the draw inside the step kernel: two launches per step
+                _capi.check(lib.dn_step_squashed(h, out8.data_ptr(), self.seed, int(self.deterministic), buf.actions[p].data_ptr(), None, *outs))
+            else:
+                _capi.check(lib.dn_squashed_sample(h, out8.data_ptr(), self.seed, int(self.deterministic), buf.actions[p].data_ptr(), None, sptr))
+                _capi.check(lib.dn_step(h, buf.actions[p].data_ptr(), *outs))
             buf.pos = p + 1
             if buf.pos == T:
                 buf.pos, buf.full, self._carry = 0, True, True

@@ -404,7 +404,7 @@ int32_t dn_step(dn_env *env, const float *actions, float *obs, float *reward, ui
     io.actions = actions; io.obs = obs; io.reward = reward; io.done = done; io.truncated = truncated;
     io.found_targets = found_targets; io.terminal_obs = terminal_obs; io.ep_return = ep_return;
     io.ep_length = ep_length; io.done_mask = (unsigned long long *)done_mask;
-    io.mean = nullptr; io.act_out = nullptr; io.logp_out = nullptr;
+    io.mean = nullptr; io.act_out = nullptr; io.logp_out = nullptr; io.sample_squash = 0;
     DN_HIP(dn_launch_step_many(env->p, io, 1, env->cfg.compute_f32 != 0, env->waves_single, (hipStream_t)stream));
     return DN_OK;
 }
@@ -428,8 +428,31 @@ int32_t dn_step_sampled(dn_env *env, const float *mean, const float *log_std, ui
     io.ep_length = ep_length; io.done_mask = (unsigned long long *)done_mask;
     io.mean = mean; io.act_out = actions_out; io.logp_out = log_prob_out;
     for (int j = 0; j < 4; ++j) io.log_std[j] = log_std[j];
-    io.sample_seed = seed; io.sample_deterministic = deterministic != 0;
+    io.sample_seed = seed; io.sample_deterministic = deterministic != 0; io.sample_squash = 0;
     // the sampling lives in the single-step kernels (one wave, or three waves cut by dependency)
+    DN_HIP(dn_launch_step_many(env->p, io, 1, env->cfg.compute_f32 != 0, env->waves_single == 3 ? 3 : 1, (hipStream_t)stream));
+    return DN_OK;
+}
+
+int32_t dn_step_squashed(dn_env *env, const float *mu_log_std, uint64_t seed, int32_t deterministic, float *actions_out,
+                         float *log_prob_out, float *obs, float *reward, uint8_t *done, uint8_t *truncated, int32_t *found_targets,
+                         float *terminal_obs, float *ep_return, int32_t *ep_length, uint64_t *done_mask, void *stream)
+{
+    if (!env) return fail(DN_ERR_INVALID_ARGUMENT, "env is NULL");
+    if (!mu_log_std || !actions_out || !obs || !reward || !done || !truncated || !found_targets)
+        return fail(DN_ERR_INVALID_ARGUMENT, "mu_log_std, actions_out, obs, reward, done, truncated and found_targets are required");
+    if (((uintptr_t)mu_log_std & 15u) || ((uintptr_t)actions_out & 15u) || ((uintptr_t)obs & 15u))
+        return fail(DN_ERR_INVALID_ARGUMENT, "mu_log_std, actions_out and obs must be 16-byte aligned");
+    if (env->cfg.clip_rew || env->cfg.norm_rew || env->cfg.physics != 0 || env->cfg.action_type != 0)
+        return fail(DN_ERR_INVALID_ARGUMENT, "dn_step_squashed is built for the configuration without reward wrappers / extra physics terms / RPM actions; "
+                                             "use dn_squashed_sample + dn_step there");
+    DnStepIO io;
+    io.actions = nullptr; io.obs = obs; io.reward = reward; io.done = done; io.truncated = truncated;
+    io.found_targets = found_targets; io.terminal_obs = terminal_obs; io.ep_return = ep_return;
+    io.ep_length = ep_length; io.done_mask = (unsigned long long *)done_mask;
+    io.mean = mu_log_std; io.act_out = actions_out; io.logp_out = log_prob_out;
+    for (int j = 0; j < 4; ++j) io.log_std[j] = 0.0f;
+    io.sample_seed = seed; io.sample_deterministic = deterministic != 0; io.sample_squash = 1;
     DN_HIP(dn_launch_step_many(env->p, io, 1, env->cfg.compute_f32 != 0, env->waves_single == 3 ? 3 : 1, (hipStream_t)stream));
     return DN_OK;
 }
@@ -475,7 +498,7 @@ int32_t dn_step_many(dn_env *env, int64_t k, const float *actions, float *obs, f
     io.actions = actions; io.obs = obs; io.reward = reward; io.done = done; io.truncated = truncated;
     io.found_targets = found_targets; io.terminal_obs = terminal_obs; io.ep_return = ep_return;
     io.ep_length = ep_length; io.done_mask = (unsigned long long *)done_mask;
-    io.mean = nullptr; io.act_out = nullptr; io.logp_out = nullptr;
+    io.mean = nullptr; io.act_out = nullptr; io.logp_out = nullptr; io.sample_squash = 0;
     DN_HIP(dn_launch_step_many(env->p, io, (int)k, env->cfg.compute_f32 != 0, env->waves_fused, (hipStream_t)stream));
     return DN_OK;
 }

@@ -75,6 +75,7 @@ struct DnStepIO {
     float log_std[4];
     unsigned long long sample_seed;
     int sample_deterministic;
+    int sample_squash;                 // dn_step_squashed: `mean` holds [N][8] rows (mu[4], log_std[4]); action = tanh(mu + sigma z)
 };
 
 // Scalars of the environment, in both precisions (the float32 build must not touch float64).

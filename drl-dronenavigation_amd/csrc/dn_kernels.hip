@@ -1671,19 +1671,32 @@ DN_DEV Flight<R> fly(const DnParams &p, unsigned long long gid, unsigned long lo
 // rollout buffer, the clipped one into the step.  Same expressions as dn_policy_sample_kernel (same bits).
 DN_DEV float4 sample_action(const DnStepIO &io, const unsigned long long gid, const unsigned long long step, const long long i, const bool active)
 {
-    const float4 m = reinterpret_cast<const float4 *>(io.mean)[i];
-    const float mu[4] = {m.x, m.y, m.z, m.w};
     float z[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     if (!io.sample_deterministic) noise4(io.sample_seed, gid, step, 9u, z);
     float a[4], lp = 0.0f;
+    if (io.sample_squash) {
+        // dn_step_squashed: SAC's Actor on the (mu | log_std) rows of dn_mlp_forward(arch = SAC) -- the expressions of
+        // dn_squashed_sample_kernel (same bits); the squashed action is already inside the action box
+        const float4 m = reinterpret_cast<const float4 *>(io.mean)[2 * i], l = reinterpret_cast<const float4 *>(io.mean)[2 * i + 1];
+        const float mu[4] = {m.x, m.y, m.z, m.w};
+        const float ls[4] = {clipv(l.x, -20.0f, 2.0f), clipv(l.y, -20.0f, 2.0f), clipv(l.z, -20.0f, 2.0f), clipv(l.w, -20.0f, 2.0f)};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        a[j] = mu[j] + expf(io.log_std[j]) * z[j];
-        lp += -0.5f * z[j] * z[j] - io.log_std[j] - 0.91893853320467274178f;
+        for (int j = 0; j < 4; ++j) {
+            a[j] = tanhf(mu[j] + expf(ls[j]) * z[j]);
+            lp += (-0.5f * z[j] * z[j] - ls[j] - 0.91893853320467274178f) - logf(1.0f - a[j] * a[j] + 1e-6f);
+        }
+    } else {
+        const float4 m = reinterpret_cast<const float4 *>(io.mean)[i];
+        const float mu[4] = {m.x, m.y, m.z, m.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            a[j] = mu[j] + expf(io.log_std[j]) * z[j];
+            lp += -0.5f * z[j] * z[j] - io.log_std[j] - 0.91893853320467274178f;
+        }
     }
     if (active) {
         reinterpret_cast<float4 *>(io.act_out)[i] = make_float4(a[0], a[1], a[2], a[3]);
-        io.logp_out[i] = lp;
+        if (io.logp_out) io.logp_out[i] = lp;
     }
     return make_float4(clipv(a[0], -1.0f, 1.0f), clipv(a[1], -1.0f, 1.0f), clipv(a[2], -1.0f, 1.0f), clipv(a[3], -1.0f, 1.0f));
 }

@@ -846,10 +846,10 @@ __global__ __launch_bounds__(64 * XWAVES) __attribute__((amdgpu_waves_per_eu(1, 
 // SB3's SAC Actor with policy_kwargs net_arch = dict(pi=[256, 256]), activation_fn = ReLU (PBDroneSimulator.py:297-303):
 // latent_pi = ReLU(W2 ReLU(W1 obs + b1) + b2), mu = Wm latent + bm, log_std = Ws latent + bs; the two heads are stacked
 // into one [8, 256] matrix by the host, so the whole actor is three layers of the same transposed product as above and a
-// 32-drone tile needs 71 k multiply-adds per drone against the PPO pair's 2 x 400 k.  It is far too small to be worth the
-// LDS machinery: one wavefront per tile, the 142 KB of weights (284 KB in the fp32 grade) straight from L2 through an
-// 8-deep register ring, activations in registers (64 per layer, 128 with the hi / lo split).  Both grades in one body:
-// X3 = the split-bf16 float32 grade of dn_mlp_x3_kernel (three MFMAs per fragment pair, w_lo x_hi + w_hi x_lo + w_hi x_hi).
+// 32-drone tile needs 71 k multiply-adds per drone against the PPO pair's 2 x 400 k.  First shape (DN_MLP_SAC_SHAPE=1): one
+// wavefront per tile, the 142 KB of weights (284 KB in the fp32 grade) straight from L2 through an 8-deep register ring,
+// activations in registers (64 per layer, 128 with the hi / lo split).  Both grades in one body: X3 = the split-bf16
+// float32 grade of dn_mlp_x3_kernel (three MFMAs per fragment pair, w_lo x_hi + w_hi x_lo + w_hi x_hi).
 // -----------------------------------------------------------------------------------------------------
 constexpr int S1 = 256, S2 = 256;
 constexpr int SAC_RING = 8;
@@ -964,6 +964,160 @@ __global__ __launch_bounds__(64) void dn_mlp_sac_kernel(const MlpArgs a)
     }
 }
 
+
+// The same actor with the weight stream shared by four wavefronts through LDS (default).  Straight from L2 every wave pulls the
+// whole 142 KB (284 KB) itself: 1 024 waves x 284 KB in 22 us is 13 TB/s out of L2 (rocprof: 10.5 / 22.0 us for 32 768 drones
+// in the bf16 / float32 grade; with the stream shared: 10.8 / 19.5 us -- at this size launch, first round trip and the chunk
+// barriers weigh as much as the 2.5 / 7.7 us of MFMA time).  Here a workgroup of four waves
+// (128 drones) brings every fragment in once by LDS-DMA, chunks of 32 fragments double-buffered exactly as dn_mlp_lds_kernel
+// does: chunk 0 = layer 1 (8 fragments; 16 with the hi / lo split), then layer 2 in M-tile order (float32 grade: one M-tile =
+// 16 hi + 16 lo fragments = one chunk; bf16 grade: two M-tiles per chunk), then the stacked heads (16 / 32 fragments).
+constexpr int SAC_WAVES = 4;
+template <int NF>
+MLP_DEV void sac_dma(const uint4 *__restrict__ src, uint4 *lds, const int wave, const int lane)
+{   // NF fragments (8, 16 or 32) shared by 4 waves: NF / 4 consecutive fragments each
+    constexpr int per = NF / SAC_WAVES;
+    const int f = wave * per;
+    const uint4 *gsrc = src + f * 64 + lane;
+    const unsigned lds_dst = (unsigned)(uintptr_t)(lds + f * 64);
+    unsigned keep;
+    if (per == 8) {
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\t"
+                     "global_load_lds_dwordx4 %1, off offset:2048\n\tglobal_load_lds_dwordx4 %1, off offset:3072\n\t"
+                     "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\t"
+                     "global_load_lds_dwordx4 %1, off offset:2048\n\tglobal_load_lds_dwordx4 %1, off offset:3072\n\t"
+                     "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc + 4 * 64), "s"(lds_dst + 4096u) : "memory");
+    } else if (per == 4) {
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\t"
+                     "global_load_lds_dwordx4 %1, off offset:2048\n\tglobal_load_lds_dwordx4 %1, off offset:3072\n\t"
+                     "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    } else {
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\t"
+                     "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    }
+}
+// ReLU, pack (and split) the 16 accumulator values of an M-tile into the next layer's K-steps 2m, 2m + 1
+template <bool X3>
+MLP_DEV void sac_epilogue(const f32x16 &acc, u32x4 &h0, u32x4 &h1, u32x4 &l0, u32x4 &l1)
+{
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const float v0 = fmaxf(acc[2 * q], 0.0f), v1 = fmaxf(acc[2 * q + 1], 0.0f);
+        unsigned hi, lo = 0u;
+        if (X3) split_pair(v0, v1, hi, lo); else hi = pack2(v0, v1);
+        if (q < 4) { h0[q] = hi; if (X3) l0[q] = lo; }
+        else { h1[q - 4] = hi; if (X3) l1[q - 4] = lo; }
+    }
+}
+// one M-tile over KS K-steps from an LDS chunk: hi fragments at chunk[off + kk], lo fragments at chunk[off + KS + kk]
+template <int KS, bool X3>
+MLP_DEV f32x16 sac_tile(const uint4 *chunk, const int off, const float *__restrict__ bias, const int m, const int g, const int lane,
+                        const u32x4 (&inh)[KS], const u32x4 (&inl)[KS])
+{
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = bias[acc_row(m, g, r)];
+    constexpr int RG = KS < 4 ? KS : 4;
+    uint4 rh[RG], rl[RG];
+#pragma unroll
+    for (int kk = 0; kk < RG; ++kk) {
+        rh[kk] = chunk[(off + kk) * 64 + lane];
+        if (X3) rl[kk] = chunk[(off + KS + kk) * 64 + lane];
+    }
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+        const uint4 ah = rh[kk % RG], al = rl[kk % RG];
+        if (kk + RG < KS) {
+            rh[kk % RG] = chunk[(off + kk + RG) * 64 + lane];
+            if (X3) rl[kk % RG] = chunk[(off + KS + kk + RG) * 64 + lane];
+        }
+        if (X3) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al), __builtin_bit_cast(bf16x8, inh[kk]), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, inl[kk]), acc, 0, 0, 0);
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, inh[kk]), acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+template <bool X3>
+__global__ __launch_bounds__(64 * SAC_WAVES) void dn_mlp_sac_lds_kernel(const MlpArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint4 lds[2 * CHUNK * 64 + 1];     // ONE __shared__ object (see dn_mlp_lds_kernel)
+    int *s_any = reinterpret_cast<int *>(lds + 2 * CHUNK * 64);
+    constexpr int PER = X3 ? 2 : 1;
+    constexpr int TPC = X3 ? 1 : 2;                         // layer-2 M-tiles per 32-fragment chunk
+    constexpr int NL2 = (S2 / 32) / TPC;                    // layer-2 chunks
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 5, col = lane & 31;
+    const MlpNetDev &net = a.net[blockIdx.y];
+    const long long row0 = ((long long)blockIdx.x * SAC_WAVES + wave) * TILE;
+    const bool live = row0 + col < a.n;
+    const long long row = live ? row0 + col : a.n - 1;
+    bool tile_wanted = true;
+    if (a.row_mask) {
+        const bool wanted = live && a.row_mask[row0 + col] != 0;
+        tile_wanted = __ballot(wanted) != 0ull;
+        if (lane == 0) s_any[wave] = tile_wanted;
+        __syncthreads();
+        if ((s_any[0] | s_any[1] | s_any[2] | s_any[3]) == 0) {
+            if (g == 0 && live)
+                for (int j = 0; j < net.out_dim; ++j) net.out[(row0 + col) * net.out_dim + j] = 0.0f;
+            return;
+        }
+    }
+    sac_dma<(S1 / 32) * PER>(net.w1, lds, wave, lane);      // chunk 0 = layer 1 -> buffer 0
+    float ob[8];
+    load_obs8(a, row, g, ob);
+    u32x4 x0h[1], x0l[1];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        unsigned hi, lo = 0u;
+        if (X3) split_pair(ob[2 * q], ob[2 * q + 1], hi, lo); else hi = pack2(ob[2 * q], ob[2 * q + 1]);
+        x0h[0][q] = hi; x0l[0][q] = lo;
+    }
+    chunk_barrier();
+    u32x4 h1h[S1 / 16], h1l[S1 / 16];
+    sac_dma<CHUNK>(net.w2, lds + CHUNK * 64, wave, lane);   // layer 2, chunk 0 -> buffer 1
+#pragma unroll
+    for (int m = 0; m < S1 / 32; ++m) {
+        const f32x16 acc = sac_tile<1, X3>(lds, m * PER, net.b1, m, g, lane, x0h, x0l);
+        sac_epilogue<X3>(acc, h1h[2 * m], h1h[2 * m + 1], h1l[2 * m], h1l[2 * m + 1]);
+    }
+    chunk_barrier();
+    u32x4 h2h[S2 / 16], h2l[S2 / 16];
+#pragma unroll
+    for (int c = 0; c < NL2; ++c) {
+        const uint4 *cur = lds + ((1 + c) & 1) * (CHUNK * 64);
+        uint4 *nxt = lds + ((2 + c) & 1) * (CHUNK * 64);
+        if (c + 1 < NL2) sac_dma<CHUNK>(net.w2 + (size_t)(c + 1) * CHUNK * 64, nxt, wave, lane);
+        else sac_dma<(S2 / 16) * PER>(net.wh, nxt, wave, lane);
+#pragma unroll
+        for (int j = 0; j < TPC; ++j) {
+            const int m = c * TPC + j;
+            const f32x16 acc = sac_tile<S1 / 16, X3>(cur, j * (S1 / 16), net.b2, m, g, lane, h1h, h1l);
+            sac_epilogue<X3>(acc, h2h[2 * m], h2h[2 * m + 1], h2l[2 * m], h2l[2 * m + 1]);
+        }
+        chunk_barrier();
+    }
+    // heads: one M-tile (8 rows used), float32 straight from the accumulator; its chunk is in buffer (1 + NL2) & 1
+    const f32x16 acc = sac_tile<S2 / 16, X3>(lds + ((1 + NL2) & 1) * (CHUNK * 64), 0, net.bh, 0, g, lane, h2h, h2l);
+    if (live) {
+        float *o = net.out + (row0 + col) * net.out_dim;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = acc_row(0, g, r);
+            if (j < net.out_dim) o[j] = tile_wanted ? acc[r] : 0.0f;
+        }
+    }
+}
+
 }  // namespace
 
 hipError_t dn_launch_mlp(const dn_mlp_net *nets, int num_nets, const float *obs, const uint8_t *row_mask, long long n, int obs_dim,
@@ -980,8 +1134,16 @@ hipError_t dn_launch_mlp(const dn_mlp_net *nets, int num_nets, const float *obs,
     a.obs = obs; a.row_mask = row_mask; a.n = n; a.obs_dim = obs_dim;
     const unsigned tiles = (unsigned)((n + TILE - 1) / TILE);
     if (nets[0].arch == DN_MLP_ARCH_SAC) {
-        if (nets[0].grade == 1) hipLaunchKernelGGL(dn_mlp_sac_kernel<true>, dim3(tiles, num_nets), dim3(64), 0, stream, a);
-        else hipLaunchKernelGGL(dn_mlp_sac_kernel<false>, dim3(tiles, num_nets), dim3(64), 0, stream, a);
+        const char *es = getenv("DN_MLP_SAC_SHAPE");        // 1 = one wave per workgroup straight from L2 | 4 = four waves sharing the stream through LDS
+        const bool direct = es && atoi(es) == 1;
+        const dim3 grid4((tiles + SAC_WAVES - 1) / SAC_WAVES, num_nets);
+        if (nets[0].grade == 1) {
+            if (direct) hipLaunchKernelGGL(dn_mlp_sac_kernel<true>, dim3(tiles, num_nets), dim3(64), 0, stream, a);
+            else hipLaunchKernelGGL(dn_mlp_sac_lds_kernel<true>, grid4, dim3(64 * SAC_WAVES), 0, stream, a);
+        } else {
+            if (direct) hipLaunchKernelGGL(dn_mlp_sac_kernel<false>, dim3(tiles, num_nets), dim3(64), 0, stream, a);
+            else hipLaunchKernelGGL(dn_mlp_sac_lds_kernel<false>, grid4, dim3(64 * SAC_WAVES), 0, stream, a);
+        }
         return hipGetLastError();
     }
     if (nets[0].grade == 1) {                                // fp32-grade networks (split-bf16 x3): their own kernel and packing

@@ -282,6 +282,14 @@ int32_t dn_policy_sample(dn_env *env, const float *mean, const float *log_std, u
  * log_prob: device float[N] or NULL (sum over the four dims of log N(pre; mu, sigma) - log(1 - a^2 + 1e-6)). */
 int32_t dn_squashed_sample(dn_env *env, const float *mu_log_std, uint64_t seed, int32_t deterministic, float *actions,
                            float *log_prob, void *stream);
+/* dn_squashed_sample + dn_step in one launch (the SAC collection loop's per-step pair): the action is drawn inside the step
+ * kernel from the (mu | log_std) rows exactly as dn_squashed_sample draws it (same Philox stream, same bits); actions_out
+ * receives it (the replay buffer's action), log_prob_out (may be NULL) its log-probability.  Other arguments as dn_step; same
+ * configuration limits as dn_step_sampled. */
+int32_t dn_step_squashed(dn_env *env, const float *mu_log_std, uint64_t seed, int32_t deterministic, float *actions_out,
+                         float *log_prob_out, float *obs, float *reward, uint8_t *done, uint8_t *truncated,
+                         int32_t *found_targets, float *terminal_obs, float *ep_return, int32_t *ep_length,
+                         uint64_t *done_mask, void *stream);
 int32_t dn_add_bootstrap(float *reward, const float *terminal_value, const uint8_t *truncated, double gamma,
                          int64_t num_envs, int32_t device_id, void *stream);
 /* dn_policy_sample + dn_step in one launch (the rollout loop's per-step pair): the action is drawn inside the step kernel

@@ -269,3 +269,30 @@ def test_ring_replay_buffer_across_wraps_matches_the_oracle():
     batch = buf.sample(512)
     assert batch["obs"].shape == (512, 13) and batch["next_obs"].shape == (512, 13) and batch["dones"].max() <= 1.0
     env.close()
+
+
+def test_step_squashed_equals_squashed_sample_then_step():
+    """dn_step_squashed (the draw inside the step kernel) against dn_squashed_sample + dn_step: the two collection loops leave
+    bit-identical replay rings -- one-wave and three-wave single-step kernels, with and without noise / normaliser."""
+    pkg = _pkg()
+    from drl_dronenavigation_amd import tracks
+    from drl_dronenavigation_amd.collector import OffPolicyCollector
+    track = tracks.reaching()
+    torch.manual_seed(8)
+    actor = pkg.SacActor().to("cuda:0")
+    for n, kw in ((4096, dict(max_steps=9, normalize_obs=True, act_noise_sigma=0.002, obs_noise_sigma=0.01, seed=4)),
+                  (2 * 65536 + 64, dict(max_steps=9, normalize_obs=False, seed=4))):          # the large fleet takes the one-wave kernel
+        rings = []
+        for fused_sample in (True, False):
+            env = pkg.DroneVecEnv(track, n, device="cuda:0", **kw)
+            fused = pkg.FusedSacActor(actor, n, env.device, grade="bf16")
+            col = OffPolicyCollector(env, fused, buffer_size=12, seed=21, fused_sample=fused_sample)
+            assert col._fused_sample == fused_sample
+            col.collect(12)
+            torch.cuda.synchronize()
+            b = col.buffer
+            rings.append([t.clone() for t in (b.obs_ring, b.terminal_obs, b.actions, b.rewards, b.done_flags, b.timeout_flags)])
+            env.close()
+        for a, b in zip(*rings):
+            assert torch.equal(a, b)
+        assert float(rings[0][4].sum()) > 0

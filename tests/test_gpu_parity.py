@@ -1558,13 +1558,15 @@ def test_done_compaction_is_ordered_at_every_size(n):
         assert bool((idx[want.size:] == -1).all())         # nothing written past the count
 
 
+@pytest.mark.parametrize("shape", ["4", "1"])
 @pytest.mark.parametrize("n", [1, 33, 4096 + 5])
-def test_sac_actor_kernel_matches_the_float32_torch_actor(n):
+def test_sac_actor_kernel_matches_the_float32_torch_actor(n, shape, monkeypatch):
     """dn_mlp_forward with arch = DN_MLP_ARCH_SAC (obs -> 256 -> 256 -> mu | log_std, ReLU; PBDroneSimulator.py:297-303)
     against the float64 evaluation of the float32 SacActor: fp32 grade <= 1e-4 on mu and log_std, the bf16 grade an order
     coarser; ragged tile sizes; masked forward; and FusedSacActor's deterministic action = tanh(mu)."""
     pkg = _gpu()
     from drl_dronenavigation_amd import policy_mfma as pm
+    monkeypatch.setenv("DN_MLP_SAC_SHAPE", shape)             # 4: four waves share the weight stream through LDS (default); 1: one wave, from L2
     dev = torch.device("cuda:0")
     torch.manual_seed(n + 11)
     actor = pkg.SacActor().to(dev)
