@@ -1669,6 +1669,26 @@ DN_DEV Flight<R> fly(const DnParams &p, unsigned long long gid, unsigned long lo
 // where the action is consumed: action = mean + exp(log_std) z, z ~ N(0,1) from the environment's Philox stream (seed,
 // global drone id, the tile's vector-step counter, stream 9); the unclipped action and its log-probability go to the
 // rollout buffer, the clipped one into the step.  Same expressions as dn_policy_sample_kernel (same bits).
+// tanh(x) = 1 - 2 / (1 + e^{2x}): v_exp_f32 + v_rcp_f32 (absolute error ~1e-7; +-1 exactly once e^{2x} over- or underflows)
+DN_DEV float tanh_squash(const float x)
+{
+    const float e = __builtin_amdgcn_exp2f(x * 2.88539008177792681472f);        // 2 log2(e)
+    return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
+}
+// One drone's squashed-Gaussian draw (SB3 SAC Actor [3P-recall]): shared by dn_squashed_sample_kernel and the step kernels
+// (dn_step_squashed), so that the two produce the same bits.  The log-probability costs four logf: only on request.
+DN_DEV void squashed_draw(const float4 m, const float4 l, const float z[4], const bool want_lp, float a[4], float &lp)
+{
+    const float mu[4] = {m.x, m.y, m.z, m.w};
+    const float ls[4] = {clipv(l.x, -20.0f, 2.0f), clipv(l.y, -20.0f, 2.0f), clipv(l.z, -20.0f, 2.0f), clipv(l.w, -20.0f, 2.0f)};
+    lp = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[j] = tanh_squash(mu[j] + expf(ls[j]) * z[j]);
+    if (want_lp) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lp += (-0.5f * z[j] * z[j] - ls[j] - 0.91893853320467274178f) - logf(1.0f - a[j] * a[j] + 1e-6f);
+    }
+}
 DN_DEV float4 sample_action(const DnStepIO &io, const unsigned long long gid, const unsigned long long step, const long long i, const bool active)
 {
     float z[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -1677,14 +1697,8 @@ DN_DEV float4 sample_action(const DnStepIO &io, const unsigned long long gid, co
     if (io.sample_squash) {
         // dn_step_squashed: SAC's Actor on the (mu | log_std) rows of dn_mlp_forward(arch = SAC) -- the expressions of
         // dn_squashed_sample_kernel (same bits); the squashed action is already inside the action box
-        const float4 m = reinterpret_cast<const float4 *>(io.mean)[2 * i], l = reinterpret_cast<const float4 *>(io.mean)[2 * i + 1];
-        const float mu[4] = {m.x, m.y, m.z, m.w};
-        const float ls[4] = {clipv(l.x, -20.0f, 2.0f), clipv(l.y, -20.0f, 2.0f), clipv(l.z, -20.0f, 2.0f), clipv(l.w, -20.0f, 2.0f)};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            a[j] = tanhf(mu[j] + expf(ls[j]) * z[j]);
-            lp += (-0.5f * z[j] * z[j] - ls[j] - 0.91893853320467274178f) - logf(1.0f - a[j] * a[j] + 1e-6f);
-        }
+        squashed_draw(reinterpret_cast<const float4 *>(io.mean)[2 * i], reinterpret_cast<const float4 *>(io.mean)[2 * i + 1], z,
+                      io.logp_out != nullptr, a, lp);
     } else {
         const float4 m = reinterpret_cast<const float4 *>(io.mean)[i];
         const float mu[4] = {m.x, m.y, m.z, m.w};
@@ -2592,18 +2606,11 @@ __global__ __launch_bounds__(256) void dn_squashed_sample_kernel(const DnParams 
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= p.n) return;
-    const float4 m = mu_log_std[2 * i], l = mu_log_std[2 * i + 1];
-    const float mu[4] = {m.x, m.y, m.z, m.w};
-    const float ls[4] = {clipv(l.x, -20.0f, 2.0f), clipv(l.y, -20.0f, 2.0f), clipv(l.z, -20.0f, 2.0f), clipv(l.w, -20.0f, 2.0f)};
     float z[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     if (!deterministic)
         noise4(seed, (unsigned long long)(p.env_id_offset + i), p.st.stats[i / DN_BLOCK].step_count, 9u, z);
-    float a[4], lp = 0.0f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        a[j] = tanhf(mu[j] + expf(ls[j]) * z[j]);
-        lp += (-0.5f * z[j] * z[j] - ls[j] - 0.91893853320467274178f) - logf(1.0f - a[j] * a[j] + 1e-6f);
-    }
+    float a[4], lp;
+    squashed_draw(mu_log_std[2 * i], mu_log_std[2 * i + 1], z, log_prob != nullptr, a, lp);
     actions[i] = make_float4(a[0], a[1], a[2], a[3]);
     if (log_prob) log_prob[i] = lp;
 }
