@@ -38,6 +38,7 @@ inline double norm3d(const double v[3]) { return std::sqrt(v[0] * v[0] + v[1] * 
 
 constexpr long long DN_TWO_WAVE_MAX_TILES = 1024;   // 65536 drones: one tile per SIMD
 constexpr long long DN_PQX_MAX_TILES = 1024;        // three-wave single step: while the tiles alone leave SIMDs idle
+constexpr long long DN_FOUR_WAVE_MAX_TILES = 256;   // four-wave fused step: one tile per CU, every wave alone on its SIMD
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -267,6 +268,12 @@ int32_t dn_create(const dn_config *cfg, dn_env **out)
     if (!plain && !cfg->normalize_obs) max_three = DN_TWO_WAVE_MAX_TILES * 3 / 4;
     else if (noisy) max_three = DN_TWO_WAVE_MAX_TILES / 4;
     e->waves_fused = e->blocks <= max_multi ? (e->blocks <= max_three ? 3 : 2) : 1;
+    // Four waves (dn_step_many_4w_kernel: the recurrence itself on two waves): while every wave of a tile has a SIMD to itself --
+    // one tile per CU, <= 256 tiles -- the shorter chain wins 9-10 % (4 096 / 8 192 / 16 384 drones: 1.14 / 1.16 / 1.17 us per
+    // step against 1.26 / 1.28 / 1.28 with three waves); from two tiles per CU on the eight waves share SIMDs and it loses
+    // (24 576: 1.48 against 1.29; 32 768: 1.49 against 1.27), as it does with the normaliser on the report wave (16 384: 1.78
+    // against 1.50).  Plain configuration without the ground-contact term, no noise.
+    if (plain && !cfg->ground_contact && !noisy && !cfg->normalize_obs && e->blocks <= DN_FOUR_WAVE_MAX_TILES) e->waves_fused = 4;
     // dn_step (one control step per launch) is latency bound: ~2.9 us of launch-to-launch floor that an empty kernel
     // already pays (profiles/r02_dispatch_floor.txt) plus the dependent instruction stream of the step.  Cutting the step
     // by dependency over three waves (dn_step_pqx_kernel) shortens that stream while the chip has idle SIMDs; built for the
@@ -281,6 +288,9 @@ int32_t dn_create(const dn_config *cfg, dn_env **out)
         else if (w[0] == '2') e->waves_fused = e->waves_single = 2;
         else if (w[0] == '3') {
             e->waves_fused = 3;
+            e->waves_single = pqx_ok ? 3 : 1;
+        } else if (w[0] == '4') {                              // the recurrence itself on two waves (dn_step_many_4w_kernel): plain configuration only
+            e->waves_fused = pqx_ok ? 4 : 3;
             e->waves_single = pqx_ok ? 3 : 1;
         }
     }

@@ -2267,6 +2267,219 @@ __global__ __launch_bounds__(3 * DN_BLOCK, NORM ? 2 : 3) void dn_step_many_3w_ke
 }
 
 // -----------------------------------------------------------------------------------------------------
+// Four-wave kernel (fused launches of the plain configuration): the recurrence itself is cut in two.
+//
+// In the three-wave kernel the flight wave carries physics + rules, ~420 vector instructions per step that nothing else
+// can start without, and sets the pace (1.27 us per step at 32 768 drones with the SIMDs issuing 84 % of the time).  The
+// rigid-body step is two halves that share only their inputs (physics_linear / physics_angular, see there), and the rules
+// read the new POSITION only (no ground-contact term here), so the recurrence runs on two waves that exchange one small
+// message per step:
+//
+//   L (linear, rules)    thrust fz(t) | physics_linear(t) with the entry attitude | rules_verdict, rules_commit (t)   -> MailL[t & 1]
+//   A (angular, pose)    torques(t)   | physics_angular(t) | attitude of the new pose (Euler terms, forward vector)  -> MailG[t & 1]
+//   Q (observation)      MailL, MailG [(t-1) & 1] -> observation columns, reward candidates (t-1)                     -> MailA[(t-1) & 1]
+//   X (thrust, report)   thrust(t+1) -> tmail | MailA[(t-2) & 1] -> [normaliser] report(t-2), observation rows
+//                                                                                                  == barrier t ==
+// L needs A's new quaternion of step t-1 (a float4) and applies its own verdict's reset to it; A needs L's verdict of step
+// t-1 (one flag) to reset its half of the body.  ~255 instructions each instead of ~420 on one wave.  Same device functions,
+// same typed values across LDS, one spelled-out arithmetic sequence: bit-identical to the other shapes
+// (test_kernel_shapes_are_bit_identical under DN_WAVES=4).
+// -----------------------------------------------------------------------------------------------------
+template <typename R> struct MailL {      // L -> Q (and its flag word -> A): the linear half of the new state and the verdict
+    R f64[4][DN_BLOCK];                   // position (3), Verdict.d_obs
+    float4 f32[2][DN_BLOCK];              // (vx, vy, vz, d_e), (vex, vey, vez, dprev_e)
+    int flags[DN_BLOCK];                  // idx_e | just_found_e << 8 | truncated << 9 | coll1 << 10 | terminated << 11
+};
+template <typename R> struct MailG {      // A -> L (qnew) and A -> Q (the rest): the angular half and the attitude read-outs
+    float4 qnew[DN_BLOCK];                // the new attitude as the float32 state words (before any reset)
+    R fw[3][DN_BLOCK];                    // forward vector of the new pose
+    float4 eul[DN_BLOCK];                 // roll_num32, roll_den32, pitch32, yaw32
+    float4 w[DN_BLOCK];                   // new angular velocity (float32 state words)
+    float4 we[DN_BLOCK];                  // entry angular velocity (prev_ang_v of the smoothness term)
+};
+
+template <typename R, bool NORM, bool NOISE>
+__global__ __launch_bounds__(4 * DN_BLOCK, 2) void dn_step_many_4w_kernel(const DnParams p, const DnStepIO io0, const int k_steps)
+{
+    __shared__ R s_tab[DN_MAX_WAYPOINTS * DN_T_STRIDE];
+    __shared__ MailL<R> maill[2];
+    __shared__ __attribute__((aligned(16))) MailG<R> mailg[2];
+    __shared__ MailA<R> maila[2];
+    __shared__ __attribute__((aligned(16))) ThrustMail<R> tmail[2];
+    const unsigned lane = threadIdx.x & (DN_BLOCK - 1);
+    // roles: 0 L, 1 A, 2 Q, 3 X.  Wave order L, X, A, Q: waves w and w + 4 of two co-resident tiles share a SIMD round-robin, and
+    // consecutive waves of one tile alternate SIMD halves (see MI355X_MICROARCH: 0 -> 2 -> 1 -> 3)
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int role = wv == 0 ? 0 : (wv == 1 ? 3 : (wv == 2 ? 1 : 2));
+    const long long tile_base = (long long)blockIdx.x * DN_BLOCK;
+    const long long left = p.n - tile_base;
+    const unsigned rows = left < DN_BLOCK ? (unsigned)left : DN_BLOCK;
+    const bool active = lane < rows;
+    const unsigned li = active ? lane : rows - 1;
+    __builtin_assume(li < DN_BLOCK);
+    const long long i = tile_base + li;
+    const unsigned long long gid = (unsigned long long)(p.env_id_offset + i);
+    const BlockState b = block_state(p.st, tile_base);
+    const DnConsts<R> &c = consts<R>(p);
+    const long long n = p.n, words = (p.n + 63) / 64;
+    const unsigned long long sc0 = p.st.stats[blockIdx.x].step_count;
+    stage_table<R>(p, s_tab);
+    // every wave passes barrier P and the barriers of iterations 0 .. k_steps (k_steps + 1 of them)
+    if (role == 0) {
+        __builtin_amdgcn_s_setprio(3);
+        float4 G0 = b.g0[li], G1 = b.g1[li], G2 = b.g2[li], G3 = b.g3[li];
+        block_lds_barrier();                                               // P
+        const R wp0[3] = {s_tab[DN_T_WP], s_tab[DN_T_WP + 1], s_tab[DN_T_WP + 2]};
+        bool done_prev = false;
+#pragma clang loop unroll(disable)
+        for (int t = 0; t <= k_steps; ++t) {
+            if (t < k_steps) {
+                if (t > 0) {                                               // entry attitude: A's step t-1, reset by my verdict of t-1
+                    const float4 qn = mailg[(t - 1) & 1].qnew[lane];
+                    G1 = done_prev ? make_float4(0.0f, 0.0f, 0.0f, 1.0f) : qn;
+                }
+                const GateRow<R> row_e = load_gate_row<R>(s_tab, unpack_meta(G3.w).idx);
+                const R fz = tmail[t & 1].v[0][lane];
+                const Lin<R> lin = physics_linear<R>(G0, G1, G2, fz, R(0.0), R(0.0), R(0.0), false);
+                Flight<R> fl;
+                flight_entry<R>(fl, G0, G2, G3, p.max_steps);
+                fl.px = lin.px; fl.py = lin.py; fl.pz = lin.pz;
+                fl.vx = (float)lin.vx; fl.vy = (float)lin.vy; fl.vz = (float)lin.vz;
+                fl.qx = fl.qy = fl.qz = R(0.0); fl.qw = R(1.0);            // the attitude belongs to A (no ground-contact term here)
+                fl.wx = fl.wy = fl.wz = 0.0f;
+                RulesMid<R> m;
+                const Verdict<R> v = rules_verdict<R>(p, c, s_tab, row_e, fl, G3, m);
+                MailL<R> &ml = maill[t & 1];
+                ml.f64[0][lane] = fl.px; ml.f64[1][lane] = fl.py; ml.f64[2][lane] = fl.pz; ml.f64[3][lane] = v.d_obs;
+                ml.f32[0][lane] = make_float4(fl.vx, fl.vy, fl.vz, fl.d_e);
+                ml.f32[1][lane] = make_float4(fl.vex, fl.vey, fl.vez, fl.dprev_e);
+                ml.flags[lane] = fl.idx_e | (fl.just_found_e << 8) | (fl.truncated << 9) | (v.coll1 << 10) | (v.terminated << 11);
+                float4 S0, S1, S2, S3;
+                rules_commit<R>(c, wp0, fl, m, G0, G3, b.g6, li, active, S0, S1, S2, S3);
+                G0 = S0; G2 = S2; G3.w = S3.w;
+                done_prev = v.terminated != 0 || fl.truncated != 0;
+            }
+            block_lds_barrier();                                           // barrier t
+        }
+        if (active) {
+            b.g0[li] = G0; b.g2[li] = G2;
+            reinterpret_cast<float *>(b.g3 + li)[3] = G3.w;
+        }
+    } else if (role == 1) {
+        __builtin_amdgcn_s_setprio(3);
+        float4 G1 = b.g1[li], G3 = b.g3[li];                               // G3.xyz: angular velocity (the .w belongs to L)
+        block_lds_barrier();                                               // P
+#pragma clang loop unroll(disable)
+        for (int t = 0; t <= k_steps; ++t) {
+            if (t > 0) {                                                   // L's verdict of step t-1: a finished drone restarts level, at rest
+                const int fb = maill[(t - 1) & 1].flags[lane];
+                if (((fb >> 9) | (fb >> 11)) & 1) { G1 = make_float4(0.0f, 0.0f, 0.0f, 1.0f); G3.x = G3.y = G3.z = 0.0f; }
+            }
+            if (t < k_steps) {
+                const R tx = tmail[t & 1].v[1][lane], ty = tmail[t & 1].v[2][lane], zt = tmail[t & 1].v[3][lane];
+                const Ang<R> ang = physics_angular<R>(G1, G3, tx, ty, zt);
+                Flight<R> fl;
+                fl.qx = ang.qx; fl.qy = ang.qy; fl.qz = ang.qz; fl.qw = ang.qw;
+                attitude_phase<R>(fl);
+                MailG<R> &mg = mailg[t & 1];
+                const float4 qn = make_float4((float)ang.qx, (float)ang.qy, (float)ang.qz, (float)ang.qw);
+                const float4 wn = make_float4((float)ang.wx, (float)ang.wy, (float)ang.wz, 0.0f);
+                mg.qnew[lane] = qn;
+                mg.fw[0][lane] = fl.fwx; mg.fw[1][lane] = fl.fwy; mg.fw[2][lane] = fl.fwz;
+                mg.eul[lane] = make_float4(fl.roll_num32, fl.roll_den32, fl.pitch32, fl.yaw32);
+                mg.w[lane] = wn;
+                mg.we[lane] = make_float4(G3.x, G3.y, G3.z, 0.0f);
+                G1 = qn; G3.x = wn.x; G3.y = wn.y; G3.z = wn.z;
+            }
+            block_lds_barrier();                                           // barrier t
+        }
+        if (active) {
+            b.g1[li] = G1;
+            float *g3 = reinterpret_cast<float *>(b.g3 + li);
+            g3[0] = G3.x; g3[1] = G3.y; g3[2] = G3.z;
+        }
+    } else if (role == 2) {
+        __builtin_amdgcn_s_setprio(2);
+        float4 P4 = b.g4[li], P5 = b.g5[li];                               // .xyz: prev_vel, prev_ang_v
+        Rms rms;                                                           // never touched here: the observation leaves raw
+        block_lds_barrier();                                               // P
+#pragma clang loop unroll(disable)
+        for (int t = 0; t <= k_steps; ++t) {
+            if (t > 0) {                                                   // the step L and A finished last iteration
+                const int u = t - 1;
+                const MailL<R> &ml = maill[u & 1];
+                const MailG<R> &mg = mailg[u & 1];
+                Flight<R> fl;
+                Verdict<R> v;
+                fl.px = ml.f64[0][lane]; fl.py = ml.f64[1][lane]; fl.pz = ml.f64[2][lane]; v.d_obs = ml.f64[3][lane];
+                const float4 a0 = ml.f32[0][lane], a1 = ml.f32[1][lane];
+                fl.vx = a0.x; fl.vy = a0.y; fl.vz = a0.z; fl.d_e = a0.w;
+                fl.vex = a1.x; fl.vey = a1.y; fl.vez = a1.z; fl.dprev_e = a1.w;
+                const int fb = ml.flags[lane];
+                fl.idx_e = fb & 0xFF; fl.just_found_e = (fb >> 8) & 1; fl.truncated = (fb >> 9) & 1;
+                v.coll1 = (fb >> 10) & 1; v.terminated = (fb >> 11) & 1;
+                const float4 qn = mg.qnew[lane], e = mg.eul[lane], wn = mg.w[lane], we = mg.we[lane];
+                fl.qx = (R)qn.x; fl.qy = (R)qn.y; fl.qz = (R)qn.z; fl.qw = (R)qn.w;      // not read by the observation / reward (attitude came over)
+                fl.fwx = mg.fw[0][lane]; fl.fwy = mg.fw[1][lane]; fl.fwz = mg.fw[2][lane];
+                fl.roll_num32 = e.x; fl.roll_den32 = e.y; fl.pitch32 = e.z; fl.yaw32 = e.w;
+                fl.wx = wn.x; fl.wy = wn.y; fl.wz = wn.z;
+                fl.aex = we.x; fl.aey = we.y; fl.aez = we.z;
+                const Observed<R> ob = observe_phase<R, false, NOISE>(p, c, s_tab, fl, P4, P5, gid, sc0 + (unsigned long long)u, rms);
+                post_maila<R>(maila[u & 1], lane, fl, v, ob);
+                // prev_vel / prev_ang_v: _update_state_post_step (skipped on a terminated step, quirk Q5), zero after a reset
+                if (!v.terminated) { P4 = make_float4(fl.vex, fl.vey, fl.vez, 0.0f); P5 = make_float4(fl.aex, fl.aey, fl.aez, 0.0f); }
+                if (v.terminated || fl.truncated) P4 = P5 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+            block_lds_barrier();                                           // barrier t
+        }
+        if (active) {
+            float *g4 = reinterpret_cast<float *>(b.g4 + li), *g5 = reinterpret_cast<float *>(b.g5 + li);
+            g4[0] = P4.x; g4[1] = P4.y; g4[2] = P4.z; g5[0] = P5.x; g5[1] = P5.y; g5[2] = P5.z;
+        }
+    } else {
+        float4 G4 = b.g4[li], G5 = b.g5[li];                               // .w: Monitor return / length
+        StatAcc acc;
+        Rms rms;
+        if (NORM) load_rms(p, i, rms);
+        RewNorm rn = {0.0, 0.0, 1.0, 1e-4};
+        const float4 *act = reinterpret_cast<const float4 *>(io0.actions) + tile_base;
+        float4 A = act[li];
+        {
+            const float4 A1 = (act + (long long)(k_steps > 1 ? 1 : 0) * n)[li];
+            post_thrust<R>(tmail[0], lane, thrust_phase<NOISE>(p, gid, sc0, A));
+            A = A1;
+        }
+        block_lds_barrier();                                               // P: table and thrust(0) published
+#pragma clang loop unroll(disable)
+        for (int t = 0; t <= k_steps + 1; ++t) {
+            if (t + 1 < k_steps) {                                         // thrust(t+1), for the next iteration of L and A
+                const float4 A_next = (act + (long long)(t + 2 < k_steps ? t + 2 : t + 1) * n)[li];
+                post_thrust<R>(tmail[(t + 1) & 1], lane, thrust_phase<NOISE>(p, gid, sc0 + (unsigned long long)(t + 1), A));
+                A = A_next;
+            }
+            if (t > 1) {                                                   // the step Q finished last iteration
+                const int u = t - 2;
+                const unsigned long long sc = sc0 + (unsigned long long)u;
+                Flight<R> fl;
+                Verdict<R> v;
+                Observed<R> ob;
+                take_maila<R>(maila[u & 1], lane, fl, v, ob);
+                if (NORM) normalize_obs(rms, ob.o);                            // the step observation (= terminal_observation)
+                const StepOut out = block_out(io0, tile_base, (long long)u * n, (long long)u * words);
+                report_phase<R, NORM, NOISE, false, 2>(p, c, nullptr, out, fl, v, ob, gid, sc, li, lane, rows, active, G4, G5, acc, rms, rn);
+            }
+            if (t <= k_steps) block_lds_barrier();                         // barrier t
+        }
+        flush_stats(p, acc, sc0 + (unsigned long long)k_steps, lane);
+        if (NORM && active) store_rms(p, i, rms);
+        if (active) {
+            reinterpret_cast<float *>(b.g4 + li)[3] = G4.w;
+            reinterpret_cast<float *>(b.g5 + li)[3] = G5.w;
+        }
+    }
+}
+
+// -----------------------------------------------------------------------------------------------------
 // Single-step kernel on three waves, cut by DEPENDENCY (dn_step / dn_step_sampled at small fleets).
 //
 // A lone control step has no "previous step" to overlap with, so the skewed pipelines above buy nothing for it; what
@@ -2691,6 +2904,19 @@ hipError_t dn_launch_step_many_mw(const DnParams &p, const DnStepIO &io, int k, 
     const bool noise = p.act_noise_sigma > 0.0f || p.obs_noise_sigma > 0.0f;
     // the rarely used options share one set of instantiations (runtime switches inside): reward wrappers, N4 physics terms
     const bool rew = p.clip_rew != 0 || p.norm_rew != 0 || p.gnd != 0 || p.drag != 0 || p.rpm_actions != 0 || p.pid_mode != 0 || p.random_spawn != 0 || p.zero_damping != 0;
+    if (waves == 4 && k > 1) {                             // four waves per tile: fused launches of the plain configuration (the caller checked)
+        const dim3 blk(4 * DN_BLOCK);
+        const bool norm = p.normalize_obs != 0;
+#define DN_L4(R, NORM)                                                                                                      \
+        do {                                                                                                                \
+            if (noise) hipLaunchKernelGGL((dn_step_many_4w_kernel<R, NORM, true>), dim3(grid), blk, 0, stream, p, io, k);    \
+            else hipLaunchKernelGGL((dn_step_many_4w_kernel<R, NORM, false>), dim3(grid), blk, 0, stream, p, io, k);         \
+        } while (0)
+        if (f32) { if (norm) DN_L4(float, true); else DN_L4(float, false); }
+        else { if (norm) DN_L4(double, true); else DN_L4(double, false); }
+#undef DN_L4
+        return hipGetLastError();
+    }
     if (waves == 3 && k > 1) {                             // three waves per tile: fused launches
         const dim3 blk(3 * DN_BLOCK);
         const bool norm = p.normalize_obs != 0;
@@ -2759,7 +2985,7 @@ hipError_t dn_launch_step_many(const DnParams &p, const DnStepIO &io, int k, boo
 #undef DN_LP
         return hipGetLastError();
     }
-    if ((waves >= 2 && !norm) || (waves == 3 && k > 1)) return dn_launch_step_many_mw(p, io, k, f32, waves, stream);
+    if ((waves >= 2 && !norm) || (waves >= 3 && k > 1)) return dn_launch_step_many_mw(p, io, k, f32, waves, stream);
     const bool two_wave = waves >= 2;       // with the normaliser: the two-wave kernels (there is no three-wave one)
     const unsigned grid = (unsigned)((p.n + DN_BLOCK - 1) / DN_BLOCK);
     const bool noise = p.act_noise_sigma > 0.0f || p.obs_noise_sigma > 0.0f;
