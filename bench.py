@@ -163,14 +163,17 @@ def ppo_rollout(pkg, track, n, max_steps, dev, rank):
     res = {}
     fused = pkg.FusedMlpPolicy(net, n, dev)
     fused32 = pkg.FusedMlpPolicy(net, n, dev, grade="fp32")
+    fused16 = pkg.FusedMlpPolicy(net, n, dev, grade="fp16")
     for label, use_graph, trunk in (("eager", False, None), ("graph", True, None), ("graph_bf16", True, torch.bfloat16),
                                     ("graph_mfma", True, "mfma"), ("eager_mfma", False, "mfma"),
                                     ("fused_eager", False, "fused"), ("fused_graph", True, "fused"),
-                                    ("fused_graph_fp32", True, "fused32")):
-        net.trunk_dtype = trunk if trunk not in ("mfma", "fused", "fused32") else None
+                                    ("fused_graph_fp32", True, "fused32"), ("fused_graph_fp16", True, "fused16")):
+        net.trunk_dtype = trunk if trunk not in ("mfma", "fused", "fused32", "fused16") else None
         env = pkg.DroneVecEnv(track, n, max_steps=max_steps, normalize_obs=True, env_id_offset=rank * n, device=dev)
         if trunk == "fused32":
             col = FusedRolloutCollector(env, fused32, n_steps, use_graph=use_graph, seed=1 + rank)
+        elif trunk == "fused16":
+            col = FusedRolloutCollector(env, fused16, n_steps, use_graph=use_graph, seed=1 + rank)
         elif trunk == "fused":
             col = FusedRolloutCollector(env, fused, n_steps, use_graph=use_graph, seed=1 + rank)
         elif trunk == "mfma":
@@ -191,6 +194,9 @@ def ppo_rollout(pkg, track, n, max_steps, dev, rank):
     return {"value": round(res["fused_graph"], 1), "unit": "env-steps/s",
             "policy": "fused MFMA MLP (dn_mlp_forward, bf16 weights/activations, float32 accumulate) + dn_step_sampled "
                       "(Gaussian sample + step): two launches per step, the truncation bootstrap as one masked critic pass per rollout, hipGraph replay",
+            "value_fp16_grade": round(res["fused_graph_fp16"], 1),
+            "policy_fp16_grade": "the same loop with float16 weights and activations (dn_mlp_forward grade 2): the bf16 grade's speed at an eighth "
+                                 "of its rounding error (~1e-3 on the action mean against the float32 torch network; bf16: ~9e-3)",
             "value_fp32_grade": round(res["fused_graph_fp32"], 1),
             "policy_fp32_grade": "the same loop with the networks at the reference's float32 precision (dn_mlp_forward grade 1: split-bf16 "
                                  "operands, three MFMAs per product; <= 1e-4 on the action mean against the float32 torch network)",
@@ -200,6 +206,7 @@ def ppo_rollout(pkg, track, n, max_steps, dev, rank):
                          "fused MFMA policy, torch glue, hipGraph": round(res["graph_mfma"], 1),
                          "fused collector eager": round(res["fused_eager"], 1),
                          "fused collector hipGraph": round(res["fused_graph"], 1),
+                         "fused collector hipGraph, fp16-grade networks": round(res["fused_graph_fp16"], 1),
                          "fused collector hipGraph, fp32-grade networks": round(res["fused_graph_fp32"], 1)},
             "n_steps": n_steps, "num_envs": n,
             "what": "policy-in-the-loop rollout: MLP 13-512-512-256 (pi, vf; Tanh) + Gaussian sample + dn_step + "

@@ -103,6 +103,37 @@ MLP_DEV void epilogue(const f32x16 &acc, const bool tanh_on, u32x4 &lo, u32x4 &h
     }
 }
 
+// The 16-bit operand format of a grade: bfloat16 (grade 0: 8 mantissa bits, float32's range) or float16 (grade 2: 11 mantissa
+// bits -- an eighth of bf16's rounding error at the same MFMA rate; tanh activations, |w| << 1 and observations sit far inside
+// its range).  Same fragment layout, same MFMA shape.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <bool F16> MLP_DEV unsigned pack2t(const float a, const float b)
+{
+    if (F16) {
+        typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+        f16x2 pk;
+        pk[0] = (_Float16)a;
+        pk[1] = (_Float16)b;
+        return __builtin_bit_cast(unsigned, pk);             // round to nearest even (v_cvt_pk_f16_f32 on gfx950)
+    }
+    return pack2(a, b);
+}
+template <bool F16> MLP_DEV f32x16 mfma16(const uint4 a, const u32x4 b, const f32x16 c)
+{
+    if (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+template <bool F16> MLP_DEV void epilogue_pair_t(const f32x16 &acc, const int q, u32x4 &lo, u32x4 &hi)
+{
+    const unsigned u = pack2t<F16>(tanh_fast(acc[2 * q]), tanh_fast(acc[2 * q + 1]));
+    if (q < 4) lo[q] = u; else hi[q - 4] = u;
+}
+template <bool F16> MLP_DEV void epilogue_t(const f32x16 &acc, u32x4 &lo, u32x4 &hi)
+{
+#pragma unroll
+    for (int q = 0; q < 8; ++q) epilogue_pair_t<F16>(acc, q, lo, hi);
+}
+
 // One Linear(+Tanh) layer for this wave's 32 drones.  KS = K-steps of 16 input features, MT = M-tiles of 32 output
 // features.  in[kk] is the B operand of K-step kk; out[2m], out[2m+1] become K-steps 2m, 2m+1 of the next layer.
 // The layer's MT*KS weight fragments are consumed in storage order; a ring of RING fragments (16 B per lane each)
@@ -437,7 +468,7 @@ MLP_DEV void merge_partial(const float4 *xb, const int parity, const int lane, f
 // A 512-input layer for wave-half HALF: K-steps [16 HALF, 16 HALF + 16) of every M-tile, owner of tiles
 // [HALF MT/2, (HALF + 1) MT/2).  inh = this half's 16 B operands; outh = the owned tiles' outputs = this half's B
 // operands of the next layer.
-template <int HALF, int MT, int PAR, int NEXT_FR>
+template <bool F16, int HALF, int MT, int PAR, int NEXT_FR>
 MLP_DEV void layer_pair(const uint4 *__restrict__ w, const float *lbias, const uint4 *__restrict__ next, const u32x4 (&inh)[16],
                         u32x4 (&outh)[MT], uint4 *wbuf, float4 *xb, const int wave, const int lane)
 {
@@ -464,10 +495,10 @@ MLP_DEV void layer_pair(const uint4 *__restrict__ w, const float *lbias, const u
         for (int kk = 0; kk < 16; ++kk) {
             const uint4 a = ring[kk % LDS_RING];
             if (kk + LDS_RING < 16) ring[kk % LDS_RING] = cur[(HALF * 16 + kk + LDS_RING) * 64 + lane];
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, inh[kk]), acc, 0, 0, 0);
+            acc = mfma16<F16>(a, inh[kk], acc);
             if (fin && (kk & 1)) {
                 const int ml = (m - 1) - HALF * (MT / 2);
-                epilogue_pair(prev, kk >> 1, outh[2 * ml], outh[2 * ml + 1]);
+                epilogue_pair_t<F16>(prev, kk >> 1, outh[2 * ml], outh[2 * ml + 1]);
             }
         }
         if ((m >= MT / 2) == (HALF == 1)) prev = acc;                         // mine: keep, finish next round
@@ -476,11 +507,11 @@ MLP_DEV void layer_pair(const uint4 *__restrict__ w, const float *lbias, const u
     }
     if (HALF == 1) {                                                         // the last tile belongs to half 1
         merge_partial(xb, (MT - 1) & 1, lane, prev);
-        epilogue(prev, true, outh[MT - 2], outh[MT - 1]);
+        epilogue_t<F16>(prev, outh[MT - 2], outh[MT - 1]);
     }
 }
 
-template <int HALF>
+template <bool F16, int HALF>
 MLP_DEV void mlp_pair_body(const MlpArgs &a, const MlpNetDev &net, uint4 *wbuf, float4 *xb, const float *lbias, const int wave,
                            const int lane, const long long row0, const bool live, const long long row, const bool tile_wanted)
 {
@@ -491,7 +522,7 @@ MLP_DEV void mlp_pair_body(const MlpArgs &a, const MlpNetDev &net, uint4 *wbuf, 
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int k = 8 * g + 2 * q;
-            x0[q] = pack2(k < a.obs_dim ? o[k] : 0.0f, k + 1 < a.obs_dim ? o[k + 1] : 0.0f);
+            x0[q] = pack2t<F16>(k < a.obs_dim ? o[k] : 0.0f, k + 1 < a.obs_dim ? o[k + 1] : 0.0f);
         }
     }
     // layer 1 (K = 16: one K-step, no split): this half computes its own 8 tiles outright.  Its 16 fragments are in buffer 0.
@@ -503,14 +534,14 @@ MLP_DEV void mlp_pair_body(const MlpArgs &a, const MlpNetDev &net, uint4 *wbuf, 
         f32x16 acc;
         bias_init(lbias, m, g, acc);
         const uint4 w = wbuf[m * 64 + lane];
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x0), acc, 0, 0, 0);
-        epilogue(acc, true, h1[2 * ml], h1[2 * ml + 1]);
+        acc = mfma16<F16>(w, x0, acc);
+        epilogue_t<F16>(acc, h1[2 * ml], h1[2 * ml + 1]);
     }
     chunk_barrier();
     u32x4 h2[16];
-    layer_pair<HALF, H2 / 32, 1, CHUNK>(net.w2, lbias + H1, net.w3, h1, h2, wbuf, xb, wave, lane);
+    layer_pair<F16, HALF, H2 / 32, 1, CHUNK>(net.w2, lbias + H1, net.w3, h1, h2, wbuf, xb, wave, lane);
     u32x4 h3[8];
-    layer_pair<HALF, H3 / 32, 1, H3 / 16>(net.w3, lbias + H1 + H2, net.wh, h2, h3, wbuf, xb, wave, lane);
+    layer_pair<F16, HALF, H3 / 32, 1, H3 / 16>(net.w3, lbias + H1 + H2, net.wh, h2, h3, wbuf, xb, wave, lane);
     // head: one tile, K = 256 = 16 K-steps, 8 per half; fragments in buffer 1 (parity 1 + 16 + 8 -> 1)
     f32x16 acc;
     if (HALF == 0) bias_init(lbias + H1 + H2 + H3, 0, g, acc);
@@ -522,7 +553,7 @@ MLP_DEV void mlp_pair_body(const MlpArgs &a, const MlpNetDev &net, uint4 *wbuf, 
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) {
         const uint4 w = cur[(HALF * 8 + kk) * 64 + lane];
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, h3[kk]), acc, 0, 0, 0);
+        acc = mfma16<F16>(w, h3[kk], acc);
     }
     if (HALF == 1) park_partial(xb, 0, lane, acc);
     chunk_barrier();
@@ -539,6 +570,7 @@ MLP_DEV void mlp_pair_body(const MlpArgs &a, const MlpNetDev &net, uint4 *wbuf, 
     }
 }
 
+template <bool F16>
 __global__ __launch_bounds__(64 * PWAVES) void dn_mlp_pair_kernel(const MlpArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint4 lds[LDS_PAIR_U4];         // ONE __shared__ object (see dn_mlp_lds_kernel)
@@ -571,8 +603,8 @@ __global__ __launch_bounds__(64 * PWAVES) void dn_mlp_pair_kernel(const MlpArgs 
         lbias[i] = i < H1 ? net.b1[i] : i < H1 + H2 ? net.b2[i - H1] : i < H1 + H2 + H3 ? net.b3[i - H1 - H2] : net.bh[i - H1 - H2 - H3];
     dma_pair<H1 / 32>(net.w1, wbuf, wave, lane);
     chunk_barrier();
-    if (half == 0) mlp_pair_body<0>(a, net, wbuf, xb, lbias, wave, lane, row0, live, row, tile_wanted);
-    else mlp_pair_body<1>(a, net, wbuf, xb, lbias, wave, lane, row0, live, row, tile_wanted);
+    if (half == 0) mlp_pair_body<F16, 0>(a, net, wbuf, xb, lbias, wave, lane, row0, live, row, tile_wanted);
+    else mlp_pair_body<F16, 1>(a, net, wbuf, xb, lbias, wave, lane, row0, live, row, tile_wanted);
 }
 
 // -----------------------------------------------------------------------------------------------------
@@ -1150,10 +1182,14 @@ hipError_t dn_launch_mlp(const dn_mlp_net *nets, int num_nets, const float *obs,
         hipLaunchKernelGGL(dn_mlp_x3_kernel, dim3((tiles + 1) / 2, num_nets), dim3(64 * XWAVES), 0, stream, a);
         return hipGetLastError();
     }
+    if (nets[0].grade == 2) {                                // float16 operands: the pair shape only
+        hipLaunchKernelGGL(dn_mlp_pair_kernel<true>, dim3((tiles + 3) / 4, num_nets), dim3(64 * PWAVES), 0, stream, a);
+        return hipGetLastError();
+    }
     const char *e = getenv("DN_MLP_SHAPE");                  // 1 | 4 | 8 waves per workgroup (A/B measurements, tests)
     const int shape = e ? atoi(e) : DN_MLP_DEFAULT_SHAPE;
     if (shape == 1) hipLaunchKernelGGL(dn_mlp_kernel, dim3(tiles, num_nets), dim3(64), 0, stream, a);
-    else if (shape == 8) hipLaunchKernelGGL(dn_mlp_pair_kernel, dim3((tiles + 3) / 4, num_nets), dim3(64 * PWAVES), 0, stream, a);
+    else if (shape == 8) hipLaunchKernelGGL(dn_mlp_pair_kernel<false>, dim3((tiles + 3) / 4, num_nets), dim3(64 * PWAVES), 0, stream, a);
     else hipLaunchKernelGGL(dn_mlp_lds_kernel, dim3((tiles + WAVES - 1) / WAVES, num_nets), dim3(64 * WAVES), 0, stream, a);
     return hipGetLastError();
 }

@@ -62,16 +62,18 @@ def pack_layer(weight, bias, first, scale=1.0, grade="bf16"):
         hi = pt.to(torch.bfloat16)
         lo = (pt - hi.float()).to(torch.bfloat16)
         return torch.stack((hi, lo), dim=1).contiguous(), torch.from_numpy(bp)          # [MT, 2, KS, 64, 8]
+    if grade == "fp16":
+        return pt.to(torch.float16).contiguous(), torch.from_numpy(bp)
     return pt.to(torch.bfloat16).contiguous(), torch.from_numpy(bp)
 
 
-GRADES = {"bf16": 0, "fp32": 1}
+GRADES = {"bf16": 0, "fp32": 1, "fp16": 2}
 
 
 def pack_mlp(layers, device, grade="bf16"):
     """layers: [(W1, b1), (W2, b2), (W3, b3), (Wh, bh)] of one network -> dict of device tensors for dn_mlp_net.
-    grade: "bf16" (speed: bf16 operands, ~1e-3 on the outputs) or "fp32" (the reference's precision through split-bf16
-    operands and three MFMAs per product, <= 1e-4; about 2.5x the time)."""
+    grade: "bf16" (bf16 operands, ~1e-2 on the outputs), "fp16" (float16 operands: the same speed, ~1e-3) or "fp32" (the
+    reference's precision through split-bf16 operands and three MFMAs per product, <= 1e-4; about 3x the time)."""
     if grade not in GRADES:
         raise ValueError(f"grade must be one of {sorted(GRADES)}")
     if [tuple(w.shape) for w, _ in layers[1:3]] != [(HIDDEN[1], HIDDEN[0]), (HIDDEN[2], HIDDEN[1])] or \
@@ -95,8 +97,8 @@ def pack_sac_actor(layers, device, grade="bf16"):
     """layers: [(W1, b1), (W2, b2), (Wmu, bmu), (Wls, bls)] of the reference's SAC actor (obs -> 256 -> 256 -> mu | log_std,
     ReLU; PBDroneSimulator.py:297-303) -> dict of device tensors for dn_mlp_net with arch = DN_MLP_ARCH_SAC: the two heads
     are stacked into one [2 act_dim, 256] matrix (rows [0, act_dim) mu, [act_dim, 2 act_dim) log_std)."""
-    if grade not in GRADES:
-        raise ValueError(f"grade must be one of {sorted(GRADES)}")
+    if grade not in ("bf16", "fp32"):
+        raise ValueError("the SAC actor kernels are built for grade 'bf16' or 'fp32'")
     (w1, b1), (w2, b2), (wm, bm), (ws, bs) = layers
     if w1.shape[0] != SAC_HIDDEN[0] or tuple(w2.shape) != (SAC_HIDDEN[1], SAC_HIDDEN[0]) or wm.shape[1] != SAC_HIDDEN[1] \
             or tuple(ws.shape) != tuple(wm.shape):
