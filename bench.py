@@ -167,7 +167,7 @@ def ppo_rollout(pkg, track, n, max_steps, dev, rank):
     for label, use_graph, trunk in (("eager", False, None), ("graph", True, None), ("graph_bf16", True, torch.bfloat16),
                                     ("graph_mfma", True, "mfma"), ("eager_mfma", False, "mfma"),
                                     ("fused_eager", False, "fused"), ("fused_graph", True, "fused"),
-                                    ("fused_graph_fp32", True, "fused32"), ("fused_graph_fp16", True, "fused16")):
+                                    ("fused_graph_fp16", True, "fused16"), ("fused_graph_fp32", True, "fused32")):
         net.trunk_dtype = trunk if trunk not in ("mfma", "fused", "fused32", "fused16") else None
         env = pkg.DroneVecEnv(track, n, max_steps=max_steps, normalize_obs=True, env_id_offset=rank * n, device=dev)
         if trunk == "fused32":
@@ -183,13 +183,14 @@ def ppo_rollout(pkg, track, n, max_steps, dev, rank):
         for _ in range(3):
             col.collect()
         torch.cuda.synchronize(dev)
-        reps = 5
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            col.collect()
-        torch.cuda.synchronize(dev)
-        dt = time.perf_counter() - t0
-        res[label] = n * n_steps * reps / dt
+        reps, best = 10, 0.0                                # a window is 20-70 ms; the best of three (a host hiccup of a few ms would
+        for _ in range(3):                                  # otherwise halve a 12 ms reading)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                col.collect()
+            torch.cuda.synchronize(dev)
+            best = max(best, n * n_steps * reps / (time.perf_counter() - t0))
+        res[label] = best
         env.close()
     return {"value": round(res["fused_graph"], 1), "unit": "env-steps/s",
             "policy": "fused MFMA MLP (dn_mlp_forward, bf16 weights/activations, float32 accumulate) + dn_step_sampled "
@@ -225,6 +226,7 @@ def sac_collect(pkg, track, n, max_steps, dev, rank):
     steps = 64
     for label, grade, graph in (("torch fp32 actor, eager", None, False), ("torch fp32 actor, hipGraph", None, True),
                                 ("fused MFMA actor bf16 grade, two launches per step, hipGraph", "bf16", True),
+                                ("fused MFMA actor fp16 grade, two launches per step, hipGraph", "fp16", True),
                                 ("fused MFMA actor fp32 grade, two launches per step, eager", "fp32", False),
                                 ("fused MFMA actor fp32 grade, two launches per step, hipGraph", "fp32", True)):
         env = pkg.DroneVecEnv(track, n, max_steps=max_steps, normalize_obs=True, act_noise_sigma=0.002, obs_noise_sigma=0.01,
@@ -235,12 +237,14 @@ def sac_collect(pkg, track, n, max_steps, dev, rank):
         for _ in range(3):
             run()
         torch.cuda.synchronize(dev)
-        reps = 5
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            run()
-        torch.cuda.synchronize(dev)
-        res[label] = round(n * steps * reps / (time.perf_counter() - t0), 1)
+        reps, best = 10, 0.0                                # best of three ~20-60 ms windows
+        for _ in range(3):
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                run()
+            torch.cuda.synchronize(dev)
+            best = max(best, n * steps * reps / (time.perf_counter() - t0))
+        res[label] = round(best, 1)
         env.close()
     fused = pkg.FusedSacActor(actor, n, dev, grade="fp32")
     obs = torch.rand(n, 13, device=dev)

@@ -776,7 +776,6 @@ int32_t dn_mlp_forward(const dn_mlp_net *nets, int32_t num_nets, const float *ob
             return fail(DN_ERR_INVALID_ARGUMENT, "net %d: every weight, bias and output pointer is required", k);
         if (n.out_dim < 1 || n.out_dim > 32) return fail(DN_ERR_INVALID_ARGUMENT, "net %d: out_dim must be in 1..32", k);
         if (n.grade < 0 || n.grade > 2) return fail(DN_ERR_INVALID_ARGUMENT, "net %d: grade must be 0 (bf16), 1 (fp32 grade) or 2 (fp16)", k);
-        if (n.grade == 2 && n.arch != DN_MLP_ARCH_PPO) return fail(DN_ERR_INVALID_ARGUMENT, "net %d: the fp16 grade is built for the PPO networks", k);
         if (n.grade != nets[0].grade || n.arch != nets[0].arch)
             return fail(DN_ERR_INVALID_ARGUMENT, "all networks of one call must share grade and arch");
         if (((uintptr_t)n.w1 | (uintptr_t)n.w2 | (three ? (uintptr_t)n.w3 : 0) | (uintptr_t)n.wh) & 15u)

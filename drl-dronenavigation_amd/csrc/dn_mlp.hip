@@ -1034,20 +1034,20 @@ MLP_DEV void sac_dma(const uint4 *__restrict__ src, uint4 *lds, const int wave, 
     }
 }
 // ReLU, pack (and split) the 16 accumulator values of an M-tile into the next layer's K-steps 2m, 2m + 1
-template <bool X3>
+template <bool X3, bool F16>
 MLP_DEV void sac_epilogue(const f32x16 &acc, u32x4 &h0, u32x4 &h1, u32x4 &l0, u32x4 &l1)
 {
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const float v0 = fmaxf(acc[2 * q], 0.0f), v1 = fmaxf(acc[2 * q + 1], 0.0f);
         unsigned hi, lo = 0u;
-        if (X3) split_pair(v0, v1, hi, lo); else hi = pack2(v0, v1);
+        if (X3) split_pair(v0, v1, hi, lo); else hi = pack2t<F16>(v0, v1);
         if (q < 4) { h0[q] = hi; if (X3) l0[q] = lo; }
         else { h1[q - 4] = hi; if (X3) l1[q - 4] = lo; }
     }
 }
 // one M-tile over KS K-steps from an LDS chunk: hi fragments at chunk[off + kk], lo fragments at chunk[off + KS + kk]
-template <int KS, bool X3>
+template <int KS, bool X3, bool F16>
 MLP_DEV f32x16 sac_tile(const uint4 *chunk, const int off, const float *__restrict__ bias, const int m, const int g, const int lane,
                         const u32x4 (&inh)[KS], const u32x4 (&inl)[KS])
 {
@@ -1072,12 +1072,12 @@ MLP_DEV f32x16 sac_tile(const uint4 *chunk, const int off, const float *__restri
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al), __builtin_bit_cast(bf16x8, inh[kk]), acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, inl[kk]), acc, 0, 0, 0);
         }
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, inh[kk]), acc, 0, 0, 0);
+        acc = mfma16<F16>(ah, inh[kk], acc);
     }
     return acc;
 }
 
-template <bool X3>
+template <bool X3, bool F16>
 __global__ __launch_bounds__(64 * SAC_WAVES) void dn_mlp_sac_lds_kernel(const MlpArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint4 lds[2 * CHUNK * 64 + 1];     // ONE __shared__ object (see dn_mlp_lds_kernel)
@@ -1111,7 +1111,7 @@ __global__ __launch_bounds__(64 * SAC_WAVES) void dn_mlp_sac_lds_kernel(const Ml
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         unsigned hi, lo = 0u;
-        if (X3) split_pair(ob[2 * q], ob[2 * q + 1], hi, lo); else hi = pack2(ob[2 * q], ob[2 * q + 1]);
+        if (X3) split_pair(ob[2 * q], ob[2 * q + 1], hi, lo); else hi = pack2t<F16>(ob[2 * q], ob[2 * q + 1]);
         x0h[0][q] = hi; x0l[0][q] = lo;
     }
     chunk_barrier();
@@ -1119,8 +1119,8 @@ __global__ __launch_bounds__(64 * SAC_WAVES) void dn_mlp_sac_lds_kernel(const Ml
     sac_dma<CHUNK>(net.w2, lds + CHUNK * 64, wave, lane);   // layer 2, chunk 0 -> buffer 1
 #pragma unroll
     for (int m = 0; m < S1 / 32; ++m) {
-        const f32x16 acc = sac_tile<1, X3>(lds, m * PER, net.b1, m, g, lane, x0h, x0l);
-        sac_epilogue<X3>(acc, h1h[2 * m], h1h[2 * m + 1], h1l[2 * m], h1l[2 * m + 1]);
+        const f32x16 acc = sac_tile<1, X3, F16>(lds, m * PER, net.b1, m, g, lane, x0h, x0l);
+        sac_epilogue<X3, F16>(acc, h1h[2 * m], h1h[2 * m + 1], h1l[2 * m], h1l[2 * m + 1]);
     }
     chunk_barrier();
     u32x4 h2h[S2 / 16], h2l[S2 / 16];
@@ -1133,13 +1133,13 @@ __global__ __launch_bounds__(64 * SAC_WAVES) void dn_mlp_sac_lds_kernel(const Ml
 #pragma unroll
         for (int j = 0; j < TPC; ++j) {
             const int m = c * TPC + j;
-            const f32x16 acc = sac_tile<S1 / 16, X3>(cur, j * (S1 / 16), net.b2, m, g, lane, h1h, h1l);
-            sac_epilogue<X3>(acc, h2h[2 * m], h2h[2 * m + 1], h2l[2 * m], h2l[2 * m + 1]);
+            const f32x16 acc = sac_tile<S1 / 16, X3, F16>(cur, j * (S1 / 16), net.b2, m, g, lane, h1h, h1l);
+            sac_epilogue<X3, F16>(acc, h2h[2 * m], h2h[2 * m + 1], h2l[2 * m], h2l[2 * m + 1]);
         }
         chunk_barrier();
     }
     // heads: one M-tile (8 rows used), float32 straight from the accumulator; its chunk is in buffer (1 + NL2) & 1
-    const f32x16 acc = sac_tile<S2 / 16, X3>(lds + ((1 + NL2) & 1) * (CHUNK * 64), 0, net.bh, 0, g, lane, h2h, h2l);
+    const f32x16 acc = sac_tile<S2 / 16, X3, F16>(lds + ((1 + NL2) & 1) * (CHUNK * 64), 0, net.bh, 0, g, lane, h2h, h2l);
     if (live) {
         float *o = net.out + (row0 + col) * net.out_dim;
 #pragma unroll
@@ -1169,12 +1169,14 @@ hipError_t dn_launch_mlp(const dn_mlp_net *nets, int num_nets, const float *obs,
         const char *es = getenv("DN_MLP_SAC_SHAPE");        // 1 = one wave per workgroup straight from L2 | 4 = four waves sharing the stream through LDS
         const bool direct = es && atoi(es) == 1;
         const dim3 grid4((tiles + SAC_WAVES - 1) / SAC_WAVES, num_nets);
-        if (nets[0].grade == 1) {
+        if (nets[0].grade == 2) {                            // float16 operands: the shared-stream shape only
+            hipLaunchKernelGGL((dn_mlp_sac_lds_kernel<false, true>), grid4, dim3(64 * SAC_WAVES), 0, stream, a);
+        } else if (nets[0].grade == 1) {
             if (direct) hipLaunchKernelGGL(dn_mlp_sac_kernel<true>, dim3(tiles, num_nets), dim3(64), 0, stream, a);
-            else hipLaunchKernelGGL(dn_mlp_sac_lds_kernel<true>, grid4, dim3(64 * SAC_WAVES), 0, stream, a);
+            else hipLaunchKernelGGL((dn_mlp_sac_lds_kernel<true, false>), grid4, dim3(64 * SAC_WAVES), 0, stream, a);
         } else {
             if (direct) hipLaunchKernelGGL(dn_mlp_sac_kernel<false>, dim3(tiles, num_nets), dim3(64), 0, stream, a);
-            else hipLaunchKernelGGL(dn_mlp_sac_lds_kernel<false>, grid4, dim3(64 * SAC_WAVES), 0, stream, a);
+            else hipLaunchKernelGGL((dn_mlp_sac_lds_kernel<false, false>), grid4, dim3(64 * SAC_WAVES), 0, stream, a);
         }
         return hipGetLastError();
     }

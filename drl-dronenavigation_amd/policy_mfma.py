@@ -97,8 +97,8 @@ def pack_sac_actor(layers, device, grade="bf16"):
     """layers: [(W1, b1), (W2, b2), (Wmu, bmu), (Wls, bls)] of the reference's SAC actor (obs -> 256 -> 256 -> mu | log_std,
     ReLU; PBDroneSimulator.py:297-303) -> dict of device tensors for dn_mlp_net with arch = DN_MLP_ARCH_SAC: the two heads
     are stacked into one [2 act_dim, 256] matrix (rows [0, act_dim) mu, [act_dim, 2 act_dim) log_std)."""
-    if grade not in ("bf16", "fp32"):
-        raise ValueError("the SAC actor kernels are built for grade 'bf16' or 'fp32'")
+    if grade not in GRADES:
+        raise ValueError(f"grade must be one of {sorted(GRADES)}")
     (w1, b1), (w2, b2), (wm, bm), (ws, bs) = layers
     if w1.shape[0] != SAC_HIDDEN[0] or tuple(w2.shape) != (SAC_HIDDEN[1], SAC_HIDDEN[0]) or wm.shape[1] != SAC_HIDDEN[1] \
             or tuple(ws.shape) != tuple(wm.shape):

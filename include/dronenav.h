@@ -252,7 +252,7 @@ typedef struct dn_mlp_net {
                                                    1: float32 grade -- both operands split into two bf16 words, three MFMAs per product
                                                       (pack_mlp / pack_sac_actor(..., grade="fp32") pack the hi / lo fragment streams); matches the
                                                       reference's float32 networks to <= 1e-4.
-                                                   2: float16 weights and activations, float32 accumulate (DN_MLP_ARCH_PPO): the speed of grade 0 with an
+                                                   2: float16 weights and activations, float32 accumulate: the speed of grade 0 with an
                                                       eighth of its rounding error (11 mantissa bits: ~1e-3 on the action mean).
                                                    All networks of one call share grade and arch. */
     int32_t arch;                               /* DN_MLP_ARCH_* (appended in ABI 5) */

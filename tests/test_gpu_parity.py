@@ -1591,14 +1591,15 @@ def test_sac_actor_kernel_matches_the_float32_torch_actor(n, shape, monkeypatch)
                           h @ actor.log_std.weight.double().t() + actor.log_std.bias.double()), 1)
     layers = [(l.weight, l.bias) for l in lin] + [(actor.mu.weight, actor.mu.bias), (actor.log_std.weight, actor.log_std.bias)]
     errs = {}
-    for grade in ("fp32", "bf16"):
+    for grade in ("fp32", "fp16", "bf16"):
         (got,) = pm.mlp_forward([pm.pack_sac_actor(layers, dev, grade)], obs)
         torch.cuda.synchronize()
         assert got.shape == (n, 8)
         errs[grade] = float((got.double() - want).abs().max())
-    print(f"n={n}: SAC actor max |err| vs float64 -- fp32 grade {errs['fp32']:.2e}, bf16 grade {errs['bf16']:.2e}")
+    print(f"n={n}: SAC actor max |err| vs float64 -- fp32 grade {errs['fp32']:.2e}, fp16 grade {errs['fp16']:.2e}, bf16 grade {errs['bf16']:.2e}")
     assert errs["fp32"] <= 1e-4, errs
     assert errs["bf16"] <= 5e-2 and errs["bf16"] > 3 * errs["fp32"], errs
+    assert errs["fp16"] <= 5e-3 and errs["fp16"] < 0.4 * errs["bf16"], errs
     fused = pkg.FusedSacActor(actor, n, dev, grade="fp32")
     mean, log_std = fused.mean_log_std(obs)
     assert float((mean.double() - want[:, :4]).abs().max()) <= 1e-4
