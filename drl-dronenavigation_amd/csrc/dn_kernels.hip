@@ -2402,9 +2402,23 @@ __global__ __launch_bounds__(4 * DN_BLOCK, 2) void dn_step_many_4w_kernel(const 
         __builtin_amdgcn_s_setprio(2);
         float4 P4 = b.g4[li], P5 = b.g5[li];                               // .xyz: prev_vel, prev_ang_v
         Rms rms;                                                           // never touched here: the observation leaves raw
+        // with the normaliser the report wave is the heavier of the two slack waves: the thrust chain moves here
+        const float4 *act = reinterpret_cast<const float4 *>(io0.actions) + tile_base;
+        float4 A = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (NORM) {
+            A = act[li];
+            const float4 A1 = (act + (long long)(k_steps > 1 ? 1 : 0) * n)[li];
+            post_thrust<R>(tmail[0], lane, thrust_phase<NOISE>(p, gid, sc0, A));
+            A = A1;
+        }
         block_lds_barrier();                                               // P
 #pragma clang loop unroll(disable)
         for (int t = 0; t <= k_steps; ++t) {
+            if (NORM && t + 1 < k_steps) {                                 // thrust(t+1), for the next iteration of L and A
+                const float4 A_next = (act + (long long)(t + 2 < k_steps ? t + 2 : t + 1) * n)[li];
+                post_thrust<R>(tmail[(t + 1) & 1], lane, thrust_phase<NOISE>(p, gid, sc0 + (unsigned long long)(t + 1), A));
+                A = A_next;
+            }
             if (t > 0) {                                                   // the step L and A finished last iteration
                 const int u = t - 1;
                 const MailL<R> &ml = maill[u & 1];
@@ -2443,8 +2457,9 @@ __global__ __launch_bounds__(4 * DN_BLOCK, 2) void dn_step_many_4w_kernel(const 
         if (NORM) load_rms(p, i, rms);
         RewNorm rn = {0.0, 0.0, 1.0, 1e-4};
         const float4 *act = reinterpret_cast<const float4 *>(io0.actions) + tile_base;
-        float4 A = act[li];
-        {
+        float4 A = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (!NORM) {
+            A = act[li];
             const float4 A1 = (act + (long long)(k_steps > 1 ? 1 : 0) * n)[li];
             post_thrust<R>(tmail[0], lane, thrust_phase<NOISE>(p, gid, sc0, A));
             A = A1;
@@ -2452,7 +2467,7 @@ __global__ __launch_bounds__(4 * DN_BLOCK, 2) void dn_step_many_4w_kernel(const 
         block_lds_barrier();                                               // P: table and thrust(0) published
 #pragma clang loop unroll(disable)
         for (int t = 0; t <= k_steps + 1; ++t) {
-            if (t + 1 < k_steps) {                                         // thrust(t+1), for the next iteration of L and A
+            if (!NORM && t + 1 < k_steps) {                                // thrust(t+1), for the next iteration of L and A
                 const float4 A_next = (act + (long long)(t + 2 < k_steps ? t + 2 : t + 1) * n)[li];
                 post_thrust<R>(tmail[(t + 1) & 1], lane, thrust_phase<NOISE>(p, gid, sc0 + (unsigned long long)(t + 1), A));
                 A = A_next;
