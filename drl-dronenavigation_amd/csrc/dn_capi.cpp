@@ -38,8 +38,7 @@ inline double norm3d(const double v[3]) { return std::sqrt(v[0] * v[0] + v[1] * 
 
 constexpr long long DN_TWO_WAVE_MAX_TILES = 1024;   // 65536 drones: one tile per SIMD
 constexpr long long DN_PQX_MAX_TILES = 1024;        // three-wave single step: while the tiles alone leave SIMDs idle
-constexpr long long DN_FOUR_WAVE_MAX_TILES = 256;   // four-wave fused step: one tile per CU, every wave alone on its SIMD
-constexpr long long DN_FOUR_WAVE_NORM_MAX_TILES = 768;   // with the normaliser: up to three tiles per CU
+constexpr long long DN_FOUR_WAVE_MAX_TILES = 768;   // four-wave fused step: up to three tiles per CU
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -270,13 +269,11 @@ int32_t dn_create(const dn_config *cfg, dn_env **out)
     else if (noisy) max_three = DN_TWO_WAVE_MAX_TILES / 4;
     e->waves_fused = e->blocks <= max_multi ? (e->blocks <= max_three ? 3 : 2) : 1;
     // Four waves (dn_step_many_4w_kernel: the recurrence itself on two waves; plain configuration without the ground-contact term,
-    // no noise).  Without the normaliser it wins while every wave of a tile has a SIMD to itself -- one tile per CU, <= 256 tiles:
-    // 4 096 / 8 192 / 16 384 drones 1.14 / 1.16 / 1.17 us per step against 1.26 / 1.28 / 1.28 with three waves -- and loses from two
-    // tiles per CU on (24 576: 1.48 against 1.29; 32 768: 1.49 against 1.27).  With the normaliser (the thrust chain then sits on
-    // the observation wave, the report wave carries the statistics) it wins throughout: 4 096 / 16 384 / 24 576 / 32 768 drones
-    // 1.36 / 1.39 / 1.74 / 1.75 against 1.46 / 1.50 / 1.87 / 1.89, 40 960 / 49 152: 2.91 / 3.26 against 3.3 / 3.36 with one wave.
-    if (plain && !cfg->ground_contact && !noisy && e->blocks <= (cfg->normalize_obs ? DN_FOUR_WAVE_NORM_MAX_TILES : DN_FOUR_WAVE_MAX_TILES))
-        e->waves_fused = 4;
+    // no noise), us per step against three waves (one wave beyond their range):
+    //   normaliser off   8 192 / 16 384 / 24 576 / 32 768 / 49 152 drones   1.01 / 1.02 / 1.23 / 1.23 / 1.66   against 1.28 / 1.29 / 1.29 / 1.28 / 1.71
+    //                    65 536: 2.58 against 1.92 -> up to 768 tiles
+    //   normaliser on    8 192 / 16 384 / 24 576 / 32 768 / 49 152           1.37 / 1.39 / 1.73 / 1.76 / 3.27   against 1.48 / 1.50 / 1.87 / 1.89 / 3.36 -> up to 768 tiles
+    if (plain && !cfg->ground_contact && !noisy && e->blocks <= DN_FOUR_WAVE_MAX_TILES) e->waves_fused = 4;
     // dn_step (one control step per launch) is latency bound: ~2.9 us of launch-to-launch floor that an empty kernel
     // already pays (profiles/r02_dispatch_floor.txt) plus the dependent instruction stream of the step.  Cutting the step
     // by dependency over three waves (dn_step_pqx_kernel) shortens that stream while the chip has idle SIMDs; built for the

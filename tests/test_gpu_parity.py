@@ -983,12 +983,12 @@ def test_baseline_full_size_matches_oracle_free_running():
 
 def test_baseline_full_size_fused_launch_matches_oracle(monkeypatch):
     """The bench's own launch -- 32768 drones, race track, 64 steps of U(-1,1)^4 actions in ONE dn_step_many (the
-    three-wave kernel) -- against the oracle, every drone, every step, every output; then the mixed stream."""
+    four-wave kernel) -- against the oracle, every drone, every step, every output; then the mixed stream."""
     monkeypatch.delenv("DN_WAVES", raising=False)         # the bench's shape is the library's own pick
     track = _tracks().reaching()
     n, K = 32768, 64
     env, ora = make_pair(track, n, f32_state=True, max_steps=4096, normalize_obs=False)
-    assert env.kernel_waves(fused=True) == 3
+    assert env.kernel_waves(fused=True) == 4
     np.testing.assert_allclose(env.reset_tensor().cpu().numpy(), ora.reset(), rtol=0, atol=1e-6)
     rng = np.random.default_rng(64)
     dev = torch.device("cuda:0")
