@@ -610,9 +610,9 @@ def main():
                                                      + (f" + {ALGO_BYTES_NORMALISER} B statistics" if args.normalize_obs else "")
                                                      + " per drone and launch (SURVEY 8(d) split into per-step I/O and per-launch state)"),
                          "avg_launch_us": round(launch_us, 4), "us_per_vector_step": round(step_us, 4),
-                         "note": "at 32768 drones neither launch shape is bandwidth bound: the fused launch is bound by the dependent "
-                                 "instruction stream of the flight wave, the single-step launch by load + launch latency (DESIGN.md 4.3)",
-                         "issue_bound_evidence": {"source": "profiles/r01_x_instmix_3w_fused32k.txt (rocprofv3 --pmc SQ_* passes of this kernel)",
+                         "note": "at 32768 drones neither launch shape is bandwidth bound: the fused launch is bound by instruction issue (two tiles "
+                                 "of four waves per CU), the single-step launch by load + launch latency (DESIGN.md 4.1, 4.3)",
+                         "issue_bound_evidence": {"source": "profiles/r01_x_instmix_3w_fused32k.txt (rocprofv3 --pmc SQ_* passes of the three-wave kernel of the same step)",
                                                   "valu_instructions_per_64_drone_step": 810, "salu_instructions_per_64_drone_step": 184,
                                                   "simd_issue_busy": 0.84,
                                                   "what": "two 64-drone tiles per CU: the four SIMDs issue 84 % of the step time; the same kernel at "
