@@ -612,10 +612,10 @@ def main():
                          "avg_launch_us": round(launch_us, 4), "us_per_vector_step": round(step_us, 4),
                          "note": "at 32768 drones neither launch shape is bandwidth bound: the fused launch is bound by instruction issue (two tiles "
                                  "of four waves per CU), the single-step launch by load + launch latency (DESIGN.md 4.1, 4.3)",
-                         "issue_bound_evidence": {"source": "profiles/r01_x_instmix_3w_fused32k.txt (rocprofv3 --pmc SQ_* passes of the three-wave kernel of the same step)",
-                                                  "valu_instructions_per_64_drone_step": 810, "salu_instructions_per_64_drone_step": 184,
-                                                  "simd_issue_busy": 0.84,
-                                                  "what": "two 64-drone tiles per CU: the four SIMDs issue 84 % of the step time; the same kernel at "
+                         "issue_bound_evidence": {"source": "profiles/r02_f_instmix_4w.txt (rocprofv3 --pmc SQ_* passes of the four-wave kernel; recipe profiles/instmix.sh)",
+                                                  "valu_instructions_per_64_drone_step": 813, "salu_instructions_per_64_drone_step": 192,
+                                                  "simd_issue_busy": 0.95,
+                                                  "what": "two 64-drone tiles (eight waves) per CU: the four SIMDs issue 95 % of the step time; the same step at "
                                                           "2 097 152 drones, one step per launch, is the HBM-bound case (hbm_bound_fleet)"}},
             "single_step": single_step,
             "normalize_obs_on": norm_on,
