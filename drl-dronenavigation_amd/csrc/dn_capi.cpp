@@ -269,11 +269,13 @@ int32_t dn_create(const dn_config *cfg, dn_env **out)
     else if (noisy) max_three = DN_TWO_WAVE_MAX_TILES / 4;
     e->waves_fused = e->blocks <= max_multi ? (e->blocks <= max_three ? 3 : 2) : 1;
     // Four waves (dn_step_many_4w_kernel: the recurrence itself on two waves; plain configuration without the ground-contact term,
-    // no noise), us per step against three waves (one wave beyond their range):
+    // us per step against the three- / two- / one-wave pick of the table above):
     //   normaliser off   8 192 / 16 384 / 24 576 / 32 768 / 49 152 drones   1.01 / 1.02 / 1.23 / 1.23 / 1.66   against 1.28 / 1.29 / 1.29 / 1.28 / 1.71
     //                    65 536: 2.58 against 1.92 -> up to 768 tiles
     //   normaliser on    8 192 / 16 384 / 24 576 / 32 768 / 49 152           1.37 / 1.39 / 1.73 / 1.76 / 3.27   against 1.48 / 1.50 / 1.87 / 1.89 / 3.36 -> up to 768 tiles
-    if (plain && !cfg->ground_contact && !noisy && e->blocks <= DN_FOUR_WAVE_MAX_TILES) e->waves_fused = 4;
+    //   with noise       16 384 / 32 768 / 49 152                            2.99 / 4.47 / 4.84   against 3.75 / 4.85 / 4.84 (normaliser on: 3.43 / 3.75 / 7.44 against
+    //                    3.62 / 5.73 / 6.98) -> up to 512 tiles
+    if (plain && !cfg->ground_contact && e->blocks <= (noisy ? DN_FOUR_WAVE_MAX_TILES * 2 / 3 : DN_FOUR_WAVE_MAX_TILES)) e->waves_fused = 4;
     // dn_step (one control step per launch) is latency bound: ~2.9 us of launch-to-launch floor that an empty kernel
     // already pays (profiles/r02_dispatch_floor.txt) plus the dependent instruction stream of the step.  Cutting the step
     // by dependency over three waves (dn_step_pqx_kernel) shortens that stream while the chip has idle SIMDs; built for the

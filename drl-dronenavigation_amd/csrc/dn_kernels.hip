@@ -2312,6 +2312,10 @@ __global__ __launch_bounds__(4 * DN_BLOCK, 2) void dn_step_many_4w_kernel(const 
     // orders x four permutations for the second tile of a CU (tiles 256 .. 511 land beside tiles 0 .. 255): without the
     // normaliser L A X Q with waves 2 <-> 0, 3 <-> 1 swapped in the second tile (1.23 us per step; worst order 1.45), with the
     // normaliser L X A Q in both (1.76; the mirrored orders 1.77).  One tile per CU (<= 16 384 drones) does not care: 1.01-1.02.
+    // the thrust chain sits on the observation wave -- except with noise and no normaliser: the observation draws (13 normals a
+    // step) already make that wave the longest, so the thrust and its action-noise draw go to the report wave (32 768 drones:
+    // 4.47 us per step against 4.74; with the normaliser, which also lives on the report wave, 3.85 against 3.75)
+    constexpr bool THRUST_ON_Q = !NOISE || NORM;
     const int wv0 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wv = (!NORM && ((blockIdx.x >> 8) & 1)) ? (wv0 ^ 2) : wv0;
     const int role = NORM ? (wv == 0 ? 0 : (wv == 1 ? 3 : (wv == 2 ? 1 : 2)))      // L X A Q
@@ -2410,8 +2414,9 @@ __global__ __launch_bounds__(4 * DN_BLOCK, 2) void dn_step_many_4w_kernel(const 
         // the thrust chain lives here: with it on the report wave (its stores, the episode statistics, the normaliser) that wave was
         // the longest of the four and set the pace (16 384 drones: 1.17 us per step against 1.02 with it here)
         const float4 *act = reinterpret_cast<const float4 *>(io0.actions) + tile_base;
-        float4 A = act[li];
-        {
+        float4 A = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (THRUST_ON_Q) {
+            A = act[li];
             const float4 A1 = (act + (long long)(k_steps > 1 ? 1 : 0) * n)[li];
             post_thrust<R>(tmail[0], lane, thrust_phase<NOISE>(p, gid, sc0, A));
             A = A1;
@@ -2419,7 +2424,7 @@ __global__ __launch_bounds__(4 * DN_BLOCK, 2) void dn_step_many_4w_kernel(const 
         block_lds_barrier();                                               // P: table and thrust(0) published
 #pragma clang loop unroll(disable)
         for (int t = 0; t <= k_steps; ++t) {
-            if (t + 1 < k_steps) {                                         // thrust(t+1), for the next iteration of L and A
+            if (THRUST_ON_Q && t + 1 < k_steps) {                          // thrust(t+1), for the next iteration of L and A
                 const float4 A_next = (act + (long long)(t + 2 < k_steps ? t + 2 : t + 1) * n)[li];
                 post_thrust<R>(tmail[(t + 1) & 1], lane, thrust_phase<NOISE>(p, gid, sc0 + (unsigned long long)(t + 1), A));
                 A = A_next;
@@ -2461,9 +2466,22 @@ __global__ __launch_bounds__(4 * DN_BLOCK, 2) void dn_step_many_4w_kernel(const 
         Rms rms;
         if (NORM) load_rms(p, i, rms);
         RewNorm rn = {0.0, 0.0, 1.0, 1e-4};
+        const float4 *act = reinterpret_cast<const float4 *>(io0.actions) + tile_base;
+        float4 A = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (!THRUST_ON_Q) {
+            A = act[li];
+            const float4 A1 = (act + (long long)(k_steps > 1 ? 1 : 0) * n)[li];
+            post_thrust<R>(tmail[0], lane, thrust_phase<NOISE>(p, gid, sc0, A));
+            A = A1;
+        }
         block_lds_barrier();                                               // P
 #pragma clang loop unroll(disable)
         for (int t = 0; t <= k_steps + 1; ++t) {
+            if (!THRUST_ON_Q && t + 1 < k_steps) {                         // thrust(t+1), for the next iteration of L and A
+                const float4 A_next = (act + (long long)(t + 2 < k_steps ? t + 2 : t + 1) * n)[li];
+                post_thrust<R>(tmail[(t + 1) & 1], lane, thrust_phase<NOISE>(p, gid, sc0 + (unsigned long long)(t + 1), A));
+                A = A_next;
+            }
             if (t > 1) {                                                   // the step Q finished last iteration
                 const int u = t - 2;
                 const unsigned long long sc = sc0 + (unsigned long long)u;
