@@ -676,96 +676,56 @@ MLP_DEV f32x16 mfma3(const uint4 whi, const uint4 wlo, const u32x4 xhi, const u3
     return acc;
 }
 
-// Symmetric halves.  Accumulator registers [0, 8) of a lane are the rows that pack into the next layer's K-step 2m, registers
-// [8, 16) those of K-step 2m + 1, so wave-half HALF KEEPS registers [8 HALF, 8 HALF + 8) of every M-tile and parks the other
-// eight for its partner: it multiplies the K-steps of parity HALF, and both waves of a pair do the same work in every M-tile
-// (half the merge, half the tanh and split) instead of one finishing whole tiles while the other waits at the chunk barrier.
-// The two waves sit on different SIMDs here, so nothing else hides the owner's epilogue (the bf16 pair shape, two waves on
-// ONE SIMD, measured no gain from the same change: there the partner's MFMAs run under it).  xb slots: [parity of m][sender][2][64].
-template <int HALF>
-MLP_DEV void park_half(float4 *xb, const int parity, const int lane, const f32x16 &acc)
-{
-    constexpr int o = 8 * (1 - HALF);
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-        xb[((parity * 2 + HALF) * 2 + j) * 64 + lane] = make_float4(acc[o + 4 * j], acc[o + 4 * j + 1], acc[o + 4 * j + 2], acc[o + 4 * j + 3]);
-}
-// kept half = mine + the partner's parked half + the bias (accumulators start from the inline constant 0)
-template <int HALF>
-MLP_DEV void merge_half(const float4 *xb, const int parity, const int lane, const float *lbias, const int m, const int g,
-                        const f32x16 &acc, float (&kept)[8])
-{
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const float4 p = xb[((parity * 2 + (1 - HALF)) * 2 + j) * 64 + lane];
-        const float4 b = *reinterpret_cast<const float4 *>(lbias + 32 * m + 4 * g + 8 * (2 * HALF + j));   // rows acc_row(m, g, 8 HALF + 4j ..)
-        kept[4 * j] = (acc[8 * HALF + 4 * j] + p.x) + b.x;
-        kept[4 * j + 1] = (acc[8 * HALF + 4 * j + 1] + p.y) + b.y;
-        kept[4 * j + 2] = (acc[8 * HALF + 4 * j + 2] + p.z) + b.z;
-        kept[4 * j + 3] = (acc[8 * HALF + 4 * j + 3] + p.w) + b.w;
-    }
-}
-template <int HALF>
-MLP_DEV void bias_half(const float *lbias, const int m, const int g, const f32x16 &acc, float (&kept)[8])
-{   // layer 1 has nothing to merge
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const float4 b = *reinterpret_cast<const float4 *>(lbias + 32 * m + 4 * g + 8 * (2 * HALF + j));
-        kept[4 * j] = acc[8 * HALF + 4 * j] + b.x; kept[4 * j + 1] = acc[8 * HALF + 4 * j + 1] + b.y;
-        kept[4 * j + 2] = acc[8 * HALF + 4 * j + 2] + b.z; kept[4 * j + 3] = acc[8 * HALF + 4 * j + 3] + b.w;
-    }
-}
-MLP_DEV void epilogue3_kept(const float (&kept)[8], const int q, u32x4 &h, u32x4 &l)
-{   // kept elements 2q, 2q + 1 -> tanh -> dword q of the hi and of the lo operand
-    unsigned hh, ll;
-    split2(tanh_fast(kept[2 * q]), tanh_fast(kept[2 * q + 1]), hh, ll);
-    h[q] = hh; l[q] = ll;
-}
-
-// A 512-input layer for wave-half HALF in the x3 shape: K-steps 2j + HALF (j = 0..15) of every M-tile; inh / inl[j] = that K-step's
-// hi / lo B operand; outh / outl[m] = the kept half of M-tile m = K-step 2m + HALF of the next layer.  A chunk holds fragments
-// [0, 32) = hi, [32, 64) = lo of one M-tile.  The merge + tanh + split of tile m - 1 are spread over tile m's MFMA stream.
+// A 512-input layer for wave-half HALF in the x3 shape (see layer_pair): K-steps [16 HALF, 16 HALF + 16) of every M-tile,
+// owner of tiles [HALF MT/2, (HALF + 1) MT/2).  A chunk holds fragments [0, 32) = hi, [32, 64) = lo of one M-tile.
 template <int HALF, int MT, int PAR, int NEXT_FR>
 MLP_DEV void layer_x3(const uint4 *__restrict__ w, const float *lbias, const uint4 *__restrict__ next, const u32x4 (&inh)[16],
                       const u32x4 (&inl)[16], u32x4 (&outh)[MT], u32x4 (&outl)[MT], uint4 *wbuf, float4 *xb, const int wave, const int lane)
 {
     const int g = lane >> 5;
     f32x16 prev;
-    float kept[8];
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         uint4 *cur = wbuf + ((PAR + m) & 1) * (CH3 * 64);
         uint4 *nxt = wbuf + ((PAR + m + 1) & 1) * (CH3 * 64);
         if (m + 1 < MT) dma_x3<CH3>(w + (size_t)(m + 1) * CH3 * 64, nxt, wave, lane);
         else dma_x3<NEXT_FR>(next, nxt, wave, lane);
-        if (m > 0) merge_half<HALF>(xb, (m - 1) & 1, lane, lbias, m - 1, g, prev, kept);
+        const bool fin = m > 0 && (((m - 1) >= MT / 2) == (HALF == 1));      // I own tile m-1: finish it under this tile's MFMAs
+        if (fin) merge_partial(xb, (m - 1) & 1, lane, prev);
         f32x16 acc;
+        if ((m >= MT / 2) == (HALF == 1)) bias_init(lbias, m, g, acc);       // mine: start from the bias
+        else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        }
         constexpr int RG = 4;                                                // ring depth (fragment PAIRS in flight)
         uint4 rh[RG], rl[RG];
 #pragma unroll
         for (int kk = 0; kk < RG; ++kk) {
-            rh[kk] = cur[(2 * kk + HALF) * 64 + lane];
-            rl[kk] = cur[(CHUNK + 2 * kk + HALF) * 64 + lane];
+            rh[kk] = cur[(HALF * 16 + kk) * 64 + lane];
+            rl[kk] = cur[(CHUNK + HALF * 16 + kk) * 64 + lane];
         }
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) {
             const uint4 ah = rh[kk % RG], al = rl[kk % RG];
             if (kk + RG < 16) {
-                rh[kk % RG] = cur[(2 * (kk + RG) + HALF) * 64 + lane];
-                rl[kk % RG] = cur[(CHUNK + 2 * (kk + RG) + HALF) * 64 + lane];
+                rh[kk % RG] = cur[(HALF * 16 + kk + RG) * 64 + lane];
+                rl[kk % RG] = cur[(CHUNK + HALF * 16 + kk + RG) * 64 + lane];
             }
             acc = mfma3(ah, al, inh[kk], inl[kk], acc);
-            if (m > 0 && (kk & 3) == 3) epilogue3_kept(kept, kk >> 2, outh[m - 1], outl[m - 1]);
+            if (fin && (kk & 1)) {
+                const int ml = (m - 1) - HALF * (MT / 2);
+                epilogue3_pair(prev, kk >> 1, outh[2 * ml], outh[2 * ml + 1], outl[2 * ml], outl[2 * ml + 1]);
+            }
         }
-        park_half<HALF>(xb, m & 1, lane, acc);
-        prev = acc;
+        if ((m >= MT / 2) == (HALF == 1)) prev = acc;                         // mine: keep, finish next round
+        else park_partial(xb, m & 1, lane, acc);                             // partner's: hand over through LDS
         chunk_barrier();
     }
-    merge_half<HALF>(xb, (MT - 1) & 1, lane, lbias, MT - 1, g, prev, kept);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) epilogue3_kept(kept, q, outh[MT - 1], outl[MT - 1]);
+    if (HALF == 1) {                                                         // the last tile belongs to half 1
+        merge_partial(xb, (MT - 1) & 1, lane, prev);
+        epilogue3(prev, outh[MT - 2], outh[MT - 1], outl[MT - 2], outl[MT - 1]);
+    }
 }
 
 template <int HALF>
@@ -775,39 +735,34 @@ MLP_DEV void mlp_x3_body(const MlpArgs &a, const MlpNetDev &net, uint4 *wbuf, fl
     const int g = lane >> 5, col = lane & 31;
     u32x4 x0h, x0l;
     {
-        float ob[8];
-        load_obs8(a, row, g, ob);
+        const float *o = a.obs + row * a.obs_dim;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
+            const int k = 8 * g + 2 * q;
             unsigned h, l;
-            split2(ob[2 * q], ob[2 * q + 1], h, l);
+            split2(k < a.obs_dim ? o[k] : 0.0f, k + 1 < a.obs_dim ? o[k + 1] : 0.0f, h, l);
             x0h[q] = h; x0l[q] = l;
         }
     }
-    // layer 1 (K = 16: one K-step, nothing to split): both halves multiply all 16 tiles and finish the half they keep.  Its 16
-    // (hi, lo) fragment pairs are in buffer 0, stored per M-tile as hi then lo.
+    // layer 1 (K = 16: one K-step, no split): this half computes its own 8 tiles outright.  Its 16 (hi, lo) fragment pairs are in
+    // buffer 0, stored per M-tile as hi then lo.
     u32x4 h1h[16], h1l[16];
     dma_x3<CH3>(net.w2, wbuf + CH3 * 64, wave, lane);                        // layer 2, chunk 0 -> buffer 1
 #pragma unroll
-    for (int m = 0; m < 16; ++m) {
+    for (int ml = 0; ml < 8; ++ml) {
+        const int m = HALF * 8 + ml;
         f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        bias_init(lbias, m, g, acc);
         const uint4 wh = wbuf[(2 * m) * 64 + lane], wl = wbuf[(2 * m + 1) * 64 + lane];
         acc = mfma3(wh, wl, x0h, x0l, acc);
-        float kept[8];
-        bias_half<HALF>(lbias, m, g, acc, kept);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) epilogue3_kept(kept, q, h1h[m], h1l[m]);
-        __builtin_amdgcn_sched_barrier(0);                                   // one tile at a time: sixteen in flight spill
+        epilogue3(acc, h1h[2 * ml], h1h[2 * ml + 1], h1l[2 * ml], h1l[2 * ml + 1]);
     }
     chunk_barrier();
     u32x4 h2h[16], h2l[16];
     layer_x3<HALF, H2 / 32, 1, CH3>(net.w2, lbias + H1, net.w3, h1h, h1l, h2h, h2l, wbuf, xb, wave, lane);
     u32x4 h3h[8], h3l[8];
     layer_x3<HALF, H3 / 32, 1, 2 * (H3 / 16)>(net.w3, lbias + H1 + H2, net.wh, h2h, h2l, h3h, h3l, wbuf, xb, wave, lane);
-    // head: one tile, K = 256 = 16 K-steps, those of parity HALF here; chunk in buffer 1 as [16 hi][16 lo].  The four (or one)
-    // output rows are few: half 1 parks its whole partial, half 0 merges and stores.
+    // head: one tile, K = 256 = 16 K-steps, 8 per half; chunk in buffer 1 as [16 hi][16 lo]
     f32x16 acc;
     if (HALF == 0) bias_init(lbias + H1 + H2 + H3, 0, g, acc);
     else {
@@ -817,7 +772,7 @@ MLP_DEV void mlp_x3_body(const MlpArgs &a, const MlpNetDev &net, uint4 *wbuf, fl
     const uint4 *cur = wbuf + CH3 * 64;
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) {
-        const uint4 wh = cur[(2 * kk + HALF) * 64 + lane], wl = cur[(H3 / 16 + 2 * kk + HALF) * 64 + lane];
+        const uint4 wh = cur[(HALF * 8 + kk) * 64 + lane], wl = cur[(H3 / 16 + HALF * 8 + kk) * 64 + lane];
         acc = mfma3(wh, wl, h3h[kk], h3l[kk], acc);
     }
     if (HALF == 1) park_partial(xb, 0, lane, acc);
