@@ -11,7 +11,8 @@ from . import build as _build
 MAX_WAYPOINTS = 64
 OBS_DIM = 13
 ACT_DIM = 4
-ABI_VERSION = 5
+ABI_VERSION = 6
+GROUND_CONTACT_AUTO = 2
 
 DN_OK = 0
 STATUS_NAMES = {0: "DN_OK", -1: "DN_ERR_INVALID_ARGUMENT", -2: "DN_ERR_HIP", -3: "DN_ERR_OUT_OF_MEMORY",
@@ -75,6 +76,9 @@ PROTOTYPES = {
     "dn_create": (_I32, [C.POINTER(DnConfig), C.POINTER(_VP)]),
     "dn_destroy": (_I32, [_VP]),
     "dn_num_envs": (_I64, [_VP]),
+    "dn_get_config": (_I32, [_VP, C.POINTER(DnConfig)]),
+    "dn_get_num_cus": (_I32, [_VP]),
+    "dn_resolve_ground_contact": (_I32, [C.POINTER(DnConfig)]),
     "dn_reset": (_I32, [_VP, _VP, _VP]),
     "dn_step": (_I32, [_VP] * 12),
     "dn_step_many": (_I32, [_VP, _I64] + [_VP] * 11),

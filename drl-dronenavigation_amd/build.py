@@ -12,7 +12,8 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libdronenav.so")
 SOURCES = ["dn_kernels.hip", "dn_kernels_mw.hip", "dn_mlp.hip", "dn_capi.cpp"]
 HEADERS = ["dn_internal.h", os.path.join("..", "..", "include", "dronenav.h")]
-# -ffp-contract=off: the reference (numpy, Bullet) rounds every operation, so no fused multiply-add.
+# -ffp-contract=off: no multiply-add is fused BY LICENCE -- the float32 action chain rounds every operation as numpy does, and the
+# float64 part writes its fused multiply-adds out explicitly so that every kernel shape produces the same bits.
 # Correctly rounded float32 divide/sqrt is hipcc's default; stated explicitly because parity relies on it.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-Wall", "-Wno-unused-function"]

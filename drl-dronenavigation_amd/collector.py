@@ -305,7 +305,8 @@ class OffPolicyCollector:
             self.buffer.obs_ring[0].copy_(env.reset_tensor())
             self._found = torch.zeros(env.num_envs, dtype=torch.int32, device=env.device)
             cfg = env.cfg
-            self._fused_sample = fused_sample and not (cfg.clip_rew or cfg.norm_rew or cfg.physics or cfg.action_type)   # dn_step_squashed's scope
+            self._fused_sample = fused_sample and not (cfg.clip_rew or cfg.norm_rew or cfg.physics or cfg.action_type or cfg.random_spawn
+                                                       or cfg.zero_damping)               # dn_step_squashed's scope
         else:
             self.buffer = ReplayBuffer(buffer_size, env.num_envs, env.obs_dim, ACT_DIM, env.device)
             self._obs = env.reset_tensor().clone()
@@ -417,7 +418,7 @@ class FusedRolloutCollector:
             last_values=torch.empty((n, 1), dtype=f32, device=dev))
         self._mean = torch.empty((n, ACT_DIM), dtype=f32, device=dev)
         cfg = env.cfg
-        self._sampled_step = not (cfg.clip_rew or cfg.norm_rew or cfg.physics or cfg.action_type)   # dn_step_sampled's scope
+        self._sampled_step = not (cfg.clip_rew or cfg.norm_rew or cfg.physics or cfg.action_type or cfg.random_spawn or cfg.zero_damping)   # dn_step_sampled's scope
         self._clipped = None if self._sampled_step else torch.empty((n, ACT_DIM), dtype=f32, device=dev)
         self._trunc = torch.zeros((T, n), dtype=u8, device=dev)
         self._found = torch.zeros(n, dtype=torch.int32, device=dev)

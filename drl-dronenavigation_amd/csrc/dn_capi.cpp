@@ -36,9 +36,15 @@ int32_t fail(dn_status st, const char *fmt, ...)
 
 inline double norm3d(const double v[3]) { return std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
 
-constexpr long long DN_TWO_WAVE_MAX_TILES = 1024;   // 65536 drones: one tile per SIMD
-constexpr long long DN_PQX_MAX_TILES = 1024;        // three-wave single step: while the tiles alone leave SIMDs idle
-constexpr long long DN_FOUR_WAVE_MAX_TILES = 768;   // four-wave fused step: up to three tiles per CU
+// Shape crossovers, measured on the 256-CU MI355X and kept as TILES PER CU (a 64-drone tile is one workgroup): what decides a
+// shape is how many waves meet on a SIMD, so a partitioned (CPX) or smaller device scales the fleet sizes with its own
+// hipDeviceProp_t.multiProcessorCount (dn_create) instead of inheriting the 256-CU figures.
+constexpr long long DN_CALIBRATION_CUS = 256;
+constexpr long long DN_TWO_WAVE_TILES_PER_CU = 4;   // 1024 tiles = 65536 drones on 256 CUs: one tile per SIMD
+constexpr long long DN_PQX_TILES_PER_CU = 4;        // three-wave single step: while the tiles alone leave SIMDs idle
+constexpr long long DN_FOUR_WAVE_TILES_PER_CU = 3;  // four-wave fused step: up to three tiles per CU (768 tiles on 256 CUs)
+constexpr double DN_CONTACT_MARGIN = 0.02;          // Bullet's contact-breaking threshold (dn_kernels.hip collision_common)
+constexpr double DN_COLL_R = 0.06, DN_COLL_H = 0.025;   // base_link collision cylinder, cf2x.urdf:34
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -52,6 +58,7 @@ struct dn_env {
     double *tab64 = nullptr;
     float *tab32 = nullptr;
     long long blocks = 0;
+    int num_cus = (int)DN_CALIBRATION_CUS;   // hipDeviceProp_t.multiProcessorCount of cfg.device_id
     int waves_fused = 2;        // kernel shape of dn_step_many (k > 1), see dn_launch_step_many
     int waves_single = 1;       // kernel shape of dn_step (k == 1)
 };
@@ -146,12 +153,48 @@ int32_t validate(const dn_config *c)
     for (int j = 0; j < 3; ++j)
         if (!(c->aviary_dim[3 + j] != 0.0)) return fail(DN_ERR_INVALID_ARGUMENT, "aviary_dim high bounds must be non-zero");
     if (c->act_noise_sigma < 0.0f || c->obs_noise_sigma < 0.0f) return fail(DN_ERR_INVALID_ARGUMENT, "noise sigma must be >= 0");
+    if (c->ground_contact < 0 || c->ground_contact > DN_GROUND_CONTACT_AUTO)
+        return fail(DN_ERR_INVALID_ARGUMENT, "ground_contact must be 0 (off), 1 (on) or 2 (DN_GROUND_CONTACT_AUTO; got %d)", c->ground_contact);
     if (c->physics < 0 || c->physics > 4) return fail(DN_ERR_INVALID_ARGUMENT, "physics must be 0..4 (PYB, PYB_GND, PYB_DRAG, PYB_DW, PYB_GND_DRAG_DW; got %d)", c->physics);
     if (c->action_type < 0 || c->action_type > 5)
         return fail(DN_ERR_INVALID_ARGUMENT, "action_type must be 0 THRUST | 1 RPM | 2 PID | 3 VEL | 4 ONE_D_RPM | 5 ONE_D_PID (got %d)", c->action_type);
     for (int j = 0; j < c->num_waypoints * 3; ++j)
         if (!std::isfinite(c->waypoints[j])) return fail(DN_ERR_INVALID_ARGUMENT, "waypoint %d is not finite", j / 3);
     return DN_OK;
+}
+
+// DN_GROUND_CONTACT_AUTO: is the ground-contact term of _has_collision_occurred (PBDroneEnv.py:699) reachable at all?
+// The approximated contact fires when the lowest point of the collision cylinder is within the contact margin of z = 0, i.e.
+// only for z <= margin + max over tilt of (H/2 |c| + R s) = margin + sqrt(H^2/4 + R^2).  Every other term of the same
+// predicate is evaluated on the same fresh position (:678-707), so if the corridor test is on and every point that low is
+// already outside the corridor of EVERY segment (a drone is only ever tested against the segment of its current target), the
+// term can never change `terminated`: the predicate is an OR.  Then it is dropped (and the kernels built without it are used);
+// otherwise -- corridor off, or a track whose corridor reaches down to the floor (spawn / gates at z = 0.1 ... 0.5 with the
+// 0.3 + 0.2 corridor) -- it stays on, as in the reference, which always has it.
+bool ground_contact_reachable(const dn_config &c)
+{
+    if (!c.cylinder) return true;                                      // no corridor: nothing else keeps a drone off the floor
+    const double z_contact = DN_CONTACT_MARGIN + std::sqrt(0.25 * DN_COLL_H * DN_COLL_H + DN_COLL_R * DN_COLL_R);
+    double z_min;                                                       // lowest z inside any corridor
+    if (c.circle) z_min = 1.0 - c.threshold;                            // torus around the unit circle at z = 1 (:723-741)
+    else {
+        z_min = 1e300;
+        for (int k = 0; k < c.num_waypoints; ++k) {
+            const double *b1 = (k == 0) ? c.spawn : &c.waypoints[3 * (k - 1)];
+            const double *b2 = &c.waypoints[3 * k];
+            const double lv[3] = {b2[0] - b1[0], b2[1] - b1[1], b2[2] - b1[2]};
+            const double ll = norm3d(lv);
+            double lo;
+            if (ll == 0.0) lo = b1[2] - c.threshold;                    // degenerate segment: a ball of the bare threshold (:756-757)
+            else {
+                const double uz = lv[2] / ll;                           // capsule around the segment extended by 0.2 at both ends
+                const double e1z = b1[2] - 0.2 * uz, e2z = b2[2] + 0.2 * uz;
+                lo = (e1z < e2z ? e1z : e2z) - (c.threshold + 0.2);
+            }
+            if (lo < z_min) z_min = lo;
+        }
+    }
+    return !(z_min > z_contact + 1e-9);
 }
 
 int32_t init_state_rms(dn_env *e, hipStream_t s)
@@ -215,7 +258,7 @@ void dn_config_default(dn_config *cfg)
     cfg->cylinder = 1;                // PBDroneSimulator.py:167
     cfg->include_distance = 1;        // PBDroneSimulator.py:661
     cfg->normalize_actions = 1;       // PBDroneSimulator.py:662
-    cfg->ground_contact = 0;          // the contact test is an approximation (include/dronenav.h); off unless asked for
+    cfg->ground_contact = DN_GROUND_CONTACT_AUTO;   // on wherever the term can fire at all (the reference always has it, PBDroneEnv.py:699)
     cfg->aviary_dim[0] = cfg->aviary_dim[1] = -1.0;   // make_env default aviary_dim, PBDroneSimulator.py:141
     cfg->aviary_dim[3] = cfg->aviary_dim[4] = cfg->aviary_dim[5] = 1.0;
 }
@@ -242,8 +285,17 @@ int32_t dn_create(const dn_config *cfg, dn_env **out)
     dn_env *e = new (std::nothrow) dn_env();
     if (!e) return fail(DN_ERR_OUT_OF_MEMORY, "host allocation failed");
     e->cfg = *cfg;
+    if (e->cfg.ground_contact == DN_GROUND_CONTACT_AUTO) e->cfg.ground_contact = ground_contact_reachable(*cfg) ? 1 : 0;
+    cfg = &e->cfg;                                      // from here on: the resolved configuration (dn_get_config returns it)
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device_id) == hipSuccess && cus > 0) e->num_cus = cus;
+    }
     const long long n = cfg->num_envs;
     e->blocks = (n + DN_BLOCK - 1) / DN_BLOCK;
+    const long long DN_TWO_WAVE_MAX_TILES = DN_TWO_WAVE_TILES_PER_CU * e->num_cus;
+    const long long DN_PQX_MAX_TILES = DN_PQX_TILES_PER_CU * e->num_cus;
+    const long long DN_FOUR_WAVE_MAX_TILES = DN_FOUR_WAVE_TILES_PER_CU * e->num_cus;
     // Measured on MI355X (profiles/r01_r_sweep_shapes.txt): the fused K-step kernel is bound by the dependent
     // instruction stream of a wave, and two or three waves per tile win while the tiles alone leave SIMDs idle
     // (<= 1024 tiles = 65536 drones on 1024 SIMDs); the single-step launch is latency bound (launch + load round
@@ -395,6 +447,23 @@ int32_t dn_destroy(dn_env *env)
 
 int64_t dn_num_envs(const dn_env *env) { return env ? env->cfg.num_envs : 0; }
 
+int32_t dn_get_config(const dn_env *env, dn_config *out)
+{
+    if (!env || !out) return fail(DN_ERR_INVALID_ARGUMENT, "env and out are required");
+    *out = env->cfg;                                  // ground_contact resolved to 0 / 1
+    return DN_OK;
+}
+
+int32_t dn_get_num_cus(const dn_env *env) { return env ? env->num_cus : 0; }
+
+int32_t dn_resolve_ground_contact(const dn_config *cfg)
+{
+    const int32_t rc = validate(cfg);
+    if (rc != DN_OK) return rc;
+    if (cfg->ground_contact != DN_GROUND_CONTACT_AUTO) return cfg->ground_contact;
+    return ground_contact_reachable(*cfg) ? 1 : 0;
+}
+
 int32_t dn_reset(dn_env *env, float *obs, void *stream)
 {
     if (!env) return fail(DN_ERR_INVALID_ARGUMENT, "env is NULL");
@@ -431,8 +500,8 @@ int32_t dn_step_sampled(dn_env *env, const float *mean, const float *log_std, ui
         return fail(DN_ERR_INVALID_ARGUMENT, "mean, log_std, actions_out, log_prob_out, obs, reward, done, truncated and found_targets are required");
     if (((uintptr_t)mean & 15u) || ((uintptr_t)actions_out & 15u) || ((uintptr_t)obs & 15u))
         return fail(DN_ERR_INVALID_ARGUMENT, "mean, actions_out and obs must be 16-byte aligned");
-    if (env->cfg.clip_rew || env->cfg.norm_rew || env->cfg.physics != 0 || env->cfg.action_type != 0)
-        return fail(DN_ERR_INVALID_ARGUMENT, "dn_step_sampled is built for the configuration without reward wrappers / extra physics terms / RPM actions; "
+    if (env->cfg.clip_rew || env->cfg.norm_rew || env->cfg.physics != 0 || env->cfg.action_type != 0 || env->cfg.random_spawn || env->cfg.zero_damping)
+        return fail(DN_ERR_INVALID_ARGUMENT, "dn_step_sampled is built for the configuration without reward wrappers / extra physics terms / RPM actions / random spawn / zero damping; "
                                              "use dn_policy_sample + dn_step there");
     DnStepIO io;
     io.actions = nullptr; io.obs = obs; io.reward = reward; io.done = done; io.truncated = truncated;
@@ -455,8 +524,8 @@ int32_t dn_step_squashed(dn_env *env, const float *mu_log_std, uint64_t seed, in
         return fail(DN_ERR_INVALID_ARGUMENT, "mu_log_std, actions_out, obs, reward, done, truncated and found_targets are required");
     if (((uintptr_t)mu_log_std & 15u) || ((uintptr_t)actions_out & 15u) || ((uintptr_t)obs & 15u))
         return fail(DN_ERR_INVALID_ARGUMENT, "mu_log_std, actions_out and obs must be 16-byte aligned");
-    if (env->cfg.clip_rew || env->cfg.norm_rew || env->cfg.physics != 0 || env->cfg.action_type != 0)
-        return fail(DN_ERR_INVALID_ARGUMENT, "dn_step_squashed is built for the configuration without reward wrappers / extra physics terms / RPM actions; "
+    if (env->cfg.clip_rew || env->cfg.norm_rew || env->cfg.physics != 0 || env->cfg.action_type != 0 || env->cfg.random_spawn || env->cfg.zero_damping)
+        return fail(DN_ERR_INVALID_ARGUMENT, "dn_step_squashed is built for the configuration without reward wrappers / extra physics terms / RPM actions / random spawn / zero damping; "
                                              "use dn_squashed_sample + dn_step there");
     DnStepIO io;
     io.actions = nullptr; io.obs = obs; io.reward = reward; io.done = done; io.truncated = truncated;
@@ -478,9 +547,9 @@ int32_t dn_eval_kinematics(dn_env *env, const double *kinematics, float *obs, fl
     if (((uintptr_t)kinematics & 7u) || ((uintptr_t)obs & 15u))
         return fail(DN_ERR_INVALID_ARGUMENT, "kinematics must be 8-byte and obs 16-byte aligned");
     const dn_config &c = env->cfg;
-    if (c.act_noise_sigma > 0.0f || c.obs_noise_sigma > 0.0f || c.clip_rew || c.norm_rew || c.physics != 0 || c.action_type != 0)
+    if (c.act_noise_sigma > 0.0f || c.obs_noise_sigma > 0.0f || c.clip_rew || c.norm_rew || c.physics != 0 || c.action_type != 0 || c.random_spawn)
         return fail(DN_ERR_INVALID_ARGUMENT, "dn_eval_kinematics is built for the reference configuration (no noise, no reward wrappers, "
-                                             "Physics.PYB, ActionType.THRUST)");
+                                             "Physics.PYB, ActionType.THRUST, fixed spawn)");
     DnStepIO io;
     memset(&io, 0, sizeof io);
     io.obs = obs; io.reward = reward; io.done = done; io.truncated = truncated; io.found_targets = found_targets;
@@ -532,7 +601,7 @@ static float ret_lo_decode(float hi, int k)
     uint32_t bits;
     memcpy(&bits, &hi, 4);
     const int eb = (int)((bits >> 23) & 0xFFu);
-    return eb > 31 ? (float)ldexp((double)k, eb - 127 - 31) : 0.0f;
+    return (eb > 31 && eb != 255) ? (float)ldexp((double)k, eb - 127 - 31) : 0.0f;      // inf / NaN carry no low part (ret_lo_encode)
 }
 static int ret_lo_encode(float hi, float lo)
 {

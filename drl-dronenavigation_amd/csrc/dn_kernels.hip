@@ -1,6 +1,7 @@
 // dn_kernels.hip -- hand-written HIP kernels (gfx950 / CDNA4) for the drone-navigation environment step.
 //
-// One drone per lane, one 64-lane wave per workgroup.  The whole reference step
+// One drone per lane, 64 drones (one tile) per workgroup, one to four 64-lane waves per tile (the step cut by data
+// dependency over waves that exchange LDS mail).  The whole reference step
 //   PBDroneEnv.step -> BaseAviary.step -> p.stepSimulation -> obs / reward / done -> post-step
 //   -> SubprocVecEnv auto-reset + Monitor (+ optional per-drone NormalizeObservation)
 // is one kernel: the float32 state is read once as six float4 groups (16 B per lane, coalesced),
@@ -12,7 +13,9 @@
 // Arithmetic: the action chain (rescale -> thrust -> PWM -> RPM -> forces) is float32 exactly as the
 // reference's numpy float32 arrays; everything after it is computed in `R` = double (parity grade: the
 // reference is float64 throughout, Bullet included) or float (fast mode).  The file is compiled with
-// -ffp-contract=off so that no multiply-add is fused: numpy and Bullet round every operation.
+// -ffp-contract=off: the float32 action chain rounds every operation as numpy does, and in the float64 part every fused
+// multiply-add is WRITTEN OUT (FM<R>::fma) in one fixed nesting, never left to the compiler's licence, so that every kernel
+// shape -- hence every split of a fleet over ranks -- produces the same bits.
 //
 // Reference citations are file:line under /root/reference:
 //   PBDroneEnv.py = Sol/Model/Environments/PBDroneEnv.py, BaseAviary.py = Sol/PyBullet/BaseAviary.py,

@@ -114,6 +114,23 @@ def pack_sac_actor(layers, device, grade="bf16"):
     return out
 
 
+def _repack_into(dst, src):
+    """Refresh a packed network IN PLACE: a hipGraph that captured dn_mlp_forward holds the device addresses of the packed
+    weights, so a refresh after an optimiser step must land in the same allocations (a re-pack into fresh tensors would leave
+    every captured launch reading the old, freed buffers).  `dst` is the pack the kernels were given, `src` a new pack of the
+    same network shape and grade."""
+    if dst is None:
+        return src
+    for k, v in src.items():
+        if torch.is_tensor(v):
+            if k not in dst or dst[k].shape != v.shape or dst[k].dtype != v.dtype:
+                raise ValueError(f"refresh() changed the packed shape of {k!r}: build a new policy object (and recapture)")
+            dst[k].copy_(v)
+        elif dst.get(k) != v:
+            raise ValueError(f"refresh() changed {k!r} ({dst.get(k)} -> {v}): build a new policy object (and recapture)")
+    return dst
+
+
 def _net_struct(pk, out_tensor):
     n = _capi.DnMlpNet()
     for k in ("w1", "w2", "w3", "wh", "b1", "b2", "b3", "bh"):
@@ -149,14 +166,17 @@ class FusedMlpPolicy:
         self.module, self.device, self.grade = module, torch.device(device), grade
         self._mean = torch.empty((num_envs, module.action_net.out_features), dtype=torch.float32, device=self.device)
         self._value = torch.empty((num_envs, 1), dtype=torch.float32, device=self.device)
+        self.pi = self.vf = None
         self.refresh()
 
     def refresh(self):
+        """Re-pack the module's current weights into the SAME device tensors (captured graphs keep working)."""
         m = self.module
         lin = lambda seq: [l for l in seq if isinstance(l, torch.nn.Linear)]           # noqa: E731
         pi = [(l.weight, l.bias) for l in lin(m.pi)] + [(m.action_net.weight, m.action_net.bias)]
         vf = [(l.weight, l.bias) for l in lin(m.vf)] + [(m.value_net.weight, m.value_net.bias)]
-        self.pi, self.vf = pack_mlp(pi, self.device, self.grade), pack_mlp(vf, self.device, self.grade)
+        self.pi = _repack_into(self.pi, pack_mlp(pi, self.device, self.grade))
+        self.vf = _repack_into(self.vf, pack_mlp(vf, self.device, self.grade))
         self.log_std = m.log_std.detach().to(self.device).float()
         self.log_std_host = [float(x) for x in m.log_std.detach().cpu().float()]     # dn_policy_sample takes it by value
 
@@ -185,13 +205,16 @@ class FusedSacActor:
         self.module, self.device, self.grade = module, torch.device(device), grade
         self.act_dim = module.mu.out_features
         self._out = torch.empty((num_envs, 2 * self.act_dim), dtype=torch.float32, device=self.device)
+        self.pack = None
         self.refresh()
 
     def refresh(self):
+        """Re-pack the module's current weights into the SAME device tensors: OffPolicyCollector.collect_cycle's hipGraph
+        holds their addresses, and SAC refreshes after every cycle."""
         m = self.module
         lin = [l for l in m.latent_pi if isinstance(l, torch.nn.Linear)]
         layers = [(l.weight, l.bias) for l in lin] + [(m.mu.weight, m.mu.bias), (m.log_std.weight, m.log_std.bias)]
-        self.pack = pack_sac_actor(layers, self.device, self.grade)
+        self.pack = _repack_into(self.pack, pack_sac_actor(layers, self.device, self.grade))
 
     def mean_log_std(self, obs):
         from .policy import LOG_STD_MAX, LOG_STD_MIN

@@ -38,6 +38,48 @@ OBS_DIM = _capi.OBS_DIM
 ACT_DIM = _capi.ACT_DIM
 
 
+class _SparseInfo(dict):
+    """info dict of one drone in `info_mode="sparse"`: the keys every step carries (`found_targets`, PBDroneEnv.py:442;
+    `TimeLimit.truncated`, False while the episode runs) are answered from the step's host arrays on demand instead of being
+    written into 32 768 dicts per step; the keys of a finished episode (`terminal_observation`, `episode`, the true
+    `TimeLimit.truncated`) are stored as usual.  Reads like the dict SubprocVecEnv returns: `info["found_targets"]`
+    (FoundTargetsCallback, Sol/Utilities/Callbacks.py:59), `info.get("TimeLimit.truncated", False)`, `"episode" in info`."""
+    __slots__ = ("_env", "_i")
+    _ALWAYS = ("found_targets", "TimeLimit.truncated")
+
+    def __init__(self, env, i):
+        super().__init__()
+        self._env, self._i = env, i
+
+    def __missing__(self, key):
+        if key == "found_targets":
+            return int(self._env._h_found[self._i])
+        if key == "TimeLimit.truncated":
+            return False
+        raise KeyError(key)
+
+    def get(self, key, default=None):
+        try:
+            return self[key]
+        except KeyError:
+            return default
+
+    def __contains__(self, key):
+        return key in self._ALWAYS or dict.__contains__(self, key)
+
+    def keys(self):
+        return list(dict.keys(self)) + [k for k in self._ALWAYS if not dict.__contains__(self, k)]
+
+    def items(self):
+        return [(k, self[k]) for k in self.keys()]
+
+    def __iter__(self):
+        return iter(self.keys())
+
+    def __len__(self):
+        return len(self.keys())
+
+
 # enums.Physics / enums.ActionType values of the reference (Sol/PyBullet/enums.py:12-21, :36-44) -> dn_config codes.
 # The reference only ever runs "pyb" + "thrust" (BaseAviary.py:411 pins the physics); the others are its dormant options.
 PHYSICS = {"pyb": 0, "pyb_gnd": 1, "pyb_drag": 2, "pyb_dw": 3, "pyb_gnd_drag_dw": 4}
@@ -54,10 +96,12 @@ def _enum_value(v):
 
 def make_config(*, num_envs, target_points, initial_xyzs, aviary_dim, threshold=0.3, max_steps=4096, circle=False,
                 cylinder=True, include_distance=True, normalize_actions=True, normalize_obs=True,
-                ground_contact=False, compute_dtype="float64", act_noise_sigma=0.0, obs_noise_sigma=0.0, seed=0,
+                ground_contact=None, compute_dtype="float64", act_noise_sigma=0.0, obs_noise_sigma=0.0, seed=0,
                 env_id_offset=0, device_id=0, clip_rew=False, norm_rew=False, physics="pyb", act="thrust", random_spawn=False,
                 zero_damping=False):
-    """Fill a dn_config (include/dronenav.h) from PBDroneEnv-style arguments."""
+    """Fill a dn_config (include/dronenav.h) from PBDroneEnv-style arguments.  ground_contact: True / False, or None =
+    DN_GROUND_CONTACT_AUTO (the reference always tests contact, PBDroneEnv.py:699; dn_create keeps the term wherever it can
+    fire and drops it where the corridor test provably ends the episode first)."""
     wp = np.asarray(target_points, dtype=np.float64).reshape(-1, 3)
     if not 1 <= len(wp) <= _capi.MAX_WAYPOINTS:
         raise ValueError(f"target_points must hold 1..{_capi.MAX_WAYPOINTS} waypoints, got {len(wp)}")
@@ -80,7 +124,8 @@ def make_config(*, num_envs, target_points, initial_xyzs, aviary_dim, threshold=
     cfg.max_steps = int(max_steps)
     cfg.circle, cfg.cylinder = int(bool(circle)), int(bool(cylinder))
     cfg.include_distance, cfg.normalize_actions = int(bool(include_distance)), int(bool(normalize_actions))
-    cfg.normalize_obs, cfg.ground_contact = int(bool(normalize_obs)), int(bool(ground_contact))
+    cfg.normalize_obs = int(bool(normalize_obs))
+    cfg.ground_contact = _capi.GROUND_CONTACT_AUTO if ground_contact is None else int(bool(ground_contact))
     cfg.compute_f32 = int(compute_dtype == "float32")
     cfg.act_noise_sigma, cfg.obs_noise_sigma = float(act_noise_sigma), float(obs_noise_sigma)
     cfg.seed, cfg.env_id_offset = int(seed), int(env_id_offset)
@@ -98,7 +143,7 @@ class DroneVecEnv(_VecEnvBase):
 
     def __init__(self, track=None, num_envs=12, *, target_points=None, initial_xyzs=None, aviary_dim=None,
                  circle=None, target_factor=0, threshold=0.3, discount=0.999, max_steps=4096, cylinder=True,
-                 include_distance=True, normalize_actions=True, normalize_obs=True, ground_contact=False,
+                 include_distance=True, normalize_actions=True, normalize_obs=True, ground_contact=None,
                  compute_dtype="float64", act_noise_sigma=0.0, obs_noise_sigma=0.0, seed=0, env_id_offset=0,
                  device=None, info_mode="full", clip_rew=False, norm_rew=False, physics="pyb", act="thrust", random_spawn=False,
                  zero_damping=False):
@@ -134,6 +179,8 @@ class DroneVecEnv(_VecEnvBase):
                                physics=physics, act=act, random_spawn=random_spawn, zero_damping=zero_damping)
         self._handle = C.c_void_p()
         _capi.check(self._lib.dn_create(C.byref(self.cfg), C.byref(self._handle)))
+        _capi.check(self._lib.dn_get_config(self._handle, C.byref(self.cfg)))     # the resolved configuration (ground_contact 0 / 1)
+        self.ground_contact = bool(self.cfg.ground_contact)
 
         n = int(num_envs)
         self.num_envs = n
@@ -187,7 +234,7 @@ class DroneVecEnv(_VecEnvBase):
         self._views = (self._obs[:, :self.obs_dim], self._term_obs[:, :self.obs_dim])
         self._t_start = time.time()
         self._pending = False
-        self._infos = [{} for _ in range(n)]
+        self._infos = None                     # sparse info mode: one persistent list of _SparseInfo, built on first use
         self._dirty = []                       # sparse info mode: the dicts filled by the previous step
         self._closed = False
 
@@ -288,7 +335,6 @@ class DroneVecEnv(_VecEnvBase):
     def reset(self):
         obs = self.reset_tensor().cpu().numpy()
         self.reset_infos = [{} for _ in range(self.num_envs)]
-        self._t_start_episode = time.time()
         return obs
 
     def step_async(self, actions):
@@ -312,6 +358,8 @@ class DroneVecEnv(_VecEnvBase):
         if self.info_mode == "full":
             infos = [{"found_targets": f, "TimeLimit.truncated": False} for f in found.tolist()]
         else:
+            if self._infos is None:
+                self._infos = [_SparseInfo(self, i) for i in range(self.num_envs)]
             infos = self._infos                # one persistent list; only the dicts the last step filled are cleared
             for i in self._dirty:
                 infos[i].clear()
@@ -404,6 +452,16 @@ class DroneVecEnv(_VecEnvBase):
         self.set_state(st)
 
     def env_method(self, method_name, *args, indices=None, **kwargs):
+        """SB3's env_method for the PBDroneEnv methods that make sense on a device-resident fleet: the getters the reference's
+        own tooling calls (`getDroneIds`, `getPyBulletClient`, BaseAviary.py:466-487) answer per drone; everything that would
+        run Python inside a worker process has no counterpart here and raises."""
+        idx = self._indices(indices)
+        if method_name == "getDroneIds":
+            return [np.array([1]) for _ in idx]          # one drone per world, Bullet body id 1 (plane.urdf is 0)
+        if method_name == "getPyBulletClient":
+            return [-1 for _ in idx]                     # no Bullet client: the physics runs in the HIP kernels
+        if method_name in ("get_wrapper_attr", "get_attr"):
+            return self.get_attr(args[0], indices)
         raise AttributeError(f"env_method({method_name!r}) is not available on the device-resident env")
 
     # The wrappers make_env puts around every PBDroneEnv (PBDroneSimulator.py:181-196) are applied in-kernel, so the
@@ -450,9 +508,14 @@ class DroneVecEnv(_VecEnvBase):
         _capi.check(self._lib.dn_reset_stats(self._handle, self._stream()))
 
     def kernel_waves(self, fused=False):
-        """Kernel shape of dn_step (fused=False) / dn_step_many (fused=True): 2 = flight wave + report wave per 64
-        drones, 1 = one wave per 64 drones (dn_get_kernel_waves)."""
+        """Kernel shape of dn_step (fused=False: 3 = three waves cut by dependency, 1 = one wave) / dn_step_many (fused=True:
+        4 = linear | angular | observation | report waves, 3 = flight | report | aux, 2 = flight | report, 1 = one wave) per
+        64-drone tile (dn_get_kernel_waves; the crossovers are tiles per CU of this device, `num_cus`)."""
         return int(self._lib.dn_get_kernel_waves(self._handle, int(bool(fused))))
+
+    @property
+    def num_cus(self):
+        return int(self._lib.dn_get_num_cus(self._handle))
 
     @property
     def step_count(self):

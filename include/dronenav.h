@@ -34,10 +34,11 @@
 extern "C" {
 #endif
 
-#define DN_ABI_VERSION 5
+#define DN_ABI_VERSION 6
 #define DN_MAX_WAYPOINTS 64
 #define DN_OBS_DIM 13      /* 12 kinematic + distance, PBDroneEnv._computeObs, PBDroneEnv.py:296-336 */
 #define DN_ACT_DIM 4       /* four rotor thrust commands, PBDroneEnv._actionSpace, PBDroneEnv.py:225-243 */
+#define DN_GROUND_CONTACT_AUTO 2   /* dn_config.ground_contact: resolved by dn_create (see the field) */
 
 typedef enum dn_status {
     DN_OK = 0,
@@ -65,10 +66,14 @@ typedef struct dn_config {
     int32_t include_distance;                   /* obs[12] = distance/max_target_dist (True in the driver) */
     int32_t normalize_actions;                  /* PBDroneEnv.rescale_action (True in the driver) */
     int32_t normalize_obs;                      /* per-drone normalize.NormalizeObservation (always on in make_env) */
-    int32_t ground_contact;                     /* approximate len(p.getContactPoints())>0 vs plane.urdf (PBDroneEnv.py:699): lowest point of the
-                                                   collision cylinder within Bullet's contact margin of z = 0 -- the one term of the step that is
-                                                   neither pinned nor exact, so OFF by default; in the reference's configurations the corridor
-                                                   test ends the episode first (every waypoint sits >= 0.5 above the floor) */
+    int32_t ground_contact;                     /* len(p.getContactPoints())>0 vs plane.urdf (PBDroneEnv.py:699), which the reference always tests,
+                                                   APPROXIMATED as: lowest point of the collision cylinder within Bullet's contact margin of z = 0
+                                                   (the one term of the step that is neither pinned nor exact).  0 off | 1 on |
+                                                   DN_GROUND_CONTACT_AUTO (2, the default): on unless the term is provably unreachable -- corridor
+                                                   test on and every point low enough to touch the floor already outside the corridor of every track
+                                                   segment, so that `terminated` cannot depend on it (true for the circle tracks at z = 1 and the
+                                                   8-gate race track; false for the registry tracks that spawn at z = 0.1).  dn_create resolves it;
+                                                   dn_get_config returns the resolved value */
     int32_t compute_f32;                        /* 0: float64 arithmetic in registers over the float32 state
                                                       (parity grade, default); 1: float32 arithmetic */
     float act_noise_sigma;                      /* sim-to-real: Gaussian action noise (0 = reference) */
@@ -137,7 +142,7 @@ const char *dn_last_error(void);
 int32_t dn_device_count(void);
 
 /* Fills *cfg with the driver's literals (threshold 0.3, max_steps 4096, cylinder, include_distance,
- * normalize_actions on; circle/normalize_obs/ground_contact/noise off) and an empty track. */
+ * normalize_actions on; ground_contact = DN_GROUND_CONTACT_AUTO; circle/normalize_obs/noise off) and an empty track. */
 void dn_config_default(dn_config *cfg);
 
 /* Replaces N x PBDroneEnv.__init__ + the env.reset(seed=seed+rank) of make_env
@@ -145,6 +150,15 @@ void dn_config_default(dn_config *cfg);
 int32_t dn_create(const dn_config *cfg, dn_env **out);
 int32_t dn_destroy(dn_env *env);
 int64_t dn_num_envs(const dn_env *env);
+/* The configuration the environment runs with: *out = the dn_config given to dn_create with ground_contact resolved
+ * to 0 / 1 (ABI 6).  What `PBDroneEnv.__dict__` answers in the reference. */
+int32_t dn_get_config(const dn_env *env, dn_config *out);
+/* What dn_create makes of cfg->ground_contact (host arithmetic on the track geometry only, no device needed): 0 / 1, or a
+ * negative dn_status for an invalid configuration (ABI 6). */
+int32_t dn_resolve_ground_contact(const dn_config *cfg);
+/* Compute units of the environment's device (hipDeviceProp_t.multiProcessorCount): the kernel-shape crossovers below are
+ * tiles (64 drones) per CU, calibrated on the 256-CU MI355X (ABI 6). */
+int32_t dn_get_num_cus(const dn_env *env);
 
 /* Replaces VecEnv.reset() -> N x Monitor.reset/NormalizeObservation.reset/PBDroneEnv.reset
  * (PBDroneEnv.py:609-665, BaseAviary.py:276-320).  obs: device float[N*13]. */
@@ -202,11 +216,13 @@ int32_t dn_set_state(dn_env *env, const dn_env_state *states, int64_t count);
 int32_t dn_get_stats(dn_env *env, dn_stats *out, void *stream);
 int32_t dn_reset_stats(dn_env *env, void *stream);
 
-/* Kernel shape chosen for this environment's launches (fused != 0: dn_step_many with k > 1; fused == 0: dn_step):
- * 3 = flight + report + aux wave per 64 drones (fused launches of small fleets: the step is bound by one wave's
- * dependent instruction stream and the other waves run on otherwise idle SIMDs), 2 = a flight wave + a report wave
- * (mid-size fleets with the optional terms, where three waves cost occupancy), 1 = one wave per 64 drones.  All
- * shapes produce identical bits.  Environment variable DN_WAVES=1|2|3 (read by dn_create) forces a shape. */
+/* Kernel shape chosen for this environment's launches (fused != 0: dn_step_many with k > 1; fused == 0: dn_step), as waves
+ * per 64-drone tile.  Fused: 4 = the recurrence itself on two waves (linear + rules | angular + attitude) plus an observation
+ * and a report wave (the default for the plain configuration up to 3 tiles per CU), 3 = flight + report + aux wave, 2 = a
+ * flight wave + a report wave (mid-size fleets with the optional terms, where more waves cost occupancy), 1 = one wave.
+ * Single step: 3 = three waves cut by dependency (dn_step_pqx_kernel, plain configuration up to 4 tiles per CU), 1 = one wave.
+ * The multi-wave shapes win while the tiles alone leave SIMDs idle; crossovers are tiles per CU (dn_get_num_cus).  All shapes
+ * produce identical bits.  Environment variables DN_WAVES=1|2|3|4 and DN_WAVES_SINGLE=1|3 (read by dn_create) force a shape. */
 int32_t dn_get_kernel_waves(const dn_env *env, int32_t fused);
 
 /* Vector-step counter: the Philox counter word of the noise streams and the source of dn_stats.env_steps.  It
@@ -298,8 +314,8 @@ int32_t dn_add_bootstrap(float *reward, const float *terminal_value, const uint8
 /* dn_policy_sample + dn_step in one launch (the rollout loop's per-step pair): the action is drawn inside the step kernel
  * from `mean` exactly as dn_policy_sample draws it (same Philox stream, same bits); actions_out receives the UNclipped
  * action (what SB3's collect_rollouts stores), log_prob_out its log-probability, the clipped action goes into the step.
- * Other arguments as dn_step.  Built for the configuration without reward wrappers / extra physics terms / RPM actions
- * (DN_ERR_INVALID_ARGUMENT otherwise: use dn_policy_sample + dn_step there). */
+ * Other arguments as dn_step.  Built for the configuration without reward wrappers / extra physics terms / RPM actions /
+ * random spawn / zero damping (DN_ERR_INVALID_ARGUMENT otherwise: use dn_policy_sample + dn_step there). */
 int32_t dn_step_sampled(dn_env *env, const float *mean, const float *log_std, uint64_t seed, int32_t deterministic,
                         float *actions_out, float *log_prob_out, float *obs, float *reward, uint8_t *done, uint8_t *truncated,
                         int32_t *found_targets, float *terminal_obs, float *ep_return, int32_t *ep_length,

@@ -11,7 +11,10 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+# DN_ORACLE_LIB=liboracle_asan.so: the AddressSanitizer / UBSan build of the same restatement (tests/test_oracle_asan.py runs
+# golden-fixture replays under it in a child process with libasan preloaded)
+_LIB_NAME = os.environ.get("DN_ORACLE_LIB", "liboracle.so")
+_LIB_PATH = os.path.join(_HERE, _LIB_NAME)
 MAX_WAYPOINTS = 64
 OBS_DIM = 13
 
@@ -91,7 +94,7 @@ def build(force=False):
     stale = (not os.path.exists(_LIB_PATH)
              or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(src), os.path.getmtime(hdr)))
     if force or stale:
-        subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"] + (["-B"] if force else []))
+        subprocess.check_call(["make", "-s", "-C", _HERE, _LIB_NAME] + (["-B"] if force else []))
     return _LIB_PATH
 
 

@@ -79,5 +79,36 @@ int main(int argc,char**argv){
                timeit([&]{ hipLaunchKernelGGL(k_skel<1000>, dim3(512), dim3(blk), 0, 0, p); }, it),
                timeit([&]{ hipLaunchKernelGGL(k_skel<2000>, dim3(512), dim3(blk), 0, 0, p); }, it));
     }
+    // Round 3: the same kernels as nodes of a hipGraph (64 dependent kernel nodes, replayed back to back): the period per node is the
+    // GPU-side dependent-kernel boundary, with no host launch cadence in it (the eager loops above are host bound below ~3 us).
+    {
+        hipStream_t st; CK(hipStreamCreate(&st));
+        auto graph_period = [&](auto launch, const char *name, int grid, int blk) -> int {
+            hipGraph_t g; hipGraphExec_t ge;
+            CK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
+            for (int i = 0; i < 64; ++i) launch(st);
+            CK(hipStreamEndCapture(st, &g));
+            CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+            for (int i = 0; i < 20; ++i) CK(hipGraphLaunch(ge, st));
+            CK(hipStreamSynchronize(st));
+            hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+            const int reps = 200;
+            CK(hipEventRecord(a, st));
+            for (int i = 0; i < reps; ++i) CK(hipGraphLaunch(ge, st));
+            CK(hipEventRecord(b, st)); CK(hipEventSynchronize(b));
+            float ms; CK(hipEventElapsedTime(&ms, a, b));
+            printf("graph replay, 64 dependent nodes  %-28s grid %4d x %3d: %.3f us per node\n", name, grid, blk, ms * 1e3f / (reps * 64));
+            CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
+            return 0;
+        };
+        for (int blk : {64, 192, 256}) {
+            if (graph_period([&](hipStream_t s) { hipLaunchKernelGGL(k_empty, dim3(512), dim3(blk), 0, s, ts); }, "empty", 512, blk)) return 1;
+            if (graph_period([&](hipStream_t s) { hipLaunchKernelGGL(k_stamp<8>, dim3(512), dim3(blk), 0, s, ts); }, "stamp<8>", 512, blk)) return 1;
+            if (graph_period([&](hipStream_t s) { hipLaunchKernelGGL(k_skel<0>, dim3(512), dim3(blk), 0, s, p); }, "memory skeleton (work 0)", 512, blk)) return 1;
+            if (graph_period([&](hipStream_t s) { hipLaunchKernelGGL(k_skel<500>, dim3(512), dim3(blk), 0, s, p); }, "memory skeleton (work 500)", 512, blk)) return 1;
+        }
+        if (graph_period([&](hipStream_t s) { hipLaunchKernelGGL(k_empty, dim3(1), dim3(64), 0, s, ts); }, "empty", 1, 64)) return 1;
+        if (graph_period([&](hipStream_t s) { hipLaunchKernelGGL(k_empty, dim3(256), dim3(256), 0, s, ts); }, "empty", 256, 256)) return 1;
+    }
     return 0;
 }

@@ -67,7 +67,7 @@ int main(void) {
     assert got == [C.sizeof(K.DnConfig), C.sizeof(K.DnEnvState), C.sizeof(K.DnStats), C.sizeof(K.DnMlpNet),
                    K.DnConfig.random_spawn.offset, K.DnConfig.seed.offset, K.DnEnvState.pid.offset,
                    K.DnEnvState.rms_mean.offset, K.ABI_VERSION], got
-    assert pkg._capi.load().dn_abi_version() == pkg._capi.ABI_VERSION == 5
+    assert pkg._capi.load().dn_abi_version() == pkg._capi.ABI_VERSION == 6
 
 
 def test_config_defaults_follow_the_driver(pkg):
@@ -76,6 +76,70 @@ def test_config_defaults_follow_the_driver(pkg):
     assert cfg.threshold == 0.3 and cfg.max_steps == 4096 and cfg.cylinder == 1
     assert cfg.include_distance == 1 and cfg.normalize_actions == 1 and cfg.compute_f32 == 0
     assert cfg.act_noise_sigma == 0 and cfg.obs_noise_sigma == 0
+    assert cfg.ground_contact == pkg._capi.GROUND_CONTACT_AUTO == 2
+
+
+def test_ground_contact_auto_is_on_wherever_the_term_can_fire(pkg):
+    """The reference always tests len(p.getContactPoints()) > 0 (PBDroneEnv.py:699).  DN_GROUND_CONTACT_AUTO keeps the
+    (approximated) term unless the corridor test provably fires first: off for the circle tracks at z = 1 and the 8-gate
+    race track (BASELINE's configs), ON for the registry tracks that spawn at z = 0.1 with the floor inside the 0.3 + 0.2
+    corridor, and on whenever the corridor test is off."""
+    lib = pkg._capi.load()
+    from drl_dronenavigation_amd import tracks
+    from drl_dronenavigation_amd.vec_env import make_config
+
+    def resolved(t, **kw):
+        cfg = make_config(num_envs=8, target_points=t.targets(), initial_xyzs=t.initial_xyzs, aviary_dim=t.aviary_dim,
+                          circle=t.is_circle, **kw)
+        return lib.dn_resolve_ground_contact(C.byref(cfg))
+
+    for name in ("circle4", "circle6", "reaching"):
+        assert resolved(tracks.REGISTRY[name]()) == 0, name
+    for name in ("up", "half_up_forward", "up_circle", "up_sharp_back_turn"):
+        assert resolved(tracks.REGISTRY[name]()) == 1, name
+    assert resolved(tracks.reaching(), cylinder=False) == 1             # no corridor: nothing else keeps a drone off the floor
+    assert resolved(tracks.circle(1, 4, 1), threshold=0.95) == 1        # a torus fat enough to reach the floor
+    assert resolved(tracks.reaching(), ground_contact=True) == 1 and resolved(tracks.up(), ground_contact=False) == 0
+    # geometry check of the bound itself: the lowest point of the race track's corridor
+    t = tracks.reaching()
+    pts = np.vstack([t.initial_xyzs.reshape(1, 3), t.targets()])
+    lows = []
+    for a, b in zip(pts[:-1], pts[1:]):
+        ll = np.linalg.norm(b - a)
+        if ll == 0:
+            lows.append(a[2] - 0.3)
+            continue
+        uz = (b - a)[2] / ll
+        lows.append(min(a[2] - 0.2 * uz, b[2] + 0.2 * uz) - 0.5)
+    assert min(lows) > 0.02 + np.hypot(0.0125, 0.06)                    # margin + the collision cylinder's largest extent below its centre
+    cfg = make_config(num_envs=8, target_points=t.targets(), initial_xyzs=t.initial_xyzs, aviary_dim=t.aviary_dim)
+    cfg.ground_contact = 3
+    assert lib.dn_resolve_ground_contact(C.byref(cfg)) == -1
+
+
+def test_sparse_info_dicts_answer_the_reference_callbacks():
+    """info_mode="sparse" leaves the dicts of running drones unwritten; they must still read like SubprocVecEnv's:
+    FoundTargetsCallback does infos[0]["found_targets"] unconditionally (Sol/Utilities/Callbacks.py:59), SB3 does
+    info.get("TimeLimit.truncated", False) and info.get("episode")."""
+    from drl_dronenavigation_amd.vec_env import _SparseInfo
+
+    class FakeEnv:
+        _h_found = np.array([3, 0, 7], np.int32)
+
+    env = FakeEnv()
+    infos = [_SparseInfo(env, i) for i in range(3)]
+    assert [i["found_targets"] for i in infos] == [3, 0, 7]
+    assert infos[0]["TimeLimit.truncated"] is False and infos[1].get("TimeLimit.truncated", True) is False
+    assert infos[2].get("episode") is None and "episode" not in infos[2] and "found_targets" in infos[2]
+    with pytest.raises(KeyError):
+        infos[0]["terminal_observation"]
+    infos[1]["episode"] = {"r": 1.0, "l": 2, "t": 0.0}
+    infos[1]["TimeLimit.truncated"] = True
+    assert infos[1]["TimeLimit.truncated"] is True and set(infos[1].keys()) == {"episode", "TimeLimit.truncated", "found_targets"}
+    assert dict(infos[1])["found_targets"] == 0 and len(infos[1]) == 3
+    env._h_found[1] = 5                                                  # the next step's host mirror
+    infos[1].clear()
+    assert infos[1]["found_targets"] == 5 and infos[1]["TimeLimit.truncated"] is False
 
 
 def test_create_fails_loudly(pkg):

@@ -33,7 +33,7 @@ def make_pair(track, n, *, f32_state, max_steps=4096, **kw):
                                                 "act_noise_sigma", "obs_noise_sigma", "seed", "env_id_offset",
                                                 "ground_contact", "threshold", "cylinder", "clip_rew", "norm_rew", "random_spawn")}
     okw.setdefault("normalize_obs", True)
-    okw.setdefault("ground_contact", False)        # DroneVecEnv's default: the contact approximation is opt-in
+    okw["ground_contact"] = env.ground_contact     # DroneVecEnv's default is DN_GROUND_CONTACT_AUTO: the oracle gets what dn_create resolved
     cfg = O.make_config(track.targets(), track.initial_xyzs, track.aviary_dim, circle=track.is_circle,
                         max_steps=max_steps, f32_state=f32_state, **okw)
     return env, O.OracleVecEnv(cfg, n, threads=8)
@@ -1340,7 +1340,7 @@ def test_three_wave_kernel_short_rollouts_and_ragged_tiles(n, K, waves, monkeypa
 @pytest.mark.parametrize("opts", [
     dict(track="circle4"), dict(track="circle6", cylinder=False), dict(include_distance=False),
     dict(normalize_actions=False), dict(obs_noise_sigma=0.02, act_noise_sigma=0.01, seed=9),
-    dict(threshold=5.0), dict(ground_contact=False, max_steps=7), dict(normalize_obs=True),
+    dict(threshold=5.0), dict(ground_contact=True, max_steps=7), dict(normalize_obs=True),
     dict(clip_rew=True, norm_rew=True), dict(physics="pyb_gnd_drag_dw"), dict(physics="pyb_drag", normalize_obs=True),
     dict(act="rpm", normalize_actions=False), dict(physics="pyb_gnd", norm_rew=True, obs_noise_sigma=0.02, act_noise_sigma=0.01),
 ])
