@@ -91,17 +91,23 @@ def parse():
     ap.add_argument("--num-envs", type=int, default=32768, help="drones per GPU")
     ap.add_argument("--track", default="reaching")
     ap.add_argument("--compute-dtype", default="float64", choices=["float64", "float32"])
-    ap.add_argument("--normalize-obs", action="store_true", help="fuse the per-drone NormalizeObservation (+432 B)")
+    ap.add_argument("--normalize-obs", dest="normalize_obs", action="store_true", default=True,
+                    help="per-drone NormalizeObservation fused in (+432 B of statistics per drone and launch): the DEFAULT, because the "
+                         "reference wraps every env in it (PBDroneSimulator.py:181)")
+    ap.add_argument("--no-normalize-obs", dest="normalize_obs", action="store_false",
+                    help="headline without the normaliser (otherwise reported as the `normalize_obs_off` sub-leg)")
     ap.add_argument("--mode", default="many", choices=["many", "single", "graph"],
                     help="many: one dn_step_many call; single: K python-level dn_step calls; graph: hipGraph replay")
     ap.add_argument("--action-batches", type=int, default=64, help="distinct resident action batches cycled")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ppo-rollout", action="store_true", help="skip the policy-in-the-loop rollout measurement")
-    ap.add_argument("--ppo-sharded", action="store_true",
+    ap.add_argument("--ppo-sharded", dest="ppo_sharded", action="store_true", default=None,
                     help="BASELINE configs[3]: also time the policy-in-the-loop rollout on every rank with the per-rollout RCCL "
-                         "all-gather of advantages/returns (opt-in: a collective inside the bench line is not worth risking "
-                         "the scaling run for)")
+                         "all-gather of advantages/returns.  On by default whenever WORLD_SIZE > 1 (the one collective the design "
+                         "has must be seen by the scaling run); a watchdog ends the process with a non-zero code if it hangs")
+    ap.add_argument("--no-ppo-sharded", dest="ppo_sharded", action="store_false")
+    ap.add_argument("--sharded-timeout", type=float, default=240.0, help="seconds the sharded leg may take before the watchdog exits(3)")
     ap.add_argument("--profile-lite", action="store_true",
                     help="for rocprofv3 --pmc passes (every dispatch costs tens of ms there): no pre-roll, a few launches per leg, "
                          "no NumPy-surface legs; timings of such a run mean nothing, only the counters do")
@@ -152,6 +158,35 @@ def cpu_baseline(track, num_envs, max_steps, seconds):
             "single_thread_value": round(one["value"], 1),
             "thread_ladder": {str(t): round(v, 1) for t, v in probe.items()}}
 
+MFMA_PEAK_FLOPS = 2.5e15               # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA peak (the 5 PF headline includes 2:1 sparsity)
+PPO_MACS_MFMA = 16 * 512 + 512 * 512 + 512 * 256 + 256 * 32      # per drone and network as the MFMA tiles see it (K, M padded to 16 / 32)
+PPO_MACS = 13 * 512 + 512 * 512 + 512 * 256                      # + 256 * out_dim: the network's own multiply-adds
+SAC_MACS_MFMA = 16 * 256 + 256 * 256 + 256 * 32
+SAC_MACS = 13 * 256 + 256 * 256 + 256 * 8
+
+
+def time_launches(torch, dev, fn, reps=200, warm=20):
+    """Average duration of one launch of `fn` (HIP events on the current stream around `reps` back-to-back launches)."""
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(dev)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize(dev)
+    return e0.elapsed_time(e1) * 1e3 / reps
+
+
+def mlp_kernel_leg(torch, dev, name, fn, n, macs_mfma, macs, nets, passes):
+    us = time_launches(torch, dev, fn)
+    mfma_flop = 2.0 * macs_mfma * n * nets * passes
+    return {"kernel": name, "avg_us": round(us, 2), "mfma_flop": mfma_flop, "useful_flop": 2.0 * macs * n * nets,
+            "mfma_tflops": round(mfma_flop / (us * 1e-6) / 1e12, 1), "mfma_frac": round(mfma_flop / (us * 1e-6) / MFMA_PEAK_FLOPS, 4),
+            "passes": passes, "what": "HIP events around 200 back-to-back launches of this kernel alone; mfma_frac = MFMA flop issued "
+                                      "(padded tiles; x3 for the split-bf16 float32 grade) / time / 2.5 PFLOP/s dense peak"}
+
 
 def ppo_rollout(pkg, track, n, max_steps, dev, rank):
     """BASELINE configs[2] as the learner sees it: SB3-PPO-shaped rollout collection with the policy in the loop --
@@ -194,7 +229,38 @@ def ppo_rollout(pkg, track, n, max_steps, dev, rank):
             best = max(best, n * n_steps * reps / (time.perf_counter() - t0))
         res[label] = best
         env.close()
-    return {"value": round(res["fused_graph"], 1), "unit": "env-steps/s",
+    # the kernels of the fused loop on their own (what rocprofv3 --kernel-trace --stats shows for the same launches: profiles/r03_*)
+    from drl_dronenavigation_amd.policy_mfma import mlp_forward
+    kernels = {}
+    try:
+        env = pkg.DroneVecEnv(track, n, max_steps=max_steps, normalize_obs=True, env_id_offset=rank * n, device=dev)
+        obs = env.reset_tensor().clone()
+        mean, val = torch.zeros((n, 4), device=dev), torch.zeros((n, 1), device=dev)
+        for gname, pol, kname, passes in (("bf16", fused, "dn_mlp_pair_kernel<false>", 1), ("fp16", fused16, "dn_mlp_pair_kernel<true>", 1),
+                                          ("fp32", fused32, "dn_mlp_x3_kernel", 3)):
+            kernels["mlp_" + gname] = mlp_kernel_leg(torch, dev, kname, lambda pol=pol: mlp_forward([pol.pi, pol.vf], obs, [mean, val]),
+                                                     n, PPO_MACS_MFMA, PPO_MACS + 256 * 2.5, 2, passes)
+        lib, h = pkg._capi.load(), env._handle
+        sp = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        bufs = dict(act=torch.zeros((n, 4), device=dev), logp=torch.zeros(n, device=dev), obs=torch.zeros((n, 13), device=dev),
+                    rew=torch.zeros(n, device=dev), done=torch.zeros(n, dtype=torch.uint8, device=dev),
+                    trunc=torch.zeros(n, dtype=torch.uint8, device=dev), found=torch.zeros(n, dtype=torch.int32, device=dev),
+                    term=torch.zeros((n, 13), device=dev))
+        log_std = (C.c_float * 4)(0.0, 0.0, 0.0, 0.0)
+
+        def step_sampled():
+            pkg._capi.check(lib.dn_step_sampled(h, mean.data_ptr(), log_std, 1, 0, bufs["act"].data_ptr(), bufs["logp"].data_ptr(),
+                                                bufs["obs"].data_ptr(), bufs["rew"].data_ptr(), bufs["done"].data_ptr(),
+                                                bufs["trunc"].data_ptr(), bufs["found"].data_ptr(), bufs["term"].data_ptr(), None, None, None, sp))
+        us = time_launches(torch, dev, step_sampled)
+        kernels["step_sampled"] = {"kernel": f"dn_step_pqx_kernel<double, true, false, true> ({env.kernel_waves(fused=False)} waves per tile)"
+                                             if env.kernel_waves(fused=False) == 3 else "dn_step_many_1w_kernel<double, true, false, true, false, true>",
+                                   "avg_us": round(us, 2), "what": "Gaussian draw + clip + log-probability + the control step, obs normaliser on; "
+                                                                   "eager back-to-back launches (host-bound below ~3 us)"}
+        env.close()
+    except Exception as exc:  # noqa: BLE001
+        kernels["error"] = f"{type(exc).__name__}: {exc}"
+    return {"value": round(res["fused_graph"], 1), "unit": "env-steps/s", "kernels": kernels,
             "policy": "fused MFMA MLP (dn_mlp_forward, bf16 weights/activations, float32 accumulate) + dn_step_sampled "
                       "(Gaussian sample + step): two launches per step, the truncation bootstrap as one masked critic pass per rollout, hipGraph replay",
             "value_fp16_grade": round(res["fused_graph_fp16"], 1),
@@ -248,23 +314,37 @@ def sac_collect(pkg, track, n, max_steps, dev, rank):
             best = max(best, n * steps * reps / (time.perf_counter() - t0))
         res[label] = round(best, 1)
         env.close()
-    fused = pkg.FusedSacActor(actor, n, dev, grade="fp32")
     obs = torch.rand(n, 13, device=dev)
-    kern = {}
-    for grade in ("bf16", "fp32"):
-        fused.grade = grade
-        fused.refresh()
-        for _ in range(5):
-            fused.mean_log_std(obs)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(50):
-            fused.mean_log_std(obs)
-        e1.record()
-        torch.cuda.synchronize(dev)
-        kern[grade] = round(e0.elapsed_time(e1) * 1e3 / 50, 2)
+    kern, kernels = {}, {}
+    for grade, kname, passes in (("bf16", "dn_mlp_sac_lds_kernel<false, false>", 1), ("fp16", "dn_mlp_sac_lds_kernel<false, true>", 1),
+                                 ("fp32", "dn_mlp_sac_lds_kernel<true, false>", 3)):
+        fa = pkg.FusedSacActor(actor, n, dev, grade=grade)
+        kernels["actor_" + grade] = mlp_kernel_leg(torch, dev, kname, lambda fa=fa: fa.mean_log_std(obs), n, SAC_MACS_MFMA, SAC_MACS, 1, passes)
+        kern[grade] = kernels["actor_" + grade]["avg_us"]
+    try:
+        env = pkg.DroneVecEnv(track, n, max_steps=max_steps, normalize_obs=True, act_noise_sigma=0.002, obs_noise_sigma=0.01,
+                              seed=1, env_id_offset=rank * n, device=dev)
+        env.reset_tensor()
+        lib, h = pkg._capi.load(), env._handle
+        sp = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        mls = torch.zeros((n, 8), device=dev)
+        b = dict(act=torch.zeros((n, 4), device=dev), obs=torch.zeros((n, 13), device=dev), rew=torch.zeros(n, device=dev),
+                 done=torch.zeros(n, dtype=torch.uint8, device=dev), trunc=torch.zeros(n, dtype=torch.uint8, device=dev),
+                 found=torch.zeros(n, dtype=torch.int32, device=dev), term=torch.zeros((n, 13), device=dev))
+
+        def step_squashed():
+            pkg._capi.check(lib.dn_step_squashed(h, mls.data_ptr(), 1, 0, b["act"].data_ptr(), None, b["obs"].data_ptr(), b["rew"].data_ptr(),
+                                                 b["done"].data_ptr(), b["trunc"].data_ptr(), b["found"].data_ptr(), b["term"].data_ptr(),
+                                                 None, None, None, sp))
+        kernels["step_squashed"] = {"kernel": "dn_step_pqx_kernel<double, true, true, true>" if env.kernel_waves(fused=False) == 3
+                                    else "dn_step_many_1w_kernel<double, true, true, true, false, true>",
+                                    "avg_us": round(time_launches(torch, dev, step_squashed), 2),
+                                    "what": "clamp + Philox draw + tanh + the control step with action / observation noise and the obs normaliser"}
+        env.close()
+    except Exception as exc:  # noqa: BLE001
+        kernels["error"] = f"{type(exc).__name__}: {exc}"
     return {"value": res["fused MFMA actor fp32 grade, two launches per step, hipGraph"], "unit": "env-steps/s", "variants": res, "num_envs": n, "steps": steps,
-            "actor_forward_us_python_loop": kern,
+            "actor_forward_us_python_loop": kern, "kernels": kernels,
             "what": "SAC collection loop of config 5 on one shard: dn_mlp_forward (actor 13-256-256 ReLU -> mu | log_std) and dn_step_squashed "
                     "(clamp, Philox draw, tanh inside the step kernel; Philox action + observation noise, per-drone obs normaliser), every output "
                     "written in place into the replay ring; `value` = float32-grade actor, the whole ring-buffer cycle replayed from a hipGraph"}
@@ -293,10 +373,11 @@ def ppo_rollout_sharded(pkg, track, n, max_steps, dev, rank, world, dist):
     torch.cuda.synchronize(dev)
     tw = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
     dist.all_reduce(tw, op=dist.ReduceOp.MAX)
-    assert out["advantages_global"].shape == (n_steps, n * world)
+    assert tuple(out["advantages_global"].shape) == (n_steps, world, n)      # strided views of the static receive buffer
     env.close()
     return {"value": round(n * world * n_steps * reps / float(tw[0]), 1), "unit": "env-steps/s", "n_steps": n_steps,
             "global_num_envs": n * world, "all_gather_bytes_sent_per_rank_per_rollout": 2 * n_steps * n * 4,
+            "rccl_world_size": dist.get_world_size(),
             "what": "FusedRolloutCollector(gather=True) on every rank: policy in the loop + one RCCL all-gather of the packed "
                     "advantages/returns per rollout"}
 
@@ -493,11 +574,13 @@ def main():
     single_step["launched_from"] = "hipGraph replay of dn_step launches" if "graph" in others else "python loop of dn_step calls"
     single_step["python_loop_us_per_vector_step"] = others["single"]["us_per_vector_step"]
 
-    # the configuration the reference actually runs: NormalizeObservation on every env (PBDroneSimulator.py:181)
-    norm_on = None
-    if world == 1 and not args.normalize_obs:
+    # the same workload with the normaliser switched the OTHER way (the headline has it on, as the reference does,
+    # PBDroneSimulator.py:181; the sub-leg shows what the bare step costs)
+    other_norm = not args.normalize_obs
+    norm_leg = None
+    if world == 1:
         try:
-            env_n = pkg.DroneVecEnv(track, n, max_steps=max_steps, normalize_obs=True, compute_dtype=args.compute_dtype,
+            env_n = pkg.DroneVecEnv(track, n, max_steps=max_steps, normalize_obs=other_norm, compute_dtype=args.compute_dtype,
                                     env_id_offset=rank * n, device=dev)
             env_n.reset_tensor()
             hn = env_n._handle
@@ -518,13 +601,15 @@ def main():
                     if rc:
                         pkg._capi.check(rc)
 
-            norm_on = {"fused": leg("many", many_n, k_many, A, True, env_n.kernel_waves(fused=True)),
-                       "single_step": leg("single", single_n, k_single, 1, True, env_n.kernel_waves(fused=False)),
-                       "what": "same workload with the per-drone NormalizeObservation fused in (the reference always wraps it, "
-                               "PBDroneSimulator.py:181): +432 B of statistics per drone and launch"}
+            norm_leg = {"fused": leg("many", many_n, k_many, A, other_norm, env_n.kernel_waves(fused=True)),
+                        "single_step": leg("single", single_n, k_single, 1, other_norm, env_n.kernel_waves(fused=False)),
+                        "what": ("same workload WITHOUT the per-drone NormalizeObservation (the bare step; the reference never runs it "
+                                 "this way)" if not other_norm else
+                                 "same workload with the per-drone NormalizeObservation fused in (the reference always wraps it, "
+                                 "PBDroneSimulator.py:181): +432 B of statistics per drone and launch")}
             env_n.close()
         except Exception as exc:  # noqa: BLE001
-            norm_on = {"error": f"{type(exc).__name__}: {exc}"}
+            norm_leg = {"error": f"{type(exc).__name__}: {exc}"}
 
     # where HBM IS the bound: the same step kernel over a fleet that fills the chip many times over (one wave per 64 drones,
     # 32768 workgroups), one control step per launch -- the regime the byte model of SURVEY 8(d) describes
@@ -574,8 +659,23 @@ def main():
             others["sb3_numpy_step_infos_" + mode_] = {"us_per_vector_step": round(us, 1), "value": round(n / (us * 1e-6), 1)}
 
     sharded = None
-    if args.ppo_sharded and dist is not None:
-        sharded = ppo_rollout_sharded(pkg, track, n, max_steps, dev, rank, world, dist)
+    want_sharded = (world > 1) if args.ppo_sharded is None else args.ppo_sharded
+    if want_sharded and dist is not None:
+        # the one collective of the design (RCCL all-gather of advantages / returns per rollout).  A hung collective must not
+        # hang the scaling run: a watchdog thread ends THIS process with a non-zero code (never a re-exec) if the leg overruns.
+        import threading
+
+        def _overrun():
+            print(f"bench.py: rank {rank}: the sharded PPO leg (RCCL all-gather) did not finish within {args.sharded_timeout:.0f} s; "
+                  "exiting with code 3", file=sys.stderr, flush=True)
+            os._exit(3)
+        dog = threading.Timer(args.sharded_timeout, _overrun)
+        dog.daemon = True
+        dog.start()
+        try:
+            sharded = ppo_rollout_sharded(pkg, track, n, max_steps, dev, rank, world, dist)
+        finally:
+            dog.cancel()
     if rank == 0:
         value = n * world * K / wall
         step_us = gpu_ms * 1e3 / K
@@ -597,6 +697,10 @@ def main():
                        "num_envs_per_gpu": n, "global_num_envs": n * world, "track": args.track,
                        "state_dtype": "f32", "launch_mode": args.mode, "parallelism": f"env-shard x{world} (no data-path collective)",
                        "episodes_finished_rank0": st["episodes"],
+                       "rccl_world_size": (dist.get_world_size() if dist is not None else 1),
+                       "ground_contact": ("on" if env.ground_contact else
+                                          "resolved off by DN_GROUND_CONTACT_AUTO: on this track every point low enough to touch the floor is "
+                                          "already outside the corridor of every segment, so the contact term of PBDroneEnv.py:699 cannot fire"),
                        "preroll": {"seconds": PREROLL_SECONDS, "vector_steps": pre_steps,
                                    "what": "untimed fused stepping before --warmup so that the timed region runs at a settled clock"}},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -618,7 +722,7 @@ def main():
                                                   "what": "two 64-drone tiles (eight waves) per CU: the four SIMDs issue 95 % of the step time; the same step at "
                                                           "2 097 152 drones, one step per launch, is the HBM-bound case (hbm_bound_fleet)"}},
             "single_step": single_step,
-            "normalize_obs_on": norm_on,
+            ("normalize_obs_on" if other_norm else "normalize_obs_off"): norm_leg,
             "hbm_bound_fleet": large,
             "other_launch_shapes": others,
         }

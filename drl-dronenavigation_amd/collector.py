@@ -58,7 +58,8 @@ def all_gather_rollout(advantages, returns, group=None):
     """All-gather the per-rank [n_steps, N_local] advantages and returns into [n_steps, N_global] tensors whose
     columns are in global drone order.  One collective for both arrays (packed [2, T, N_local] send buffer ->
     [R*2, T, N_local] receive buffer), none at all without a process group (a one-rank group still goes through the
-    collective, which keeps that code path testable on one GPU)."""
+    collective, which keeps that code path testable on one GPU).  Convenience form: it allocates the receive buffer and a
+    permuted copy on every call; a collector that gathers every rollout uses RolloutGather below, which does neither."""
     import torch.distributed as dist
     if advantages.shape != returns.shape or advantages.dim() != 2:
         raise ValueError("advantages and returns must both be [n_steps, N_local]")
@@ -71,6 +72,34 @@ def all_gather_rollout(advantages, returns, group=None):
     dist.all_gather_into_tensor(recv, send, group=group)
     out = recv.view(world, 2, T, n).permute(1, 2, 0, 3).reshape(2, T, world * n)   # rank-major columns = global order
     return out[0], out[1]
+
+
+class RolloutGather:
+    """The per-rollout exchange of BASELINE config 4 with every buffer allocated ONCE: `send` [2, T, N_local] is the storage the
+    collector's advantages / returns live in (`advantages = send[0]`, `returns = send[1]`: dn_gae writes straight into the send
+    buffer, no packing copy), `recv` [R, 2, T, N_local] is what `all_gather_into_tensor` fills, and the global arrays are
+    returned as strided VIEWS of it, shaped [T, R, N_local]: element [t, r, i] belongs to global drone r * N_local + i (rank-major
+    = global drone order), so `view.reshape(T, R * N_local)` is the [n_steps, N_global] array where a consumer needs it flat.
+    67 MB per rollout at R = 8, n_steps = 32, 32 768 drones per rank: neither allocated nor copied per rollout.
+    Without a process group gather() returns the local arrays as [T, 1, N_local] views (no collective)."""
+
+    def __init__(self, n_steps, num_envs, device, group=None, dtype=torch.float32):
+        import torch.distributed as dist
+        self.group = group
+        self.active = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if self.active else 1
+        self.send = torch.zeros((2, int(n_steps), int(num_envs)), dtype=dtype, device=device)
+        self.recv = torch.zeros((self.world, 2, int(n_steps), int(num_envs)), dtype=dtype, device=device) if self.active else None
+
+    advantages = property(lambda self: self.send[0])
+    returns = property(lambda self: self.send[1])
+
+    def gather(self):
+        if not self.active:
+            return self.send[0].unsqueeze(1), self.send[1].unsqueeze(1)
+        import torch.distributed as dist
+        dist.all_gather_into_tensor(self.recv.view(self.world * 2, *self.send.shape[1:]), self.send, group=self.group)
+        return self.recv[:, 0].permute(1, 0, 2), self.recv[:, 1].permute(1, 0, 2)      # [T, R, n] views, no copy
 
 
 class RolloutCollector:
@@ -392,8 +421,10 @@ class FusedRolloutCollector:
     value SB3 computes on the spot) and ONE dn_add_bootstrap adds it; then dn_gae.  The whole rollout is captured into one
     hipGraph on the second call (`use_graph`).  Same results contract as RolloutCollector (SB3 collect_rollouts
     semantics); the action noise comes from Philox (seed, global drone id, step counter), so a rollout is reproducible
-    and independent of how the drones are sharded.  Call `policy.refresh()` after optimiser steps and `recapture()`
-    if log_std changed (it is baked into the captured launches)."""
+    and independent of how the drones are sharded.  Call `policy.refresh()` after optimiser steps (it re-packs in place, so
+    the captured launches see the new weights) and `recapture()` if log_std changed (it is baked into the captured launches).
+    With `gather`, `advantages_global` / `returns_global` are [n_steps, R, N_local] views of a static receive buffer
+    (RolloutGather: one all_gather_into_tensor per rollout, nothing allocated or copied per rollout)."""
 
     def __init__(self, env, policy, n_steps, *, gamma=0.99, gae_lambda=0.95, bootstrap_truncated=True, gather=False,
                  group=None, use_graph=True, seed=0):
@@ -414,8 +445,13 @@ class FusedRolloutCollector:
             values=torch.empty((T, n), dtype=f32, device=dev), log_probs=torch.empty((T, n), dtype=f32, device=dev),
             rewards=torch.empty((T, n), dtype=f32, device=dev),
             episode_starts=torch.ones((T + 1, n), dtype=u8, device=dev),          # SB3: _last_episode_starts = True
-            advantages=torch.empty((T, n), dtype=f32, device=dev), returns=torch.empty((T, n), dtype=f32, device=dev),
             last_values=torch.empty((n, 1), dtype=f32, device=dev))
+        # advantages / returns live in the all-gather's send buffer (RolloutGather): dn_gae writes them where RCCL reads them
+        self._gather = RolloutGather(T, n, dev, group) if self.gather else None
+        if self._gather is not None:
+            self.buf["advantages"], self.buf["returns"] = self._gather.advantages, self._gather.returns
+        else:
+            self.buf["advantages"], self.buf["returns"] = torch.empty((T, n), dtype=f32, device=dev), torch.empty((T, n), dtype=f32, device=dev)
         self._mean = torch.empty((n, ACT_DIM), dtype=f32, device=dev)
         cfg = env.cfg
         self._sampled_step = not (cfg.clip_rew or cfg.norm_rew or cfg.physics or cfg.action_type or cfg.random_spawn or cfg.zero_damping)   # dn_step_sampled's scope
@@ -490,5 +526,6 @@ class FusedRolloutCollector:
                    episode_starts=b["episode_starts"][:T], advantages=b["advantages"], returns=b["returns"],
                    last_values=b["last_values"].view(-1), last_dones=b["episode_starts"][T], next_obs=b["obs"][T])
         if self.gather:
-            out["advantages_global"], out["returns_global"] = all_gather_rollout(out["advantages"], out["returns"], self.group)
+            # [n_steps, R, N_local] strided views of the static receive buffer ([t, r, i] = global drone r * N_local + i)
+            out["advantages_global"], out["returns_global"] = self._gather.gather()
         return out

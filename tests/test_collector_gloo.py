@@ -1,4 +1,4 @@
-"""Multi-rank path on CPU: world_size 2 over gloo (the GPU job uses the same calls over RCCL).
+"""Multi-rank path on CPU: world_size 2 and 4 over gloo (the GPU job uses the same calls over RCCL).
 
 Each rank steps its shard of drones with the CPU oracle standing in for the device (test infrastructure),
 computes GAE on the shard and all-gathers advantages/returns through the product's
@@ -57,7 +57,7 @@ def _worker(rank, world, port, tmp):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from drl_dronenavigation_amd.collector import ShardPlan, all_gather_rollout
+        from drl_dronenavigation_amd.collector import RolloutGather, ShardPlan, all_gather_rollout
         plan = ShardPlan.from_env(N_GLOBAL)
         assert (plan.rank, plan.world_size, plan.num_envs, plan.env_id_offset) == (rank, world, N_GLOBAL // world,
                                                                                   rank * N_GLOBAL // world)
@@ -65,6 +65,18 @@ def _worker(rank, world, port, tmp):
         adv, ret, _ = _run_shard(plan, acts)
         g_adv, g_ret = all_gather_rollout(torch.from_numpy(adv), torch.from_numpy(ret))
         assert g_adv.shape == (T, N_GLOBAL) and g_ret.shape == (T, N_GLOBAL)
+        # the collector's form: static send / receive buffers, the results strided views of the receive buffer -- twice, to show
+        # that a second rollout lands in the same storage without a new allocation
+        rg = RolloutGather(T, plan.num_envs, "cpu")
+        assert rg.world == world and rg.recv.shape == (world, 2, T, plan.num_envs)
+        ptr = rg.recv.data_ptr()
+        for rep in range(2):
+            rg.advantages.copy_(torch.from_numpy(adv) + rep)
+            rg.returns.copy_(torch.from_numpy(ret) - rep)
+            v_adv, v_ret = rg.gather()
+            assert v_adv.shape == (T, world, plan.num_envs) and v_adv.data_ptr() == ptr and rg.recv.data_ptr() == ptr
+            assert v_adv._base is not None and v_ret._base is not None          # views, not copies
+            assert torch.equal(v_adv.reshape(T, N_GLOBAL), g_adv + rep) and torch.equal(v_ret.reshape(T, N_GLOBAL), g_ret - rep)
         # every rank holds the full arrays, identical bits
         chk = torch.stack((g_adv.double().sum(), g_ret.double().sum()))
         lo, hi = chk.clone(), chk.clone()
@@ -78,13 +90,14 @@ def _worker(rank, world, port, tmp):
         dist.destroy_process_group()
 
 
-def test_sharded_rollout_all_gather_matches_single_process(tmp_path):
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_rollout_all_gather_matches_single_process(tmp_path, world):
     from drl_dronenavigation_amd.collector import ShardPlan
     rng = np.random.default_rng(0)
     acts = np.where(rng.random((T, N_GLOBAL, 1)) < 0.5, rng.uniform(-1, 1, (T, N_GLOBAL, 4)),
                     0.0922 + 0.003 * rng.standard_normal((T, N_GLOBAL, 4))).astype(np.float32)
     np.save(tmp_path / "acts.npy", acts)
-    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     adv1, ret1, n_done = _run_shard(ShardPlan(N_GLOBAL, 1, 0), acts)
     assert n_done >= 0
     adv2, ret2 = np.load(tmp_path / "adv.npy"), np.load(tmp_path / "ret.npy")
@@ -103,5 +116,8 @@ def test_shard_plan_validation():
         ShardPlan(64, 2, 2)
     a = torch.zeros(3, 4)
     assert all_gather_rollout(a, a)[0] is a            # no process group: identity, no collective
+    from drl_dronenavigation_amd.collector import RolloutGather
+    rg = RolloutGather(3, 4, "cpu")
+    assert not rg.active and rg.gather()[0].shape == (3, 1, 4) and rg.gather()[0].data_ptr() == rg.send.data_ptr()
     with pytest.raises(ValueError):
         all_gather_rollout(a, torch.zeros(3, 5))
