@@ -106,7 +106,8 @@ _lib = None
 
 
 def library_path():
-    return _build.LIB_PATH
+    # DN_LIB_PATH: an alternative build of the same ABI (A/B measurements of kernel variants); default = the in-tree library
+    return os.environ.get("DN_LIB_PATH") or _build.LIB_PATH
 
 
 def load():

@@ -422,7 +422,8 @@ class FusedRolloutCollector:
     hipGraph on the second call (`use_graph`).  Same results contract as RolloutCollector (SB3 collect_rollouts
     semantics); the action noise comes from Philox (seed, global drone id, step counter), so a rollout is reproducible
     and independent of how the drones are sharded.  Call `policy.refresh()` after optimiser steps (it re-packs in place, so
-    the captured launches see the new weights) and `recapture()` if log_std changed (it is baked into the captured launches).
+    the captured launches see the new weights); a changed log_std (baked into the captured launches by value) is noticed at the
+    next collect(), which captures again (`recapture()` forces it).
     With `gather`, `advantages_global` / `returns_global` are [n_steps, R, N_local] views of a static receive buffer
     (RolloutGather: one all_gather_into_tensor per rollout, nothing allocated or copied per rollout)."""
 
@@ -464,7 +465,7 @@ class FusedRolloutCollector:
         self._tv = torch.zeros((T * n, 1), dtype=f32, device=dev)
         self.buf["obs"][0].copy_(env.reset_tensor())
         self.num_timesteps = 0
-        self._graph, self._calls = None, 0
+        self._graph, self._calls, self._captured_log_std = None, 0, None
 
     def recapture(self):
         self._graph = None
@@ -512,9 +513,14 @@ class FusedRolloutCollector:
                 b["obs"][0].copy_(b["obs"][T])
                 b["episode_starts"][0].copy_(b["episode_starts"][T])
             if self.use_graph and self._calls >= 1:
+                # dn_step_sampled takes log_std by value (a HOST float[4]): it is baked into the captured launches, so a
+                # refresh() that moved it (PPO trains log_std) makes the graph stale -- capture again
+                if self._graph is not None and tuple(self.policy.log_std_host) != self._captured_log_std:
+                    self._graph = None
                 if self._graph is None:
                     torch.cuda.synchronize(env.device)
                     self._graph = torch.cuda.CUDAGraph()
+                    self._captured_log_std = tuple(self.policy.log_std_host)
                     with torch.cuda.graph(self._graph):
                         self._rollout()
                 self._graph.replay()

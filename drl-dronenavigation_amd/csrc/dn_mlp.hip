@@ -88,6 +88,18 @@ MLP_DEV unsigned pack2(float a, float b)
     pk[1] = (__bf16)b;
     return __builtin_bit_cast(unsigned, pk);                 // one v_cvt_pk_bf16_f32
 }
+// The machine scheduler sinks every LDS fragment read next to the MFMA that consumes it (it minimises live ranges), which
+// collapses the software ring below to a depth of one or two: the ISA then reads `ds_read_b128; s_waitcnt lgkmcnt(0); v_mfma`
+// and every MFMA waits out a full LDS round trip (measured: 92 cycles per MFMA in the four-wave shape against 32.6 for the same
+// stream with the ring kept, profiles/microbench/mfma_multiacc.hip).  A zero-mask sched_barrier after every K-step pins the
+// source order across K-steps -- fragment read issued RING steps ahead of its MFMA, one slice of the previous tile's epilogue
+// per step -- and leaves the order inside a step to the compiler.
+#define MLP_PIN() __builtin_amdgcn_sched_barrier(0)
+#ifndef DN_X3_DMA_SPREAD
+#define DN_X3_DMA_SPREAD 2    // float32-grade kernel: LDS-DMA pieces issued this many per K-step, between the MFMAs, instead of in one burst at the
+                              // top of the tile (0 = burst).  Measured, interleaved A/B at 32 768 drones: 197.7 (burst) / 191 (1) / 187.7 us (2)
+#endif
+
 MLP_DEV void epilogue_pair(const f32x16 &acc, const int q, u32x4 &lo, u32x4 &hi)
 {   // accumulator elements 2q, 2q+1 -> one dword of the packed B operand
     const unsigned u = pack2(tanh_fast(acc[2 * q]), tanh_fast(acc[2 * q + 1]));
@@ -150,6 +162,7 @@ MLP_DEV void layer(const uint4 *__restrict__ w, const float *__restrict__ bias, 
     uint4 ring[P];
 #pragma unroll
     for (int t = 0; t < P; ++t) ring[t] = wl[t * 64];
+    MLP_PIN();
     f32x16 prev;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
@@ -164,6 +177,7 @@ MLP_DEV void layer(const uint4 *__restrict__ w, const float *__restrict__ bias, 
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, in[kk]), acc, 0, 0, 0);
             // the previous tile's epilogue, one pair of elements every fourth MFMA (KS = 32)
             if (TANH && KS == 32 && m > 0 && (kk & 3) == 3) epilogue_pair(prev, kk >> 2, out[2 * (m - 1)], out[2 * (m - 1) + 1]);
+            MLP_PIN();
         }
         if (TANH && KS == 32 && m + 1 < MT) prev = acc;
         else epilogue(acc, TANH, out[2 * m], out[2 * m + 1]);
@@ -273,6 +287,32 @@ MLP_DEV void chunk_barrier()
     __builtin_amdgcn_s_waitcnt(0x0070);                    // vmcnt(0) & lgkmcnt(0): my DMA pieces landed, my LDS reads done
     __builtin_amdgcn_s_barrier();
 }
+// Timing builds (-DDN_MLP_STAMP; never shipped): s_memtime before and after every chunk barrier of workgroup 0's waves, dumped by
+// dn_launch_mlp to the file named by DN_MLP_STAMP_FILE.  STP_PARAM / STP_ARG thread the per-wave counter through the bodies.
+#ifdef DN_MLP_STAMP
+__device__ long long g_stamp[8][256];
+struct Stamp { int n, wave; bool on; };
+MLP_DEV void stamp(Stamp &s)
+{
+    if (s.on && s.n < 256) g_stamp[s.wave][s.n] = (long long)__builtin_readcyclecounter();
+    ++s.n;
+}
+MLP_DEV void chunk_barrier_stamped(Stamp &s)
+{
+    stamp(s);
+    __builtin_amdgcn_s_waitcnt(0x0070);
+    stamp(s);
+    __builtin_amdgcn_s_barrier();
+    stamp(s);
+}
+#define STP_PARAM , Stamp &stp
+#define STP_ARG , stp
+#define CHUNK_BARRIER() chunk_barrier_stamped(stp)
+#else
+#define STP_PARAM
+#define STP_ARG
+#define CHUNK_BARRIER() chunk_barrier()
+#endif
 
 // A 512-input layer, weights through LDS: one chunk = the 32 fragments of one M-tile.  PAR = parity of the LDS buffer
 // that holds this layer's chunk 0 (requested by the previous layer, landed before its last barrier); `next` = the
@@ -302,13 +342,22 @@ MLP_DEV void layer_lds(const uint4 *__restrict__ w, const float *__restrict__ bi
         uint4 ring[LDS_RING];
 #pragma unroll
         for (int kk = 0; kk < LDS_RING; ++kk) ring[kk] = cur[kk * 64 + lane];
+        MLP_PIN();
+        float t_even = 0.0f;
 #pragma unroll
         for (int kk = 0; kk < CHUNK; ++kk) {
             const uint4 a = ring[kk % LDS_RING];
             if (kk + LDS_RING < CHUNK) ring[kk % LDS_RING] = cur[(kk + LDS_RING) * 64 + lane];
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, in[kk]), acc, 0, 0, 0);
-            // the previous tile's epilogue, one pair of elements every fourth MFMA
-            if (m > 0 && (kk & 3) == 3) epilogue_pair(prev, kk >> 2, out[2 * (m - 1)], out[2 * (m - 1) + 1]);
+            // the previous tile's epilogue, one ELEMENT every second MFMA (one wave per SIMD hides ~5 issue slots behind an
+            // MFMA: a tanh is four of them): element 2q at kk = 4q + 1, element 2q + 1 and the pack at kk = 4q + 3
+            if (m > 0 && (kk & 3) == 1) t_even = tanh_fast(prev[2 * (kk >> 2)]);
+            if (m > 0 && (kk & 3) == 3) {
+                const int q = kk >> 2;
+                const unsigned u = pack2(t_even, tanh_fast(prev[2 * q + 1]));
+                if (q < 4) out[2 * (m - 1)][q] = u; else out[2 * (m - 1) + 1][q - 4] = u;
+            }
+            MLP_PIN();
         }
         if (m + 1 < MT) prev = acc;
         else epilogue(acc, true, out[2 * m], out[2 * m + 1]);
@@ -470,7 +519,7 @@ MLP_DEV void merge_partial(const float4 *xb, const int parity, const int lane, f
 // operands of the next layer.
 template <bool F16, int HALF, int MT, int PAR, int NEXT_FR>
 MLP_DEV void layer_pair(const uint4 *__restrict__ w, const float *lbias, const uint4 *__restrict__ next, const u32x4 (&inh)[16],
-                        u32x4 (&outh)[MT], uint4 *wbuf, float4 *xb, const int wave, const int lane)
+                        u32x4 (&outh)[MT], uint4 *wbuf, float4 *xb, const int wave, const int lane STP_PARAM)
 {
     const int g = lane >> 5;
     f32x16 prev;
@@ -478,8 +527,10 @@ MLP_DEV void layer_pair(const uint4 *__restrict__ w, const float *lbias, const u
     for (int m = 0; m < MT; ++m) {
         uint4 *cur = wbuf + ((PAR + m) & 1) * (CHUNK * 64);
         uint4 *nxt = wbuf + ((PAR + m + 1) & 1) * (CHUNK * 64);
+#if !defined(DN_MLP_ABLATE_DMA)
         if (m + 1 < MT) dma_pair<CHUNK>(w + (size_t)(m + 1) * CHUNK * 64, nxt, wave, lane);
         else dma_pair<NEXT_FR>(next, nxt, wave, lane);
+#endif
         const bool fin = m > 0 && (((m - 1) >= MT / 2) == (HALF == 1));      // I own tile m-1: finish it under this tile's MFMAs
         if (fin) merge_partial(xb, (m - 1) & 1, lane, prev);
         f32x16 acc;
@@ -491,19 +542,26 @@ MLP_DEV void layer_pair(const uint4 *__restrict__ w, const float *lbias, const u
         uint4 ring[LDS_RING];
 #pragma unroll
         for (int kk = 0; kk < LDS_RING; ++kk) ring[kk] = cur[(HALF * 16 + kk) * 64 + lane];
+        MLP_PIN();
+        float t_even = 0.0f;
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) {
             const uint4 a = ring[kk % LDS_RING];
             if (kk + LDS_RING < 16) ring[kk % LDS_RING] = cur[(HALF * 16 + kk + LDS_RING) * 64 + lane];
             acc = mfma16<F16>(a, inh[kk], acc);
-            if (fin && (kk & 1)) {
-                const int ml = (m - 1) - HALF * (MT / 2);
-                epilogue_pair_t<F16>(prev, kk >> 1, outh[2 * ml], outh[2 * ml + 1]);
+            if (fin) {                                       // one element of the owned previous tile per MFMA, packed in pairs
+                const int ml = (m - 1) - HALF * (MT / 2), q = kk >> 1;
+                if (!(kk & 1)) t_even = tanh_fast(prev[2 * q]);
+                else {
+                    const unsigned u = pack2t<F16>(t_even, tanh_fast(prev[2 * q + 1]));
+                    if (q < 4) outh[2 * ml][q] = u; else outh[2 * ml + 1][q - 4] = u;
+                }
             }
+            MLP_PIN();
         }
         if ((m >= MT / 2) == (HALF == 1)) prev = acc;                         // mine: keep, finish next round
         else park_partial(xb, m & 1, lane, acc);                             // partner's: hand over through LDS
-        chunk_barrier();
+        CHUNK_BARRIER();
     }
     if (HALF == 1) {                                                         // the last tile belongs to half 1
         merge_partial(xb, (MT - 1) & 1, lane, prev);
@@ -513,7 +571,7 @@ MLP_DEV void layer_pair(const uint4 *__restrict__ w, const float *lbias, const u
 
 template <bool F16, int HALF>
 MLP_DEV void mlp_pair_body(const MlpArgs &a, const MlpNetDev &net, uint4 *wbuf, float4 *xb, const float *lbias, const int wave,
-                           const int lane, const long long row0, const bool live, const long long row, const bool tile_wanted)
+                           const int lane, const long long row0, const bool live, const long long row, const bool tile_wanted STP_PARAM)
 {
     const int g = lane >> 5, col = lane & 31;
     u32x4 x0;
@@ -537,11 +595,11 @@ MLP_DEV void mlp_pair_body(const MlpArgs &a, const MlpNetDev &net, uint4 *wbuf, 
         acc = mfma16<F16>(w, x0, acc);
         epilogue_t<F16>(acc, h1[2 * ml], h1[2 * ml + 1]);
     }
-    chunk_barrier();
+    CHUNK_BARRIER();
     u32x4 h2[16];
-    layer_pair<F16, HALF, H2 / 32, 1, CHUNK>(net.w2, lbias + H1, net.w3, h1, h2, wbuf, xb, wave, lane);
+    layer_pair<F16, HALF, H2 / 32, 1, CHUNK>(net.w2, lbias + H1, net.w3, h1, h2, wbuf, xb, wave, lane STP_ARG);
     u32x4 h3[8];
-    layer_pair<F16, HALF, H3 / 32, 1, H3 / 16>(net.w3, lbias + H1 + H2, net.wh, h2, h3, wbuf, xb, wave, lane);
+    layer_pair<F16, HALF, H3 / 32, 1, H3 / 16>(net.w3, lbias + H1 + H2, net.wh, h2, h3, wbuf, xb, wave, lane STP_ARG);
     // head: one tile, K = 256 = 16 K-steps, 8 per half; fragments in buffer 1 (parity 1 + 16 + 8 -> 1)
     f32x16 acc;
     if (HALF == 0) bias_init(lbias + H1 + H2 + H3, 0, g, acc);
@@ -556,7 +614,7 @@ MLP_DEV void mlp_pair_body(const MlpArgs &a, const MlpNetDev &net, uint4 *wbuf, 
         acc = mfma16<F16>(w, h3[kk], acc);
     }
     if (HALF == 1) park_partial(xb, 0, lane, acc);
-    chunk_barrier();
+    CHUNK_BARRIER();
     if (HALF == 0) {
         merge_partial(xb, 0, lane, acc);
         if (live) {
@@ -602,9 +660,12 @@ __global__ __launch_bounds__(64 * PWAVES) void dn_mlp_pair_kernel(const MlpArgs 
     for (int i = threadIdx.x; i < NBIAS; i += 64 * PWAVES)
         lbias[i] = i < H1 ? net.b1[i] : i < H1 + H2 ? net.b2[i - H1] : i < H1 + H2 + H3 ? net.b3[i - H1 - H2] : net.bh[i - H1 - H2 - H3];
     dma_pair<H1 / 32>(net.w1, wbuf, wave, lane);
-    chunk_barrier();
-    if (half == 0) mlp_pair_body<F16, 0>(a, net, wbuf, xb, lbias, wave, lane, row0, live, row, tile_wanted);
-    else mlp_pair_body<F16, 1>(a, net, wbuf, xb, lbias, wave, lane, row0, live, row, tile_wanted);
+#ifdef DN_MLP_STAMP
+    Stamp stp{0, wave, blockIdx.x == 0 && blockIdx.y == 0 && lane == 0};
+#endif
+    CHUNK_BARRIER();
+    if (half == 0) mlp_pair_body<F16, 0>(a, net, wbuf, xb, lbias, wave, lane, row0, live, row, tile_wanted STP_ARG);
+    else mlp_pair_body<F16, 1>(a, net, wbuf, xb, lbias, wave, lane, row0, live, row, tile_wanted STP_ARG);
 }
 
 // -----------------------------------------------------------------------------------------------------
@@ -647,6 +708,15 @@ MLP_DEV void dma_x3(const uint4 *__restrict__ src, uint4 *lds, const int wave, c
                      : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
     }
 }
+MLP_DEV void dma_piece(const uint4 *gsrc, uint4 *lds_frag)
+{   // ONE 1-KB fragment: gsrc = this lane's 16 bytes, lds_frag = the fragment's (wave-uniform) LDS address
+    const unsigned lds_dst = (unsigned)(uintptr_t)lds_frag;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
 MLP_DEV float bf16_hi_as_float(const unsigned packed, const int which)      // element 0 / 1 of a packed bf16 pair, widened
 {
     return __uint_as_float(which ? (packed & 0xFFFF0000u) : (packed << 16));
@@ -680,7 +750,7 @@ MLP_DEV f32x16 mfma3(const uint4 whi, const uint4 wlo, const u32x4 xhi, const u3
 // owner of tiles [HALF MT/2, (HALF + 1) MT/2).  A chunk holds fragments [0, 32) = hi, [32, 64) = lo of one M-tile.
 template <int HALF, int MT, int PAR, int NEXT_FR>
 MLP_DEV void layer_x3(const uint4 *__restrict__ w, const float *lbias, const uint4 *__restrict__ next, const u32x4 (&inh)[16],
-                      const u32x4 (&inl)[16], u32x4 (&outh)[MT], u32x4 (&outl)[MT], uint4 *wbuf, float4 *xb, const int wave, const int lane)
+                      const u32x4 (&inl)[16], u32x4 (&outh)[MT], u32x4 (&outl)[MT], uint4 *wbuf, float4 *xb, const int wave, const int lane STP_PARAM)
 {
     const int g = lane >> 5;
     f32x16 prev;
@@ -688,8 +758,17 @@ MLP_DEV void layer_x3(const uint4 *__restrict__ w, const float *lbias, const uin
     for (int m = 0; m < MT; ++m) {
         uint4 *cur = wbuf + ((PAR + m) & 1) * (CH3 * 64);
         uint4 *nxt = wbuf + ((PAR + m + 1) & 1) * (CH3 * 64);
+#if DN_X3_DMA_SPREAD && !defined(DN_MLP_ABLATE_DMA)
+        // the wave's pieces of the next chunk go out DN_X3_DMA_SPREAD per K-step, between the MFMAs: with one wave per SIMD a burst of
+        // 16 pieces at the top of the tile is ~1 000 cycles in which the matrix pipe idles (every wave of the CU queues on the one
+        // 64 B/clk vector-memory path right after the barrier); one piece behind an MFMA hides in that MFMA's 32 cycles
+        const int NPER = (m + 1 < MT ? CH3 : NEXT_FR) / XWAVES;
+        const uint4 *nsrc = (m + 1 < MT ? w + (size_t)(m + 1) * CH3 * 64 : next) + (size_t)wave * NPER * 64 + lane;
+        uint4 *ndst = nxt + (size_t)wave * NPER * 64;
+#elif !defined(DN_MLP_ABLATE_DMA)
         if (m + 1 < MT) dma_x3<CH3>(w + (size_t)(m + 1) * CH3 * 64, nxt, wave, lane);
         else dma_x3<NEXT_FR>(next, nxt, wave, lane);
+#endif
         const bool fin = m > 0 && (((m - 1) >= MT / 2) == (HALF == 1));      // I own tile m-1: finish it under this tile's MFMAs
         if (fin) merge_partial(xb, (m - 1) & 1, lane, prev);
         f32x16 acc;
@@ -705,22 +784,33 @@ MLP_DEV void layer_x3(const uint4 *__restrict__ w, const float *lbias, const uin
             rh[kk] = cur[(HALF * 16 + kk) * 64 + lane];
             rl[kk] = cur[(CHUNK + HALF * 16 + kk) * 64 + lane];
         }
+        MLP_PIN();
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) {
             const uint4 ah = rh[kk % RG], al = rl[kk % RG];
+#ifndef DN_MLP_ABLATE_READS
             if (kk + RG < 16) {
                 rh[kk % RG] = cur[(HALF * 16 + kk + RG) * 64 + lane];
                 rl[kk % RG] = cur[(CHUNK + HALF * 16 + kk + RG) * 64 + lane];
             }
+#endif
             acc = mfma3(ah, al, inh[kk], inl[kk], acc);
+#if DN_X3_DMA_SPREAD && !defined(DN_MLP_ABLATE_DMA)
+#pragma unroll
+            for (int j = 0; j < DN_X3_DMA_SPREAD; ++j) {
+                const int pc = kk * DN_X3_DMA_SPREAD + j;
+                if (pc < NPER) dma_piece(nsrc + pc * 64, ndst + pc * 64);
+            }
+#endif
             if (fin && (kk & 1)) {
                 const int ml = (m - 1) - HALF * (MT / 2);
                 epilogue3_pair(prev, kk >> 1, outh[2 * ml], outh[2 * ml + 1], outl[2 * ml], outl[2 * ml + 1]);
             }
+            MLP_PIN();
         }
         if ((m >= MT / 2) == (HALF == 1)) prev = acc;                         // mine: keep, finish next round
         else park_partial(xb, m & 1, lane, acc);                             // partner's: hand over through LDS
-        chunk_barrier();
+        CHUNK_BARRIER();
     }
     if (HALF == 1) {                                                         // the last tile belongs to half 1
         merge_partial(xb, (MT - 1) & 1, lane, prev);
@@ -730,7 +820,7 @@ MLP_DEV void layer_x3(const uint4 *__restrict__ w, const float *lbias, const uin
 
 template <int HALF>
 MLP_DEV void mlp_x3_body(const MlpArgs &a, const MlpNetDev &net, uint4 *wbuf, float4 *xb, const float *lbias, const int wave,
-                         const int lane, const long long row0, const bool live, const long long row, const bool tile_wanted)
+                         const int lane, const long long row0, const bool live, const long long row, const bool tile_wanted STP_PARAM)
 {
     const int g = lane >> 5, col = lane & 31;
     u32x4 x0h, x0l;
@@ -757,11 +847,11 @@ MLP_DEV void mlp_x3_body(const MlpArgs &a, const MlpNetDev &net, uint4 *wbuf, fl
         acc = mfma3(wh, wl, x0h, x0l, acc);
         epilogue3(acc, h1h[2 * ml], h1h[2 * ml + 1], h1l[2 * ml], h1l[2 * ml + 1]);
     }
-    chunk_barrier();
+    CHUNK_BARRIER();
     u32x4 h2h[16], h2l[16];
-    layer_x3<HALF, H2 / 32, 1, CH3>(net.w2, lbias + H1, net.w3, h1h, h1l, h2h, h2l, wbuf, xb, wave, lane);
+    layer_x3<HALF, H2 / 32, 1, CH3>(net.w2, lbias + H1, net.w3, h1h, h1l, h2h, h2l, wbuf, xb, wave, lane STP_ARG);
     u32x4 h3h[8], h3l[8];
-    layer_x3<HALF, H3 / 32, 1, 2 * (H3 / 16)>(net.w3, lbias + H1 + H2, net.wh, h2h, h2l, h3h, h3l, wbuf, xb, wave, lane);
+    layer_x3<HALF, H3 / 32, 1, 2 * (H3 / 16)>(net.w3, lbias + H1 + H2, net.wh, h2h, h2l, h3h, h3l, wbuf, xb, wave, lane STP_ARG);
     // head: one tile, K = 256 = 16 K-steps, 8 per half; chunk in buffer 1 as [16 hi][16 lo]
     f32x16 acc;
     if (HALF == 0) bias_init(lbias + H1 + H2 + H3, 0, g, acc);
@@ -776,7 +866,7 @@ MLP_DEV void mlp_x3_body(const MlpArgs &a, const MlpNetDev &net, uint4 *wbuf, fl
         acc = mfma3(wh, wl, h3h[kk], h3l[kk], acc);
     }
     if (HALF == 1) park_partial(xb, 0, lane, acc);
-    chunk_barrier();
+    CHUNK_BARRIER();
     if (HALF == 0) {
         merge_partial(xb, 0, lane, acc);
         if (live) {
@@ -821,9 +911,12 @@ __global__ __launch_bounds__(64 * XWAVES) __attribute__((amdgpu_waves_per_eu(1, 
     for (int i = threadIdx.x; i < NBIAS; i += 64 * XWAVES)
         lbias[i] = i < H1 ? net.b1[i] : i < H1 + H2 ? net.b2[i - H1] : i < H1 + H2 + H3 ? net.b3[i - H1 - H2] : net.bh[i - H1 - H2 - H3];
     dma_x3<2 * (H1 / 32)>(net.w1, wbuf, wave, lane);
-    chunk_barrier();
-    if (half == 0) mlp_x3_body<0>(a, net, wbuf, xb, lbias, wave, lane, row0, live, row, tile_wanted);
-    else mlp_x3_body<1>(a, net, wbuf, xb, lbias, wave, lane, row0, live, row, tile_wanted);
+#ifdef DN_MLP_STAMP
+    Stamp stp{0, wave, blockIdx.x == 0 && blockIdx.y == 0 && lane == 0};
+#endif
+    CHUNK_BARRIER();
+    if (half == 0) mlp_x3_body<0>(a, net, wbuf, xb, lbias, wave, lane, row0, live, row, tile_wanted STP_ARG);
+    else mlp_x3_body<1>(a, net, wbuf, xb, lbias, wave, lane, row0, live, row, tile_wanted STP_ARG);
 }
 
 
@@ -1016,6 +1109,7 @@ MLP_DEV f32x16 sac_tile(const uint4 *chunk, const int off, const float *__restri
         rh[kk] = chunk[(off + kk) * 64 + lane];
         if (X3) rl[kk] = chunk[(off + KS + kk) * 64 + lane];
     }
+    MLP_PIN();
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
         const uint4 ah = rh[kk % RG], al = rl[kk % RG];
@@ -1028,6 +1122,7 @@ MLP_DEV f32x16 sac_tile(const uint4 *chunk, const int off, const float *__restri
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, inl[kk]), acc, 0, 0, 0);
         }
         acc = mfma16<F16>(ah, inh[kk], acc);
+        MLP_PIN();
     }
     return acc;
 }
@@ -1107,6 +1202,29 @@ __global__ __launch_bounds__(64 * SAC_WAVES) void dn_mlp_sac_lds_kernel(const Ml
 
 }  // namespace
 
+#ifdef DN_MLP_STAMP
+#include <cstdio>
+static void dump_stamps(const char *kernel)
+{
+    const char *path = getenv("DN_MLP_STAMP_FILE");
+    if (!path) return;
+    long long h[8][256];
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamp), sizeof h) != hipSuccess) return;
+    FILE *f = fopen(path, "a");
+    if (!f) return;
+    for (int w = 0; w < 8; ++w) {
+        fprintf(f, "%s wave %d:", kernel, w);
+        for (int i = 0; i < 256 && h[w][i]; ++i) fprintf(f, " %lld", h[w][i] - h[w][0]);
+        fprintf(f, "\n");
+    }
+    fclose(f);
+    static long long zero[8][256];
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), zero, sizeof zero);
+}
+#else
+static void dump_stamps(const char *) {}
+#endif
+
 hipError_t dn_launch_mlp(const dn_mlp_net *nets, int num_nets, const float *obs, const uint8_t *row_mask, long long n, int obs_dim,
                          hipStream_t stream)
 {
@@ -1137,6 +1255,7 @@ hipError_t dn_launch_mlp(const dn_mlp_net *nets, int num_nets, const float *obs,
     }
     if (nets[0].grade == 1) {                                // fp32-grade networks (split-bf16 x3): their own kernel and packing
         hipLaunchKernelGGL(dn_mlp_x3_kernel, dim3((tiles + 1) / 2, num_nets), dim3(64 * XWAVES), 0, stream, a);
+        dump_stamps("x3");
         return hipGetLastError();
     }
     if (nets[0].grade == 2) {                                // float16 operands: the pair shape only
@@ -1146,7 +1265,7 @@ hipError_t dn_launch_mlp(const dn_mlp_net *nets, int num_nets, const float *obs,
     const char *e = getenv("DN_MLP_SHAPE");                  // 1 | 4 | 8 waves per workgroup (A/B measurements, tests)
     const int shape = e ? atoi(e) : DN_MLP_DEFAULT_SHAPE;
     if (shape == 1) hipLaunchKernelGGL(dn_mlp_kernel, dim3(tiles, num_nets), dim3(64), 0, stream, a);
-    else if (shape == 8) hipLaunchKernelGGL(dn_mlp_pair_kernel<false>, dim3((tiles + 3) / 4, num_nets), dim3(64 * PWAVES), 0, stream, a);
+    else if (shape == 8) { hipLaunchKernelGGL(dn_mlp_pair_kernel<false>, dim3((tiles + 3) / 4, num_nets), dim3(64 * PWAVES), 0, stream, a); dump_stamps("pair"); }
     else hipLaunchKernelGGL(dn_mlp_lds_kernel, dim3((tiles + WAVES - 1) / WAVES, num_nets), dim3(64 * WAVES), 0, stream, a);
     return hipGetLastError();
 }

@@ -2,20 +2,21 @@
 # Instruction-mix counters of the fused step kernel (run on the GPU box through gpurun):   profiles/instmix.sh <tag>
 # One rocprofv3 pass per counter pair (kernel trace only; --pmc is never combined with other trace domains), the bench in
 # --profile-lite mode; profiles/instmix.py <dir> prints per-launch and per 64-drone-step values.
-TAG=$1; shift
+set -eu
+TAG=${1:?usage: profiles/instmix.sh <tag> [bench args]}; shift
 export TMPDIR=/tmp
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-OUT=$ROOT/gpurun_out/instmix_$TAG
-mkdir -p $OUT
+OUT="$ROOT/gpurun_out/instmix_$TAG"
+mkdir -p "$OUT"
 cd /tmp
 i=0
 for pair in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU" "SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS" "SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
             "SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_LDS SQ_INSTS_BRANCH" "SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64" "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_CVT" \
             "SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_TRANS_F32"; do
     i=$((i+1))
-    rocprofv3 --kernel-trace --pmc $pair -d $OUT/p$i -o p$i -- python3 $ROOT/bench.py --no-cpu-baseline --no-ppo-rollout --profile-lite "$@" > $OUT/bench_p$i.log 2>&1
+    rocprofv3 --kernel-trace --pmc $pair -d "$OUT/p$i" -o p$i -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-ppo-rollout --profile-lite "$@" > "$OUT/bench_p$i.log" 2>&1 || true
 done
-cd $ROOT
-python profiles/instmix.py $OUT > $ROOT/gpurun_out/instmix_$TAG.txt
-rm -rf $OUT            # the raw databases exceed what gpurun copies back
-cat $ROOT/gpurun_out/instmix_$TAG.txt
+cd "$ROOT"
+python3 profiles/instmix.py "$OUT" > "$ROOT/gpurun_out/instmix_$TAG.txt"
+rm -rf "$OUT"          # the raw databases exceed what gpurun copies back (TAG is non-empty: set -u / the usage check above)
+cat "$ROOT/gpurun_out/instmix_$TAG.txt"

@@ -155,6 +155,8 @@ def test_refresh_repacks_in_place_so_that_captured_graphs_see_the_new_weights():
         outs = [{k: v.clone() for k, v in col.collect().items()} for col, _, _ in runs]
         for k in outs[0]:
             assert torch.equal(outs[0][k], outs[1][k]), (it, k)
+    # the perturbation moved log_std too (by value in the captured dn_step_sampled launches): the collector noticed and re-captured
+    assert runs[0][0]._captured_log_std == tuple(runs[0][1].log_std_host) != tuple([-5.0] * 4)
     net.load_state_dict(snapshot)
     for _, _, env in runs:
         env.close()
