@@ -204,10 +204,13 @@ def ppo_rollout(pkg, track, n, max_steps, dev, rank):
     for label, use_graph, trunk in (("eager", False, None), ("graph", True, None), ("graph_bf16", True, torch.bfloat16),
                                     ("graph_mfma", True, "mfma"), ("eager_mfma", False, "mfma"),
                                     ("fused_eager", False, "fused"), ("fused_graph", True, "fused"),
-                                    ("fused_graph_fp16", True, "fused16"), ("fused_graph_fp32", True, "fused32")):
-        net.trunk_dtype = trunk if trunk not in ("mfma", "fused", "fused32", "fused16") else None
+                                    ("fused_graph_fp16", True, "fused16"), ("fused_graph_fp32", True, "fused32"),
+                                    ("one_launch_graph", True, "one"), ("one_launch_graph_fp32", True, "one32")):
+        net.trunk_dtype = trunk if trunk not in ("mfma", "fused", "fused32", "fused16", "one", "one32") else None
         env = pkg.DroneVecEnv(track, n, max_steps=max_steps, normalize_obs=True, env_id_offset=rank * n, device=dev)
-        if trunk == "fused32":
+        if trunk in ("one", "one32"):
+            col = FusedRolloutCollector(env, fused if trunk == "one" else fused32, n_steps, use_graph=use_graph, seed=1 + rank, one_launch=True)
+        elif trunk == "fused32":
             col = FusedRolloutCollector(env, fused32, n_steps, use_graph=use_graph, seed=1 + rank)
         elif trunk == "fused16":
             col = FusedRolloutCollector(env, fused16, n_steps, use_graph=use_graph, seed=1 + rank)
@@ -276,7 +279,9 @@ def ppo_rollout(pkg, track, n, max_steps, dev, rank):
                          "fused collector eager": round(res["fused_eager"], 1),
                          "fused collector hipGraph": round(res["fused_graph"], 1),
                          "fused collector hipGraph, fp16-grade networks": round(res["fused_graph_fp16"], 1),
-                         "fused collector hipGraph, fp32-grade networks": round(res["fused_graph_fp32"], 1)},
+                         "fused collector hipGraph, fp32-grade networks": round(res["fused_graph_fp32"], 1),
+                         "ONE launch per step (dn_mlp_step_sampled), hipGraph, bf16-grade networks": round(res["one_launch_graph"], 1),
+                         "ONE launch per step (dn_mlp_step_sampled), hipGraph, fp32-grade networks": round(res["one_launch_graph_fp32"], 1)},
             "n_steps": n_steps, "num_envs": n,
             "what": "policy-in-the-loop rollout: MLP 13-512-512-256 (pi, vf; Tanh) + Gaussian sample + dn_step + "
                     "V(terminal_obs) bootstrap per step, dn_gae per rollout, per-drone obs normaliser on"}
@@ -517,9 +522,9 @@ def main():
     e0.record(stream)                                     # a torch event creates its hipEvent on first use (~30 us, measured):
     e1.record(stream)                                     # not inside a timed region that is one 31 us launch
     torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    e0.record(stream)
-    ta = time.perf_counter()
+    e0.record(stream)                                     # the roofline's HIP event; the stream is idle, so it completes at once and is not
+    t0 = time.perf_counter()                              # part of the K steps the wall clock brackets
+    ta = t0
     run(K)
     tb = time.perf_counter()
     e1.record(stream)

@@ -98,6 +98,7 @@ PROTOTYPES = {
     "dn_add_bootstrap": (_I32, [_VP, _VP, _VP, C.c_double, _I64, _I32, _VP]),
     "dn_step_sampled": (_I32, [_VP, _VP, C.POINTER(C.c_float), C.c_uint64, _I32] + [_VP] * 12),
     "dn_mlp_forward": (_I32, [_VP, _I32, _VP, _VP, _I64, _I32, _I32, _VP]),
+    "dn_mlp_step_sampled": (_I32, [_VP, _VP, _I32, _VP, _I32, C.POINTER(C.c_float), C.c_uint64, _I32] + [_VP] * 12),
     "dn_gae": (_I32, [_VP] * 5 + [_I64, _I64, C.c_double, C.c_double, _VP, _VP, _I32, _VP]),
     "dn_state_bytes": (_I64, [_I64, _I32]),
 }

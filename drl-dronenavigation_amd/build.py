@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libdronenav.so")
-SOURCES = ["dn_kernels.hip", "dn_kernels_mw.hip", "dn_mlp.hip", "dn_capi.cpp"]
+SOURCES = ["dn_kernels.hip", "dn_kernels_mw.hip", "dn_mlp.hip", "dn_fused.hip", "dn_capi.cpp"]
 HEADERS = ["dn_internal.h", os.path.join("..", "..", "include", "dronenav.h")]
 # -ffp-contract=off: no multiply-add is fused BY LICENCE -- the float32 action chain rounds every operation as numpy does, and the
 # float64 part writes its fused multiply-adds out explicitly so that every kernel shape produces the same bits.

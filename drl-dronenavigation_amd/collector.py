@@ -414,7 +414,11 @@ class FusedRolloutCollector:
         dn_mlp_forward (actor + critic, one launch; the value lands in the rollout buffer)
         dn_step_sampled (Gaussian sample from the environment's Philox streams, clip, log-probability -> buffer, and the
                          step itself: next observation, reward and episode-start flag straight into the buffer slots)
-    two launches per step instead of ~25 small torch kernels; then, once per rollout, SB3's TimeLimit bootstrap
+    two launches per step instead of ~25 small torch kernels -- or ONE with `one_launch=True` (dn_mlp_step_sampled: the policy kernel's
+    workgroups step the drones they evaluated; the same bits).  Off by default because it measured SLOWER on MI355X at 32 768 drones
+    (80.7 against 69.9 us per step with bf16 networks, 179.9 against 174.1 in the float32 grade): the single step is latency bound, inside
+    the policy kernel it runs on the critical path of every actor workgroup with nothing to overlap it (LDS keeps one workgroup per CU),
+    and the step's registers push spills into the MFMA loops; the kernel boundary it removes costs 1.7 us (profiles/r03_notes.md); then, once per rollout, SB3's TimeLimit bootstrap
     (rewards[t] += gamma V(terminal_observation) where TimeLimit.truncated): the step kernel leaves the terminal
     observations and truncation flags of all n_steps in the buffer, ONE dn_mlp_forward masked by those flags evaluates
     the critic on the tiles that hold a truncated drone (the weights do not change inside a rollout, so this is the
@@ -428,7 +432,7 @@ class FusedRolloutCollector:
     (RolloutGather: one all_gather_into_tensor per rollout, nothing allocated or copied per rollout)."""
 
     def __init__(self, env, policy, n_steps, *, gamma=0.99, gae_lambda=0.95, bootstrap_truncated=True, gather=False,
-                 group=None, use_graph=True, seed=0):
+                 group=None, use_graph=True, seed=0, one_launch=False):
         from .policy_mfma import FusedMlpPolicy
         from .vec_env import ACT_DIM, OBS_DIM, DroneVecEnv
         if not isinstance(env, DroneVecEnv) or not isinstance(policy, FusedMlpPolicy):
@@ -457,6 +461,11 @@ class FusedRolloutCollector:
         cfg = env.cfg
         self._sampled_step = not (cfg.clip_rew or cfg.norm_rew or cfg.physics or cfg.action_type or cfg.random_spawn or cfg.zero_damping)   # dn_step_sampled's scope
         self._clipped = None if self._sampled_step else torch.empty((n, ACT_DIM), dtype=f32, device=dev)
+        # ONE launch per step (dn_mlp_step_sampled: the actor's workgroups step the drones they evaluated) where that kernel is built:
+        # the float64 reference configuration without noise / ground contact, fleets on the three-wave single step, whole workgroups
+        self._one_launch = bool(one_launch) and self._sampled_step and not (cfg.ground_contact or cfg.act_noise_sigma > 0 or cfg.obs_noise_sigma > 0
+                                                                          or cfg.compute_f32) \
+            and env.kernel_waves(fused=False) == 3 and n % (64 if policy.grade == "fp32" else 128) == 0
         self._trunc = torch.zeros((T, n), dtype=u8, device=dev)
         self._found = torch.zeros(n, dtype=torch.int32, device=dev)
         # terminal observations of every step of the rollout (rows are written where a drone finished; the rest is stale
@@ -478,10 +487,19 @@ class FusedRolloutCollector:
         lib, h, n, dev = _capi.load(), env._handle, env.num_envs, env.device
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         log_std = (C.c_float * 4)(*[float(x) for x in pol.log_std_host])
+        from .policy_mfma import _net_struct
         for t in range(T):
             obs_t = b["obs"][t]
-            mlp_forward([pol.pi, pol.vf], obs_t, [self._mean, b["values"][t].view(n, 1)])
             term = self._term_obs[t].data_ptr() if self.bootstrap_truncated else None
+            if self._one_launch:
+                # policy forward (actor + critic), Gaussian sample, clip, log-probability and the environment step in ONE launch
+                nets = (_capi.DnMlpNet * 2)(_net_struct(pol.pi, self._mean), _net_struct(pol.vf, b["values"][t].view(n, 1)))
+                _capi.check(lib.dn_mlp_step_sampled(h, C.cast(nets, C.c_void_p), 2, obs_t.data_ptr(), obs_t.shape[1], log_std, self.seed, 0,
+                                                    b["actions"][t].data_ptr(), b["log_probs"][t].data_ptr(), b["obs"][t + 1].data_ptr(),
+                                                    b["rewards"][t].data_ptr(), b["episode_starts"][t + 1].data_ptr(), self._trunc[t].data_ptr(),
+                                                    self._found.data_ptr(), term, None, None, None, stream))
+                continue
+            mlp_forward([pol.pi, pol.vf], obs_t, [self._mean, b["values"][t].view(n, 1)])
             if self._sampled_step:
                 # Gaussian sample (Philox), clip, log-probability and the environment step in ONE launch (dn_step_sampled)
                 _capi.check(lib.dn_step_sampled(h, self._mean.data_ptr(), log_std, self.seed, 0, b["actions"][t].data_ptr(),

@@ -538,6 +538,49 @@ int32_t dn_step_squashed(dn_env *env, const float *mu_log_std, uint64_t seed, in
     return DN_OK;
 }
 
+int32_t dn_mlp_step_sampled(dn_env *env, const dn_mlp_net *nets, int32_t num_nets, const float *policy_obs, int32_t obs_dim,
+                            const float *log_std, uint64_t seed, int32_t deterministic, float *actions_out, float *log_prob_out,
+                            float *obs, float *reward, uint8_t *done, uint8_t *truncated, int32_t *found_targets, float *terminal_obs,
+                            float *ep_return, int32_t *ep_length, uint64_t *done_mask, void *stream)
+{
+    if (!env) return fail(DN_ERR_INVALID_ARGUMENT, "env is NULL");
+    if (!nets || !policy_obs || !log_std || !actions_out || !log_prob_out || !obs || !reward || !done || !truncated || !found_targets)
+        return fail(DN_ERR_INVALID_ARGUMENT, "nets, policy_obs, log_std, actions_out, log_prob_out, obs, reward, done, truncated and found_targets are required");
+    if (num_nets < 1 || num_nets > 2) return fail(DN_ERR_INVALID_ARGUMENT, "num_nets must be 1 (actor) or 2 (actor, critic)");
+    if (obs_dim < 1 || obs_dim > 16) return fail(DN_ERR_INVALID_ARGUMENT, "obs_dim must be in 1..16 (got %d)", obs_dim);
+    if (((uintptr_t)actions_out & 15u) || ((uintptr_t)obs & 15u)) return fail(DN_ERR_INVALID_ARGUMENT, "actions_out and obs must be 16-byte aligned");
+    const dn_config &c = env->cfg;
+    for (int k = 0; k < num_nets; ++k) {
+        const dn_mlp_net &n = nets[k];
+        if (n.arch != DN_MLP_ARCH_PPO) return fail(DN_ERR_INVALID_ARGUMENT, "net %d: dn_mlp_step_sampled runs the PPO networks (arch 0)", k);
+        if (!n.w1 || !n.w2 || !n.w3 || !n.wh || !n.b1 || !n.b2 || !n.b3 || !n.bh || !n.out)
+            return fail(DN_ERR_INVALID_ARGUMENT, "net %d: every weight, bias and output pointer is required", k);
+        if (n.grade < 0 || n.grade > 2 || n.grade != nets[0].grade) return fail(DN_ERR_INVALID_ARGUMENT, "net %d: grade must be 0 | 1 | 2 and the same for both networks", k);
+        if (n.out_dim < 1 || n.out_dim > 32) return fail(DN_ERR_INVALID_ARGUMENT, "net %d: out_dim must be in 1..32", k);
+        if (((uintptr_t)n.w1 | (uintptr_t)n.w2 | (uintptr_t)n.w3 | (uintptr_t)n.wh) & 15u)
+            return fail(DN_ERR_INVALID_ARGUMENT, "net %d: packed weights must be 16-byte aligned", k);
+    }
+    if (nets[0].out_dim != DN_ACT_DIM) return fail(DN_ERR_INVALID_ARGUMENT, "nets[0] must be the actor (out_dim 4)");
+    // the tail is the three-wave single step: the plain configuration dn_step_sampled covers, without noise and without the
+    // ground-contact term, on fleets for which dn_create picked that shape; whole workgroups of the policy kernel only
+    if (c.clip_rew || c.norm_rew || c.physics != 0 || c.action_type != 0 || c.random_spawn || c.zero_damping || c.ground_contact ||
+        c.act_noise_sigma > 0.0f || c.obs_noise_sigma > 0.0f || c.compute_f32 || env->waves_single != 3)
+        return fail(DN_ERR_INVALID_ARGUMENT, "dn_mlp_step_sampled is built for the float64 reference configuration without noise / reward wrappers / extra "
+                                             "physics / ground contact on fleets that take the three-wave single step; use dn_mlp_forward + dn_step_sampled");
+    const long long per_wg = nets[0].grade == 1 ? 64 : 128;
+    if (c.num_envs % per_wg) return fail(DN_ERR_INVALID_ARGUMENT, "dn_mlp_step_sampled needs num_envs %% %lld == 0 (got %lld)", per_wg, (long long)c.num_envs);
+    DnStepIO io;
+    io.actions = nullptr; io.obs = obs; io.reward = reward; io.done = done; io.truncated = truncated;
+    io.found_targets = found_targets; io.terminal_obs = terminal_obs; io.ep_return = ep_return;
+    io.ep_length = ep_length; io.done_mask = (unsigned long long *)done_mask;
+    io.mean = nullptr; io.act_out = actions_out; io.logp_out = log_prob_out;
+    for (int j = 0; j < 4; ++j) io.log_std[j] = log_std[j];
+    io.sample_seed = seed; io.sample_deterministic = deterministic != 0; io.sample_squash = 0;
+    DN_HIP(hipSetDevice(c.device_id));
+    DN_HIP(dn_launch_mlp_step(env->p, io, nets, num_nets, policy_obs, obs_dim, (hipStream_t)stream));
+    return DN_OK;
+}
+
 int32_t dn_eval_kinematics(dn_env *env, const double *kinematics, float *obs, float *reward, uint8_t *done, uint8_t *truncated,
                            int32_t *found_targets, float *terminal_obs, float *ep_return, int32_t *ep_length, void *stream)
 {

@@ -131,6 +131,8 @@ hipError_t dn_launch_add_bootstrap(float *reward, const float *terminal_value, c
 hipError_t dn_launch_set_step_count(DnStatSlot *slots, long long blocks, unsigned long long value, hipStream_t stream);
 hipError_t dn_launch_mlp(const dn_mlp_net *nets, int num_nets, const float *obs, const uint8_t *row_mask, long long n, int obs_dim,
                          hipStream_t stream);
+hipError_t dn_launch_mlp_step(const DnParams &p, const DnStepIO &io, const dn_mlp_net *nets, int num_nets, const float *obs, int obs_dim,
+                              hipStream_t stream);                                                                             // dn_fused.hip
 hipError_t dn_launch_compact(const unsigned long long *mask, long long n, int32_t *indices, int32_t *count,
                              hipStream_t stream);
 

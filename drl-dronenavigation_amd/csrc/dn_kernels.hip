@@ -582,7 +582,7 @@ DN_DEV StepOut block_out(const DnStepIO &io, long long tile_base, long long step
     o.terminal_obs = io.terminal_obs ? io.terminal_obs + e * DN_OBS_DIM : nullptr;
     o.ep_return = io.ep_return ? io.ep_return + e : nullptr;
     o.ep_length = io.ep_length ? io.ep_length + e : nullptr;
-    o.done_word = io.done_mask ? io.done_mask + word_off + blockIdx.x : nullptr;
+    o.done_word = io.done_mask ? io.done_mask + word_off + tile_base / DN_BLOCK : nullptr;     // the tile's ballot word (not blockIdx.x: a fused launch steps several tiles per workgroup)
     return o;
 }
 
@@ -1491,13 +1491,14 @@ DN_DEV void flush_stats(const DnParams &p, const StatAcc &a, unsigned long long 
 }
 // The same with the slot read at the TOP of the kernel (the single-step launches: a read-modify-write at the end would put
 // a whole memory round trip, ~0.5 us, on the tail of a 5 us kernel; the slot belongs to this workgroup alone).
-DN_DEV void flush_stats_preloaded(const DnParams &p, DnStatSlot sl, const StatAcc &a, unsigned long long steps_after, unsigned lane)
+DN_DEV void flush_stats_preloaded(const DnParams &p, DnStatSlot sl, const StatAcc &a, unsigned long long steps_after, unsigned lane,
+                                  const long long tile)
 {
     if (lane == 0) {
         sl.episodes += a.episodes; sl.truncated += a.truncated; sl.completed += a.completed;
         sl.sum_len += a.sum_len; sl.sum_found += a.sum_found; sl.sum_ret_fix += a.sum_ret_fix;
         sl.step_count = steps_after;
-        p.st.stats[blockIdx.x] = sl;
+        p.st.stats[tile] = sl;
     }
 }
 
@@ -1692,7 +1693,10 @@ DN_DEV void squashed_draw(const float4 m, const float4 l, const float z[4], cons
         for (int j = 0; j < 4; ++j) lp += (-0.5f * z[j] * z[j] - ls[j] - 0.91893853320467274178f) - logf(1.0f - a[j] * a[j] + 1e-6f);
     }
 }
-DN_DEV float4 sample_action(const DnStepIO &io, const unsigned long long gid, const unsigned long long step, const long long i, const bool active)
+// m = the policy's mean row (PPO) or its mu row with l = the log_std row (SAC, io.sample_squash); taken by value so that a kernel
+// that has just COMPUTED them (the fused policy + step launch, dn_fused.hip) hands them over without a trip through memory
+DN_DEV float4 sample_action_from(const DnStepIO &io, const float4 m, const float4 l, const unsigned long long gid, const unsigned long long step,
+                                 const long long i, const bool active)
 {
     float z[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     if (!io.sample_deterministic) noise4(io.sample_seed, gid, step, 9u, z);
@@ -1700,10 +1704,8 @@ DN_DEV float4 sample_action(const DnStepIO &io, const unsigned long long gid, co
     if (io.sample_squash) {
         // dn_step_squashed: SAC's Actor on the (mu | log_std) rows of dn_mlp_forward(arch = SAC) -- the expressions of
         // dn_squashed_sample_kernel (same bits); the squashed action is already inside the action box
-        squashed_draw(reinterpret_cast<const float4 *>(io.mean)[2 * i], reinterpret_cast<const float4 *>(io.mean)[2 * i + 1], z,
-                      io.logp_out != nullptr, a, lp);
+        squashed_draw(m, l, z, io.logp_out != nullptr, a, lp);
     } else {
-        const float4 m = reinterpret_cast<const float4 *>(io.mean)[i];
         const float mu[4] = {m.x, m.y, m.z, m.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -1716,6 +1718,12 @@ DN_DEV float4 sample_action(const DnStepIO &io, const unsigned long long gid, co
         if (io.logp_out) io.logp_out[i] = lp;
     }
     return make_float4(clipv(a[0], -1.0f, 1.0f), clipv(a[1], -1.0f, 1.0f), clipv(a[2], -1.0f, 1.0f), clipv(a[3], -1.0f, 1.0f));
+}
+DN_DEV float4 sample_action(const DnStepIO &io, const unsigned long long gid, const unsigned long long step, const long long i, const bool active)
+{
+    const float4 *rows = reinterpret_cast<const float4 *>(io.mean);
+    if (io.sample_squash) return sample_action_from(io, rows[2 * i], rows[2 * i + 1], gid, step, i, active);
+    return sample_action_from(io, rows[i], make_float4(0.0f, 0.0f, 0.0f, 0.0f), gid, step, i, active);
 }
 
 // -----------------------------------------------------------------------------------------------------
@@ -1784,7 +1792,7 @@ __global__ __launch_bounds__(DN_BLOCK) void dn_step_many_1w_kernel(const DnParam
         report_phase<R, NORM, NOISE, XOPT, 0, XOPT>(p, c, s_tile, out, fl, v, ob, gid, sc, li, lane, rows, active, G4, G5, acc, rms, rn);
         A = A_next;
     }
-    if (ONE) flush_stats_preloaded(p, slot0, acc, sc0 + 1ull, lane);
+    if (ONE) flush_stats_preloaded(p, slot0, acc, sc0 + 1ull, lane, (long long)blockIdx.x);
     else flush_stats(p, acc, sc0 + (unsigned long long)k_steps, lane);
     if (NORM && active) store_rms(p, i, rms);
     if (XOPT && p.norm_rew && active) store_rewnorm(p, i, rn);
@@ -2534,17 +2542,31 @@ template <typename R> struct VerdictMail {
     R d_obs[DN_BLOCK];
     int flags[DN_BLOCK];                  // coll1 | terminated << 1
 };
-template <typename R, bool NORM, bool NOISE, bool SAMPLE>
-__global__ __launch_bounds__(3 * DN_BLOCK) void dn_step_pqx_kernel(const DnParams p, const DnStepIO io0)
+// The LDS of one three-wave single step (one 64-drone tile): the table and the four mails.  A struct, so that a kernel that runs the
+// step as its TAIL (dn_fused.hip: the policy network's workgroup steps the drones it has just evaluated) can place it in LDS it
+// already owns.
+template <typename R> struct __attribute__((aligned(16))) PqxShared {
+    ThrustMail<R> tmail;
+    PosMail<R> pmail;
+    R qmail[4][DN_BLOCK];
+    VerdictMail<R> vmail;
+    R s_tab[DN_MAX_WAYPOINTS * DN_T_STRIDE];
+};
+// One control step of tile `tile` on three waves; `role` 0 = P, 1 = Q, 2 = X, `tid2` = this thread's index among the 128 threads of
+// the tile's P and Q waves (they stage the table).  EXT: the action's mean row (and log_std row) is handed over in `ext_m` / `ext_l`
+// instead of being read from io.mean.  Every barrier is a WORKGROUP barrier: all waves of the launch that are still alive must run
+// this function together (two tiles side by side in one workgroup keep step, which is harmless).
+template <typename R, bool NORM, bool NOISE, bool SAMPLE, bool EXT = false>
+DN_DEV void pqx_step(const DnParams &p, const DnStepIO &io0, PqxShared<R> &sh, const long long tile, const int role, const unsigned lane,
+                     const unsigned tid2, const float4 ext_m = make_float4(0.0f, 0.0f, 0.0f, 0.0f),
+                     const float4 ext_l = make_float4(0.0f, 0.0f, 0.0f, 0.0f))
 {
-    __shared__ R s_tab[DN_MAX_WAYPOINTS * DN_T_STRIDE];
-    __shared__ __attribute__((aligned(16))) ThrustMail<R> tmail;
-    __shared__ __attribute__((aligned(16))) PosMail<R> pmail;
-    __shared__ R qmail[4][DN_BLOCK];
-    __shared__ VerdictMail<R> vmail;
-    const unsigned lane = threadIdx.x & (DN_BLOCK - 1);
-    const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);       // 0 = P, 1 = Q, 2 = X
-    const long long tile_base = (long long)blockIdx.x * DN_BLOCK;
+    R *const s_tab = sh.s_tab;
+    ThrustMail<R> &tmail = sh.tmail;
+    PosMail<R> &pmail = sh.pmail;
+    R (&qmail)[4][DN_BLOCK] = sh.qmail;
+    VerdictMail<R> &vmail = sh.vmail;
+    const long long tile_base = tile * DN_BLOCK;
     const long long left = p.n - tile_base;
     const unsigned rows = left < DN_BLOCK ? (unsigned)left : DN_BLOCK;
     const bool active = lane < rows;
@@ -2559,9 +2581,9 @@ __global__ __launch_bounds__(3 * DN_BLOCK) void dn_step_pqx_kernel(const DnParam
         // ---- X: the action chain first (nothing else can start without it), the value side of the step last
         const float4 *act = reinterpret_cast<const float4 *>(io0.actions) + tile_base;
         float4 A = SAMPLE ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : act[li];
-        const DnStatSlot slot0 = p.st.stats[blockIdx.x];                   // the whole slot now (see flush_stats_preloaded)
+        const DnStatSlot slot0 = p.st.stats[tile];                   // the whole slot now (see flush_stats_preloaded)
         const unsigned long long sc0 = slot0.step_count;
-        if (SAMPLE) A = sample_action(io0, gid, sc0, i, active);
+        if (SAMPLE) A = EXT ? sample_action_from(io0, ext_m, ext_l, gid, sc0, i, active) : sample_action(io0, gid, sc0, i, active);
         post_thrust<R>(tmail, lane, thrust_phase<NOISE>(p, gid, sc0, A));
         // the entry state this wave reads is not needed before B2: requested only now, so that the action is the first
         // word back from memory and nothing queues ahead of it
@@ -2588,12 +2610,12 @@ __global__ __launch_bounds__(3 * DN_BLOCK) void dn_step_pqx_kernel(const DnParam
         StatAcc acc;
         RewNorm rn = {0.0, 0.0, 1.0, 1e-4};
         report_scalars<R, false>(p, c, out, fl, v, r_normal, r_found32, li, lane, active, G4, G5, acc, rn);
-        flush_stats_preloaded(p, slot0, acc, sc0 + 1ull, lane);
+        flush_stats_preloaded(p, slot0, acc, sc0 + 1ull, lane, tile);
         if (active) { b.g4[li] = G4; b.g5[li] = G5; }
     } else if (role == 0) {
         // ---- P: the linear half of the rigid-body step, then the rules on the new position
         const float4 G0 = b.g0[li], G1 = b.g1[li], G2 = b.g2[li], G3 = b.g3[li];
-        stage_table_by<R>(p, s_tab, threadIdx.x, 2 * DN_BLOCK);            // P and Q (threads 0..127) stage the table; X is busy with the thrust
+        stage_table_by<R>(p, s_tab, tid2, 2 * DN_BLOCK);            // P and Q (threads 0..127) stage the table; X is busy with the thrust
         block_lds_barrier();                                               // B1
         const GateRow<R> row_e = load_gate_row<R>(s_tab, unpack_meta(G3.w).idx);
         const R wp0[3] = {s_tab[DN_T_WP], s_tab[DN_T_WP + 1], s_tab[DN_T_WP + 2]};
@@ -2622,8 +2644,8 @@ __global__ __launch_bounds__(3 * DN_BLOCK) void dn_step_pqx_kernel(const DnParam
     } else {
         // ---- Q: the angular half, then everything that reads the attitude
         const float4 G0 = b.g0[li], G1 = b.g1[li], G3 = b.g3[li];
-        const unsigned long long sc0 = NOISE ? p.st.stats[blockIdx.x].step_count : 0ull;
-        stage_table_by<R>(p, s_tab, threadIdx.x, 2 * DN_BLOCK);            // before the statistics: memory returns in order, and B1 waits for the table
+        const unsigned long long sc0 = NOISE ? p.st.stats[tile].step_count : 0ull;
+        stage_table_by<R>(p, s_tab, tid2, 2 * DN_BLOCK);            // before the statistics: memory returns in order, and B1 waits for the table
         Rms rms;
         if (NORM) load_rms(p, i, rms);
         block_lds_barrier();                                               // B1
@@ -2657,6 +2679,14 @@ __global__ __launch_bounds__(3 * DN_BLOCK) void dn_step_pqx_kernel(const DnParam
             g3[0] = done ? 0.0f : fl.wx; g3[1] = done ? 0.0f : fl.wy; g3[2] = done ? 0.0f : fl.wz;
         }
     }
+}
+
+template <typename R, bool NORM, bool NOISE, bool SAMPLE>
+__global__ __launch_bounds__(3 * DN_BLOCK) void dn_step_pqx_kernel(const DnParams p, const DnStepIO io0)
+{
+    __shared__ PqxShared<R> sh;
+    pqx_step<R, NORM, NOISE, SAMPLE>(p, io0, sh, (long long)blockIdx.x, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6),
+                                     threadIdx.x & (DN_BLOCK - 1), threadIdx.x);
 }
 
 // =====================================================================================================
@@ -2967,7 +2997,7 @@ hipError_t dn_launch_step_many_mw(const DnParams &p, const DnStepIO &io, int k, 
     else { if (noise) DN_LAUNCH(double, false, true); else DN_LAUNCH(double, false, false); }
     return hipGetLastError();
 }
-#else
+#elif DN_TU == 1
 hipError_t dn_launch_step_many(const DnParams &p, const DnStepIO &io, int k, bool f32, int waves, hipStream_t stream)
 {
     const bool norm = p.normalize_obs != 0;

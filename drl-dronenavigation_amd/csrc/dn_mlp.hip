@@ -34,6 +34,13 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define MLP_DEV __device__ __forceinline__
 
+// A policy kernel may carry a TAIL: work its workgroup does with the head's output before it leaves (dn_fused.hip: the workgroup that
+// evaluated the actor for 128 / 64 drones draws their actions and runs their control step -- one launch per closed-loop step).
+// NoTail = the plain forward pass (dn_mlp_forward).
+struct NoTail {
+    static constexpr bool active = false;
+};
+
 constexpr int H1 = 512, H2 = 512, H3 = 256;        // net_arch of PBDroneSimulator.py:251-258
 constexpr int TILE = 32;                           // drones per wavefront (the N of the 32x32x16 MFMA)
 
@@ -281,6 +288,15 @@ MLP_DEV void dma_chunk(const uint4 *__restrict__ src, uint4 *lds, const int nfra
                          : "memory");
         }
     }
+}
+MLP_DEV void dma_piece(const uint4 *gsrc, uint4 *lds_frag)
+{   // ONE 1-KB fragment: gsrc = this lane's 16 bytes, lds_frag = the fragment's (wave-uniform) LDS address
+    const unsigned lds_dst = (unsigned)(uintptr_t)lds_frag;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 MLP_DEV void chunk_barrier()
 {
@@ -571,7 +587,8 @@ MLP_DEV void layer_pair(const uint4 *__restrict__ w, const float *lbias, const u
 
 template <bool F16, int HALF>
 MLP_DEV void mlp_pair_body(const MlpArgs &a, const MlpNetDev &net, uint4 *wbuf, float4 *xb, const float *lbias, const int wave,
-                           const int lane, const long long row0, const bool live, const long long row, const bool tile_wanted STP_PARAM)
+                           const int lane, const long long row0, const bool live, const long long row, const bool tile_wanted,
+                           f32x16 &head STP_PARAM)
 {
     const int g = lane >> 5, col = lane & 31;
     u32x4 x0;
@@ -617,6 +634,7 @@ MLP_DEV void mlp_pair_body(const MlpArgs &a, const MlpNetDev &net, uint4 *wbuf, 
     CHUNK_BARRIER();
     if (HALF == 0) {
         merge_partial(xb, 0, lane, acc);
+        head = acc;
         if (live) {
             float *o = net.out + (row0 + col) * net.out_dim;
 #pragma unroll
@@ -628,8 +646,8 @@ MLP_DEV void mlp_pair_body(const MlpArgs &a, const MlpNetDev &net, uint4 *wbuf, 
     }
 }
 
-template <bool F16>
-__global__ __launch_bounds__(64 * PWAVES) void dn_mlp_pair_kernel(const MlpArgs a)
+template <bool F16, typename TAIL = NoTail>
+__global__ __launch_bounds__(64 * PWAVES) void dn_mlp_pair_kernel(const MlpArgs a, const TAIL tail)
 {
     __shared__ __attribute__((aligned(16))) uint4 lds[LDS_PAIR_U4];         // ONE __shared__ object (see dn_mlp_lds_kernel)
     uint4 *wbuf = lds;
@@ -664,8 +682,14 @@ __global__ __launch_bounds__(64 * PWAVES) void dn_mlp_pair_kernel(const MlpArgs 
     Stamp stp{0, wave, blockIdx.x == 0 && blockIdx.y == 0 && lane == 0};
 #endif
     CHUNK_BARRIER();
-    if (half == 0) mlp_pair_body<F16, 0>(a, net, wbuf, xb, lbias, wave, lane, row0, live, row, tile_wanted STP_ARG);
-    else mlp_pair_body<F16, 1>(a, net, wbuf, xb, lbias, wave, lane, row0, live, row, tile_wanted STP_ARG);
+    f32x16 head;
+    if (half == 0) mlp_pair_body<F16, 0>(a, net, wbuf, xb, lbias, wave, lane, row0, live, row, tile_wanted, head STP_ARG);
+    else mlp_pair_body<F16, 1>(a, net, wbuf, xb, lbias, wave, lane, row0, live, row, tile_wanted, head STP_ARG);
+    // the tail of network 0 (the actor): its workgroup holds the action means of drones [128 b, 128 b + 128) in the half-0 waves'
+    // accumulators (lane group 0: rows 0..3 of drone `col`); every weight buffer is free by now
+    if constexpr (TAIL::active) {
+        if (blockIdx.y == 0) tail.template run<2>(lds, wave, lane, half == 0, pair * TILE + col, head, (long long)blockIdx.x);
+    }
 }
 
 // -----------------------------------------------------------------------------------------------------
@@ -707,15 +731,6 @@ MLP_DEV void dma_x3(const uint4 *__restrict__ src, uint4 *lds, const int wave, c
                      "s_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
     }
-}
-MLP_DEV void dma_piece(const uint4 *gsrc, uint4 *lds_frag)
-{   // ONE 1-KB fragment: gsrc = this lane's 16 bytes, lds_frag = the fragment's (wave-uniform) LDS address
-    const unsigned lds_dst = (unsigned)(uintptr_t)lds_frag;
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, off\n\t"
-                 "s_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 MLP_DEV float bf16_hi_as_float(const unsigned packed, const int which)      // element 0 / 1 of a packed bf16 pair, widened
 {
@@ -820,7 +835,8 @@ MLP_DEV void layer_x3(const uint4 *__restrict__ w, const float *lbias, const uin
 
 template <int HALF>
 MLP_DEV void mlp_x3_body(const MlpArgs &a, const MlpNetDev &net, uint4 *wbuf, float4 *xb, const float *lbias, const int wave,
-                         const int lane, const long long row0, const bool live, const long long row, const bool tile_wanted STP_PARAM)
+                         const int lane, const long long row0, const bool live, const long long row, const bool tile_wanted,
+                         f32x16 &head STP_PARAM)
 {
     const int g = lane >> 5, col = lane & 31;
     u32x4 x0h, x0l;
@@ -869,6 +885,7 @@ MLP_DEV void mlp_x3_body(const MlpArgs &a, const MlpNetDev &net, uint4 *wbuf, fl
     CHUNK_BARRIER();
     if (HALF == 0) {
         merge_partial(xb, 0, lane, acc);
+        head = acc;
         if (live) {
             float *o = net.out + (row0 + col) * net.out_dim;
 #pragma unroll
@@ -880,7 +897,8 @@ MLP_DEV void mlp_x3_body(const MlpArgs &a, const MlpNetDev &net, uint4 *wbuf, fl
     }
 }
 
-__global__ __launch_bounds__(64 * XWAVES) __attribute__((amdgpu_waves_per_eu(1, 1))) void dn_mlp_x3_kernel(const MlpArgs a)
+template <typename TAIL = NoTail>
+__global__ __launch_bounds__(64 * XWAVES) __attribute__((amdgpu_waves_per_eu(1, 1))) void dn_mlp_x3_kernel(const MlpArgs a, const TAIL tail)
 {
     __shared__ __attribute__((aligned(16))) uint4 lds[LDS_X3_U4];           // ONE __shared__ object (see dn_mlp_lds_kernel)
     uint4 *wbuf = lds;
@@ -915,8 +933,12 @@ __global__ __launch_bounds__(64 * XWAVES) __attribute__((amdgpu_waves_per_eu(1, 
     Stamp stp{0, wave, blockIdx.x == 0 && blockIdx.y == 0 && lane == 0};
 #endif
     CHUNK_BARRIER();
-    if (half == 0) mlp_x3_body<0>(a, net, wbuf, xb, lbias, wave, lane, row0, live, row, tile_wanted STP_ARG);
-    else mlp_x3_body<1>(a, net, wbuf, xb, lbias, wave, lane, row0, live, row, tile_wanted STP_ARG);
+    f32x16 head;
+    if (half == 0) mlp_x3_body<0>(a, net, wbuf, xb, lbias, wave, lane, row0, live, row, tile_wanted, head STP_ARG);
+    else mlp_x3_body<1>(a, net, wbuf, xb, lbias, wave, lane, row0, live, row, tile_wanted, head STP_ARG);
+    if constexpr (TAIL::active) {                            // see dn_mlp_pair_kernel: here the workgroup holds 64 drones = one step tile
+        if (blockIdx.y == 0) tail.template run<1>(lds, wave, lane, half == 0, pair * TILE + col, head, (long long)blockIdx.x);
+    }
 }
 
 
@@ -1202,6 +1224,7 @@ __global__ __launch_bounds__(64 * SAC_WAVES) void dn_mlp_sac_lds_kernel(const Ml
 
 }  // namespace
 
+#ifndef DN_MLP_NO_LAUNCHER
 #ifdef DN_MLP_STAMP
 #include <cstdio>
 static void dump_stamps(const char *kernel)
@@ -1254,18 +1277,20 @@ hipError_t dn_launch_mlp(const dn_mlp_net *nets, int num_nets, const float *obs,
         return hipGetLastError();
     }
     if (nets[0].grade == 1) {                                // fp32-grade networks (split-bf16 x3): their own kernel and packing
-        hipLaunchKernelGGL(dn_mlp_x3_kernel, dim3((tiles + 1) / 2, num_nets), dim3(64 * XWAVES), 0, stream, a);
+        hipLaunchKernelGGL(dn_mlp_x3_kernel<NoTail>, dim3((tiles + 1) / 2, num_nets), dim3(64 * XWAVES), 0, stream, a, NoTail());
         dump_stamps("x3");
-        return hipGetLastError();
-    }
-    if (nets[0].grade == 2) {                                // float16 operands: the pair shape only
-        hipLaunchKernelGGL(dn_mlp_pair_kernel<true>, dim3((tiles + 3) / 4, num_nets), dim3(64 * PWAVES), 0, stream, a);
         return hipGetLastError();
     }
     const char *e = getenv("DN_MLP_SHAPE");                  // 1 | 4 | 8 waves per workgroup (A/B measurements, tests)
     const int shape = e ? atoi(e) : DN_MLP_DEFAULT_SHAPE;
+
+    if (nets[0].grade == 2) {                                // float16 operands: the pair shapes only
+        hipLaunchKernelGGL((dn_mlp_pair_kernel<true, NoTail>), dim3((tiles + 3) / 4, num_nets), dim3(64 * PWAVES), 0, stream, a, NoTail());
+        return hipGetLastError();
+    }
     if (shape == 1) hipLaunchKernelGGL(dn_mlp_kernel, dim3(tiles, num_nets), dim3(64), 0, stream, a);
-    else if (shape == 8) { hipLaunchKernelGGL(dn_mlp_pair_kernel<false>, dim3((tiles + 3) / 4, num_nets), dim3(64 * PWAVES), 0, stream, a); dump_stamps("pair"); }
+    else if (shape == 8) { hipLaunchKernelGGL((dn_mlp_pair_kernel<false, NoTail>), dim3((tiles + 3) / 4, num_nets), dim3(64 * PWAVES), 0, stream, a, NoTail()); dump_stamps("pair"); }
     else hipLaunchKernelGGL(dn_mlp_lds_kernel, dim3((tiles + WAVES - 1) / WAVES, num_nets), dim3(64 * WAVES), 0, stream, a);
     return hipGetLastError();
 }
+#endif  // DN_MLP_NO_LAUNCHER

@@ -321,6 +321,20 @@ int32_t dn_step_sampled(dn_env *env, const float *mean, const float *log_std, ui
                         int32_t *found_targets, float *terminal_obs, float *ep_return, int32_t *ep_length,
                         uint64_t *done_mask, void *stream);
 
+/* dn_mlp_forward + dn_step_sampled in ONE launch (ABI 6): the policy kernel's workgroup that evaluated the actor (nets[0], out_dim 4)
+ * for 128 drones (64 in the float32 grade) draws their actions and runs their control step before it leaves -- no kernel boundary
+ * and no round trip of the action means between the policy and the environment (SB3 collect_rollouts' forward -> sample -> clip ->
+ * env.step, Sol/Model/PBDroneSimulator.py:261-286).  nets[1] (optional) is the critic, evaluated by the other workgroups of the same
+ * launch; both write their `out` as dn_mlp_forward does.  policy_obs: device float[N * obs_dim], the observation the networks read
+ * (must not alias `obs`, the step's output).  Same results, bit for bit, as the two calls it replaces.  Limits: PPO arch, the float64
+ * reference configuration without noise / reward wrappers / extra physics / ground contact, fleets on which dn_create picked the
+ * three-wave single step (dn_get_kernel_waves(env, 0) == 3), num_envs a multiple of 128 (64 in the float32 grade);
+ * DN_ERR_INVALID_ARGUMENT otherwise (use the two calls). */
+int32_t dn_mlp_step_sampled(dn_env *env, const dn_mlp_net *nets, int32_t num_nets, const float *policy_obs, int32_t obs_dim,
+                            const float *log_std, uint64_t seed, int32_t deterministic, float *actions_out, float *log_prob_out,
+                            float *obs, float *reward, uint8_t *done, uint8_t *truncated, int32_t *found_targets, float *terminal_obs,
+                            float *ep_return, int32_t *ep_length, uint64_t *done_mask, void *stream);
+
 /* Bytes of HBM the persistent state of `num_envs` drones occupies (capacity planning). */
 int64_t dn_state_bytes(int64_t num_envs, int32_t normalize_obs);
 
