@@ -539,6 +539,11 @@ MLP_DEV void layer_pair(const uint4 *__restrict__ w, const float *lbias, const u
 {
     const int g = lane >> 5;
     f32x16 prev;
+#ifdef DN_ABL_PARK_STALE
+    f32x16 stale;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) stale[r] = (float)lane;
+#endif
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         uint4 *cur = wbuf + ((PAR + m) & 1) * (CHUNK * 64);
@@ -576,7 +581,11 @@ MLP_DEV void layer_pair(const uint4 *__restrict__ w, const float *lbias, const u
             MLP_PIN();
         }
         if ((m >= MT / 2) == (HALF == 1)) prev = acc;                         // mine: keep, finish next round
+#ifdef DN_ABL_PARK_STALE
+        else { park_partial(xb, m & 1, lane, stale); stale[0] += acc[0]; }   // timing ablation: the parked registers do not wait for the MFMAs
+#else
         else park_partial(xb, m & 1, lane, acc);                             // partner's: hand over through LDS
+#endif
         CHUNK_BARRIER();
     }
     if (HALF == 1) {                                                         // the last tile belongs to half 1
