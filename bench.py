@@ -440,14 +440,18 @@ def main():
              done=torch.empty((A, n), dtype=torch.uint8, device=dev), trunc=torch.empty((A, n), dtype=torch.uint8, device=dev),
              found=torch.empty((A, n), dtype=torch.int32, device=dev))
 
+    step_many = lib.dn_step_many                          # addresses taken once: the driver's timed region is ONE launch, every
+    many_tail = (acts.data_ptr(), o["obs"].data_ptr(), o["reward"].data_ptr(), o["done"].data_ptr(), o["trunc"].data_ptr(),
+                 o["found"].data_ptr(), None, None, None, None, sptr)           # microsecond of Python in front of it counts
+
     def run_many(k):
         """k steps as ceil(k/A) dn_step_many calls over the A resident action batches."""
         done = 0
         while done < k:
             c = min(A, k - done)
-            pkg._capi.check(lib.dn_step_many(h, c, acts.data_ptr(), o["obs"].data_ptr(), o["reward"].data_ptr(),
-                                             o["done"].data_ptr(), o["trunc"].data_ptr(), o["found"].data_ptr(),
-                                             None, None, None, None, sptr))
+            rc = step_many(h, c, *many_tail)
+            if rc:
+                pkg._capi.check(rc)
             done += c
 
     ptrs = [(acts[j].data_ptr(), o["obs"][j].data_ptr(), o["reward"][j].data_ptr(), o["done"][j].data_ptr(),
@@ -663,24 +667,7 @@ def main():
             us = (time.perf_counter() - t0_) * 1e6 / reps_
             others["sb3_numpy_step_infos_" + mode_] = {"us_per_vector_step": round(us, 1), "value": round(n / (us * 1e-6), 1)}
 
-    sharded = None
-    want_sharded = (world > 1) if args.ppo_sharded is None else args.ppo_sharded
-    if want_sharded and dist is not None:
-        # the one collective of the design (RCCL all-gather of advantages / returns per rollout).  A hung collective must not
-        # hang the scaling run: a watchdog thread ends THIS process with a non-zero code (never a re-exec) if the leg overruns.
-        import threading
-
-        def _overrun():
-            print(f"bench.py: rank {rank}: the sharded PPO leg (RCCL all-gather) did not finish within {args.sharded_timeout:.0f} s; "
-                  "exiting with code 3", file=sys.stderr, flush=True)
-            os._exit(3)
-        dog = threading.Timer(args.sharded_timeout, _overrun)
-        dog.daemon = True
-        dog.start()
-        try:
-            sharded = ppo_rollout_sharded(pkg, track, n, max_steps, dev, rank, world, dist)
-        finally:
-            dog.cancel()
+    line = None
     if rank == 0:
         value = n * world * K / wall
         step_us = gpu_ms * 1e3 / K
@@ -731,8 +718,6 @@ def main():
             "hbm_bound_fleet": large,
             "other_launch_shapes": others,
         }
-        if sharded is not None:
-            line["ppo_rollout_sharded"] = sharded
         # the two side legs must never cost the headline line: a failure is reported in place of the numbers
         if world == 1 and not args.no_ppo_rollout:
             try:
@@ -748,6 +733,32 @@ def main():
                 line["cpu_baseline"] = cpu_baseline(track, n, max_steps, args.cpu_baseline_seconds)
             except Exception as exc:  # noqa: BLE001
                 line["cpu_baseline"] = {"error": f"{type(exc).__name__}: {exc}"}
+    # BASELINE configs[3]: the one collective of the design (RCCL all-gather of advantages / returns per rollout), timed on every rank
+    # whenever WORLD_SIZE > 1.  It runs AFTER the headline line is assembled: an exception is reported inside the line, and if the
+    # collective hangs a watchdog thread ends THIS process with a non-zero code (never a re-exec) -- rank 0 printing the headline it
+    # already holds first, so that a scaling run does not lose its measurement to the optional leg.
+    want_sharded = (world > 1) if args.ppo_sharded is None else args.ppo_sharded
+    if want_sharded and dist is not None:
+        import threading
+
+        def _overrun():
+            print(f"bench.py: rank {rank}: the sharded PPO leg (RCCL all-gather) did not finish within {args.sharded_timeout:.0f} s; "
+                  "exiting with code 3", file=sys.stderr, flush=True)
+            if rank == 0 and line is not None:
+                line["ppo_rollout_sharded"] = {"error": f"timeout after {args.sharded_timeout:.0f} s (watchdog; exit code 3)"}
+                print(json.dumps(line), flush=True)
+            os._exit(3)
+        dog = threading.Timer(args.sharded_timeout, _overrun)
+        dog.daemon = True
+        dog.start()
+        try:
+            sharded = ppo_rollout_sharded(pkg, track, n, max_steps, dev, rank, world, dist)
+        except Exception as exc:  # noqa: BLE001
+            sharded = {"error": f"{type(exc).__name__}: {exc}"}
+        finally:
+            dog.cancel()
+        if rank == 0:
+            line["ppo_rollout_sharded"] = sharded
     env.close()
     if dist is not None:
         # RCCL writes its NCCL_DEBUG=VERSION banner to STDOUT through C stdio (buffered on a pipe, flushed at exit): push every
