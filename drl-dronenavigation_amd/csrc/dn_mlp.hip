@@ -1127,12 +1127,14 @@ MLP_DEV void sac_epilogue(const f32x16 &acc, u32x4 &h0, u32x4 &h1, u32x4 &l0, u3
 }
 // one M-tile over KS K-steps from an LDS chunk: hi fragments at chunk[off + kk], lo fragments at chunk[off + KS + kk]
 template <int KS, bool X3, bool F16>
-MLP_DEV f32x16 sac_tile(const uint4 *chunk, const int off, const float *__restrict__ bias, const int m, const int g, const int lane,
+MLP_DEV f32x16 sac_tile(const uint4 *chunk, const int off, const float *lbias, const int m, const int g, const int lane,
                         const u32x4 (&inh)[KS], const u32x4 (&inl)[KS])
 {
+    // The biases come from LDS (staged once, as in the pair kernel).  Read from global memory per tile -- as this kernel did until round
+    // 3 -- the load's s_waitcnt vmcnt(0) sits right behind the LDS-DMA of the NEXT chunk, issued a moment earlier, and every chunk of
+    // this latency-bound kernel (0.3-0.8 us of MFMA work per chunk) waited out a full DMA round trip (~1 us) before its first MFMA.
     f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = bias[acc_row(m, g, r)];
+    bias_init(lbias, m, g, acc);
     constexpr int RG = KS < 4 ? KS : 4;
     uint4 rh[RG], rl[RG];
 #pragma unroll
@@ -1161,8 +1163,10 @@ MLP_DEV f32x16 sac_tile(const uint4 *chunk, const int off, const float *__restri
 template <bool X3, bool F16>
 __global__ __launch_bounds__(64 * SAC_WAVES) void dn_mlp_sac_lds_kernel(const MlpArgs a)
 {
-    __shared__ __attribute__((aligned(16))) uint4 lds[2 * CHUNK * 64 + 1];     // ONE __shared__ object (see dn_mlp_lds_kernel)
-    int *s_any = reinterpret_cast<int *>(lds + 2 * CHUNK * 64);
+    constexpr int NB_SAC = S1 + S2 + 32;                   // float32 biases of the three layers, staged in LDS
+    __shared__ __attribute__((aligned(16))) uint4 lds[2 * CHUNK * 64 + NB_SAC / 4 + 1];     // ONE __shared__ object (see dn_mlp_lds_kernel)
+    float *lbias = reinterpret_cast<float *>(lds + 2 * CHUNK * 64);
+    int *s_any = reinterpret_cast<int *>(lds + 2 * CHUNK * 64 + NB_SAC / 4);
     constexpr int PER = X3 ? 2 : 1;
     constexpr int TPC = X3 ? 1 : 2;                         // layer-2 M-tiles per 32-fragment chunk
     constexpr int NL2 = (S2 / 32) / TPC;                    // layer-2 chunks
@@ -1185,6 +1189,8 @@ __global__ __launch_bounds__(64 * SAC_WAVES) void dn_mlp_sac_lds_kernel(const Ml
             return;
         }
     }
+    for (int i = threadIdx.x; i < NB_SAC; i += 64 * SAC_WAVES)
+        lbias[i] = i < S1 ? net.b1[i] : i < S1 + S2 ? net.b2[i - S1] : net.bh[i - S1 - S2];
     sac_dma<(S1 / 32) * PER>(net.w1, lds, wave, lane);      // chunk 0 = layer 1 -> buffer 0
     float ob[8];
     load_obs8(a, row, g, ob);
@@ -1200,7 +1206,7 @@ __global__ __launch_bounds__(64 * SAC_WAVES) void dn_mlp_sac_lds_kernel(const Ml
     sac_dma<CHUNK>(net.w2, lds + CHUNK * 64, wave, lane);   // layer 2, chunk 0 -> buffer 1
 #pragma unroll
     for (int m = 0; m < S1 / 32; ++m) {
-        const f32x16 acc = sac_tile<1, X3, F16>(lds, m * PER, net.b1, m, g, lane, x0h, x0l);
+        const f32x16 acc = sac_tile<1, X3, F16>(lds, m * PER, lbias, m, g, lane, x0h, x0l);
         sac_epilogue<X3, F16>(acc, h1h[2 * m], h1h[2 * m + 1], h1l[2 * m], h1l[2 * m + 1]);
     }
     chunk_barrier();
@@ -1214,13 +1220,13 @@ __global__ __launch_bounds__(64 * SAC_WAVES) void dn_mlp_sac_lds_kernel(const Ml
 #pragma unroll
         for (int j = 0; j < TPC; ++j) {
             const int m = c * TPC + j;
-            const f32x16 acc = sac_tile<S1 / 16, X3, F16>(cur, j * (S1 / 16), net.b2, m, g, lane, h1h, h1l);
+            const f32x16 acc = sac_tile<S1 / 16, X3, F16>(cur, j * (S1 / 16), lbias + S1, m, g, lane, h1h, h1l);
             sac_epilogue<X3, F16>(acc, h2h[2 * m], h2h[2 * m + 1], h2l[2 * m], h2l[2 * m + 1]);
         }
         chunk_barrier();
     }
     // heads: one M-tile (8 rows used), float32 straight from the accumulator; its chunk is in buffer (1 + NL2) & 1
-    const f32x16 acc = sac_tile<S2 / 16, X3, F16>(lds + ((1 + NL2) & 1) * (CHUNK * 64), 0, net.bh, 0, g, lane, h2h, h2l);
+    const f32x16 acc = sac_tile<S2 / 16, X3, F16>(lds + ((1 + NL2) & 1) * (CHUNK * 64), 0, lbias + S1 + S2, 0, g, lane, h2h, h2l);
     if (live) {
         float *o = net.out + (row0 + col) * net.out_dim;
 #pragma unroll
