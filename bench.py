@@ -239,8 +239,10 @@ def ppo_rollout(pkg, track, n, max_steps, dev, rank):
         env = pkg.DroneVecEnv(track, n, max_steps=max_steps, normalize_obs=True, env_id_offset=rank * n, device=dev)
         obs = env.reset_tensor().clone()
         mean, val = torch.zeros((n, 4), device=dev), torch.zeros((n, 1), device=dev)
-        for gname, pol, kname, passes in (("bf16", fused, "dn_mlp_pair_kernel<false>", 1), ("fp16", fused16, "dn_mlp_pair_kernel<true>", 1),
-                                          ("fp32", fused32, "dn_mlp_x3_kernel", 3)):
+        shape = os.environ.get("DN_MLP_SHAPE", "4")        # the library's default: four waves per workgroup sharing the weight stream
+        kn = {"8": "dn_mlp_pair_kernel<%s, NoTail>", "1": "dn_mlp_kernel"}.get(shape, "dn_mlp_lds_kernel<%s>")
+        for gname, pol, kname, passes in (("bf16", fused, kn % "false" if "%" in kn else kn, 1), ("fp16", fused16, (kn if "%" in kn else "dn_mlp_lds_kernel<%s>") % "true", 1),
+                                          ("fp32", fused32, "dn_mlp_x3_kernel<NoTail>", 3)):
             kernels["mlp_" + gname] = mlp_kernel_leg(torch, dev, kname, lambda pol=pol: mlp_forward([pol.pi, pol.vf], obs, [mean, val]),
                                                      n, PPO_MACS_MFMA, PPO_MACS + 256 * 2.5, 2, passes)
         lib, h = pkg._capi.load(), env._handle

@@ -7,8 +7,8 @@
 // profiles/r03_dispatch_floor.txt).  Here the workgroup of dn_mlp_pair_kernel / dn_mlp_x3_kernel that has just evaluated
 // the actor for 128 (64) drones steps exactly those drones before it leaves: the head's accumulators go to LDS, and the
 // three-wave single step (pqx_step, dn_kernels.hip) runs on the workgroup's first six (three) waves in the LDS the weight
-// buffers no longer need.  Same device functions as dn_mlp_forward and dn_step_sampled, hence the same bits
-// (tests/test_gpu_round3.py::test_fused_policy_step_equals_forward_then_step_sampled); the critic's workgroups are
+// buffers no longer need.  Same device functions as dn_mlp_forward's pair shape (DN_MLP_SHAPE=8) and dn_step_sampled, hence the same
+// bits (tests/test_gpu_round3.py::test_fused_policy_step_equals_forward_then_step_sampled); the critic's workgroups are
 // untouched.  Built for the plain configuration of dn_step_sampled without the ground-contact term (what pqx_step covers).
 //
 // This translation unit includes the two kernel sources for their device functions; neither contributes a host launcher

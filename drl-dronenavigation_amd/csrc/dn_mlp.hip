@@ -291,7 +291,7 @@ MLP_DEV void dma_chunk(const uint4 *__restrict__ src, uint4 *lds, const int nfra
 }
 MLP_DEV void dma_piece(const uint4 *gsrc, uint4 *lds_frag)
 {   // ONE 1-KB fragment: gsrc = this lane's 16 bytes, lds_frag = the fragment's (wave-uniform) LDS address
-    const unsigned lds_dst = (unsigned)(uintptr_t)lds_frag;
+    const unsigned lds_dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds_frag);
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
                  "global_load_lds_dwordx4 %1, off\n\t"
@@ -333,9 +333,9 @@ MLP_DEV void chunk_barrier_stamped(Stamp &s)
 // A 512-input layer, weights through LDS: one chunk = the 32 fragments of one M-tile.  PAR = parity of the LDS buffer
 // that holds this layer's chunk 0 (requested by the previous layer, landed before its last barrier); `next` = the
 // following layer's weights, whose first NEXT_FR fragments are requested during this layer's last chunk.
-template <int MT, int PAR, int NEXT_FR>
+template <bool F16, int MT, int PAR, int NEXT_FR>
 MLP_DEV void layer_lds(const uint4 *__restrict__ w, const float *__restrict__ bias, const uint4 *__restrict__ next,
-                       const u32x4 (&in)[CHUNK], u32x4 (&out)[2 * MT], uint4 *lds, const int wave, const int lane)
+                       const u32x4 (&in)[CHUNK], u32x4 (&out)[2 * MT], uint4 *lds, const int wave, const int lane STP_PARAM)
 {
     const int g = lane >> 5;
     // biases one M-tile ahead, requested BEFORE the chunk's DMA: memory returns in order, so a bias load queued behind
@@ -359,28 +359,41 @@ MLP_DEV void layer_lds(const uint4 *__restrict__ w, const float *__restrict__ bi
 #pragma unroll
         for (int kk = 0; kk < LDS_RING; ++kk) ring[kk] = cur[kk * 64 + lane];
         MLP_PIN();
-        float t_even = 0.0f;
+        // The previous tile's epilogue as a three-stage software pipeline over the K-steps (one wave per SIMD: a dependent
+        // exp -> add -> rcp -> fma chain inside one K-step stalls the wave past its MFMA's 32 cycles): element e has its exp at K-step 2e,
+        // add + rcp at 2e + 1, fma (and, for odd e, the pack) at 2e + 2, so no K-step waits on a transcendental it issued itself.
+        float te = 0.0f, tr = 0.0f, tdone_even = 0.0f;       // in flight: exp result, rcp result, finished even element of a pair
 #pragma unroll
         for (int kk = 0; kk < CHUNK; ++kk) {
             const uint4 a = ring[kk % LDS_RING];
             if (kk + LDS_RING < CHUNK) ring[kk % LDS_RING] = cur[(kk + LDS_RING) * 64 + lane];
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, in[kk]), acc, 0, 0, 0);
-            // the previous tile's epilogue, one ELEMENT every second MFMA (one wave per SIMD hides ~5 issue slots behind an
-            // MFMA: a tanh is four of them): element 2q at kk = 4q + 1, element 2q + 1 and the pack at kk = 4q + 3
-            if (m > 0 && (kk & 3) == 1) t_even = tanh_fast(prev[2 * (kk >> 2)]);
-            if (m > 0 && (kk & 3) == 3) {
-                const int q = kk >> 2;
-                const unsigned u = pack2(t_even, tanh_fast(prev[2 * q + 1]));
-                if (q < 4) out[2 * (m - 1)][q] = u; else out[2 * (m - 1) + 1][q - 4] = u;
+            acc = mfma16<F16>(a, in[kk], acc);
+            if (m > 0) {
+                if (kk >= 2 && !(kk & 1)) {                  // stage C of element e = kk / 2 - 1
+                    const int e = kk / 2 - 1;
+                    const float t = __builtin_fmaf(-2.0f, tr, 1.0f);
+                    if (e & 1) {
+                        const unsigned u = pack2t<F16>(tdone_even, t);
+                        const int q = e >> 1;
+                        if (q < 4) out[2 * (m - 1)][q] = u; else out[2 * (m - 1) + 1][q - 4] = u;
+                    } else tdone_even = t;
+                }
+                if (!(kk & 1)) te = __builtin_amdgcn_exp2f(prev[kk / 2]);       // stage A of element kk / 2
+                else tr = __builtin_amdgcn_rcpf(te + 1.0f);                      // stage B of element (kk - 1) / 2
             }
             MLP_PIN();
         }
+        if (m > 0) {                                         // stage C of element 15
+            const unsigned u = pack2t<F16>(tdone_even, __builtin_fmaf(-2.0f, tr, 1.0f));
+            out[2 * (m - 1) + 1][3] = u;
+        }
         if (m + 1 < MT) prev = acc;
-        else epilogue(acc, true, out[2 * m], out[2 * m + 1]);
-        chunk_barrier();                                    // everyone is done with `cur`; the next chunk has landed in `nxt`
+        else epilogue_t<F16>(acc, out[2 * m], out[2 * m + 1]);
+        CHUNK_BARRIER();                                    // everyone is done with `cur`; the next chunk has landed in `nxt`
     }
 }
 
+template <bool F16>
 __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(1, 1))) void dn_mlp_lds_kernel(const MlpArgs a)
 {
     // ONE __shared__ object (a second one makes hipcc drain the LDS-DMA before every first ds_read of a chunk):
@@ -409,6 +422,9 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(1, 1
             return;
         }
     }
+#ifdef DN_MLP_STAMP
+    Stamp stp{0, wave, blockIdx.x == 0 && blockIdx.y == 0 && lane == 0};
+#endif
     dma_chunk(net.w1, lds, H1 / 32, wave, lane);            // layer 1 = one chunk of 16 fragments, into buffer 0
     u32x4 x0[1];
     {
@@ -416,10 +432,10 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(1, 1
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int k = 8 * g + 2 * q;
-            x0[0][q] = pack2(k < a.obs_dim ? o[k] : 0.0f, k + 1 < a.obs_dim ? o[k + 1] : 0.0f);
+            x0[0][q] = pack2t<F16>(k < a.obs_dim ? o[k] : 0.0f, k + 1 < a.obs_dim ? o[k + 1] : 0.0f);
         }
     }
-    chunk_barrier();
+    CHUNK_BARRIER();
     // LDS buffer parities: layer 1 (one chunk of 16 fragments) in buffer 0; layer 2's 16 chunks start in buffer 1;
     // layer 3's 8 chunks start at 1 + 16 -> buffer 1; the head (one chunk of 16 fragments) at 17 + 8 -> buffer 1
     u32x4 h1[H1 / 16];
@@ -431,15 +447,15 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(1, 1
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = net.b1[acc_row(m, g, r)];
             const uint4 w = lds[m * 64 + lane];
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x0[0]), acc, 0, 0, 0);
-            epilogue(acc, true, h1[2 * m], h1[2 * m + 1]);
+            acc = mfma16<F16>(w, x0[0], acc);
+            epilogue_t<F16>(acc, h1[2 * m], h1[2 * m + 1]);
         }
-        chunk_barrier();
+        CHUNK_BARRIER();
     }
     u32x4 h2[H2 / 16];
-    layer_lds<H2 / 32, 1, CHUNK>(net.w2, net.b2, net.w3, h1, h2, lds, wave, lane);
+    layer_lds<F16, H2 / 32, 1, CHUNK>(net.w2, net.b2, net.w3, h1, h2, lds, wave, lane STP_ARG);
     u32x4 h3[H3 / 16];
-    layer_lds<H3 / 32, 1, H3 / 16>(net.w3, net.b3, net.wh, h2, h3, lds, wave, lane);
+    layer_lds<F16, H3 / 32, 1, H3 / 16>(net.w3, net.b3, net.wh, h2, h3, lds, wave, lane STP_ARG);
     // head: one M-tile of H3/16 = 16 fragments; float32 result straight from the accumulator
     f32x16 acc;
 #pragma unroll
@@ -448,7 +464,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(1, 1
 #pragma unroll
     for (int kk = 0; kk < H3 / 16; ++kk) {
         const uint4 w = cur[kk * 64 + lane];
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, h3[kk]), acc, 0, 0, 0);
+        acc = mfma16<F16>(w, h3[kk], acc);
     }
     if (live) {
         float *o = net.out + (row0 + col) * net.out_dim;
@@ -478,7 +494,8 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(1, 1
 //     pair), biases are staged in LDS once, and the only global traffic inside the loop is the LDS-DMA.
 // -----------------------------------------------------------------------------------------------------
 constexpr int PWAVES = 8;
-constexpr int DN_MLP_DEFAULT_SHAPE = 8;       // measured: 68.9 us (pair) vs 77.9 us (4 waves) vs 79 us (1 wave) for pi+vf at 32768 drones
+constexpr int DN_MLP_DEFAULT_SHAPE = 4;       // pi + vf at 32 768 drones, sustained (400 launches): 57.5 us (four waves, round 3: ring pinned, epilogue
+                                              // software-pipelined) vs 59.0 us (pair) vs 79 us (one wave from L2); rounds 1-2: 77.9 / 68.9 / 79
 constexpr int NBIAS = H1 + H2 + H3 + 32;                      // float32 biases of the four layers, staged in LDS
 constexpr int XB_U4 = 4 * 2 * 4 * 64;                         // exchange: 4 pairs x 2 parities x (16 f32 per lane = 4 uint4) x 64 lanes
 constexpr int LDS_PAIR_U4 = 2 * CHUNK * 64 + XB_U4 + (NBIAS + 3) / 4 + 1;
@@ -1299,13 +1316,17 @@ hipError_t dn_launch_mlp(const dn_mlp_net *nets, int num_nets, const float *obs,
     const char *e = getenv("DN_MLP_SHAPE");                  // 1 | 4 | 8 waves per workgroup (A/B measurements, tests)
     const int shape = e ? atoi(e) : DN_MLP_DEFAULT_SHAPE;
 
-    if (nets[0].grade == 2) {                                // float16 operands: the pair shapes only
-        hipLaunchKernelGGL((dn_mlp_pair_kernel<true, NoTail>), dim3((tiles + 3) / 4, num_nets), dim3(64 * PWAVES), 0, stream, a, NoTail());
-        return hipGetLastError();
+    const bool f16 = nets[0].grade == 2;                     // float16 operands: the two LDS-fed shapes
+    if (shape == 1 && !f16) hipLaunchKernelGGL(dn_mlp_kernel, dim3(tiles, num_nets), dim3(64), 0, stream, a);
+    else if (shape == 8) {
+        if (f16) hipLaunchKernelGGL((dn_mlp_pair_kernel<true, NoTail>), dim3((tiles + 3) / 4, num_nets), dim3(64 * PWAVES), 0, stream, a, NoTail());
+        else hipLaunchKernelGGL((dn_mlp_pair_kernel<false, NoTail>), dim3((tiles + 3) / 4, num_nets), dim3(64 * PWAVES), 0, stream, a, NoTail());
+        dump_stamps("pair");
+    } else {
+        if (f16) hipLaunchKernelGGL(dn_mlp_lds_kernel<true>, dim3((tiles + WAVES - 1) / WAVES, num_nets), dim3(64 * WAVES), 0, stream, a);
+        else hipLaunchKernelGGL(dn_mlp_lds_kernel<false>, dim3((tiles + WAVES - 1) / WAVES, num_nets), dim3(64 * WAVES), 0, stream, a);
+        dump_stamps("lds4");
     }
-    if (shape == 1) hipLaunchKernelGGL(dn_mlp_kernel, dim3(tiles, num_nets), dim3(64), 0, stream, a);
-    else if (shape == 8) { hipLaunchKernelGGL((dn_mlp_pair_kernel<false, NoTail>), dim3((tiles + 3) / 4, num_nets), dim3(64 * PWAVES), 0, stream, a, NoTail()); dump_stamps("pair"); }
-    else hipLaunchKernelGGL(dn_mlp_lds_kernel, dim3((tiles + WAVES - 1) / WAVES, num_nets), dim3(64 * WAVES), 0, stream, a);
     return hipGetLastError();
 }
 #endif  // DN_MLP_NO_LAUNCHER

@@ -326,7 +326,8 @@ int32_t dn_step_sampled(dn_env *env, const float *mean, const float *log_std, ui
  * and no round trip of the action means between the policy and the environment (SB3 collect_rollouts' forward -> sample -> clip ->
  * env.step, Sol/Model/PBDroneSimulator.py:261-286).  nets[1] (optional) is the critic, evaluated by the other workgroups of the same
  * launch; both write their `out` as dn_mlp_forward does.  policy_obs: device float[N * obs_dim], the observation the networks read
- * (must not alias `obs`, the step's output).  Same results, bit for bit, as the two calls it replaces.  Limits: PPO arch, the float64
+ * (must not alias `obs`, the step's output).  Same results, bit for bit, as the two calls it replaces when dn_mlp_forward runs its pair
+ * shape (DN_MLP_SHAPE=8: the kernel this launch extends; the default four-wave shape sums K in another order).  Limits: PPO arch, the float64
  * reference configuration without noise / reward wrappers / extra physics / ground contact, fleets on which dn_create picked the
  * three-wave single step (dn_get_kernel_waves(env, 0) == 3), num_envs a multiple of 128 (64 in the float32 grade);
  * DN_ERR_INVALID_ARGUMENT otherwise (use the two calls). */

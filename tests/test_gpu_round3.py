@@ -310,10 +310,14 @@ def test_fused_collector_gathers_into_static_buffers():
 
 
 @pytest.mark.parametrize("grade,norm,n", [("bf16", True, 1024), ("fp16", False, 256), ("fp32", True, 320), ("fp32", False, 4096), ("bf16", True, 32768)])
-def test_fused_policy_step_equals_forward_then_step_sampled(grade, norm, n):
+def test_fused_policy_step_equals_forward_then_step_sampled(grade, norm, n, monkeypatch):
     """dn_mlp_step_sampled (the actor's workgroups step the drones they have just evaluated: one launch per closed-loop step) against
     dn_mlp_forward + dn_step_sampled on a twin environment: action means, values, stored actions, log-probabilities, every step output
-    and the final state, bit for bit, over episodes that end and restart -- and FusedRolloutCollector with one_launch on / off."""
+    and the final state, bit for bit, over episodes that end and restart -- and FusedRolloutCollector with one_launch on / off.
+    The one-launch kernel is the PAIR shape of the policy kernel (two waves per SIMD splitting K) with the step as its tail, so
+    dn_mlp_forward is pinned to that shape here (DN_MLP_SHAPE=8; its default four-wave shape sums K in another order: same network,
+    last-bit differences)."""
+    monkeypatch.setenv("DN_MLP_SHAPE", "8")
     pkg = _pkg()
     from drl_dronenavigation_amd import _capi, tracks
     from drl_dronenavigation_amd.collector import FusedRolloutCollector
