@@ -280,6 +280,15 @@ DN_DEV void add_act_noise(const DnParams &p, unsigned long long gid, unsigned lo
         a[j] = clipv(a[j] + s, -1.0f, 1.0f);
     }
 }
+// add_obs_noise with the draws handed in: z[0..12] = the first 13 values of streams stream0 .. stream0 + 3 (the same float32 operations)
+DN_DEV void add_obs_noise_drawn(const DnParams &p, const float z[DN_OBS_DIM], float o[DN_OBS_DIM])
+{
+#pragma unroll
+    for (int j = 0; j < DN_OBS_DIM; ++j) {
+        float s = p.obs_noise_sigma * z[j];
+        o[j] = o[j] + s;
+    }
+}
 DN_DEV void add_obs_noise(const DnParams &p, unsigned long long gid, unsigned long long step, unsigned stream0, float o[DN_OBS_DIM])
 {
 #pragma unroll
@@ -293,6 +302,38 @@ DN_DEV void add_obs_noise(const DnParams &p, unsigned long long gid, unsigned lo
                 o[4 * b + j] = o[4 * b + j] + s;
             }
     }
+}
+
+// The reset observation's noise (streams stream0 .. stream0 + 3 of the drones whose episode ended) drawn ACROSS the wave: an episode
+// ends on a few of a tile's 64 drones per step, yet add_obs_noise inside the lane-divergent reset branch costs the wave its seven
+// Box-Muller pairs serially (~2 us of dn_step_squashed's tile time, on most steps of a short-episode fleet).  Here lane L draws pair
+// L % 7 of the (L / 7)-th finished drone -- nine drones per pass -- and the draws travel through `scratch` (float[15][64] of LDS owned
+// by this wave: 14 columns + the list of finished lanes).  Same counter, same key, same Box-Muller: the same bits as add_obs_noise.
+// Wave-uniform: every lane calls it; z[0..12] is meaningful on the lanes of `done_mask`.
+DN_DEV void draw_obs_noise_across(const DnParams &p, const unsigned long long gid_base, const unsigned long long step, const unsigned stream0,
+                                  const unsigned long long done_mask, const bool mine, const unsigned lane, float *scratch, float z[DN_OBS_DIM])
+{
+    int *dlist = reinterpret_cast<int *>(scratch + 14 * DN_BLOCK);
+    const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(done_mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)done_mask, 0u));
+    if (mine) dlist[rank] = (int)lane;
+    const unsigned count = (unsigned)__builtin_popcountll(done_mask);
+    const unsigned w = lane / 7u, pr = lane - 7u * w;
+    for (unsigned base = 0; base < count; base += 9u) {
+        const bool work = w < 9u && base + w < count;
+        const unsigned d = work ? (unsigned)dlist[base + w] : 0u;
+        const unsigned long long gid = gid_base + d;
+        unsigned r[4];
+        philox4x32((unsigned)gid, (unsigned)(gid >> 32), (unsigned)step, (stream0 + (pr >> 1)) | ((unsigned)(step >> 32) << 8), (unsigned)p.seed,
+                   (unsigned)(p.seed >> 32), r);
+        float z0, z1;
+        box_muller_pair((pr & 1u) ? r[2] : r[0], (pr & 1u) ? r[3] : r[1], z0, z1);
+        if (work) {
+            scratch[(2u * pr) * DN_BLOCK + d] = z0;
+            scratch[(2u * pr + 1u) * DN_BLOCK + d] = z1;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < DN_OBS_DIM; ++j) z[j] = scratch[j * DN_BLOCK + lane];
 }
 
 // ---- A10: normalize.NormalizeObservation with a batch of one (normalize.py:34-47, :94-97) ---------
@@ -1608,7 +1649,11 @@ DN_DEV void report_obs(const DnParams &p, const DnConsts<R> &c, float *s_tile, c
                        const unsigned li, const unsigned lane, const unsigned rows, const bool active, Rms &rms)
 {
     const bool done = v.terminated != 0 || truncated;
-    if (__ballot(done && active) != 0ull) {
+    const unsigned long long done_mask = __ballot(done && active);
+    if (done_mask != 0ull) {
+        const bool across = NOISE && TILE == 2 && s_tile != nullptr && p.obs_noise_sigma > 0.0f;      // pqx_step: the draws across the wave
+        float zr[DN_OBS_DIM];
+        if (across) draw_obs_noise_across(p, gid - li, step_count, 5u, done_mask, done && active, lane, s_tile, zr);
         if (done) {
             if (active && out.terminal_obs) {
 #pragma unroll
@@ -1621,7 +1666,8 @@ DN_DEV void report_obs(const DnParams &p, const DnConsts<R> &c, float *s_tile, c
 #pragma unroll
                 for (int k = 0; k < 3; ++k) o[k] = (float)((R)(float)q[k] * c.inv_dim[k]);
             }
-            if (NOISE && p.obs_noise_sigma > 0.0f) add_obs_noise(p, gid, step_count, 5u, o);
+            if (across) add_obs_noise_drawn(p, zr, o);
+            else if (NOISE && p.obs_noise_sigma > 0.0f) add_obs_noise(p, gid, step_count, 5u, o);
             if (NORM) normalize_obs(rms, o);
         }
     }
@@ -2542,6 +2588,14 @@ template <typename R> struct VerdictMail {
     R d_obs[DN_BLOCK];
     int flags[DN_BLOCK];                  // coll1 | terminated << 1
 };
+// Timing builds (-DDN_PQX_STAMP=<tile>; never shipped): the cycle counter of every role of one tile at the marks of pqx_step, read back
+// through dn_debug_pqx_stamps (profiles/r03_pqx_stamps.txt).
+#ifdef DN_PQX_STAMP
+__device__ long long g_pqx_stamp[3][16];
+#define PQX_MARK(k) do { if (lane == 0 && tile == DN_PQX_STAMP) g_pqx_stamp[role][k] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define PQX_MARK(k) do { } while (0)
+#endif
 // The LDS of one three-wave single step (one 64-drone tile): the table and the four mails.  A struct, so that a kernel that runs the
 // step as its TAIL (dn_fused.hip: the policy network's workgroup steps the drones it has just evaluated) can place it in LDS it
 // already owns.
@@ -2550,6 +2604,8 @@ template <typename R> struct __attribute__((aligned(16))) PqxShared {
     PosMail<R> pmail;
     R qmail[4][DN_BLOCK];
     VerdictMail<R> vmail;
+    float zmail[5][DN_BLOCK];             // NOISE: the observation-noise draws of columns 8..12, drawn by P (see pqx_step)
+    float zreset[15][DN_BLOCK];           // NOISE: draw_obs_noise_across's scratch (Q)
     R s_tab[DN_MAX_WAYPOINTS * DN_T_STRIDE];
 };
 // One control step of tile `tile` on three waves; `role` 0 = P, 1 = Q, 2 = X, `tid2` = this thread's index among the 128 threads of
@@ -2577,6 +2633,7 @@ DN_DEV void pqx_step(const DnParams &p, const DnStepIO &io0, PqxShared<R> &sh, c
     const BlockState b = block_state(p.st, tile_base);
     const DnConsts<R> &c = consts<R>(p);
     const StepOut out = block_out(io0, tile_base, 0, 0);
+    PQX_MARK(0);
     if (role == 2) {
         // ---- X: the action chain first (nothing else can start without it), the value side of the step last
         const float4 *act = reinterpret_cast<const float4 *>(io0.actions) + tile_base;
@@ -2589,12 +2646,12 @@ DN_DEV void pqx_step(const DnParams &p, const DnStepIO &io0, PqxShared<R> &sh, c
         // word back from memory and nothing queues ahead of it
         const float4 G0 = b.g0[li], G2 = b.g2[li], G3 = b.g3[li];
         float4 G4 = b.g4[li], G5 = b.g5[li];
-        block_lds_barrier();                                               // B1: thrust and table published
+        PQX_MARK(1); block_lds_barrier(); PQX_MARK(2);                    // B1
         Flight<R> fl;
         flight_entry<R>(fl, G0, G2, G3, p.max_steps);
         RewardPre<R> pre = reward_entry<R>(p, c, fl, G4, G5);              // while P and Q integrate
         pin(pre.r0); pin(pre.s_lin); pin(pre.s_ang); pin(pre.pen_lin); pin(pre.pen_ang);
-        block_lds_barrier();                                               // B2: position and attitude published
+        PQX_MARK(3); block_lds_barrier(); PQX_MARK(4);                    // B2
         fl.px = pmail.p[0][lane]; fl.py = pmail.p[1][lane]; fl.pz = pmail.p[2][lane];
         fl.qx = qmail[0][lane]; fl.qy = qmail[1][lane]; fl.qz = qmail[2][lane]; fl.qw = qmail[3][lane];
         attitude_phase<R, false>(fl);                                      // the forward vector of the new pose
@@ -2602,7 +2659,7 @@ DN_DEV void pqx_step(const DnParams &p, const DnStepIO &io0, PqxShared<R> &sh, c
         float r_found32;
         reward_pose<R>(p, s_tab, fl, pre, r_normal, r_found32);
         pin(r_normal); pin(r_found32);
-        block_lds_barrier();                                               // B3: verdict published
+        PQX_MARK(5); block_lds_barrier(); PQX_MARK(6);                    // B3
         Verdict<R> v;
         v.d_obs = vmail.d_obs[lane];
         const int vf = vmail.flags[lane];
@@ -2612,11 +2669,25 @@ DN_DEV void pqx_step(const DnParams &p, const DnStepIO &io0, PqxShared<R> &sh, c
         report_scalars<R, false>(p, c, out, fl, v, r_normal, r_found32, li, lane, active, G4, G5, acc, rn);
         flush_stats_preloaded(p, slot0, acc, sc0 + 1ull, lane, tile);
         if (active) { b.g4[li] = G4; b.g5[li] = G5; }
+        PQX_MARK(7);
     } else if (role == 0) {
         // ---- P: the linear half of the rigid-body step, then the rules on the new position
+        const bool obs_noise = NOISE && p.obs_noise_sigma > 0.0f;
+        const unsigned long long sc0 = NOISE ? p.st.stats[tile].step_count : 0ull;     // first: the draws below wait for nothing else
         const float4 G0 = b.g0[li], G1 = b.g1[li], G2 = b.g2[li], G3 = b.g3[li];
         stage_table_by<R>(p, s_tab, tid2, 2 * DN_BLOCK);            // P and Q (threads 0..127) stage the table; X is busy with the thrust
-        block_lds_barrier();                                               // B1
+        if (obs_noise) {
+            // The 13 Gaussian draws of the step observation's noise depend on (seed, drone, vector step) only.  Drawn by Q between B2
+            // and B3 -- where the observation exists -- their seven Box-Muller pairs were ~1.7 us of the tile's critical path; here
+            // P (columns 8..12) and Q (columns 0..7) draw them while X draws the action's and computes the thrust.
+            float z[4], z4[4];
+            noise4(p.seed, gid, sc0, 3u, z);
+            noise4(p.seed, gid, sc0, 4u, z4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sh.zmail[j][lane] = z[j];
+            sh.zmail[4][lane] = z4[0];
+        }
+        PQX_MARK(1); block_lds_barrier(); PQX_MARK(2);                    // B1
         const GateRow<R> row_e = load_gate_row<R>(s_tab, unpack_meta(G3.w).idx);
         const R wp0[3] = {s_tab[DN_T_WP], s_tab[DN_T_WP + 1], s_tab[DN_T_WP + 2]};
         const R fz = tmail.v[0][lane];
@@ -2629,30 +2700,34 @@ DN_DEV void pqx_step(const DnParams &p, const DnStepIO &io0, PqxShared<R> &sh, c
         fl.wx = fl.wy = fl.wz = 0.0f;
         pmail.p[0][lane] = fl.px; pmail.p[1][lane] = fl.py; pmail.p[2][lane] = fl.pz;
         pmail.v[lane] = make_float4(fl.vx, fl.vy, fl.vz, 0.0f);
-        block_lds_barrier();                                               // B2
+        PQX_MARK(3); block_lds_barrier(); PQX_MARK(4);                    // B2
         RulesMid<R> m;
         const Verdict<R> v = rules_verdict<R>(p, c, s_tab, row_e, fl, G3, m);
         vmail.d_obs[lane] = v.d_obs;
         vmail.flags[lane] = v.coll1 | (v.terminated << 1);
-        block_lds_barrier();                                               // B3
+        PQX_MARK(5); block_lds_barrier(); PQX_MARK(6);                    // B3
         float4 S0, S1, S2, S3;
         rules_commit<R>(c, wp0, fl, m, G0, G3, b.g6, li, active, S0, S1, S2, S3);
         if (active) {
             b.g0[li] = S0; b.g2[li] = S2;
             reinterpret_cast<float *>(b.g3 + li)[3] = S3.w;
         }
+        PQX_MARK(7);
     } else {
         // ---- Q: the angular half, then everything that reads the attitude
-        const float4 G0 = b.g0[li], G1 = b.g1[li], G3 = b.g3[li];
+        const bool obs_noise = NOISE && p.obs_noise_sigma > 0.0f;
         const unsigned long long sc0 = NOISE ? p.st.stats[tile].step_count : 0ull;
+        const float4 G0 = b.g0[li], G1 = b.g1[li], G3 = b.g3[li];
         stage_table_by<R>(p, s_tab, tid2, 2 * DN_BLOCK);            // before the statistics: memory returns in order, and B1 waits for the table
         Rms rms;
         if (NORM) load_rms(p, i, rms);
-        block_lds_barrier();                                               // B1
+        float zn[DN_OBS_DIM];
+        if (obs_noise) { noise4(p.seed, gid, sc0, 1u, zn); noise4(p.seed, gid, sc0, 2u, zn + 4); }    // columns 0..7 (see P)
+        PQX_MARK(1); block_lds_barrier(); PQX_MARK(2);                    // B1
         const R tx = tmail.v[1][lane], ty = tmail.v[2][lane], zt = tmail.v[3][lane];
         const Ang<R> ang = physics_angular<R>(G1, G3, tx, ty, zt);
         qmail[0][lane] = ang.qx; qmail[1][lane] = ang.qy; qmail[2][lane] = ang.qz; qmail[3][lane] = ang.qw;
-        block_lds_barrier();                                               // B2
+        PQX_MARK(3); block_lds_barrier(); PQX_MARK(4);                    // B2
         Flight<R> fl;
         flight_entry<R>(fl, G0, make_float4(0.0f, 0.0f, 0.0f, 0.0f), G3, p.max_steps);     // d_e, truncated: all this wave reads of it
         fl.px = pmail.p[0][lane]; fl.py = pmail.p[1][lane]; fl.pz = pmail.p[2][lane];
@@ -2663,14 +2738,18 @@ DN_DEV void pqx_step(const DnParams &p, const DnStepIO &io0, PqxShared<R> &sh, c
         attitude_phase<R>(fl);
         float o[DN_OBS_DIM];
         observe_columns<R>(p, c, fl, o);
-        if (NOISE && p.obs_noise_sigma > 0.0f) add_obs_noise(p, gid, sc0, 1u, o);
+        if (obs_noise) {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) zn[8 + j] = sh.zmail[j][lane];
+            add_obs_noise_drawn(p, zn, o);
+        }
         if (NORM) normalize_obs(rms, o);
-        block_lds_barrier();                                               // B3
+        PQX_MARK(5); block_lds_barrier(); PQX_MARK(6);                    // B3
         Verdict<R> v;
         v.d_obs = vmail.d_obs[lane];
         const int vf = vmail.flags[lane];
         v.coll1 = vf & 1; v.terminated = (vf >> 1) & 1;
-        report_obs<R, NORM, NOISE, 2>(p, c, nullptr, out, fl.truncated != 0, v, o, gid, sc0, li, lane, rows, active, rms);
+        report_obs<R, NORM, NOISE, 2>(p, c, NOISE ? &sh.zreset[0][0] : nullptr, out, fl.truncated != 0, v, o, gid, sc0, li, lane, rows, active, rms);
         if (NORM && active) store_rms(p, i, rms);
         if (active) {
             const bool done = v.terminated != 0 || fl.truncated != 0;      // the body is reloaded at rest, level (rules_commit's S1 / S3)
@@ -2678,6 +2757,7 @@ DN_DEV void pqx_step(const DnParams &p, const DnStepIO &io0, PqxShared<R> &sh, c
             float *g3 = reinterpret_cast<float *>(b.g3 + li);
             g3[0] = done ? 0.0f : fl.wx; g3[1] = done ? 0.0f : fl.wy; g3[2] = done ? 0.0f : fl.wz;
         }
+        PQX_MARK(7);
     }
 }
 
@@ -3150,4 +3230,11 @@ hipError_t dn_launch_compact(const unsigned long long *mask, long long n, int32_
     hipLaunchKernelGGL(dn_compact_kernel, dim3(blocks), dim3(1024), 0, stream, mask, n, indices, count);
     return hipGetLastError();
 }
+#ifdef DN_PQX_STAMP
+extern "C" int dn_debug_pqx_stamps(long long *out)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pqx_stamp), sizeof(long long) * 48) == hipSuccess ? 0 : 1;
+}
+#endif
 #endif  // DN_TU == 1

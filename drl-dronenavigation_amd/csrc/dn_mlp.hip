@@ -1181,7 +1181,11 @@ template <bool X3, bool F16>
 __global__ __launch_bounds__(64 * SAC_WAVES) void dn_mlp_sac_lds_kernel(const MlpArgs a)
 {
     constexpr int NB_SAC = S1 + S2 + 32;                   // float32 biases of the three layers, staged in LDS
+#ifdef DN_EXP_SAC_PAD
+    __shared__ __attribute__((aligned(16))) uint4 lds[2 * CHUNK * 64 + NB_SAC / 4 + 1 + 1280];   // > 80 KB: one workgroup per CU
+#else
     __shared__ __attribute__((aligned(16))) uint4 lds[2 * CHUNK * 64 + NB_SAC / 4 + 1];     // ONE __shared__ object (see dn_mlp_lds_kernel)
+#endif
     float *lbias = reinterpret_cast<float *>(lds + 2 * CHUNK * 64);
     int *s_any = reinterpret_cast<int *>(lds + 2 * CHUNK * 64 + NB_SAC / 4);
     constexpr int PER = X3 ? 2 : 1;
