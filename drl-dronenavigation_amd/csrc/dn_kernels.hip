@@ -2592,7 +2592,8 @@ template <typename R> struct VerdictMail {
 // through dn_debug_pqx_stamps (profiles/r03_pqx_stamps.txt).
 #ifdef DN_PQX_STAMP
 __device__ long long g_pqx_stamp[3][16];
-#define PQX_MARK(k) do { if (lane == 0 && tile == DN_PQX_STAMP) g_pqx_stamp[role][k] = (long long)__builtin_readcyclecounter(); } while (0)
+#define PQX_MARK(k) do { if (lane == 0 && tile == DN_PQX_STAMP) { g_pqx_stamp[role][k] = (long long)__builtin_readcyclecounter(); \
+        if ((k) == 0 || (k) == 7) g_pqx_stamp[role][8 + (k) / 7] = (long long)wall_clock64(); } } while (0)
 #else
 #define PQX_MARK(k) do { } while (0)
 #endif

@@ -30,7 +30,6 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));     // a B operand as the four dwords it occupies
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define MLP_DEV __device__ __forceinline__
 
@@ -262,41 +261,57 @@ constexpr int CHUNK = 32;                                  // fragments (KB) per
 constexpr int WAVES = 4;
 constexpr int LDS_RING = 8;
 
+// N (1, 2 or 4) weight pieces of 1 KB, 1 KB apart in global memory and in LDS alike (the instruction's immediate offset applies to both
+// addresses): `gbase` = the first piece's fragment (wave-uniform), `lds_dst` = its LDS byte address (wave-uniform -> M0).  The scalar-base
+// form (SGPR pair + one 32-bit lane offset) costs the requesting wave ~48 cycles a piece among ds_reads and MFMAs, the 64-bit-address-
+// per-lane form ~57 (profiles/r03_lds_dma_issue.txt), and needs no 64-bit vector add per group.
+// Inline asm on purpose: hipcc drains a builtin LDS-DMA (s_waitcnt vmcnt(0)) before the next ds_read because it cannot tell the two LDS
+// buffers apart, which would expose the whole L2 round trip at the start of every chunk; chunk_barrier() waits for the pieces explicitly.
+template <int N>
+MLP_DEV void dma_pieces(const uint4 *gbase, const unsigned lds_dst, const int lane)
+{
+    static_assert(N == 1 || N == 2 || N == 4, "");
+    const unsigned voff = (unsigned)lane * 16u;
+    const unsigned m0v = __builtin_amdgcn_readfirstlane(lds_dst);
+    const unsigned long long gb = (unsigned long long)(uintptr_t)gbase;
+    const unsigned glo = __builtin_amdgcn_readfirstlane((unsigned)gb), ghi = __builtin_amdgcn_readfirstlane((unsigned)(gb >> 32));
+    const unsigned long long gs = ((unsigned long long)ghi << 32) | glo;
+    unsigned keep;
+    if (N == 4)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, %3\n\t"
+                     "global_load_lds_dwordx4 %1, %3 offset:1024\n\t"
+                     "global_load_lds_dwordx4 %1, %3 offset:2048\n\t"
+                     "global_load_lds_dwordx4 %1, %3 offset:3072\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(m0v), "s"(gs) : "memory");
+    else if (N == 2)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, %3\n\t"
+                     "global_load_lds_dwordx4 %1, %3 offset:1024\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(m0v), "s"(gs) : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, %3\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(m0v), "s"(gs) : "memory");
+}
+
 MLP_DEV void dma_chunk(const uint4 *__restrict__ src, uint4 *lds, const int nfrag, const int wave, const int lane)
-{   // wave w brings in fragments [w*nfrag/4, (w+1)*nfrag/4) of the chunk.
-    // The LDS-DMA is issued from inline asm on purpose: hipcc drains a builtin LDS-DMA (s_waitcnt vmcnt(0)) before the
-    // next ds_read because it cannot tell the two LDS buffers apart, which would expose the whole HBM/L2 round trip at
-    // the start of every chunk.  An asm load is invisible to its counters; chunk_barrier() waits for it explicitly.
-    // A wave's pieces are contiguous both in global memory and in LDS (1 KB apart), and the instruction's immediate
-    // offset applies to both addresses, so four pieces share one M0 / one address register: offset:0 .. offset:3072.
+{   // wave w brings in fragments [w*nfrag/4, (w+1)*nfrag/4) of the chunk, contiguous both in global memory and in LDS
     const int per = nfrag / WAVES;                          // 8 (32-fragment chunk) or 4 (16-fragment chunk)
 #pragma unroll
     for (int j0 = 0; j0 < CHUNK / WAVES; j0 += 4) {
         if (j0 < per) {
             const int f = wave * per + j0;
-            const uint4 *gsrc = src + f * 64 + lane;
-            const unsigned lds_dst = (unsigned)(uintptr_t)(lds + f * 64);    // wave-uniform LDS byte address -> M0
-            unsigned keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                         "global_load_lds_dwordx4 %1, off\n\t"
-                         "global_load_lds_dwordx4 %1, off offset:1024\n\t"
-                         "global_load_lds_dwordx4 %1, off offset:2048\n\t"
-                         "global_load_lds_dwordx4 %1, off offset:3072\n\t"
-                         "s_mov_b32 m0, %0"
-                         : "=&s"(keep)
-                         : "v"(gsrc), "s"(lds_dst)
-                         : "memory");
+            dma_pieces<4>(src + f * 64, (unsigned)(uintptr_t)(lds + f * 64), lane);
         }
     }
 }
-MLP_DEV void dma_piece(const uint4 *gsrc, uint4 *lds_frag)
-{   // ONE 1-KB fragment: gsrc = this lane's 16 bytes, lds_frag = the fragment's (wave-uniform) LDS address
-    const unsigned lds_dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds_frag);
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, off\n\t"
-                 "s_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+MLP_DEV void dma_piece(const uint4 *gfrag, uint4 *lds_frag, const int lane)
+{   // ONE 1-KB fragment: both addresses wave-uniform
+    dma_pieces<1>(gfrag, (unsigned)(uintptr_t)lds_frag, lane);
 }
 MLP_DEV void chunk_barrier()
 {
@@ -505,23 +520,7 @@ MLP_DEV void dma_pair(const uint4 *__restrict__ src, uint4 *lds, const int wave,
 {   // NF fragments shared by 8 waves: 4 (NF = 32) or 2 (NF = 16) consecutive fragments each
     constexpr int per = NF / PWAVES;
     const int f = wave * per;
-    const uint4 *gsrc = src + f * 64 + lane;
-    const unsigned lds_dst = (unsigned)(uintptr_t)(lds + f * 64);
-    unsigned keep;
-    if (per == 4)
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                     "global_load_lds_dwordx4 %1, off\n\t"
-                     "global_load_lds_dwordx4 %1, off offset:1024\n\t"
-                     "global_load_lds_dwordx4 %1, off offset:2048\n\t"
-                     "global_load_lds_dwordx4 %1, off offset:3072\n\t"
-                     "s_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-    else
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                     "global_load_lds_dwordx4 %1, off\n\t"
-                     "global_load_lds_dwordx4 %1, off offset:1024\n\t"
-                     "s_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    dma_pieces<per>(src + f * 64, (unsigned)(uintptr_t)(lds + f * 64), lane);
 }
 
 MLP_DEV void park_partial(float4 *xb, const int parity, const int lane, const f32x16 &acc)
@@ -741,21 +740,12 @@ constexpr int LDS_X3_U4 = 2 * CH3 * 64 + XB3_U4 + (NBIAS + 3) / 4 + 1;
 
 template <int NF>
 MLP_DEV void dma_x3(const uint4 *__restrict__ src, uint4 *lds, const int wave, const int lane)
-{   // NF fragments (64 or 32) shared by 4 waves: 16 or 8 consecutive fragments each, four per asm group
+{   // NF fragments (64 or 32) shared by 4 waves: 16 or 8 consecutive fragments each, four per group
     constexpr int per = NF / XWAVES;
 #pragma unroll
     for (int j0 = 0; j0 < per; j0 += 4) {
         const int f = wave * per + j0;
-        const uint4 *gsrc = src + f * 64 + lane;
-        const unsigned lds_dst = (unsigned)(uintptr_t)(lds + f * 64);
-        unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                     "global_load_lds_dwordx4 %1, off\n\t"
-                     "global_load_lds_dwordx4 %1, off offset:1024\n\t"
-                     "global_load_lds_dwordx4 %1, off offset:2048\n\t"
-                     "global_load_lds_dwordx4 %1, off offset:3072\n\t"
-                     "s_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+        dma_pieces<4>(src + f * 64, (unsigned)(uintptr_t)(lds + f * 64), lane);
     }
 }
 MLP_DEV float bf16_hi_as_float(const unsigned packed, const int which)      // element 0 / 1 of a packed bf16 pair, widened
@@ -804,7 +794,7 @@ MLP_DEV void layer_x3(const uint4 *__restrict__ w, const float *lbias, const uin
         // 16 pieces at the top of the tile is ~1 000 cycles in which the matrix pipe idles (every wave of the CU queues on the one
         // 64 B/clk vector-memory path right after the barrier); one piece behind an MFMA hides in that MFMA's 32 cycles
         const int NPER = (m + 1 < MT ? CH3 : NEXT_FR) / XWAVES;
-        const uint4 *nsrc = (m + 1 < MT ? w + (size_t)(m + 1) * CH3 * 64 : next) + (size_t)wave * NPER * 64 + lane;
+        const uint4 *nsrc = (m + 1 < MT ? w + (size_t)(m + 1) * CH3 * 64 : next) + (size_t)wave * NPER * 64;
         uint4 *ndst = nxt + (size_t)wave * NPER * 64;
 #elif !defined(DN_MLP_ABLATE_DMA)
         if (m + 1 < MT) dma_x3<CH3>(w + (size_t)(m + 1) * CH3 * 64, nxt, wave, lane);
@@ -840,7 +830,7 @@ MLP_DEV void layer_x3(const uint4 *__restrict__ w, const float *lbias, const uin
 #pragma unroll
             for (int j = 0; j < DN_X3_DMA_SPREAD; ++j) {
                 const int pc = kk * DN_X3_DMA_SPREAD + j;
-                if (pc < NPER) dma_piece(nsrc + pc * 64, ndst + pc * 64);
+                if (pc < NPER) dma_piece(nsrc + pc * 64, ndst + pc * 64, lane);
             }
 #endif
             if (fin && (kk & 1)) {
@@ -1106,28 +1096,13 @@ MLP_DEV void sac_dma(const uint4 *__restrict__ src, uint4 *lds, const int wave, 
 {   // NF fragments (8, 16 or 32) shared by 4 waves: NF / 4 consecutive fragments each
     constexpr int per = NF / SAC_WAVES;
     const int f = wave * per;
-    const uint4 *gsrc = src + f * 64 + lane;
+    const uint4 *g = src + f * 64;
     const unsigned lds_dst = (unsigned)(uintptr_t)(lds + f * 64);
-    unsigned keep;
     if (per == 8) {
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                     "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\t"
-                     "global_load_lds_dwordx4 %1, off offset:2048\n\tglobal_load_lds_dwordx4 %1, off offset:3072\n\t"
-                     "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                     "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\t"
-                     "global_load_lds_dwordx4 %1, off offset:2048\n\tglobal_load_lds_dwordx4 %1, off offset:3072\n\t"
-                     "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc + 4 * 64), "s"(lds_dst + 4096u) : "memory");
-    } else if (per == 4) {
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                     "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\t"
-                     "global_load_lds_dwordx4 %1, off offset:2048\n\tglobal_load_lds_dwordx4 %1, off offset:3072\n\t"
-                     "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-    } else {
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                     "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\t"
-                     "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-    }
+        dma_pieces<4>(g, lds_dst, lane);
+        dma_pieces<4>(g + 4 * 64, lds_dst + 4096u, lane);
+    } else if (per == 4) dma_pieces<4>(g, lds_dst, lane);
+    else dma_pieces<2>(g, lds_dst, lane);
 }
 // ReLU, pack (and split) the 16 accumulator values of an M-tile into the next layer's K-steps 2m, 2m + 1
 template <bool X3, bool F16>
