@@ -408,29 +408,33 @@ def test_noise_draws_shared_out_over_the_waves_equal_the_per_drone_draws(norm, m
     the step observation's columns by the P and Q waves before the thrust exists, the reset observation's -- needed by the few
     drones whose episode just ended -- ACROSS the lanes of the Q wave (nine finished drones x seven Box-Muller pairs per pass).
     The fused kernel draws everything per drone inside the lane.  Same counters, keys and arithmetic, so the two must agree bit for
-    bit: on steps where one or two drones of a tile finish, on the step where the time limit ends ALL 64 of a tile together (eight
-    passes), and on a ragged last tile; the oracle checks the values themselves."""
+    bit: on steps where one or two drones of a tile finish, on the step where the time limit ends nearly all 64 of a tile together
+    (seven or eight passes), and on a ragged last tile; the oracle checks the values themselves."""
     pkg = _pkg()
     from drl_dronenavigation_amd import tracks
     monkeypatch.delenv("DN_WAVES", raising=False)
     monkeypatch.delenv("DN_WAVES_SINGLE", raising=False)
     track = tracks.reaching()
-    n, K, max_steps = 64 * 9 + 37, 23, 7
+    n, K, max_steps = 64 * 9 + 36, 130, 100
     kw = dict(normalize_obs=norm, max_steps=max_steps, act_noise_sigma=0.004, obs_noise_sigma=0.02, seed=31, env_id_offset=(1 << 33) + 5)
     single = pkg.DroneVecEnv(track, n, device="cuda:0", **kw)
     fused = pkg.DroneVecEnv(track, n, device="cuda:0", **kw)
     assert single.kernel_waves(fused=False) == 3
-    cfg = O.make_config(track.targets(), track.initial_xyzs, track.aviary_dim, circle=track.is_circle, max_steps=max_steps, f32_state=True,
+    cfg = O.make_config(track.targets(), track.initial_xyzs, track.aviary_dim, circle=track.is_circle, f32_state=True,
                         ground_contact=single.ground_contact, **kw)
     ora = O.OracleVecEnv(cfg, n, threads=8)
     assert torch.equal(single.reset_tensor(), fused.reset_tensor())
     ora.reset()
     rng = np.random.default_rng(5)
-    acts = np.stack([_mixed(rng, n) for _ in range(K)])
+    # hover for most (they reach the time limit together: all finished drones of a tile in one step, several passes); one drone in 29
+    # holds a constant pattern of saturated motors (it leaves the corridor after 70-odd steps: one or two finished drones in a tile)
+    pattern = np.where(rng.uniform(size=(n, 4)) < 0.5, -1.0, 1.0)
+    acts = np.stack([np.where((np.arange(n) % 29 == 0)[:, None], pattern, 0.0922 + 0.003 * rng.standard_normal((n, 4)))
+                     for _ in range(K)]).astype(np.float32)
     dev = torch.device("cuda:0")
     a_dev = torch.from_numpy(acts).to(dev)
     out = fused.rollout_tensor(a_dev, want_terminal=True)
-    few, all64 = 0, 0
+    few, many = 0, 0
     for t in range(K):
         obs, rew, done, info = single.step_tensor(a_dev[t])
         for got, want, what in ((obs, out["obs"][t], "obs"), (rew, out["reward"][t], "reward"), (done, out["done"][t], "done"),
@@ -440,11 +444,11 @@ def test_noise_draws_shared_out_over_the_waves_equal_the_per_drone_draws(norm, m
         assert torch.equal(info["terminal_obs"][d], out["terminal_obs"][t][d]), t
         per_tile = d[:64 * 9].view(9, 64).sum(1)
         few += int(((per_tile > 0) & (per_tile <= 9)).sum())
-        all64 += int((per_tile == 64).sum())
+        many += int((per_tile > 9).sum())
         ref = ora.step(acts[t])
         np.testing.assert_array_equal(done.cpu().numpy().astype(bool), ref["done"].astype(bool), err_msg=f"t={t}")
         np.testing.assert_allclose(obs.cpu().numpy(), ref["obs"], rtol=0, atol=1e-4 if norm else 1e-5, err_msg=f"t={t}")
-    assert few > 0 and all64 > 0
+    assert few > 0 and many > 0, (few, many)
     sa, sb = single.get_state(), fused.get_state()
     for k in sa.dtype.names:
         assert np.ascontiguousarray(sa[k]).tobytes() == np.ascontiguousarray(sb[k]).tobytes(), k
