@@ -166,17 +166,31 @@ SAC_MACS = 13 * 256 + 256 * 256 + 256 * 8
 
 
 def time_launches(torch, dev, fn, reps=200, warm=20):
-    """Average duration of one launch of `fn` (HIP events on the current stream around `reps` back-to-back launches)."""
-    for _ in range(warm):
-        fn()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize(dev)
-    e0.record()
-    for _ in range(reps):
-        fn()
-    e1.record()
-    torch.cuda.synchronize(dev)
-    return e0.elapsed_time(e1) * 1e3 / reps
+    """Average duration of one launch of `fn`: `reps` launches captured ONCE into a hipGraph on a side stream, the graph replayed between two
+    HIP events -- device time per launch, dispatch gap included, host launch rate excluded (a Python loop around a ctypes call issues one
+    launch per ~10-18 us, longer than the small kernels themselves).  `fn` must enqueue on torch's CURRENT stream."""
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        for _ in range(warm):
+            fn()
+        side.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            for _ in range(reps):
+                fn()
+        graph.replay()
+        side.synchronize()
+        best = float("inf")
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(side)
+            graph.replay()
+            e1.record(side)
+            side.synchronize()
+            best = min(best, e0.elapsed_time(e1) * 1e3 / reps)
+    torch.cuda.current_stream(dev).wait_stream(side)
+    return best
 
 
 def mlp_kernel_leg(torch, dev, name, fn, n, macs_mfma, macs, nets, passes):
@@ -184,7 +198,7 @@ def mlp_kernel_leg(torch, dev, name, fn, n, macs_mfma, macs, nets, passes):
     mfma_flop = 2.0 * macs_mfma * n * nets * passes
     return {"kernel": name, "avg_us": round(us, 2), "mfma_flop": mfma_flop, "useful_flop": 2.0 * macs * n * nets,
             "mfma_tflops": round(mfma_flop / (us * 1e-6) / 1e12, 1), "mfma_frac": round(mfma_flop / (us * 1e-6) / MFMA_PEAK_FLOPS, 4),
-            "passes": passes, "what": "HIP events around 200 back-to-back launches of this kernel alone; mfma_frac = MFMA flop issued "
+            "passes": passes, "what": "200 launches of this kernel alone replayed from one hipGraph between two HIP events; mfma_frac = MFMA flop issued "
                                       "(padded tiles; x3 for the split-bf16 float32 grade) / time / 2.5 PFLOP/s dense peak"}
 
 
@@ -246,7 +260,6 @@ def ppo_rollout(pkg, track, n, max_steps, dev, rank):
             kernels["mlp_" + gname] = mlp_kernel_leg(torch, dev, kname, lambda pol=pol: mlp_forward([pol.pi, pol.vf], obs, [mean, val]),
                                                      n, PPO_MACS_MFMA, PPO_MACS + 256 * 2.5, 2, passes)
         lib, h = pkg._capi.load(), env._handle
-        sp = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         bufs = dict(act=torch.zeros((n, 4), device=dev), logp=torch.zeros(n, device=dev), obs=torch.zeros((n, 13), device=dev),
                     rew=torch.zeros(n, device=dev), done=torch.zeros(n, dtype=torch.uint8, device=dev),
                     trunc=torch.zeros(n, dtype=torch.uint8, device=dev), found=torch.zeros(n, dtype=torch.int32, device=dev),
@@ -256,12 +269,13 @@ def ppo_rollout(pkg, track, n, max_steps, dev, rank):
         def step_sampled():
             pkg._capi.check(lib.dn_step_sampled(h, mean.data_ptr(), log_std, 1, 0, bufs["act"].data_ptr(), bufs["logp"].data_ptr(),
                                                 bufs["obs"].data_ptr(), bufs["rew"].data_ptr(), bufs["done"].data_ptr(),
-                                                bufs["trunc"].data_ptr(), bufs["found"].data_ptr(), bufs["term"].data_ptr(), None, None, None, sp))
+                                                bufs["trunc"].data_ptr(), bufs["found"].data_ptr(), bufs["term"].data_ptr(), None, None, None,
+                                                C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
         us = time_launches(torch, dev, step_sampled)
         kernels["step_sampled"] = {"kernel": f"dn_step_pqx_kernel<double, true, false, true> ({env.kernel_waves(fused=False)} waves per tile)"
                                              if env.kernel_waves(fused=False) == 3 else "dn_step_many_1w_kernel<double, true, false, true, false, true>",
                                    "avg_us": round(us, 2), "what": "Gaussian draw + clip + log-probability + the control step, obs normaliser on; "
-                                                                   "eager back-to-back launches (host-bound below ~3 us)"}
+                                                                   "200 launches replayed from one hipGraph"}
         env.close()
     except Exception as exc:  # noqa: BLE001
         kernels["error"] = f"{type(exc).__name__}: {exc}"
@@ -333,7 +347,6 @@ def sac_collect(pkg, track, n, max_steps, dev, rank):
                               seed=1, env_id_offset=rank * n, device=dev)
         env.reset_tensor()
         lib, h = pkg._capi.load(), env._handle
-        sp = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         mls = torch.zeros((n, 8), device=dev)
         b = dict(act=torch.zeros((n, 4), device=dev), obs=torch.zeros((n, 13), device=dev), rew=torch.zeros(n, device=dev),
                  done=torch.zeros(n, dtype=torch.uint8, device=dev), trunc=torch.zeros(n, dtype=torch.uint8, device=dev),
@@ -342,7 +355,7 @@ def sac_collect(pkg, track, n, max_steps, dev, rank):
         def step_squashed():
             pkg._capi.check(lib.dn_step_squashed(h, mls.data_ptr(), 1, 0, b["act"].data_ptr(), None, b["obs"].data_ptr(), b["rew"].data_ptr(),
                                                  b["done"].data_ptr(), b["trunc"].data_ptr(), b["found"].data_ptr(), b["term"].data_ptr(),
-                                                 None, None, None, sp))
+                                                 None, None, None, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
         kernels["step_squashed"] = {"kernel": "dn_step_pqx_kernel<double, true, true, true>" if env.kernel_waves(fused=False) == 3
                                     else "dn_step_many_1w_kernel<double, true, true, true, false, true>",
                                     "avg_us": round(time_launches(torch, dev, step_squashed), 2),
