@@ -75,10 +75,30 @@ void run(int waves_per_simd, float *out, long long *cyc)
     printf("acc %d  tanh/4mfma %d  ds_read/mfma %d  v_fma/mfma %d  waves/simd %d : %6.1f cycles per MFMA per wave, %6.1f per MFMA on the SIMD\n", NACC, TANH4, RD,
            PLAINV, waves_per_simd, (double)c / iters / 8, (double)c / iters / 8 / waves_per_simd);
 }
-int main()
+#include <chrono>
+#include <cstring>
+// `mfma_multiacc long <mix>`: ~12 s of one mix back to back, for reading clock and socket power with rocm-smi meanwhile
+// (profiles/r03_power.txt).  mix 0 = MFMA only, 1 = + one ds_read_b128 per MFMA, 2 = + half a tanh per MFMA as well; one wave per SIMD.
+template <int NACC, int TANH4, int RD, int PLAINV>
+void soak(float *out, long long *cyc, int waves)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 12.0) {
+        for (int i = 0; i < 50; ++i) hipLaunchKernelGGL((k<NACC, TANH4, RD, PLAINV>), dim3(256), dim3(256 * waves), 0, 0, out, cyc, 20000);
+        hipDeviceSynchronize();
+    }
+}
+int main(int argc, char **argv)
 {
     float *out; long long *cyc;
     hipMalloc(&out, 256 * 512 * 4); hipMalloc(&cyc, 8);
+    if (argc >= 3 && !strcmp(argv[1], "long")) {
+        const int mix = atoi(argv[2]), waves = argc >= 4 ? atoi(argv[3]) : 1;
+        if (mix == 0) soak<2, 0, 0, 0>(out, cyc, waves);
+        else if (mix == 1) soak<2, 0, 1, 0>(out, cyc, waves);
+        else soak<2, 2, 1, 0>(out, cyc, waves);
+        return 0;
+    }
     for (int w = 1; w <= 2; ++w) {
         run<1, 0, 0, 0>(w, out, cyc); run<2, 0, 0, 0>(w, out, cyc); run<4, 0, 0, 0>(w, out, cyc);
         run<1, 0, 1, 0>(w, out, cyc); run<2, 0, 1, 0>(w, out, cyc); run<4, 0, 1, 0>(w, out, cyc);
