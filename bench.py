@@ -53,6 +53,8 @@ def algo_bytes_per_launch(n, steps_per_launch, norm):
 
 def kernel_name(waves, dtype, norm, fused):
     r, nm = ("double" if dtype == "float64" else "float"), ("true" if norm else "false")
+    if waves == 5 and fused:
+        return f"dn_step_many_5w_kernel<{r}, false>"
     if waves == 4 and fused:
         return f"dn_step_many_4w_kernel<{r}, {nm}, false>"
     if waves >= 3 and fused:

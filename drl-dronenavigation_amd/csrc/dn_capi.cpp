@@ -42,6 +42,7 @@ inline double norm3d(const double v[3]) { return std::sqrt(v[0] * v[0] + v[1] * 
 constexpr long long DN_CALIBRATION_CUS = 256;
 constexpr long long DN_TWO_WAVE_TILES_PER_CU = 4;   // 1024 tiles = 65536 drones on 256 CUs: one tile per SIMD
 constexpr long long DN_PQX_TILES_PER_CU = 4;        // three-wave single step: while the tiles alone leave SIMDs idle
+constexpr long long DN_FIVE_WAVE_TILES_PER_CU = 2;  // the same with the normaliser on a fifth wave: up to two tiles per CU
 constexpr long long DN_FOUR_WAVE_TILES_PER_CU = 3;  // four-wave fused step: up to three tiles per CU (768 tiles on 256 CUs)
 constexpr double DN_CONTACT_MARGIN = 0.02;          // Bullet's contact-breaking threshold (dn_kernels.hip collision_common)
 constexpr double DN_COLL_R = 0.06, DN_COLL_H = 0.025;   // base_link collision cylinder, cf2x.urdf:34
@@ -328,6 +329,9 @@ int32_t dn_create(const dn_config *cfg, dn_env **out)
     //   with noise       16 384 / 32 768 / 49 152                            2.99 / 4.47 / 4.84   against 3.75 / 4.85 / 4.84 (normaliser on: 3.43 / 3.75 / 7.44 against
     //                    3.62 / 5.73 / 6.98) -> up to 512 tiles
     if (plain && !cfg->ground_contact && e->blocks <= (noisy ? DN_FOUR_WAVE_MAX_TILES * 2 / 3 : DN_FOUR_WAVE_MAX_TILES)) e->waves_fused = 4;
+    // Five waves (normaliser on; round 3): the four-wave kernel with the normaliser on a wave of its own (NW = 5), where the report wave set
+    // the pace.  DN_WAVES=4 keeps the four-wave shape for A/B runs; up to two tiles per CU (ten waves), see profiles/r03_notes.md.
+    if (e->waves_fused == 4 && cfg->normalize_obs && e->blocks <= DN_FIVE_WAVE_TILES_PER_CU * e->num_cus) e->waves_fused = 5;
     // dn_step (one control step per launch) is latency bound: ~2.9 us of launch-to-launch floor that an empty kernel
     // already pays (profiles/r02_dispatch_floor.txt) plus the dependent instruction stream of the step.  Cutting the step
     // by dependency over three waves (dn_step_pqx_kernel) shortens that stream while the chip has idle SIMDs; built for the
@@ -345,6 +349,9 @@ int32_t dn_create(const dn_config *cfg, dn_env **out)
             e->waves_single = pqx_ok ? 3 : 1;
         } else if (w[0] == '4') {                              // the recurrence itself on two waves (dn_step_many_4w_kernel): plain configuration only
             e->waves_fused = pqx_ok ? 4 : 3;
+            e->waves_single = pqx_ok ? 3 : 1;
+        } else if (w[0] == '5') {                              // + the normaliser on a fifth wave (normaliser on only)
+            e->waves_fused = pqx_ok ? (cfg->normalize_obs ? 5 : 4) : 3;
             e->waves_single = pqx_ok ? 3 : 1;
         }
     }

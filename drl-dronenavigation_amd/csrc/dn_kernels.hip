@@ -2355,9 +2355,15 @@ template <typename R> struct MailG {      // A -> L (qnew) and A -> Q (the rest)
     float4 we[DN_BLOCK];                  // entry angular velocity (prev_ang_v of the smoothness term)
 };
 
-template <typename R, bool NORM, bool NOISE>
-__global__ __launch_bounds__(4 * DN_BLOCK, 2) void dn_step_many_4w_kernel(const DnParams p, const DnStepIO io0, const int k_steps)
+// NW = 5 (normaliser on, round 3): the report wave is cut in two.  A wave issues one instruction per ~7.5 cycles however idle its SIMD
+// is (profiles/r03_valu_rates.txt), so the launch runs at the pace of the role with the most instructions per step -- with the
+// normaliser that was X: the step's scalars plus 247 float64 instructions of Welford update per step plus, on the 86 % of tile-steps
+// where a drone finishes, the masked second pass for the reset observation.  X keeps the scalars (reward select, Monitor, statistics),
+// a fifth wave N takes MailA's observation through the normaliser and out (report_obs): same functions, same values.
+template <typename R, bool NORM, bool NOISE, int NW>
+DN_DEV void step_many_4w_body(const DnParams &p, const DnStepIO &io0, const int k_steps)
 {
+    static_assert(NW == 4 || (NW == 5 && NORM), "the fifth wave is the normaliser's");
     __shared__ R s_tab[DN_MAX_WAYPOINTS * DN_T_STRIDE];
     __shared__ MailL<R> maill[2];
     __shared__ __attribute__((aligned(16))) MailG<R> mailg[2];
@@ -2375,8 +2381,22 @@ __global__ __launch_bounds__(4 * DN_BLOCK, 2) void dn_step_many_4w_kernel(const 
     constexpr bool THRUST_ON_Q = !NOISE || NORM;
     const int wv0 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wv = (!NORM && ((blockIdx.x >> 8) & 1)) ? (wv0 ^ 2) : wv0;
-    const int role = NORM ? (wv == 0 ? 0 : (wv == 1 ? 3 : (wv == 2 ? 1 : 2)))      // L X A Q
-                          : (wv == 0 ? 0 : (wv == 1 ? 1 : (wv == 2 ? 3 : 2)));     // L A X Q
+#ifndef DN_5W_ORDER_A
+#define DN_5W_ORDER_A "LQANX"
+#define DN_5W_ORDER_B "ANLQX"
+#endif
+    int role;
+    if (NW == 5) {
+        // five waves land on four SIMDs as 0 1 2 3 0; the second tile of a CU (tiles 256 .. 511 beside 0 .. 255) takes another order, so
+        // that the heavy waves of the two tiles pair with light ones of the other: SIMD 0: L1 X1 A2 X2, 1: Q1 N2, 2: A1 L2, 3: N1 Q2.
+        // Swept at 32 768 drones (us per step): this order 1.43, X L A N Q | Q N A L X 1.45, the same order in both tiles 1.56-1.80
+        // (profiles/r03_notes.md); the four-wave kernel 1.76.
+        constexpr char oa[6] = DN_5W_ORDER_A, ob[6] = DN_5W_ORDER_B;
+        const char ch = ((blockIdx.x >> 8) & 1) ? ob[wv0] : oa[wv0];
+        role = ch == 'L' ? 0 : ch == 'A' ? 1 : ch == 'Q' ? 2 : ch == 'X' ? 3 : 4;
+    } else
+        role = NORM ? (wv == 0 ? 0 : (wv == 1 ? 3 : (wv == 2 ? 1 : 2)))            // L X A Q
+                    : (wv == 0 ? 0 : (wv == 1 ? 1 : (wv == 2 ? 3 : 2)));           // L A X Q
     const long long tile_base = (long long)blockIdx.x * DN_BLOCK;
     const long long left = p.n - tile_base;
     const unsigned rows = left < DN_BLOCK ? (unsigned)left : DN_BLOCK;
@@ -2517,11 +2537,31 @@ __global__ __launch_bounds__(4 * DN_BLOCK, 2) void dn_step_many_4w_kernel(const 
             float *g4 = reinterpret_cast<float *>(b.g4 + li), *g5 = reinterpret_cast<float *>(b.g5 + li);
             g4[0] = P4.x; g4[1] = P4.y; g4[2] = P4.z; g5[0] = P5.x; g5[1] = P5.y; g5[2] = P5.z;
         }
+    } else if (role == 4) {
+        // ---- N (NW == 5): observation -> normaliser -> rows, the reset observation of a finished drone included
+        Rms rms;
+        load_rms(p, i, rms);
+        block_lds_barrier();                                               // P
+#pragma clang loop unroll(disable)
+        for (int t = 0; t <= k_steps + 1; ++t) {
+            if (t > 1) {
+                const int u = t - 2;
+                Flight<R> fl;
+                Verdict<R> v;
+                Observed<R> ob;
+                take_maila<R>(maila[u & 1], lane, fl, v, ob);
+                normalize_obs(rms, ob.o);                                  // the step observation (= terminal_observation)
+                const StepOut out = block_out(io0, tile_base, (long long)u * n, (long long)u * words);
+                report_obs<R, NORM, NOISE, 2>(p, c, nullptr, out, fl.truncated != 0, v, ob.o, gid, sc0 + (unsigned long long)u, li, lane, rows, active, rms);
+            }
+            if (t <= k_steps) block_lds_barrier();                         // barrier t
+        }
+        if (active) store_rms(p, i, rms);
     } else {
         float4 G4 = b.g4[li], G5 = b.g5[li];                               // .w: Monitor return / length
         StatAcc acc;
         Rms rms;
-        if (NORM) load_rms(p, i, rms);
+        if (NORM && NW == 4) load_rms(p, i, rms);
         RewNorm rn = {0.0, 0.0, 1.0, 1e-4};
         const float4 *act = reinterpret_cast<const float4 *>(io0.actions) + tile_base;
         float4 A = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -2546,19 +2586,34 @@ __global__ __launch_bounds__(4 * DN_BLOCK, 2) void dn_step_many_4w_kernel(const 
                 Verdict<R> v;
                 Observed<R> ob;
                 take_maila<R>(maila[u & 1], lane, fl, v, ob);
-                if (NORM) normalize_obs(rms, ob.o);                            // the step observation (= terminal_observation)
                 const StepOut out = block_out(io0, tile_base, (long long)u * n, (long long)u * words);
-                report_phase<R, NORM, NOISE, false, 2>(p, c, nullptr, out, fl, v, ob, gid, sc, li, lane, rows, active, G4, G5, acc, rms, rn);
+                if (NW == 5) report_scalars<R, false>(p, c, out, fl, v, ob.r_normal, ob.r_found32, li, lane, active, G4, G5, acc, rn);
+                else {
+                    if (NORM) normalize_obs(rms, ob.o);                        // the step observation (= terminal_observation)
+                    report_phase<R, NORM, NOISE, false, 2>(p, c, nullptr, out, fl, v, ob, gid, sc, li, lane, rows, active, G4, G5, acc, rms, rn);
+                }
             }
             if (t <= k_steps) block_lds_barrier();                         // barrier t
         }
         flush_stats(p, acc, sc0 + (unsigned long long)k_steps, lane);
-        if (NORM && active) store_rms(p, i, rms);
+        if (NORM && NW == 4 && active) store_rms(p, i, rms);
         if (active) {
             reinterpret_cast<float *>(b.g4 + li)[3] = G4.w;
             reinterpret_cast<float *>(b.g5 + li)[3] = G5.w;
         }
     }
+}
+
+template <typename R, bool NORM, bool NOISE>
+__global__ __launch_bounds__(4 * DN_BLOCK, 2) void dn_step_many_4w_kernel(const DnParams p, const DnStepIO io0, const int k_steps)
+{
+    step_many_4w_body<R, NORM, NOISE, 4>(p, io0, k_steps);
+}
+// five waves: two tiles per CU are ten waves on four SIMDs, i.e. FOUR waves on one of them -- 128 registers a wave
+template <typename R, bool NOISE>
+__global__ __launch_bounds__(5 * DN_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void dn_step_many_5w_kernel(const DnParams p, const DnStepIO io0, const int k_steps)
+{
+    step_many_4w_body<R, true, NOISE, 5>(p, io0, k_steps);
 }
 
 // -----------------------------------------------------------------------------------------------------
@@ -3043,6 +3098,17 @@ hipError_t dn_launch_step_many_mw(const DnParams &p, const DnStepIO &io, int k, 
     const bool noise = p.act_noise_sigma > 0.0f || p.obs_noise_sigma > 0.0f;
     // the rarely used options share one set of instantiations (runtime switches inside): reward wrappers, N4 physics terms
     const bool rew = p.clip_rew != 0 || p.norm_rew != 0 || p.gnd != 0 || p.drag != 0 || p.rpm_actions != 0 || p.pid_mode != 0 || p.random_spawn != 0 || p.zero_damping != 0;
+    if (waves == 5 && k > 1) {                             // four waves + the normaliser's: fused launches of the plain configuration, normaliser on
+        const dim3 blk(5 * DN_BLOCK);
+        if (f32) {
+            if (noise) hipLaunchKernelGGL((dn_step_many_5w_kernel<float, true>), dim3(grid), blk, 0, stream, p, io, k);
+            else hipLaunchKernelGGL((dn_step_many_5w_kernel<float, false>), dim3(grid), blk, 0, stream, p, io, k);
+        } else {
+            if (noise) hipLaunchKernelGGL((dn_step_many_5w_kernel<double, true>), dim3(grid), blk, 0, stream, p, io, k);
+            else hipLaunchKernelGGL((dn_step_many_5w_kernel<double, false>), dim3(grid), blk, 0, stream, p, io, k);
+        }
+        return hipGetLastError();
+    }
     if (waves == 4 && k > 1) {                             // four waves per tile: fused launches of the plain configuration (the caller checked)
         const dim3 blk(4 * DN_BLOCK);
         const bool norm = p.normalize_obs != 0;

@@ -645,11 +645,12 @@ def test_kernel_shapes_are_bit_identical(norm, noise, monkeypatch):
     n, K = 1000, 70                       # ragged last tile on purpose
     kw = dict(normalize_obs=norm, max_steps=30, obs_noise_sigma=noise, act_noise_sigma=noise / 10, seed=5)
     envs = {}
-    for shape in ("1", "2", "3", "4"):
+    for shape in ("1", "2", "3", "4") + (("5",) if norm else ()):
         monkeypatch.setenv("DN_WAVES", shape)
         envs[shape] = pkg.DroneVecEnv(track, n, device="cuda:0", **kw)
         envs[shape].reset()
-        # three waves: flight / report / aux; four: linear + rules / angular + attitude / observation / thrust + report (fused launches)
+        # three waves: flight / report / aux; four: linear + rules / angular + attitude / observation / thrust + report (fused launches);
+        # five: the normaliser and the observation rows on a wave of their own
         assert envs[shape].kernel_waves(fused=True) == int(shape)
     monkeypatch.delenv("DN_WAVES")
     rng = np.random.default_rng(21)
@@ -1304,14 +1305,14 @@ def test_nan_actions_propagate_like_numpy():
     env.close()
 
 
-@pytest.mark.parametrize("waves", ["3", "4"])
+@pytest.mark.parametrize("waves", ["3", "4", "5"])
 @pytest.mark.parametrize("n,K", [(12, 2), (64, 3), (100, 5), (4096, 2)])
 def test_three_wave_kernel_short_rollouts_and_ragged_tiles(n, K, waves, monkeypatch):
     """The three- and four-wave kernels trail their report wave two steps behind the flight wave(s): rollouts shorter than
     the skew, a single ragged tile and one drone short of a tile must still match the one-wave kernel bit for bit."""
     pkg = _gpu()
     track = _tracks().reaching()
-    kw = dict(normalize_obs=False, max_steps=4)
+    kw = dict(normalize_obs=waves == "5", max_steps=4)    # the fifth wave is the normaliser's
     monkeypatch.setenv("DN_WAVES", "1")
     ref = pkg.DroneVecEnv(track, n, device="cuda:0", **kw)
     monkeypatch.setenv("DN_WAVES", waves)
@@ -1357,7 +1358,7 @@ def test_fused_default_shape_equals_single_steps_over_options(opts, monkeypatch)
     kw = dict(normalize_obs=False, max_steps=25)
     kw.update(opts)
     a, b = pkg.DroneVecEnv(track, n, device="cuda:0", **kw), pkg.DroneVecEnv(track, n, device="cuda:0", **kw)
-    assert b.kernel_waves(fused=True) in (3, 4) and a.kernel_waves(fused=False) in (1, 3)   # fused: four waves for small plain fleets; single steps: three waves cut by dependency (plain), else one
+    assert b.kernel_waves(fused=True) in (3, 4, 5) and a.kernel_waves(fused=False) in (1, 3)   # fused: four waves for small plain fleets (five with the normaliser); single steps: three waves cut by dependency (plain), else one
     a.reset(); b.reset()
     rng = np.random.default_rng(17)
     dev = torch.device("cuda:0")
@@ -1493,7 +1494,7 @@ def test_random_configurations_all_shapes_bit_identical(monkeypatch):
             assert np.ascontiguousarray(sa[k]).tobytes() == np.ascontiguousarray(sb[k]).tobytes(), (it, k)
         assert ref.stats() == env.stats()
         ref.close(); env.close()
-    assert shapes >= {1, 2, 3} and shapes <= {1, 2, 3, 4}     # four waves only for small plain fleets without the normaliser
+    assert shapes >= {1, 2, 3} and shapes <= {1, 2, 3, 4, 5}  # four / five waves only for small plain fleets (five: with the normaliser)
 
 
 @pytest.mark.parametrize("deterministic", [0, 1])
