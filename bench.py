@@ -723,13 +723,16 @@ def main():
                                                      + (f" + {ALGO_BYTES_NORMALISER} B statistics" if args.normalize_obs else "")
                                                      + " per drone and launch (SURVEY 8(d) split into per-step I/O and per-launch state)"),
                          "avg_launch_us": round(launch_us, 4), "us_per_vector_step": round(step_us, 4),
-                         "note": "at 32768 drones neither launch shape is bandwidth bound: the fused launch is bound by instruction issue (two tiles "
-                                 "of four waves per CU), the single-step launch by load + launch latency (DESIGN.md 4.1, 4.3)",
+                         "note": "at 32768 drones neither launch shape is bandwidth bound: the fused launch runs at the pace of the wave (role) with the most "
+                                 "instructions per step -- a wave issues one instruction per ~7.5 cycles however idle its SIMD is (profiles/r03_valu_rates.txt) -- "
+                                 "which is why the step is cut into four / five role waves per 64 drones; the single-step launch is bound by load + launch "
+                                 "latency (DESIGN.md 4, profiles/r03_pqx_stamps.txt)",
                          "issue_bound_evidence": {"source": "profiles/r02_f_instmix_4w.txt (rocprofv3 --pmc SQ_* passes of the four-wave kernel; recipe profiles/instmix.sh)",
                                                   "valu_instructions_per_64_drone_step": 813, "salu_instructions_per_64_drone_step": 192,
                                                   "simd_issue_busy": 0.95,
-                                                  "what": "two 64-drone tiles (eight waves) per CU: the four SIMDs issue 95 % of the step time; the same step at "
-                                                          "2 097 152 drones, one step per launch, is the HBM-bound case (hbm_bound_fleet)"}},
+                                                  "what": "four-wave kernel, normaliser off, two 64-drone tiles (eight waves) per CU: SQ_ACTIVE_INST_ANY covers 95 % of the "
+                                                          "step time (quad-cycle granularity); the same step at 2 097 152 drones, one step per launch, is the HBM-bound "
+                                                          "case (hbm_bound_fleet)"}},
             "single_step": single_step,
             ("normalize_obs_on" if other_norm else "normalize_obs_off"): norm_leg,
             "hbm_bound_fleet": large,
