@@ -669,6 +669,28 @@ def main():
         except Exception as exc:  # noqa: BLE001
             large = {"error": f"{type(exc).__name__}: {exc}"}
 
+    # a measured stream-copy ceiling of THIS box beside the nominal 8 TB/s (a device-to-device copy of 1 GiB: read + write)
+    copy_ceiling = None
+    if world == 1 and not args.profile_lite:
+        try:
+            src = torch.empty(1 << 28, dtype=torch.float32, device=dev).fill_(1.0)
+            dst = torch.empty_like(src)
+            for _ in range(3):
+                dst.copy_(src)
+            e0_, e1_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize(dev)
+            e0_.record(stream)
+            for _ in range(20):
+                dst.copy_(src)
+            e1_.record(stream)
+            torch.cuda.synchronize(dev)
+            gbps = 2.0 * src.numel() * 4 * 20 / (e0_.elapsed_time(e1_) * 1e-3) / 1e9
+            copy_ceiling = {"GBps": round(gbps, 1), "frac_of_nominal": round(gbps / HBM_PEAK_GBPS, 4),
+                            "what": "torch device-to-device copy of 1 GiB float32 (1 GiB read + 1 GiB written per copy), 20 copies between two HIP events"}
+            del src, dst
+        except Exception as exc:  # noqa: BLE001
+            copy_ceiling = {"error": f"{type(exc).__name__}: {exc}"}
+
     # the SB3 NumPy surface (PCIe-inclusive: H2D actions, D2H obs/reward/done/found, N info dicts built in Python);
     # host bound, reported for the record only
     if world == 1 and not args.profile_lite:
@@ -736,6 +758,7 @@ def main():
             "single_step": single_step,
             ("normalize_obs_on" if other_norm else "normalize_obs_off"): norm_leg,
             "hbm_bound_fleet": large,
+            "hbm_copy_ceiling": copy_ceiling,
             "other_launch_shapes": others,
         }
         # the two side legs must never cost the headline line: a failure is reported in place of the numbers
