@@ -42,7 +42,7 @@ inline double norm3d(const double v[3]) { return std::sqrt(v[0] * v[0] + v[1] * 
 constexpr long long DN_CALIBRATION_CUS = 256;
 constexpr long long DN_TWO_WAVE_TILES_PER_CU = 4;   // 1024 tiles = 65536 drones on 256 CUs: one tile per SIMD
 constexpr long long DN_PQX_TILES_PER_CU = 4;        // three-wave single step: while the tiles alone leave SIMDs idle
-constexpr long long DN_FIVE_WAVE_TILES_PER_CU = 2;  // the same with the normaliser on a fifth wave: up to two tiles per CU
+constexpr long long DN_FIVE_WAVE_TILES_PER_CU = 3;  // the same with the normaliser on a fifth wave: wherever the four-wave kernel would run (40 960 / 49 152 drones: 2.65 / 2.84 us per step against 2.95 / 3.28)
 constexpr long long DN_FOUR_WAVE_TILES_PER_CU = 3;  // four-wave fused step: up to three tiles per CU (768 tiles on 256 CUs)
 constexpr double DN_CONTACT_MARGIN = 0.02;          // Bullet's contact-breaking threshold (dn_kernels.hip collision_common)
 constexpr double DN_COLL_R = 0.06, DN_COLL_H = 0.025;   // base_link collision cylinder, cf2x.urdf:34
@@ -330,7 +330,7 @@ int32_t dn_create(const dn_config *cfg, dn_env **out)
     //                    3.62 / 5.73 / 6.98) -> up to 512 tiles
     if (plain && !cfg->ground_contact && e->blocks <= (noisy ? DN_FOUR_WAVE_MAX_TILES * 2 / 3 : DN_FOUR_WAVE_MAX_TILES)) e->waves_fused = 4;
     // Five waves (normaliser on; round 3): the four-wave kernel with the normaliser on a wave of its own (NW = 5), where the report wave set
-    // the pace.  DN_WAVES=4 keeps the four-wave shape for A/B runs; up to two tiles per CU (ten waves), see profiles/r03_notes.md.
+    // the pace.  DN_WAVES=4 keeps the four-wave shape for A/B runs; see profiles/r03_notes.md.
     if (e->waves_fused == 4 && cfg->normalize_obs && e->blocks <= DN_FIVE_WAVE_TILES_PER_CU * e->num_cus) e->waves_fused = 5;
     // dn_step (one control step per launch) is latency bound: ~2.9 us of launch-to-launch floor that an empty kernel
     // already pays (profiles/r02_dispatch_floor.txt) plus the dependent instruction stream of the step.  Cutting the step
