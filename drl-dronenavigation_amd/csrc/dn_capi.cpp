@@ -43,6 +43,7 @@ constexpr long long DN_CALIBRATION_CUS = 256;
 constexpr long long DN_TWO_WAVE_TILES_PER_CU = 4;   // 1024 tiles = 65536 drones on 256 CUs: one tile per SIMD
 constexpr long long DN_PQX_TILES_PER_CU = 4;        // three-wave single step: while the tiles alone leave SIMDs idle
 constexpr long long DN_FIVE_WAVE_TILES_PER_CU = 3;  // the same with the normaliser on a fifth wave: wherever the four-wave kernel would run (40 960 / 49 152 drones: 2.65 / 2.84 us per step against 2.95 / 3.28)
+constexpr long long DN_ROLE_PIPE_TILES_PER_CU = 2;  // role-pipelined fused step (six / eight roles per tile): two tiles are twelve / sixteen waves per CU
 constexpr long long DN_FOUR_WAVE_TILES_PER_CU = 3;  // four-wave fused step: up to three tiles per CU (768 tiles on 256 CUs)
 constexpr double DN_CONTACT_MARGIN = 0.02;          // Bullet's contact-breaking threshold (dn_kernels.hip collision_common)
 constexpr double DN_COLL_R = 0.06, DN_COLL_H = 0.025;   // base_link collision cylinder, cf2x.urdf:34
@@ -332,6 +333,10 @@ int32_t dn_create(const dn_config *cfg, dn_env **out)
     // Five waves (normaliser on; round 3): the four-wave kernel with the normaliser on a wave of its own (NW = 5), where the report wave set
     // the pace.  DN_WAVES=4 keeps the four-wave shape for A/B runs; see profiles/r03_notes.md.
     if (e->waves_fused == 4 && cfg->normalize_obs && e->blocks <= DN_FIVE_WAVE_TILES_PER_CU * e->num_cus) e->waves_fused = 5;
+    // Role-pipelined kernel (round 4, dn_step_many_rp8_kernel / rp6: eight roles per tile with the normaliser, six without; plain
+    // configuration, no noise): up to two tiles per CU -- sixteen / twelve waves, at most four per SIMD.
+    const bool rp_ok = plain && !cfg->ground_contact && !noisy;
+    if (rp_ok && e->blocks <= DN_ROLE_PIPE_TILES_PER_CU * e->num_cus) e->waves_fused = cfg->normalize_obs ? 8 : 6;
     // dn_step (one control step per launch) is latency bound: ~2.9 us of launch-to-launch floor that an empty kernel
     // already pays (profiles/r02_dispatch_floor.txt) plus the dependent instruction stream of the step.  Cutting the step
     // by dependency over three waves (dn_step_pqx_kernel) shortens that stream while the chip has idle SIMDs; built for the
@@ -352,6 +357,9 @@ int32_t dn_create(const dn_config *cfg, dn_env **out)
             e->waves_single = pqx_ok ? 3 : 1;
         } else if (w[0] == '5') {                              // + the normaliser on a fifth wave (normaliser on only)
             e->waves_fused = pqx_ok ? (cfg->normalize_obs ? 5 : 4) : 3;
+            e->waves_single = pqx_ok ? 3 : 1;
+        } else if (w[0] == '6' || w[0] == '8') {               // the role-pipelined kernel (six roles, eight with the normaliser)
+            e->waves_fused = rp_ok ? (cfg->normalize_obs ? 8 : 6) : (pqx_ok ? (cfg->normalize_obs ? 5 : 4) : 3);
             e->waves_single = pqx_ok ? 3 : 1;
         }
     }
@@ -390,6 +398,7 @@ int32_t dn_create(const dn_config *cfg, dn_env **out)
     p.tab32 = e->tab32;
     p.n = n;
     p.num_waypoints = cfg->num_waypoints;
+    p.num_cus = e->num_cus;
     p.max_steps = cfg->max_steps;
     p.circle = cfg->circle != 0; p.cylinder = cfg->cylinder != 0; p.include_distance = cfg->include_distance != 0;
     p.normalize_actions = cfg->normalize_actions != 0; p.normalize_obs = cfg->normalize_obs != 0;

@@ -97,6 +97,7 @@ struct DnParams {
     long long n;
     int num_waypoints;
     int max_steps;
+    int num_cus;                    // CUs of the device: tile b lands on a CU beside tile b + num_cus (role orders of the multi-wave kernels)
     int circle, cylinder, include_distance, normalize_actions, normalize_obs, ground_contact, clip_rew, norm_rew;
     int gnd, drag, rpm_actions;     // N4: Physics.PYB_GND / PYB_DRAG force terms, ActionType.RPM (1) / ONE_D_RPM (2)
     int pid_mode;                   // N4: 0, or the dn_config.action_type of the DSLPIDControl family: 2 PID | 3 VEL | 5 ONE_D_PID

@@ -374,13 +374,16 @@ DN_DEV double rcp_f64(double x)
     e = __builtin_fma(-x, r, 1.0);
     return __builtin_fma(r, e, r);
 }
-DN_DEV void normalize_obs(Rms &r, float o[DN_OBS_DIM])
+// Columns [K0, K1) only: a kernel may give the columns of one drone to two waves (each then holds its columns' statistics and a
+// copy of the count).  The shared quantities (tot, inv, cw) and every per-column expression are the same whatever the range.
+template <int K0, int K1>
+DN_DEV void normalize_obs_cols(Rms &r, float o[DN_OBS_DIM])
 {   // explicit fused multiply-adds, no contraction licence (one arithmetic sequence for every kernel that inlines this)
     const double tot = r.count + 1.0;
     const double inv = rcp_f64(tot);
     const double cw = r.count * inv;
 #pragma unroll
-    for (int k = 0; k < DN_OBS_DIM; ++k) {
+    for (int k = K0; k < K1; ++k) {
         const double x = (double)o[k];
         const double delta = x - r.mean[k];
         const double new_mean = __builtin_fma(delta, inv, r.mean[k]);
@@ -393,6 +396,28 @@ DN_DEV void normalize_obs(Rms &r, float o[DN_OBS_DIM])
         o[k] = (float)((x - new_mean) * y);
     }
     r.count = tot;
+}
+DN_DEV void normalize_obs(Rms &r, float o[DN_OBS_DIM]) { normalize_obs_cols<0, DN_OBS_DIM>(r, o); }
+// the statistics of columns [K0, K1) of the tile's drones: uniform column bases (SGPR pairs) + the lane's 32-bit offset
+template <int K0, int K1>
+DN_DEV void load_rms_cols(const DnParams &p, const long long tile_base, const unsigned li, Rms &r)
+{
+#pragma unroll
+    for (int k = K0; k < K1; ++k) {
+        r.mean[k] = (p.st.rms_mean + ((long long)k * p.n + tile_base))[li];
+        r.var[k] = (p.st.rms_var + ((long long)k * p.n + tile_base))[li];
+    }
+    r.count = (p.st.rms_count + tile_base)[li];
+}
+template <int K0, int K1, bool COUNT>
+DN_DEV void store_rms_cols(const DnParams &p, const long long tile_base, const unsigned li, const Rms &r)
+{
+#pragma unroll
+    for (int k = K0; k < K1; ++k) {
+        (p.st.rms_mean + ((long long)k * p.n + tile_base))[li] = r.mean[k];
+        (p.st.rms_var + ((long long)k * p.n + tile_base))[li] = r.var[k];
+    }
+    if (COUNT) (p.st.rms_count + tile_base)[li] = r.count;
 }
 
 // ---- waypoint/corridor table in LDS ------------------------------------------------------------
@@ -1378,31 +1403,43 @@ template <typename R> struct Observed {
 // ---- A5 + A6 + the value side of A7 on the report wave ---------------------------------------------------
 // observe_columns: the observation row; reward_candidates: both value branches of _computeReward.  The two read the
 // same Flight and share no intermediate, so a kernel may run them on two waves; observe_phase = both on one.
+// The row in two halves that share nothing: the columns that read the linear state (position, velocity, distance: 0 1 2 6 7 8 12)
+// and those that read the attitude and the angular velocity (3 4 5 9 10 11) -- a kernel may fill them on two waves.
 template <typename R>
-DN_DEV void observe_columns(const DnParams &p, const DnConsts<R> &c, const Flight<R> &fl, float o[DN_OBS_DIM])
+DN_DEV void observe_columns_lin(const DnParams &p, const DnConsts<R> &c, const Flight<R> &fl, float o[DN_OBS_DIM])
 {
-    const float roll32 = atan2_fast32(fl.roll_num32, fl.roll_den32), pitch32 = fl.pitch32, yaw32 = fl.yaw32;    // attitude_phase
     // _computeObs (PBDroneEnv.py:296-336, :338-398), stale distance d_e (quirk Q1).  The reference clips position /
     // yaw / distance columns to the float32 range before the cast (:326); positions are bounded by the aviary box
     // plus one step at the velocity cap, so those clips can never bind and are not evaluated.  clip(v, -3, 3)/3 is
     // monotone, so it equals clip(float32(v/3), -1, 1) exactly.
-    const float inv_pi32 = (float)K<R>::INV_PI;
     o[0] = (float)(fl.px * c.inv_dim[0]);
     o[1] = (float)(fl.py * c.inv_dim[1]);
     o[2] = (float)(fl.pz * c.inv_dim[2]);
-    o[3] = roll32 * inv_pi32;
-    o[4] = pitch32 * inv_pi32;
-    o[5] = yaw32 * inv_pi32;
     const float third32 = (float)K<R>::THIRD;
     o[6] = clipv((float)((R)fl.vx * K<R>::THIRD), -1.0f, 1.0f);
     o[7] = clipv((float)((R)fl.vy * K<R>::THIRD), -1.0f, 1.0f);
     o[8] = clipv((float)((R)fl.vz * K<R>::THIRD), -third32, third32);
+    o[12] = p.include_distance ? (float)((R)fl.d_e * c.inv_max_target_dist) : 0.0f;
+}
+template <typename R>
+DN_DEV void observe_columns_att(const Flight<R> &fl, float o[DN_OBS_DIM])
+{
+    const float roll32 = atan2_fast32(fl.roll_num32, fl.roll_den32), pitch32 = fl.pitch32, yaw32 = fl.yaw32;    // attitude_phase
+    const float inv_pi32 = (float)K<R>::INV_PI;
+    o[3] = roll32 * inv_pi32;
+    o[4] = pitch32 * inv_pi32;
+    o[5] = yaw32 * inv_pi32;
     const R w2 = FM<R>::fma((R)fl.wz, (R)fl.wz, FM<R>::fma((R)fl.wy, (R)fl.wy, (R)fl.wx * (R)fl.wx));   // explicit order, see attitude_phase
     if (w2 != R(0.0)) {                                   // ang_v / |ang_v|, zero stays zero (:383-384)
         const R rw = FM<R>::rsq_f32grade(w2);
         o[9] = (float)((R)fl.wx * rw); o[10] = (float)((R)fl.wy * rw); o[11] = (float)((R)fl.wz * rw);
     } else { o[9] = fl.wx; o[10] = fl.wy; o[11] = fl.wz; }
-    o[12] = p.include_distance ? (float)((R)fl.d_e * c.inv_max_target_dist) : 0.0f;
+}
+template <typename R>
+DN_DEV void observe_columns(const DnParams &p, const DnConsts<R> &c, const Flight<R> &fl, float o[DN_OBS_DIM])
+{
+    observe_columns_lin<R>(p, c, fl, o);
+    observe_columns_att<R>(fl, o);
 }
 // _computeReward (PBDroneEnv.py:475-571), both value branches; report_scalars selects once the verdict is in.
 // reward_entry: the terms that read the ENTRY state only (distance gain, 3 e^{-2d}, smoothness penalties on the stale
@@ -2360,6 +2397,17 @@ template <typename R> struct MailG {      // A -> L (qnew) and A -> Q (the rest)
 // normaliser that was X: the step's scalars plus 247 float64 instructions of Welford update per step plus, on the 86 % of tile-steps
 // where a drone finishes, the masked second pass for the reset observation.  X keeps the scalars (reward select, Monitor, statistics),
 // a fifth wave N takes MailA's observation through the normaliser and out (report_obs): same functions, same values.
+// Timing builds (-DDN_MW_STAMP=<tile>; never shipped): the cycle counter of every role of one tile before and after the barrier of
+// iterations 8 .. 55 of a fused launch, read back through dn_debug_mw_stamps (profiles/mw_stamps.py).
+#ifdef DN_MW_STAMP
+__device__ long long g_mw_stamp[8][48][2];
+#define MW_MARK(k) do { if (lane == 0 && blockIdx.x == DN_MW_STAMP && t >= 8 && t < 56) \
+        g_mw_stamp[role][t - 8][k] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define MW_MARK(k) do { } while (0)
+#endif
+#define MW_BARRIER() do { MW_MARK(0); block_lds_barrier(); MW_MARK(1); } while (0)
+
 template <typename R, bool NORM, bool NOISE, int NW>
 DN_DEV void step_many_4w_body(const DnParams &p, const DnStepIO &io0, const int k_steps)
 {
@@ -2372,7 +2420,7 @@ DN_DEV void step_many_4w_body(const DnParams &p, const DnStepIO &io0, const int 
     const unsigned lane = threadIdx.x & (DN_BLOCK - 1);
     // roles: 0 L, 1 A, 2 Q, 3 X.  Which waves of two co-resident tiles end up sharing a SIMD is decided by the order of the waves
     // inside the workgroup (a workgroup's waves go to the SIMDs round-robin); swept at 32 768 drones (two tiles per CU) over four
-    // orders x four permutations for the second tile of a CU (tiles 256 .. 511 land beside tiles 0 .. 255): without the
+    // orders x four permutations for the second tile of a CU (tiles num_cus .. 2 num_cus - 1 land beside tiles 0 .. num_cus - 1): without the
     // normaliser L A X Q with waves 2 <-> 0, 3 <-> 1 swapped in the second tile (1.23 us per step; worst order 1.45), with the
     // normaliser L X A Q in both (1.76; the mirrored orders 1.77).  One tile per CU (<= 16 384 drones) does not care: 1.01-1.02.
     // the thrust chain sits on the observation wave -- except with noise and no normaliser: the observation draws (13 normals a
@@ -2380,7 +2428,8 @@ DN_DEV void step_many_4w_body(const DnParams &p, const DnStepIO &io0, const int 
     // 4.47 us per step against 4.74; with the normaliser, which also lives on the report wave, 3.85 against 3.75)
     constexpr bool THRUST_ON_Q = !NOISE || NORM;
     const int wv0 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wv = (!NORM && ((blockIdx.x >> 8) & 1)) ? (wv0 ^ 2) : wv0;
+    const int second_tile = (int)((blockIdx.x / (unsigned)p.num_cus) & 1u);      // the workgroup that lands beside tile blockIdx.x - num_cus on its CU
+    const int wv = (!NORM && second_tile) ? (wv0 ^ 2) : wv0;
 #ifndef DN_5W_ORDER_A
 #define DN_5W_ORDER_A "LQANX"
 #define DN_5W_ORDER_B "ANLQX"
@@ -2392,7 +2441,7 @@ DN_DEV void step_many_4w_body(const DnParams &p, const DnStepIO &io0, const int 
         // Swept at 32 768 drones (us per step): this order 1.43, X L A N Q | Q N A L X 1.45, the same order in both tiles 1.56-1.80
         // (profiles/r03_notes.md); the four-wave kernel 1.76.
         constexpr char oa[6] = DN_5W_ORDER_A, ob[6] = DN_5W_ORDER_B;
-        const char ch = ((blockIdx.x >> 8) & 1) ? ob[wv0] : oa[wv0];
+        const char ch = second_tile ? ob[wv0] : oa[wv0];
         role = ch == 'L' ? 0 : ch == 'A' ? 1 : ch == 'Q' ? 2 : ch == 'X' ? 3 : 4;
     } else
         role = NORM ? (wv == 0 ? 0 : (wv == 1 ? 3 : (wv == 2 ? 1 : 2)))            // L X A Q
@@ -2445,7 +2494,7 @@ DN_DEV void step_many_4w_body(const DnParams &p, const DnStepIO &io0, const int 
                 G0 = S0; G2 = S2; G3.w = S3.w;
                 done_prev = v.terminated != 0 || fl.truncated != 0;
             }
-            block_lds_barrier();                                           // barrier t
+            MW_BARRIER();                                                  // barrier t
         }
         if (active) {
             b.g0[li] = G0; b.g2[li] = G2;
@@ -2477,7 +2526,7 @@ DN_DEV void step_many_4w_body(const DnParams &p, const DnStepIO &io0, const int 
                 mg.we[lane] = make_float4(G3.x, G3.y, G3.z, 0.0f);
                 G1 = qn; G3.x = wn.x; G3.y = wn.y; G3.z = wn.z;
             }
-            block_lds_barrier();                                           // barrier t
+            MW_BARRIER();                                                  // barrier t
         }
         if (active) {
             b.g1[li] = G1;
@@ -2531,7 +2580,7 @@ DN_DEV void step_many_4w_body(const DnParams &p, const DnStepIO &io0, const int 
                 if (!v.terminated) { P4 = make_float4(fl.vex, fl.vey, fl.vez, 0.0f); P5 = make_float4(fl.aex, fl.aey, fl.aez, 0.0f); }
                 if (v.terminated || fl.truncated) P4 = P5 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             }
-            block_lds_barrier();                                           // barrier t
+            MW_BARRIER();                                                  // barrier t
         }
         if (active) {
             float *g4 = reinterpret_cast<float *>(b.g4 + li), *g5 = reinterpret_cast<float *>(b.g5 + li);
@@ -2554,7 +2603,7 @@ DN_DEV void step_many_4w_body(const DnParams &p, const DnStepIO &io0, const int 
                 const StepOut out = block_out(io0, tile_base, (long long)u * n, (long long)u * words);
                 report_obs<R, NORM, NOISE, 2>(p, c, nullptr, out, fl.truncated != 0, v, ob.o, gid, sc0 + (unsigned long long)u, li, lane, rows, active, rms);
             }
-            if (t <= k_steps) block_lds_barrier();                         // barrier t
+            if (t <= k_steps) MW_BARRIER();                                // barrier t
         }
         if (active) store_rms(p, i, rms);
     } else {
@@ -2593,7 +2642,7 @@ DN_DEV void step_many_4w_body(const DnParams &p, const DnStepIO &io0, const int 
                     report_phase<R, NORM, NOISE, false, 2>(p, c, nullptr, out, fl, v, ob, gid, sc, li, lane, rows, active, G4, G5, acc, rms, rn);
                 }
             }
-            if (t <= k_steps) block_lds_barrier();                         // barrier t
+            if (t <= k_steps) MW_BARRIER();                                // barrier t
         }
         flush_stats(p, acc, sc0 + (unsigned long long)k_steps, lane);
         if (NORM && NW == 4 && active) store_rms(p, i, rms);
@@ -2614,6 +2663,385 @@ template <typename R, bool NOISE>
 __global__ __launch_bounds__(5 * DN_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void dn_step_many_5w_kernel(const DnParams p, const DnStepIO io0, const int k_steps)
 {
     step_many_4w_body<R, true, NOISE, 5>(p, io0, k_steps);
+}
+
+// -----------------------------------------------------------------------------------------------------
+// Role-pipelined kernel (round 4; fused launches of the plain configuration without noise, <= 2 tiles per CU): six roles, eight with the
+// normaliser.
+//
+// Per-role stamps of the four- / five-wave kernels (profiles/mw_stamps.py, profiles/r04_stamps_base.txt) showed what paces them: not the
+// recurrence waves L and A but Q (thrust of step t + 1, observation row and reward candidates of step t - 1: ~305 vector instructions, busy
+// 2 450 cycles of a 2 620-cycle iteration at one tile per CU, 3 000-3 400 at two), then N.  A wave issues one instruction per ~7.5 cycles
+// whatever else its SIMD does and a SIMD needs four waves to issue every ~2 cycles (profiles/r03_valu_rates.txt), so the step is cut into
+// EIGHT roles of <= ~200 instructions, two tiles = sixteen waves per CU = four per SIMD:
+//
+//   T   thrust(t + 1)                                                                          -> tmail[(t + 1) & 1]
+//   L   physics_linear(t) | rules_verdict | rules_commit      (recurrence: position, gate bookkeeping) -> MailL[t % 3]
+//   A   physics_angular(t)                                    (recurrence: attitude, angular velocity)  -> MailA[t & 1]
+//   E   attitude(t - 1): Euler terms, forward vector, observation columns 3 4 5 9 10 11              -> MailE[(t - 1) & 1]
+//   Q   observation columns 0 1 2 6 7 8 12 and the entry-state reward terms of step t - 1; prev_vel / prev_ang_v  -> MailC[(t - 1) & 1]
+//   X   step t - 2: orientation term, reward select, Monitor, statistics, scalar outputs (without the normaliser also the rows)
+//   N1  step t - 2: normaliser + rows, columns 0..6        N2  columns 7..12     (terminal / reset observation of a finished drone included)
+//                                                                                                  == one LDS-only barrier per iteration ==
+// Same device functions, same typed values across LDS, one spelled-out arithmetic sequence: bit-identical to every other shape.
+// -----------------------------------------------------------------------------------------------------
+template <typename R> struct RMailA {      // A -> L (qnew), E (q, w), Q (we)
+    R q[4][DN_BLOCK];                      // the new attitude in R (what attitude_phase reads)
+    float4 qnew[DN_BLOCK];                 // the same as the float32 state words (before any reset)
+    float4 w[DN_BLOCK];                    // new angular velocity (float32 state words)
+    float4 we[DN_BLOCK];                   // entry angular velocity (prev_ang_v of the smoothness term)
+};
+template <typename R> struct RMailE {      // E -> X (forward vector), N / X (columns 3 4 5 9 10 11)
+    R fw[3][DN_BLOCK];
+    float4 oa[DN_BLOCK];                   // o3 o4 o5 o9
+    float2 ob[DN_BLOCK];                   // o10 o11
+};
+template <typename R> struct RMailC {      // Q -> X (reward terms), N / X (columns 0 1 2 6 7 8 12)
+    R r[3][DN_BLOCK];                      // RewardPre: r0, s_lin, s_ang
+    float4 oa[DN_BLOCK];                   // o0 o1 o2 o6
+    float4 ob[DN_BLOCK];                   // o7 o8 o12, bits: pen_lin | pen_ang << 1
+};
+struct __attribute__((packed, aligned(4))) ObsTri { float x, y, z; };
+
+// report_obs for the columns [K0, K1) of the row (TILE = 2 form: straight from the lane's registers)
+template <typename R, bool NORM, int K0, int K1>
+DN_DEV void report_obs_cols(const DnParams &p, const DnConsts<R> &c, const StepOut &out, const bool done, const R d_obs, float *o,
+                            const unsigned li, const bool active, Rms &rms)
+{
+    if (__ballot(done && active) != 0ull) {
+        if (done) {
+            if (active && out.terminal_obs) {
+#pragma unroll
+                for (int k = K0; k < K1; ++k) out.terminal_obs[li * DN_OBS_DIM + k] = o[k];
+            }
+#pragma unroll
+            for (int k = K0; k < K1; ++k)                                 // reset_obs<R>: BaseAviary.py:318 before :617-658 (Q2)
+                o[k] = k < 12 ? (float)c.reset_obs[k < 12 ? k : 0] : (p.include_distance ? (float)(d_obs * c.inv_max_target_dist) : 0.0f);
+            if (NORM) normalize_obs_cols<K0, K1>(rms, o);
+        }
+    }
+    if (active) {
+        float *row = out.obs + li * DN_OBS_DIM;
+        static_assert((K0 == 0 && K1 == 7) || (K0 == 7 && K1 == DN_OBS_DIM) || (K0 == 0 && K1 == DN_OBS_DIM), "column split of the row stores");
+        if (K0 == 0 && K1 == DN_OBS_DIM) store_obs_direct(row, o);
+        else if (K0 == 0) {
+            *reinterpret_cast<ObsQuad *>(row) = ObsQuad{o[0], o[1], o[2], o[3]};
+            *reinterpret_cast<ObsTri *>(row + 4) = ObsTri{o[4], o[5], o[6]};
+        } else {
+            row[7] = o[7];
+            *reinterpret_cast<ObsQuad *>(row + 8) = ObsQuad{o[8], o[9], o[10], o[11]};
+            row[12] = o[12];
+        }
+    }
+}
+
+#ifndef DN_RP_ORDER_A
+#define DN_RP_ORDER_A "LAEQTXMN"
+#define DN_RP_ORDER_B "EQLAMNTX"
+#endif
+#ifndef DN_RP6_ORDER_A
+#define DN_RP6_ORDER_A "LAEQTX"
+#define DN_RP6_ORDER_B "EQLXAT"
+#endif
+template <typename R, bool NORM>
+DN_DEV void step_many_rp_body(const DnParams &p, const DnStepIO &io0, const int k_steps)
+{
+    __shared__ R s_tab[DN_MAX_WAYPOINTS * DN_T_STRIDE];
+    __shared__ MailL<R> maill[3];
+    __shared__ __attribute__((aligned(16))) RMailA<R> maila[2];
+    __shared__ __attribute__((aligned(16))) RMailE<R> maile[2];
+    __shared__ __attribute__((aligned(16))) RMailC<R> mailc[2];
+    __shared__ __attribute__((aligned(16))) ThrustMail<R> tmail[2];
+    constexpr bool NOISE = false;
+    const unsigned lane = threadIdx.x & (DN_BLOCK - 1);
+    const int wv0 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int second_tile = (int)((blockIdx.x / (unsigned)p.num_cus) & 1u);
+    // roles: 0 L, 1 A, 2 T, 3 E, 4 Q, 5 X, 6 N1 ('M'), 7 N2 ('N').  A workgroup's waves go to the SIMDs round-robin (wave w -> SIMD w % 4), so
+    // SIMD s carries waves s and s + 4 of both tiles of its CU; the second tile takes another order so that the heavy pairs spread out.
+    constexpr char oa[9] = DN_RP_ORDER_A, ob[9] = DN_RP_ORDER_B, oa6[9] = DN_RP6_ORDER_A, ob6[9] = DN_RP6_ORDER_B;
+    const char ch = NORM ? (second_tile ? ob[wv0] : oa[wv0]) : (second_tile ? ob6[wv0] : oa6[wv0]);
+    const int role = ch == 'L' ? 0 : ch == 'A' ? 1 : ch == 'T' ? 2 : ch == 'E' ? 3 : ch == 'Q' ? 4 : ch == 'X' ? 5 : ch == 'M' ? 6 : 7;
+    const long long tile_base = (long long)blockIdx.x * DN_BLOCK;
+    const long long left = p.n - tile_base;
+    const unsigned rows = left < DN_BLOCK ? (unsigned)left : DN_BLOCK;
+    const bool active = lane < rows;
+    const unsigned li = active ? lane : rows - 1;
+    __builtin_assume(li < DN_BLOCK);
+    const unsigned long long gid = (unsigned long long)(p.env_id_offset + tile_base + li);
+    const BlockState b = block_state(p.st, tile_base);
+    const DnConsts<R> &c = consts<R>(p);
+    const long long n = p.n, words = (p.n + 63) / 64;
+    const unsigned long long sc0 = p.st.stats[blockIdx.x].step_count;
+    stage_table<R>(p, s_tab);
+    // every wave passes barrier P and the barriers of iterations 0 .. k_steps (k_steps + 1 of them); iteration k_steps + 1 has none
+    if (role == 0) {
+        // ---- L: the linear half of the recurrence and the rules
+        __builtin_amdgcn_s_setprio(3);
+        float4 G0 = b.g0[li], G1 = b.g1[li], G2 = b.g2[li], G3 = b.g3[li];
+        block_lds_barrier();                                               // P
+        const R wp0[3] = {s_tab[DN_T_WP], s_tab[DN_T_WP + 1], s_tab[DN_T_WP + 2]};
+        bool done_prev = false;
+        int s3 = 0;                                                        // t % 3
+#pragma clang loop unroll(disable)
+        for (int t = 0; t <= k_steps; ++t) {
+            if (t < k_steps) {
+                if (t > 0) {                                               // entry attitude: A's step t-1, reset by my verdict of t-1
+                    const float4 qn = maila[(t - 1) & 1].qnew[lane];
+                    G1 = done_prev ? make_float4(0.0f, 0.0f, 0.0f, 1.0f) : qn;
+                }
+                const GateRow<R> row_e = load_gate_row<R>(s_tab, unpack_meta(G3.w).idx);
+                const R fz = tmail[t & 1].v[0][lane];
+                const Lin<R> lin = physics_linear<R>(G0, G1, G2, fz, R(0.0), R(0.0), R(0.0), false);
+                Flight<R> fl;
+                flight_entry<R>(fl, G0, G2, G3, p.max_steps);
+                fl.px = lin.px; fl.py = lin.py; fl.pz = lin.pz;
+                fl.vx = (float)lin.vx; fl.vy = (float)lin.vy; fl.vz = (float)lin.vz;
+                fl.qx = fl.qy = fl.qz = R(0.0); fl.qw = R(1.0);            // the attitude belongs to A (no ground-contact term here)
+                fl.wx = fl.wy = fl.wz = 0.0f;
+                RulesMid<R> m;
+                const Verdict<R> v = rules_verdict<R>(p, c, s_tab, row_e, fl, G3, m);
+                MailL<R> &ml = maill[s3];
+                ml.f64[0][lane] = fl.px; ml.f64[1][lane] = fl.py; ml.f64[2][lane] = fl.pz; ml.f64[3][lane] = v.d_obs;
+                ml.f32[0][lane] = make_float4(fl.vx, fl.vy, fl.vz, fl.d_e);
+                ml.f32[1][lane] = make_float4(fl.vex, fl.vey, fl.vez, fl.dprev_e);
+                ml.flags[lane] = fl.idx_e | (fl.just_found_e << 8) | (fl.truncated << 9) | (v.coll1 << 10) | (v.terminated << 11);
+                float4 S0, S1, S2, S3;
+                rules_commit<R>(c, wp0, fl, m, G0, G3, b.g6, li, active, S0, S1, S2, S3);
+                G0 = S0; G2 = S2; G3.w = S3.w;
+                done_prev = v.terminated != 0 || fl.truncated != 0;
+                s3 = s3 == 2 ? 0 : s3 + 1;
+            }
+            MW_BARRIER();                                                  // barrier t
+        }
+        if (active) {
+            b.g0[li] = G0; b.g2[li] = G2;
+            reinterpret_cast<float *>(b.g3 + li)[3] = G3.w;
+        }
+    } else if (role == 1) {
+        // ---- A: the angular half of the recurrence
+        __builtin_amdgcn_s_setprio(3);
+        float4 G1 = b.g1[li], G3 = b.g3[li];                               // G3.xyz: angular velocity (the .w belongs to L)
+        block_lds_barrier();                                               // P
+        int s3p = 2;                                                       // (t - 1) % 3
+#pragma clang loop unroll(disable)
+        for (int t = 0; t <= k_steps; ++t) {
+            if (t > 0) {                                                   // L's verdict of step t-1: a finished drone restarts level, at rest
+                const int fb = maill[s3p].flags[lane];
+                if (((fb >> 9) | (fb >> 11)) & 1) { G1 = make_float4(0.0f, 0.0f, 0.0f, 1.0f); G3.x = G3.y = G3.z = 0.0f; }
+            }
+            if (t < k_steps) {
+                const R tx = tmail[t & 1].v[1][lane], ty = tmail[t & 1].v[2][lane], zt = tmail[t & 1].v[3][lane];
+                const Ang<R> ang = physics_angular<R>(G1, G3, tx, ty, zt);
+                RMailA<R> &ma = maila[t & 1];
+                const float4 qn = make_float4((float)ang.qx, (float)ang.qy, (float)ang.qz, (float)ang.qw);
+                const float4 wn = make_float4((float)ang.wx, (float)ang.wy, (float)ang.wz, 0.0f);
+                ma.q[0][lane] = ang.qx; ma.q[1][lane] = ang.qy; ma.q[2][lane] = ang.qz; ma.q[3][lane] = ang.qw;
+                ma.qnew[lane] = qn;
+                ma.w[lane] = wn;
+                ma.we[lane] = make_float4(G3.x, G3.y, G3.z, 0.0f);
+                G1 = qn; G3.x = wn.x; G3.y = wn.y; G3.z = wn.z;
+            }
+            s3p = s3p == 2 ? 0 : s3p + 1;
+            MW_BARRIER();                                                  // barrier t
+        }
+        if (active) {
+            b.g1[li] = G1;
+            float *g3 = reinterpret_cast<float *>(b.g3 + li);
+            g3[0] = G3.x; g3[1] = G3.y; g3[2] = G3.z;
+        }
+    } else if (role == 2) {
+        // ---- T: the action chain, one step ahead
+        __builtin_amdgcn_s_setprio(2);
+        const float4 *act = reinterpret_cast<const float4 *>(io0.actions) + tile_base;
+        float4 A = act[li];
+        {
+            const float4 A1 = (act + (long long)(k_steps > 1 ? 1 : 0) * n)[li];
+            post_thrust<R>(tmail[0], lane, thrust_phase<NOISE>(p, gid, sc0, A));
+            A = A1;
+        }
+        block_lds_barrier();                                               // P: table and thrust(0) published
+#pragma clang loop unroll(disable)
+        for (int t = 0; t <= k_steps; ++t) {
+            if (t + 1 < k_steps) {                                         // thrust(t+1), for the next iteration of L and A
+                const float4 A_next = (act + (long long)(t + 2 < k_steps ? t + 2 : t + 1) * n)[li];
+                post_thrust<R>(tmail[(t + 1) & 1], lane, thrust_phase<NOISE>(p, gid, sc0 + (unsigned long long)(t + 1), A));
+                A = A_next;
+            }
+            MW_BARRIER();                                                  // barrier t
+        }
+    } else if (role == 3) {
+        // ---- E: everything that reads the new attitude, one step behind A
+        __builtin_amdgcn_s_setprio(1);
+        block_lds_barrier();                                               // P
+#pragma clang loop unroll(disable)
+        for (int t = 0; t <= k_steps; ++t) {
+            if (t > 0) {
+                const int u = t - 1;
+                const RMailA<R> &ma = maila[u & 1];
+                Flight<R> fl;
+                fl.qx = ma.q[0][lane]; fl.qy = ma.q[1][lane]; fl.qz = ma.q[2][lane]; fl.qw = ma.q[3][lane];
+                const float4 wn = ma.w[lane];
+                fl.wx = wn.x; fl.wy = wn.y; fl.wz = wn.z;
+                attitude_phase<R>(fl);
+                float o[DN_OBS_DIM];
+                observe_columns_att<R>(fl, o);
+                RMailE<R> &me = maile[u & 1];
+                me.fw[0][lane] = fl.fwx; me.fw[1][lane] = fl.fwy; me.fw[2][lane] = fl.fwz;
+                me.oa[lane] = make_float4(o[3], o[4], o[5], o[9]);
+                me.ob[lane] = make_float2(o[10], o[11]);
+            }
+            MW_BARRIER();                                                  // barrier t
+        }
+    } else if (role == 4) {
+        // ---- Q: the columns and reward terms that read the linear state and the entry state, one step behind L
+        __builtin_amdgcn_s_setprio(1);
+        float4 P4 = b.g4[li], P5 = b.g5[li];                               // .xyz: prev_vel, prev_ang_v
+        block_lds_barrier();                                               // P
+        int s3p = 2;                                                       // (t - 1) % 3
+#pragma clang loop unroll(disable)
+        for (int t = 0; t <= k_steps; ++t) {
+            if (t > 0) {
+                const int u = t - 1;
+                const MailL<R> &ml = maill[s3p];
+                Flight<R> fl;
+                fl.px = ml.f64[0][lane]; fl.py = ml.f64[1][lane]; fl.pz = ml.f64[2][lane];
+                const float4 a0 = ml.f32[0][lane], a1 = ml.f32[1][lane];
+                fl.vx = a0.x; fl.vy = a0.y; fl.vz = a0.z; fl.d_e = a0.w;
+                fl.vex = a1.x; fl.vey = a1.y; fl.vez = a1.z; fl.dprev_e = a1.w;
+                const int fb = ml.flags[lane];
+                fl.idx_e = fb & 0xFF; fl.just_found_e = (fb >> 8) & 1; fl.truncated = (fb >> 9) & 1;
+                const bool terminated = ((fb >> 11) & 1) != 0;
+                const float4 we = maila[u & 1].we[lane];
+                fl.aex = we.x; fl.aey = we.y; fl.aez = we.z;
+                float o[DN_OBS_DIM];
+                observe_columns_lin<R>(p, c, fl, o);
+                const RewardPre<R> pre = reward_entry<R>(p, c, fl, P4, P5);
+                RMailC<R> &mc = mailc[u & 1];
+                mc.r[0][lane] = pre.r0; mc.r[1][lane] = pre.s_lin; mc.r[2][lane] = pre.s_ang;
+                mc.oa[lane] = make_float4(o[0], o[1], o[2], o[6]);
+                mc.ob[lane] = make_float4(o[7], o[8], o[12], __int_as_float((int)pre.pen_lin | ((int)pre.pen_ang << 1)));
+                // prev_vel / prev_ang_v: _update_state_post_step (skipped on a terminated step, quirk Q5), zero after a reset
+                if (!terminated) { P4 = make_float4(fl.vex, fl.vey, fl.vez, 0.0f); P5 = make_float4(fl.aex, fl.aey, fl.aez, 0.0f); }
+                if (terminated || fl.truncated) P4 = P5 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+            s3p = s3p == 2 ? 0 : s3p + 1;
+            MW_BARRIER();                                                  // barrier t
+        }
+        if (active) {
+            float *g4 = reinterpret_cast<float *>(b.g4 + li), *g5 = reinterpret_cast<float *>(b.g5 + li);
+            g4[0] = P4.x; g4[1] = P4.y; g4[2] = P4.z; g5[0] = P5.x; g5[1] = P5.y; g5[2] = P5.z;
+        }
+    } else if (role == 5) {
+        // ---- X: the scalars of step t - 2 (and, without the normaliser, its observation rows)
+        float4 G4 = b.g4[li], G5 = b.g5[li];                               // .w: Monitor return / length
+        StatAcc acc;
+        Rms rms;                                                           // never touched here
+        RewNorm rn = {0.0, 0.0, 1.0, 1e-4};
+        block_lds_barrier();                                               // P
+        int s3q = 1;                                                       // (t - 2) % 3
+#pragma clang loop unroll(disable)
+        for (int t = 0; t <= k_steps + 1; ++t) {
+            if (t > 1) {
+                const int u = t - 2;
+                const MailL<R> &ml = maill[s3q];
+                const RMailE<R> &me = maile[u & 1];
+                const RMailC<R> &mc = mailc[u & 1];
+                Flight<R> fl;
+                Verdict<R> v;
+                fl.px = ml.f64[0][lane]; fl.py = ml.f64[1][lane]; fl.pz = ml.f64[2][lane]; v.d_obs = ml.f64[3][lane];
+                fl.d_e = ml.f32[0][lane].w;
+                const int fb = ml.flags[lane];
+                fl.idx_e = fb & 0xFF; fl.just_found_e = (fb >> 8) & 1; fl.truncated = (fb >> 9) & 1;
+                v.coll1 = (fb >> 10) & 1; v.terminated = (fb >> 11) & 1;
+                fl.fwx = me.fw[0][lane]; fl.fwy = me.fw[1][lane]; fl.fwz = me.fw[2][lane];
+                const float4 cb = mc.ob[lane];
+                RewardPre<R> pre;
+                pre.r0 = mc.r[0][lane]; pre.s_lin = mc.r[1][lane]; pre.s_ang = mc.r[2][lane];
+                const int pb = __float_as_int(cb.w);
+                pre.pen_lin = (pb & 1) != 0; pre.pen_ang = (pb & 2) != 0;
+                pre.found_now = (R)fl.d_e <= c.threshold;                  // as reward_entry forms them
+                pre.last_gate = fl.idx_e + 1 == p.num_waypoints;
+                R r_normal;
+                float r_found32;
+                reward_pose<R>(p, s_tab, fl, pre, r_normal, r_found32);
+                fl.vex = fl.vey = fl.vez = fl.aex = fl.aey = fl.aez = 0.0f;    // prev_vel / prev_ang_v live on Q
+                const StepOut out = block_out(io0, tile_base, (long long)u * n, (long long)u * words);
+                report_scalars<R, false>(p, c, out, fl, v, r_normal, r_found32, li, lane, active, G4, G5, acc, rn);
+                if (!NORM) {
+                    const float4 ea = me.oa[lane], ca = mc.oa[lane];
+                    const float2 eb = me.ob[lane];
+                    float o[DN_OBS_DIM] = {ca.x, ca.y, ca.z, ea.x, ea.y, ea.z, ca.w, cb.x, cb.y, ea.w, eb.x, eb.y, cb.z};
+                    report_obs_cols<R, false, 0, DN_OBS_DIM>(p, c, out, v.terminated != 0 || fl.truncated != 0, v.d_obs, o, li, active, rms);
+                }
+            }
+            s3q = s3q == 2 ? 0 : s3q + 1;
+            if (t <= k_steps) MW_BARRIER();                                // barrier t
+        }
+        flush_stats(p, acc, sc0 + (unsigned long long)k_steps, lane);
+        if (active) {
+            reinterpret_cast<float *>(b.g4 + li)[3] = G4.w;
+            reinterpret_cast<float *>(b.g5 + li)[3] = G5.w;
+        }
+    } else if (NORM && role == 6) {
+        // ---- N1: columns 0..6 of step t - 2 through the normaliser and out
+        Rms rms;
+        load_rms_cols<0, 7>(p, tile_base, li, rms);
+        block_lds_barrier();                                               // P
+        int s3q = 1;
+#pragma clang loop unroll(disable)
+        for (int t = 0; t <= k_steps + 1; ++t) {
+            if (t > 1) {
+                const int u = t - 2;
+                const MailL<R> &ml = maill[s3q];
+                const int fb = ml.flags[lane];
+                const R d_obs = ml.f64[3][lane];
+                const float4 ea = maile[u & 1].oa[lane], ca = mailc[u & 1].oa[lane];
+                float o[DN_OBS_DIM] = {ca.x, ca.y, ca.z, ea.x, ea.y, ea.z, ca.w, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+                normalize_obs_cols<0, 7>(rms, o);                          // the step observation (= terminal_observation)
+                const StepOut out = block_out(io0, tile_base, (long long)u * n, (long long)u * words);
+                report_obs_cols<R, true, 0, 7>(p, c, out, (((fb >> 9) | (fb >> 11)) & 1) != 0, d_obs, o, li, active, rms);
+            }
+            s3q = s3q == 2 ? 0 : s3q + 1;
+            if (t <= k_steps) MW_BARRIER();                                // barrier t
+        }
+        if (active) store_rms_cols<0, 7, true>(p, tile_base, li, rms);
+    } else if (NORM) {
+        // ---- N2: columns 7..12
+        Rms rms;
+        load_rms_cols<7, DN_OBS_DIM>(p, tile_base, li, rms);
+        block_lds_barrier();                                               // P
+        int s3q = 1;
+#pragma clang loop unroll(disable)
+        for (int t = 0; t <= k_steps + 1; ++t) {
+            if (t > 1) {
+                const int u = t - 2;
+                const MailL<R> &ml = maill[s3q];
+                const int fb = ml.flags[lane];
+                const R d_obs = ml.f64[3][lane];
+                const float4 ea = maile[u & 1].oa[lane], cb = mailc[u & 1].ob[lane];
+                const float2 eb = maile[u & 1].ob[lane];
+                float o[DN_OBS_DIM] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, cb.x, cb.y, ea.w, eb.x, eb.y, cb.z};
+                normalize_obs_cols<7, DN_OBS_DIM>(rms, o);
+                const StepOut out = block_out(io0, tile_base, (long long)u * n, (long long)u * words);
+                report_obs_cols<R, true, 7, DN_OBS_DIM>(p, c, out, (((fb >> 9) | (fb >> 11)) & 1) != 0, d_obs, o, li, active, rms);
+            }
+            s3q = s3q == 2 ? 0 : s3q + 1;
+            if (t <= k_steps) MW_BARRIER();                                // barrier t
+        }
+        if (active) store_rms_cols<7, DN_OBS_DIM, false>(p, tile_base, li, rms);
+    }
+}
+
+// sixteen waves of two tiles on four SIMDs: four waves a SIMD, 128 registers a wave
+template <typename R>
+__global__ __launch_bounds__(8 * DN_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void dn_step_many_rp8_kernel(const DnParams p, const DnStepIO io0, const int k_steps)
+{
+    step_many_rp_body<R, true>(p, io0, k_steps);
+}
+template <typename R>
+__global__ __launch_bounds__(6 * DN_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 4))) void dn_step_many_rp6_kernel(const DnParams p, const DnStepIO io0, const int k_steps)
+{
+    step_many_rp_body<R, false>(p, io0, k_steps);
 }
 
 // -----------------------------------------------------------------------------------------------------
@@ -3098,6 +3526,16 @@ hipError_t dn_launch_step_many_mw(const DnParams &p, const DnStepIO &io, int k, 
     const bool noise = p.act_noise_sigma > 0.0f || p.obs_noise_sigma > 0.0f;
     // the rarely used options share one set of instantiations (runtime switches inside): reward wrappers, N4 physics terms
     const bool rew = p.clip_rew != 0 || p.norm_rew != 0 || p.gnd != 0 || p.drag != 0 || p.rpm_actions != 0 || p.pid_mode != 0 || p.random_spawn != 0 || p.zero_damping != 0;
+    if ((waves == 8 || waves == 6) && k > 1 && !noise && !rew) {   // role-pipelined kernel (round 4): eight roles with the normaliser, six without
+        if (p.normalize_obs) {
+            if (f32) hipLaunchKernelGGL((dn_step_many_rp8_kernel<float>), dim3(grid), dim3(8 * DN_BLOCK), 0, stream, p, io, k);
+            else hipLaunchKernelGGL((dn_step_many_rp8_kernel<double>), dim3(grid), dim3(8 * DN_BLOCK), 0, stream, p, io, k);
+        } else {
+            if (f32) hipLaunchKernelGGL((dn_step_many_rp6_kernel<float>), dim3(grid), dim3(6 * DN_BLOCK), 0, stream, p, io, k);
+            else hipLaunchKernelGGL((dn_step_many_rp6_kernel<double>), dim3(grid), dim3(6 * DN_BLOCK), 0, stream, p, io, k);
+        }
+        return hipGetLastError();
+    }
     if (waves == 5 && k > 1) {                             // four waves + the normaliser's: fused launches of the plain configuration, normaliser on
         const dim3 blk(5 * DN_BLOCK);
         if (f32) {
@@ -3144,6 +3582,13 @@ hipError_t dn_launch_step_many_mw(const DnParams &p, const DnStepIO &io, int k, 
     else { if (noise) DN_LAUNCH(double, false, true); else DN_LAUNCH(double, false, false); }
     return hipGetLastError();
 }
+#ifdef DN_MW_STAMP
+extern "C" int dn_debug_mw_stamps(long long *out)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mw_stamp), sizeof(long long) * 8 * 48 * 2) == hipSuccess ? 0 : 1;
+}
+#endif
 #elif DN_TU == 1
 hipError_t dn_launch_step_many(const DnParams &p, const DnStepIO &io, int k, bool f32, int waves, hipStream_t stream)
 {

@@ -26,6 +26,11 @@ def _tracks():
     return tracks
 
 
+def _bench_fused_waves(norm):
+    """The fused-launch shape dn_create picks at 32 768 drones (two tiles per CU): what bench.py's headline times."""
+    return 8 if norm else 6
+
+
 def make_pair(track, n, *, f32_state, max_steps=4096, **kw):
     pkg = _gpu()
     env = pkg.DroneVecEnv(track, n, max_steps=max_steps, device="cuda:0", **kw)
@@ -636,7 +641,7 @@ def test_action_chain_bit_exact_vs_reference_golden(golden):
         assert np.array_equal(zt.cpu().numpy()[sel].view(np.uint32), z_ref[sel].view(np.uint32)), norm
 
 
-@pytest.mark.parametrize("norm,noise", [(False, 0.0), (True, 0.01), (False, 0.02)])
+@pytest.mark.parametrize("norm,noise", [(False, 0.0), (True, 0.0), (True, 0.01), (False, 0.02)])
 def test_kernel_shapes_are_bit_identical(norm, noise, monkeypatch):
     """The two-wave kernels (flight wave + report wave, messages through LDS) and the one-wave kernels (same
     phases, messages in registers) must agree bit for bit: state, outputs, statistics; single steps and fused."""
@@ -645,12 +650,13 @@ def test_kernel_shapes_are_bit_identical(norm, noise, monkeypatch):
     n, K = 1000, 70                       # ragged last tile on purpose
     kw = dict(normalize_obs=norm, max_steps=30, obs_noise_sigma=noise, act_noise_sigma=noise / 10, seed=5)
     envs = {}
-    for shape in ("1", "2", "3", "4") + (("5",) if norm else ()):
+    rp = ("8" if norm else "6",) if noise == 0.0 else ()
+    for shape in ("1", "2", "3", "4") + (("5",) if norm else ()) + rp:
         monkeypatch.setenv("DN_WAVES", shape)
         envs[shape] = pkg.DroneVecEnv(track, n, device="cuda:0", **kw)
         envs[shape].reset()
         # three waves: flight / report / aux; four: linear + rules / angular + attitude / observation / thrust + report (fused launches);
-        # five: the normaliser and the observation rows on a wave of their own
+        # five: the normaliser and the observation rows on a wave of their own; six / eight: the role-pipelined kernel (no noise)
         assert envs[shape].kernel_waves(fused=True) == int(shape)
     monkeypatch.delenv("DN_WAVES")
     rng = np.random.default_rng(21)
@@ -662,8 +668,9 @@ def test_kernel_shapes_are_bit_identical(norm, noise, monkeypatch):
         first = [(o.clone(), r.clone(), d.clone(), {k: v.clone() for k, v in i.items()}) for o, r, d, i in first[-1:]]
         rest = env.rollout_tensor(acts[6:].contiguous(), want_terminal=True)   # ... then one fused launch (n % 4 == 0)
         outs[shape] = (first, rest, env.get_state(), env.stats())
-    for other in ("2", "3", "4"):
-        _assert_same_rollout(outs["1"], outs[other], n)
+    for other in outs:                    # every shape that was built, the normaliser's own wave shapes included
+        if other != "1":
+            _assert_same_rollout(outs["1"], outs[other], n)
     for env in envs.values():
         env.close()
 
@@ -982,31 +989,34 @@ def test_baseline_full_size_matches_oracle_free_running():
     env.close()
 
 
-def test_baseline_full_size_fused_launch_matches_oracle(monkeypatch):
-    """The bench's own launch -- 32768 drones, race track, 64 steps of U(-1,1)^4 actions in ONE dn_step_many (the
-    four-wave kernel) -- against the oracle, every drone, every step, every output; then the mixed stream."""
+@pytest.mark.parametrize("norm,K", [(False, 64), (True, 20), (True, 64)])
+def test_baseline_full_size_fused_launch_matches_oracle(norm, K, monkeypatch):
+    """The bench's own launches -- 32768 drones, race track, K steps of U(-1,1)^4 actions in ONE dn_step_many, with the
+    normaliser on (the reference's configuration: the headline kernel, K = 20 is the driver's launch and 64 the default
+    line's) and off -- against the oracle, every drone, every step, every output; then the mixed stream."""
     monkeypatch.delenv("DN_WAVES", raising=False)         # the bench's shape is the library's own pick
     track = _tracks().reaching()
-    n, K = 32768, 64
-    env, ora = make_pair(track, n, f32_state=True, max_steps=4096, normalize_obs=False)
-    assert env.kernel_waves(fused=True) == 4
+    n = 32768
+    env, ora = make_pair(track, n, f32_state=True, max_steps=4096, normalize_obs=norm)
+    assert env.kernel_waves(fused=True) == _bench_fused_waves(norm)
     np.testing.assert_allclose(env.reset_tensor().cpu().numpy(), ora.reset(), rtol=0, atol=1e-6)
     rng = np.random.default_rng(64)
     dev = torch.device("cuda:0")
     n_done = 0
-    for stream in ("uniform", "mixed"):
-        acts = np.stack([rng.uniform(-1, 1, (n, 4)).astype(np.float32) if stream == "uniform" else actions_mixed(rng, n)
-                         for _ in range(K)])
-        out = env.rollout_tensor(torch.from_numpy(acts).to(dev), want_terminal=True)
-        torch.cuda.synchronize()
-        for t in range(K):
-            info = dict(truncated=out["truncated"][t], found_targets=out["found_targets"][t], terminal_obs=out["terminal_obs"][t],
-                        ep_length=out["ep_length"][t], ep_return=out["ep_return"][t])
-            # free-running (both sides keep their own float32 state): a one-ulp difference in a stored attitude is amplified
-            # by a tumbling drone, one observation in 4e5 reaches 1.3e-5 -- the per-step bar (1e-5) is the teacher-forced tests'
-            n_done += compare_step((out["obs"][t], out["reward"][t], out["done"][t], info), ora.step(acts[t]),
-                                   f"fused full-size {stream} t={t}", obs_atol=1e-4, rew_atol=2e-4)
-    assert n_done > n // 2
+    for stream, launches in (("uniform", -(-100 // K)), ("mixed", 1)):     # >= 100 uniform steps: crashes, resets, second episodes
+        for rep in range(launches):
+            acts = np.stack([rng.uniform(-1, 1, (n, 4)).astype(np.float32) if stream == "uniform" else actions_mixed(rng, n)
+                             for _ in range(K)])
+            out = env.rollout_tensor(torch.from_numpy(acts).to(dev), want_terminal=True)
+            torch.cuda.synchronize()
+            for t in range(K):
+                info = dict(truncated=out["truncated"][t], found_targets=out["found_targets"][t], terminal_obs=out["terminal_obs"][t],
+                            ep_length=out["ep_length"][t], ep_return=out["ep_return"][t])
+                # free-running (both sides keep their own float32 state): a one-ulp difference in a stored attitude is amplified
+                # by a tumbling drone, one observation in 4e5 reaches 1.3e-5 -- the per-step bar (1e-5) is the teacher-forced tests'
+                n_done += compare_step((out["obs"][t], out["reward"][t], out["done"][t], info), ora.step(acts[t]),
+                                       f"fused full-size norm={norm} {stream} launch {rep} t={t}", obs_atol=1e-4, rew_atol=2e-4)
+    assert n_done > n // 8
     assert env.stats()["episodes"] == n_done
     env.close()
 
@@ -1305,14 +1315,14 @@ def test_nan_actions_propagate_like_numpy():
     env.close()
 
 
-@pytest.mark.parametrize("waves", ["3", "4", "5"])
+@pytest.mark.parametrize("waves", ["3", "4", "5", "6", "8"])
 @pytest.mark.parametrize("n,K", [(12, 2), (64, 3), (100, 5), (4096, 2)])
 def test_three_wave_kernel_short_rollouts_and_ragged_tiles(n, K, waves, monkeypatch):
     """The three- and four-wave kernels trail their report wave two steps behind the flight wave(s): rollouts shorter than
     the skew, a single ragged tile and one drone short of a tile must still match the one-wave kernel bit for bit."""
     pkg = _gpu()
     track = _tracks().reaching()
-    kw = dict(normalize_obs=waves == "5", max_steps=4)    # the fifth wave is the normaliser's
+    kw = dict(normalize_obs=waves in ("5", "8"), max_steps=4)    # the fifth wave is the normaliser's; eight roles: with it, six: without
     monkeypatch.setenv("DN_WAVES", "1")
     ref = pkg.DroneVecEnv(track, n, device="cuda:0", **kw)
     monkeypatch.setenv("DN_WAVES", waves)
@@ -1358,7 +1368,7 @@ def test_fused_default_shape_equals_single_steps_over_options(opts, monkeypatch)
     kw = dict(normalize_obs=False, max_steps=25)
     kw.update(opts)
     a, b = pkg.DroneVecEnv(track, n, device="cuda:0", **kw), pkg.DroneVecEnv(track, n, device="cuda:0", **kw)
-    assert b.kernel_waves(fused=True) in (3, 4, 5) and a.kernel_waves(fused=False) in (1, 3)   # fused: four waves for small plain fleets (five with the normaliser); single steps: three waves cut by dependency (plain), else one
+    assert b.kernel_waves(fused=True) in (3, 4, 5, 6, 8) and a.kernel_waves(fused=False) in (1, 3)   # fused: six / eight roles for small plain fleets without noise, four / five waves with noise; single steps: three waves cut by dependency (plain), else one
     a.reset(); b.reset()
     rng = np.random.default_rng(17)
     dev = torch.device("cuda:0")
@@ -1394,7 +1404,7 @@ def test_float32_compute_shapes_agree_to_rounding(norm, monkeypatch):
     a = pkg.DroneVecEnv(track, n, device="cuda:0", **kw)
     monkeypatch.delenv("DN_WAVES")
     b = pkg.DroneVecEnv(track, n, device="cuda:0", **kw)
-    assert b.kernel_waves(fused=True) == (5 if norm else 4)
+    assert b.kernel_waves(fused=True) == (8 if norm else 6)
     a.reset(); b.reset()
     for _ in range(30):                                   # teacher-forced: both sides start every launch from a's state
         b.set_state(a.get_state())
@@ -1497,7 +1507,7 @@ def test_random_configurations_all_shapes_bit_identical(monkeypatch):
             assert np.ascontiguousarray(sa[k]).tobytes() == np.ascontiguousarray(sb[k]).tobytes(), (it, k)
         assert ref.stats() == env.stats()
         ref.close(); env.close()
-    assert shapes >= {1, 2, 3} and shapes <= {1, 2, 3, 4, 5}  # four / five waves only for small plain fleets (five: with the normaliser)
+    assert shapes >= {1, 2, 3, 6, 8} and shapes <= {1, 2, 3, 4, 5, 6, 8}  # six / eight roles: small plain fleets without noise; four / five waves: with noise
 
 
 @pytest.mark.parametrize("deterministic", [0, 1])
