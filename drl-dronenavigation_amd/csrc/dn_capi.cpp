@@ -43,7 +43,7 @@ constexpr long long DN_CALIBRATION_CUS = 256;
 constexpr long long DN_TWO_WAVE_TILES_PER_CU = 4;   // 1024 tiles = 65536 drones on 256 CUs: one tile per SIMD
 constexpr long long DN_PQX_TILES_PER_CU = 4;        // three-wave single step: while the tiles alone leave SIMDs idle
 constexpr long long DN_FIVE_WAVE_TILES_PER_CU = 3;  // the same with the normaliser on a fifth wave: wherever the four-wave kernel would run (40 960 / 49 152 drones: 2.65 / 2.84 us per step against 2.95 / 3.28)
-constexpr long long DN_ROLE_PIPE_TILES_PER_CU = 2;  // role-pipelined fused step (six / eight roles per tile): two tiles are twelve / sixteen waves per CU
+constexpr long long DN_ROLE_PIPE_TILES_PER_CU = 3;  // role-pipelined fused step (eight roles per tile): up to three tiles per CU, see dn_create
 constexpr long long DN_FOUR_WAVE_TILES_PER_CU = 3;  // four-wave fused step: up to three tiles per CU (768 tiles on 256 CUs)
 constexpr double DN_CONTACT_MARGIN = 0.02;          // Bullet's contact-breaking threshold (dn_kernels.hip collision_common)
 constexpr double DN_COLL_R = 0.06, DN_COLL_H = 0.025;   // base_link collision cylinder, cf2x.urdf:34
@@ -333,10 +333,15 @@ int32_t dn_create(const dn_config *cfg, dn_env **out)
     // Five waves (normaliser on; round 3): the four-wave kernel with the normaliser on a wave of its own (NW = 5), where the report wave set
     // the pace.  DN_WAVES=4 keeps the four-wave shape for A/B runs; see profiles/r03_notes.md.
     if (e->waves_fused == 4 && cfg->normalize_obs && e->blocks <= DN_FIVE_WAVE_TILES_PER_CU * e->num_cus) e->waves_fused = 5;
-    // Role-pipelined kernel (round 4, dn_step_many_rp8_kernel / rp6: eight roles per tile with the normaliser, six without; plain
-    // configuration, no noise): up to two tiles per CU -- sixteen / twelve waves, at most four per SIMD.
+    // Role-pipelined kernel (round 4, dn_step_many_rp8_kernel: eight roles per tile; plain configuration with the normaliser, no noise).
+    // Fleet sweep, 64-step launches, us per step (five waves | eight roles; profiles/r04_sweep_rp.txt): 4 096 drones 1.08 | 0.93, 8 192
+    // 1.11 | 0.99, 16 384 1.18 | 1.05, 20 480 1.52 | 1.53, 24 576 1.53 | 1.57, 32 768 1.63 | 1.66, 40 960 2.79 | 2.37, 49 152 2.98 | 2.47
+    // -> eight roles up to one tile per CU and from two to three tiles per CU (where two of its workgroups fit a CU and the third tile
+    // follows), five waves in between, where sixteen waves saturate the vector ALUs either way.  Without the normaliser the six-role form
+    // (rp6) loses to the four-wave kernel at every size (32 768 drones: 1.68 against 1.40) and is built for DN_WAVES=6 only.
     const bool rp_ok = plain && !cfg->ground_contact && !noisy;
-    if (rp_ok && e->blocks <= DN_ROLE_PIPE_TILES_PER_CU * e->num_cus) e->waves_fused = cfg->normalize_obs ? 8 : 6;
+    if (rp_ok && cfg->normalize_obs && (e->blocks <= e->num_cus || (e->blocks > 2 * e->num_cus && e->blocks <= DN_ROLE_PIPE_TILES_PER_CU * e->num_cus)))
+        e->waves_fused = 8;
     // dn_step (one control step per launch) is latency bound: ~2.9 us of launch-to-launch floor that an empty kernel
     // already pays (profiles/r02_dispatch_floor.txt) plus the dependent instruction stream of the step.  Cutting the step
     // by dependency over three waves (dn_step_pqx_kernel) shortens that stream while the chip has idle SIMDs; built for the

@@ -392,7 +392,9 @@ DN_DEV void normalize_obs_cols(Rms &r, float o[DN_OBS_DIM])
         r.var[k] = new_var;
         const double s = new_var + 1e-8;
         double y = __builtin_amdgcn_rsq(s);
+#ifndef DN_NORM_RAW_RSQ
         y = __builtin_fma(y, __builtin_fma(-(0.5 * s * y), y, 0.5), y);
+#endif
         o[k] = (float)((x - new_mean) * y);
     }
     r.count = tot;
@@ -1060,17 +1062,29 @@ template <typename R> struct Lin {
     R px, py, pz;          // new position
     R vx, vy, vz;          // new velocity
 };
+// The thrust direction = third column of the rotation matrix of the entry attitude: all physics_linear reads of the quaternion.  Its
+// own function so that the wave that OWNS the attitude can form it (same expressions, same bits) and mail three values.
+template <typename R> struct AttCol {
+    R r02, r12, r22;
+};
 template <typename R>
-DN_DEV Lin<R> physics_linear(const float4 G0, const float4 G1, const float4 G2, const R fz, const R dax, const R day, const R daz,
-                             const bool extra, const R damp = K<R>::LIN_DAMP)
+DN_DEV AttCol<R> attitude_column(const float4 G1)
+{
+    const R qx = G1.x, qy = G1.y, qz = G1.z, qw = G1.w;
+    const QuatTerms<R> t = quat_terms<R>(qx, qy, qz, qw);
+    AttCol<R> c;
+    c.r02 = F(qx, t.zs, t.wys); c.r12 = F(qy, t.zs, -t.wxs); c.r22 = R(1.0) - F(qx, t.xs, t.yy);
+    return c;
+}
+template <typename R>
+DN_DEV Lin<R> physics_linear_col(const float4 G0, const float4 G2, const AttCol<R> col, const R fz, const R dax, const R day, const R daz,
+                                 const bool extra, const R damp = K<R>::LIN_DAMP)
 {
     Lin<R> o;
     R px = G0.x, py = G0.y, pz = G0.z;
-    const R qx = G1.x, qy = G1.y, qz = G1.z, qw = G1.w;
     R vx = G2.x, vy = G2.y, vz = G2.z;
     const R dt = K<R>::DT;
-    const QuatTerms<R> t = quat_terms<R>(qx, qy, qz, qw);
-    const R r02 = F(qx, t.zs, t.wys), r12 = F(qy, t.zs, -t.wxs), r22 = R(1.0) - F(qx, t.xs, t.yy);
+    const R r02 = col.r02, r12 = col.r12, r22 = col.r22;
     // linear: a = R[:,2] fz/M - (0,0,G) - v (c + c|v|)
     // the damping norms enter the velocity update at dt * 0.04: a float32 root moves it by 1e-12 relative
     const R kl = F(damp, (R)__builtin_amdgcn_sqrtf((float)F(vz, vz, F(vy, vy, vx * vx))), damp);
@@ -1085,6 +1099,12 @@ DN_DEV Lin<R> physics_linear(const float4 G0, const float4 G1, const float4 G2, 
     o.px = F(dt, vx, px); o.py = F(dt, vy, py); o.pz = F(dt, vz, pz);    // stepPositionsMultiDof
     o.vx = vx; o.vy = vy; o.vz = vz;
     return o;
+}
+template <typename R>
+DN_DEV Lin<R> physics_linear(const float4 G0, const float4 G1, const float4 G2, const R fz, const R dax, const R day, const R daz,
+                             const bool extra, const R damp = K<R>::LIN_DAMP)
+{
+    return physics_linear_col<R>(G0, G2, attitude_column<R>(G1), fz, dax, day, daz, extra, damp);
 }
 template <typename R> struct Ang {
     R qx, qy, qz, qw;      // new attitude (unit quaternion)
@@ -1471,12 +1491,17 @@ DN_DEV RewardPre<R> reward_entry(const DnParams &p, const DnConsts<R> &c, const 
     if (q.pen_ang) q.s_ang = (R)__builtin_amdgcn_sqrtf((float)aa2);
     return q;
 }
+// reward_pose in two halves: the orientation term against the waypoint the taken branch refers to (reads the pose), and the assembly
+// of both value branches in the reference's order of additions (reads the entry-state terms) -- a kernel may run them on two waves.
 template <typename R>
-DN_DEV void reward_pose(const DnParams &p, const R *s_tab, const Flight<R> &fl, const RewardPre<R> &q, R &r_normal, float &r_found32)
+DN_DEV int reward_orientation(const DnParams &p, const R *s_tab, const Flight<R> &fl, const bool found_now, const bool last_gate)
 {
-    // The orientation term is evaluated once, against the waypoint the taken branch refers to.
-    const int idx_ori = (q.found_now && !q.last_gate) ? fl.idx_e + 1 : fl.idx_e;
-    const int ori = orientation_reward<R>(fl.fwx, fl.fwy, fl.fwz, fl.px, fl.py, fl.pz, s_tab + idx_ori * DN_T_STRIDE);
+    const int idx_ori = (found_now && !last_gate) ? fl.idx_e + 1 : fl.idx_e;
+    return orientation_reward<R>(fl.fwx, fl.fwy, fl.fwz, fl.px, fl.py, fl.pz, s_tab + idx_ori * DN_T_STRIDE);
+}
+template <typename R>
+DN_DEV void reward_assemble(const RewardPre<R> &q, const int ori, R &r_normal, float &r_found32)
+{
     float r32 = 0.0f;
     if (q.last_gate) r32 = r32 + 200.0f;                                      // :542-546
     else { r32 = r32 + 75.0f; r32 = r32 + (float)(ori * 5); }                 // :548-552
@@ -1485,6 +1510,12 @@ DN_DEV void reward_pose(const DnParams &p, const R *s_tab, const Flight<R> &fl, 
     if (q.pen_lin) r = r - q.s_lin;
     if (q.pen_ang) r = r - q.s_ang;
     r_normal = r;
+}
+template <typename R>
+DN_DEV void reward_pose(const DnParams &p, const R *s_tab, const Flight<R> &fl, const RewardPre<R> &q, R &r_normal, float &r_found32)
+{
+    // The orientation term is evaluated once, against the waypoint the taken branch refers to.
+    reward_assemble<R>(q, reward_orientation<R>(p, s_tab, fl, q.found_now, q.last_gate), r_normal, r_found32);
 }
 template <typename R>
 DN_DEV void reward_candidates(const DnParams &p, const DnConsts<R> &c, const R *s_tab, const Flight<R> &fl, const float4 G4,
@@ -2669,39 +2700,57 @@ __global__ __launch_bounds__(5 * DN_BLOCK) __attribute__((amdgpu_waves_per_eu(4,
 // Role-pipelined kernel (round 4; fused launches of the plain configuration without noise, <= 2 tiles per CU): six roles, eight with the
 // normaliser.
 //
-// Per-role stamps of the four- / five-wave kernels (profiles/mw_stamps.py, profiles/r04_stamps_base.txt) showed what paces them: not the
-// recurrence waves L and A but Q (thrust of step t + 1, observation row and reward candidates of step t - 1: ~305 vector instructions, busy
-// 2 450 cycles of a 2 620-cycle iteration at one tile per CU, 3 000-3 400 at two), then N.  A wave issues one instruction per ~7.5 cycles
-// whatever else its SIMD does and a SIMD needs four waves to issue every ~2 cycles (profiles/r03_valu_rates.txt), so the step is cut into
-// EIGHT roles of <= ~200 instructions, two tiles = sixteen waves per CU = four per SIMD:
+// Per-role stamps of the four- / five-wave kernels (profiles/mw_stamps.py, profiles/r04_stamps.txt) showed what paces them: not the
+// recurrence waves L and A but Q (thrust of step t + 1, observation row and reward candidates of step t - 1: busy 2 450 cycles of a
+// 2 620-cycle iteration at one tile per CU, 3 000-3 400 at two), then N and L.  Here the step is cut into EIGHT roles, and the one that
+// carries the rules keeps only what the NEXT step's flags need:
 //
 //   T   thrust(t + 1)                                                                          -> tmail[(t + 1) & 1]
-//   L   physics_linear(t) | rules_verdict | rules_commit      (recurrence: position, gate bookkeeping) -> MailL[t % 3]
-//   A   physics_angular(t)                                    (recurrence: attitude, angular velocity)  -> MailA[t & 1]
-//   E   attitude(t - 1): Euler terms, forward vector, observation columns 3 4 5 9 10 11              -> MailE[(t - 1) & 1]
-//   Q   observation columns 0 1 2 6 7 8 12 and the entry-state reward terms of step t - 1; prev_vel / prev_ang_v  -> MailC[(t - 1) & 1]
-//   X   step t - 2: orientation term, reward select, Monitor, statistics, scalar outputs (without the normaliser also the rows)
+//   L   the linear recurrence: physics_linear(t) on A's attitude column, collision / corridor / gate flags, auto-reset of position,
+//       velocity, gate index, step counter; squared distances only (see found_from_d2)           -> RMailL[t & 1]
+//   A   the angular recurrence: physics_angular(t), thrust direction of the new attitude           -> RMailA[t & 1]
+//   E   step t - 1: Euler terms, forward vector, orientation term, observation columns 3 4 5 9 10 11   -> RMailE[(t - 1) & 1]
+//   Q   step t - 1: the distance bookkeeping (d, d_prev, just_found; quirks Q1-Q3), observation columns 0 1 2 6 7 8 12, the entry-state
+//       reward terms, prev_vel / prev_ang_v                                                        -> RMailC[(t - 1) & 1]
+//   X   step t - 2: reward assembly and select, Monitor, statistics, scalar outputs (without the normaliser also the rows)
 //   N1  step t - 2: normaliser + rows, columns 0..6        N2  columns 7..12     (terminal / reset observation of a finished drone included)
 //                                                                                                  == one LDS-only barrier per iteration ==
-// Same device functions, same typed values across LDS, one spelled-out arithmetic sequence: bit-identical to every other shape.
+// Same device functions / same spelled-out expressions, same typed values across LDS: bit-identical to every other shape.
 // -----------------------------------------------------------------------------------------------------
-template <typename R> struct RMailA {      // A -> L (qnew), E (q, w), Q (we)
+template <typename R> struct RMailL {      // L -> A (flags), E (position, flags), Q (everything)
+    R f64[5][DN_BLOCK];                    // new position (3), squared distance after the step, squared distance after the reset
+    float4 f32[DN_BLOCK];                  // new velocity (float32 state words), flag word
+};
+// flag word: idx_e [0:8) | truncated << 9 | coll1 << 10 | terminated << 11 | found_now << 12; Q adds pen_lin << 16 | pen_ang << 17
+template <typename R> struct RMailA {      // A -> L (thrust direction of the new attitude), E (q, w), Q (we)
     R q[4][DN_BLOCK];                      // the new attitude in R (what attitude_phase reads)
-    float4 qnew[DN_BLOCK];                 // the same as the float32 state words (before any reset)
+    R col[3][DN_BLOCK];                    // attitude_column of the new attitude as it goes back to HBM (float32 words)
     float4 w[DN_BLOCK];                    // new angular velocity (float32 state words)
     float4 we[DN_BLOCK];                   // entry angular velocity (prev_ang_v of the smoothness term)
 };
-template <typename R> struct RMailE {      // E -> X (forward vector), N / X (columns 3 4 5 9 10 11)
-    R fw[3][DN_BLOCK];
+template <typename R> struct RMailE {      // E -> X (orientation term), N / X (columns 3 4 5 9 10 11)
     float4 oa[DN_BLOCK];                   // o3 o4 o5 o9
-    float2 ob[DN_BLOCK];                   // o10 o11
+    float4 ob[DN_BLOCK];                   // o10 o11, orientation term (int bits), --
 };
-template <typename R> struct RMailC {      // Q -> X (reward terms), N / X (columns 0 1 2 6 7 8 12)
-    R r[3][DN_BLOCK];                      // RewardPre: r0, s_lin, s_ang
+template <typename R> struct RMailC {      // Q -> X (reward terms, flags), N (d_obs, flags), N / X (columns 0 1 2 6 7 8 12)
+    R r[4][DN_BLOCK];                      // RewardPre: r0, s_lin, s_ang; Verdict.d_obs
     float4 oa[DN_BLOCK];                   // o0 o1 o2 o6
-    float4 ob[DN_BLOCK];                   // o7 o8 o12, bits: pen_lin | pen_ang << 1
+    float4 ob[DN_BLOCK];                   // o7 o8 o12, flag word
 };
 struct __attribute__((packed, aligned(4))) ObsTri { float x, y, z; };
+
+// found_now of the NEXT step from the squared distance: the reference tests the stored distance, (R)(float)sqrt(d2) <= threshold
+// (PBDroneEnv.py:539 on the float32 state word).  Away from the radius the squared compare decides the same way -- the float32 rounding
+// moves d by 6e-8 relative, the band below is 1e-6 --, and inside the band (never, in practice: one test in ~1e6 per unit of band) the
+// stored form itself is evaluated, so the flag is the stored form's bit for bit.
+template <typename R>
+DN_DEV bool found_from_d2(const DnConsts<R> &c, const R d2)
+{
+    bool found = d2 < c.thr2;
+    if (__builtin_expect(__ballot(fabs(d2 - c.thr2) <= c.thr2 * R(1e-6)) != 0ull, 0))
+        found = (R)(float)FM<R>::sqrt0(d2) <= c.threshold;
+    return found;
+}
 
 // report_obs for the columns [K0, K1) of the row (TILE = 2 form: straight from the lane's registers)
 template <typename R, bool NORM, int K0, int K1>
@@ -2743,11 +2792,34 @@ DN_DEV void report_obs_cols(const DnParams &p, const DnConsts<R> &c, const StepO
 #define DN_RP6_ORDER_A "LAEQTX"
 #define DN_RP6_ORDER_B "EQLXAT"
 #endif
+#ifndef DN_RP_PRIO
+#define DN_RP_PRIO "33211000"            // s_setprio of the roles L A T E Q X N1 N2
+#endif
+// Two tiles share a CU, and the SIMD arbiter picks by priority, then AGE: left alone, the workgroup that arrived first runs at its
+// uncontended pace and the second one on what is left (stamps: 2 150 against 3 300-5 400 cycles per iteration), finishes long after it and
+// runs its tail alone with the SIMDs mostly idle.  The two tiles therefore take turns at the higher priority, in slices of the shader
+// clock (both read the same counter): each is the favoured one half of the time and both finish together.
+#ifndef DN_RP_SLICE_BITS
+#define DN_RP_SLICE_BITS 0                // measured: no gain (profiles/r04_notes.md); kept for experiments
+#endif
+#if DN_RP_SLICE_BITS > 0
+#define RP_TAKE_TURNS() do { if ((((unsigned)(__builtin_readcyclecounter() >> DN_RP_SLICE_BITS) ^ (unsigned)second_tile) & 1u) != 0u) \
+        __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(2); } while (0)
+#else
+#define RP_TAKE_TURNS() do { } while (0)
+#endif
+#ifdef DN_MW_STAMP
+__device__ long long g_mw_edge[8][8];    // per role: cycles at entry, after barrier P, at the end of the loop, at exit; wall clock (100 MHz) at entry / exit
+#define MW_EDGE(k) do { if (lane == 0 && blockIdx.x == DN_MW_STAMP) { g_mw_edge[role][k] = (long long)__builtin_readcyclecounter(); \
+        if ((k) == 0) g_mw_edge[role][4] = (long long)wall_clock64(); if ((k) == 3) g_mw_edge[role][5] = (long long)wall_clock64(); } } while (0)
+#else
+#define MW_EDGE(k) do { } while (0)
+#endif
 template <typename R, bool NORM>
 DN_DEV void step_many_rp_body(const DnParams &p, const DnStepIO &io0, const int k_steps)
 {
     __shared__ R s_tab[DN_MAX_WAYPOINTS * DN_T_STRIDE];
-    __shared__ MailL<R> maill[3];
+    __shared__ __attribute__((aligned(16))) RMailL<R> maill[2];
     __shared__ __attribute__((aligned(16))) RMailA<R> maila[2];
     __shared__ __attribute__((aligned(16))) RMailE<R> maile[2];
     __shared__ __attribute__((aligned(16))) RMailC<R> mailc[2];
@@ -2772,61 +2844,113 @@ DN_DEV void step_many_rp_body(const DnParams &p, const DnStepIO &io0, const int 
     const DnConsts<R> &c = consts<R>(p);
     const long long n = p.n, words = (p.n + 63) / 64;
     const unsigned long long sc0 = p.st.stats[blockIdx.x].step_count;
+    const bool seg_track = p.cylinder && !p.circle;
+    MW_EDGE(0);
+    {
+        constexpr char pr[9] = DN_RP_PRIO;
+        switch (pr[role] - '0') {                                          // s_setprio takes an immediate
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        case 3: __builtin_amdgcn_s_setprio(3); break;
+        default: break;
+        }
+    }
     stage_table<R>(p, s_tab);
     // every wave passes barrier P and the barriers of iterations 0 .. k_steps (k_steps + 1 of them); iteration k_steps + 1 has none
     if (role == 0) {
-        // ---- L: the linear half of the recurrence and the rules
-        __builtin_amdgcn_s_setprio(3);
-        float4 G0 = b.g0[li], G1 = b.g1[li], G2 = b.g2[li], G3 = b.g3[li];
-        block_lds_barrier();                                               // P
+        // ---- L: the linear half of the recurrence and the flags.  State: position, velocity (float32 words), gate index, step counter,
+        // next step's found_now, the stale _current_position (quirk Q3; g6 in registers for the launch, written back only if it changed).
+        float4 G0 = b.g0[li], G2 = b.g2[li];
+        const float4 G1 = b.g1[li], G3 = b.g3[li];
+        AttCol<R> col = attitude_column<R>(G1);
+        int steps = unpack_meta(G3.w).steps, idx = unpack_meta(G3.w).idx;
+        bool found_now = (R)G0.w <= c.threshold;                           // PBDroneEnv.py:539 on the stored distance
+        float g6x = 0.0f, g6y = 0.0f, g6z = 0.0f;
+        bool g6_own = false;                                               // the registers hold _current_position (else: still in HBM)
+        block_lds_barrier(); MW_EDGE(1);                                   // P
         const R wp0[3] = {s_tab[DN_T_WP], s_tab[DN_T_WP + 1], s_tab[DN_T_WP + 2]};
         bool done_prev = false;
-        int s3 = 0;                                                        // t % 3
 #pragma clang loop unroll(disable)
         for (int t = 0; t <= k_steps; ++t) {
+            RP_TAKE_TURNS();
             if (t < k_steps) {
-                if (t > 0) {                                               // entry attitude: A's step t-1, reset by my verdict of t-1
-                    const float4 qn = maila[(t - 1) & 1].qnew[lane];
-                    G1 = done_prev ? make_float4(0.0f, 0.0f, 0.0f, 1.0f) : qn;
+                if (t > 0) {                                               // thrust direction: A's step t-1, level after my reset of t-1
+                    const RMailA<R> &ma = maila[(t - 1) & 1];
+                    const R c0 = ma.col[0][lane], c1 = ma.col[1][lane], c2 = ma.col[2][lane];
+                    col.r02 = done_prev ? R(0.0) : c0; col.r12 = done_prev ? R(0.0) : c1; col.r22 = done_prev ? R(1.0) : c2;
                 }
-                const GateRow<R> row_e = load_gate_row<R>(s_tab, unpack_meta(G3.w).idx);
+                const GateRow<R> row_e = load_gate_row<R>(s_tab, idx);
                 const R fz = tmail[t & 1].v[0][lane];
-                const Lin<R> lin = physics_linear<R>(G0, G1, G2, fz, R(0.0), R(0.0), R(0.0), false);
-                Flight<R> fl;
-                flight_entry<R>(fl, G0, G2, G3, p.max_steps);
-                fl.px = lin.px; fl.py = lin.py; fl.pz = lin.pz;
-                fl.vx = (float)lin.vx; fl.vy = (float)lin.vy; fl.vz = (float)lin.vz;
-                fl.qx = fl.qy = fl.qz = R(0.0); fl.qw = R(1.0);            // the attitude belongs to A (no ground-contact term here)
-                fl.wx = fl.wy = fl.wz = 0.0f;
-                RulesMid<R> m;
-                const Verdict<R> v = rules_verdict<R>(p, c, s_tab, row_e, fl, G3, m);
-                MailL<R> &ml = maill[s3];
-                ml.f64[0][lane] = fl.px; ml.f64[1][lane] = fl.py; ml.f64[2][lane] = fl.pz; ml.f64[3][lane] = v.d_obs;
-                ml.f32[0][lane] = make_float4(fl.vx, fl.vy, fl.vz, fl.d_e);
-                ml.f32[1][lane] = make_float4(fl.vex, fl.vey, fl.vez, fl.dprev_e);
-                ml.flags[lane] = fl.idx_e | (fl.just_found_e << 8) | (fl.truncated << 9) | (v.coll1 << 10) | (v.terminated << 11);
-                float4 S0, S1, S2, S3;
-                rules_commit<R>(c, wp0, fl, m, G0, G3, b.g6, li, active, S0, S1, S2, S3);
-                G0 = S0; G2 = S2; G3.w = S3.w;
-                done_prev = v.terminated != 0 || fl.truncated != 0;
-                s3 = s3 == 2 ? 0 : s3 + 1;
+                const Lin<R> lin = physics_linear_col<R>(G0, G2, col, fz, R(0.0), R(0.0), R(0.0), false);
+                const R px = lin.px, py = lin.py, pz = lin.pz;
+                // rules_verdict's flags (no ground-contact term in this kernel: r22 of the new attitude is not needed)
+                const bool truncated = p.max_steps <= steps;               // PBDroneEnv.py:444-454 on the un-incremented _steps
+                const bool coll1 = collision_common<R>(p, c, px, py, pz, R(1.0)) ||
+                                   (seg_track && outside_segment_corridor_row<R>(c, row_e, px, py, pz));
+                const bool last_gate = idx + 1 == p.num_waypoints;
+                const int idx_e = idx, steps_e = steps;
+                bool terminated;
+                if (coll1) terminated = true;                              // :489-490
+                else if (found_now) {
+                    idx += 1;
+                    if (last_gate) terminated = true;                      // :542-546
+                    else terminated = seg_track && outside_segment_corridor<R>(c, s_tab, px, py, pz, idx);
+                } else terminated = false;
+                // _update_state_post_step's distance, squared (Q takes the root)
+                R d2n = R(0.0);
+                if (!terminated) {
+                    steps += 1;
+                    R wx = row_e.wp[0], wy = row_e.wp[1], wz = row_e.wp[2];
+                    if (idx != idx_e) {                                    // a gate was passed this step: the next waypoint (rare)
+                        const R *wp = s_tab + idx * DN_T_STRIDE;
+                        wx = wp[0]; wy = wp[1]; wz = wp[2];
+                    }
+                    const R ex = wx - px, ey = wy - py, ez = wz - pz;
+                    d2n = FM<R>::fma(ez, ez, FM<R>::fma(ey, ey, ex * ex));
+                }
+                const bool done = terminated || truncated;
+                const float nvx = (float)lin.vx, nvy = (float)lin.vy, nvz = (float)lin.vz;
+                float4 S0 = make_float4((float)px, (float)py, (float)pz, 0.0f), S2 = make_float4(nvx, nvy, nvz, 0.0f);
+                R d2r = R(0.0);
+                if (__ballot(done) != 0ull) {                              // rules_commit's reset of the body (wave-uniform skip)
+                    if (done) {
+                        R cpx, cpy, cpz;
+                        if (!terminated) { cpx = px; cpy = py; cpz = pz; }            // post-step ran: it is the new position
+                        else if (__builtin_expect(steps_e > 0, 1)) { cpx = G0.x; cpy = G0.y; cpz = G0.z; }
+                        else if (g6_own) { cpx = g6x; cpy = g6y; cpz = g6z; }
+                        else { const float4 G6 = b.g6[li]; cpx = G6.x; cpy = G6.y; cpz = G6.z; }
+                        if (!(terminated && steps_e == 0)) { g6x = (float)cpx; g6y = (float)cpy; g6z = (float)cpz; g6_own = true; }
+                        S0 = make_float4((float)c.spawn[0], (float)c.spawn[1], (float)c.spawn[2], 0.0f);
+                        S2 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                        const R ex = cpx - wp0[0], ey = cpy - wp0[1], ez = cpz - wp0[2];
+                        d2r = FM<R>::fma(ez, ez, FM<R>::fma(ey, ey, ex * ex));     // :651, squared
+                        idx = 0; steps = 0;
+                    }
+                }
+                RMailL<R> &ml = maill[t & 1];
+                ml.f64[0][lane] = px; ml.f64[1][lane] = py; ml.f64[2][lane] = pz; ml.f64[3][lane] = d2n; ml.f64[4][lane] = d2r;
+                ml.f32[lane] = make_float4(nvx, nvy, nvz, __int_as_float(idx_e | ((int)truncated << 9) | ((int)coll1 << 10) |
+                                                                          ((int)terminated << 11) | ((int)found_now << 12)));
+                found_now = found_from_d2<R>(c, done ? d2r : d2n);
+                G0 = S0; G2 = S2;
+                done_prev = done;
             }
             MW_BARRIER();                                                  // barrier t
         }
         if (active) {
-            b.g0[li] = G0; b.g2[li] = G2;
-            reinterpret_cast<float *>(b.g3 + li)[3] = G3.w;
+            float *g0 = reinterpret_cast<float *>(b.g0 + li), *g2 = reinterpret_cast<float *>(b.g2 + li);
+            g0[0] = G0.x; g0[1] = G0.y; g0[2] = G0.z; g2[0] = G2.x; g2[1] = G2.y; g2[2] = G2.z;
+            if (g6_own) { float *g6f = reinterpret_cast<float *>(b.g6 + li); g6f[0] = g6x; g6f[1] = g6y; g6f[2] = g6z; }
         }
     } else if (role == 1) {
         // ---- A: the angular half of the recurrence
-        __builtin_amdgcn_s_setprio(3);
-        float4 G1 = b.g1[li], G3 = b.g3[li];                               // G3.xyz: angular velocity (the .w belongs to L)
-        block_lds_barrier();                                               // P
-        int s3p = 2;                                                       // (t - 1) % 3
+        float4 G1 = b.g1[li], G3 = b.g3[li];                               // G3.xyz: angular velocity (the .w belongs to Q)
+        block_lds_barrier(); MW_EDGE(1);                                   // P
 #pragma clang loop unroll(disable)
         for (int t = 0; t <= k_steps; ++t) {
+            RP_TAKE_TURNS();
             if (t > 0) {                                                   // L's verdict of step t-1: a finished drone restarts level, at rest
-                const int fb = maill[s3p].flags[lane];
+                const int fb = __float_as_int(maill[(t - 1) & 1].f32[lane].w);
                 if (((fb >> 9) | (fb >> 11)) & 1) { G1 = make_float4(0.0f, 0.0f, 0.0f, 1.0f); G3.x = G3.y = G3.z = 0.0f; }
             }
             if (t < k_steps) {
@@ -2835,13 +2959,13 @@ DN_DEV void step_many_rp_body(const DnParams &p, const DnStepIO &io0, const int 
                 RMailA<R> &ma = maila[t & 1];
                 const float4 qn = make_float4((float)ang.qx, (float)ang.qy, (float)ang.qz, (float)ang.qw);
                 const float4 wn = make_float4((float)ang.wx, (float)ang.wy, (float)ang.wz, 0.0f);
+                const AttCol<R> cn = attitude_column<R>(qn);               // what physics_linear(t + 1) reads of the state word
                 ma.q[0][lane] = ang.qx; ma.q[1][lane] = ang.qy; ma.q[2][lane] = ang.qz; ma.q[3][lane] = ang.qw;
-                ma.qnew[lane] = qn;
+                ma.col[0][lane] = cn.r02; ma.col[1][lane] = cn.r12; ma.col[2][lane] = cn.r22;
                 ma.w[lane] = wn;
                 ma.we[lane] = make_float4(G3.x, G3.y, G3.z, 0.0f);
                 G1 = qn; G3.x = wn.x; G3.y = wn.y; G3.z = wn.z;
             }
-            s3p = s3p == 2 ? 0 : s3p + 1;
             MW_BARRIER();                                                  // barrier t
         }
         if (active) {
@@ -2851,7 +2975,6 @@ DN_DEV void step_many_rp_body(const DnParams &p, const DnStepIO &io0, const int 
         }
     } else if (role == 2) {
         // ---- T: the action chain, one step ahead
-        __builtin_amdgcn_s_setprio(2);
         const float4 *act = reinterpret_cast<const float4 *>(io0.actions) + tile_base;
         float4 A = act[li];
         {
@@ -2859,9 +2982,10 @@ DN_DEV void step_many_rp_body(const DnParams &p, const DnStepIO &io0, const int 
             post_thrust<R>(tmail[0], lane, thrust_phase<NOISE>(p, gid, sc0, A));
             A = A1;
         }
-        block_lds_barrier();                                               // P: table and thrust(0) published
+        block_lds_barrier(); MW_EDGE(1);                                   // P: table and thrust(0) published
 #pragma clang loop unroll(disable)
         for (int t = 0; t <= k_steps; ++t) {
+            RP_TAKE_TURNS();
             if (t + 1 < k_steps) {                                         // thrust(t+1), for the next iteration of L and A
                 const float4 A_next = (act + (long long)(t + 2 < k_steps ? t + 2 : t + 1) * n)[li];
                 post_thrust<R>(tmail[(t + 1) & 1], lane, thrust_phase<NOISE>(p, gid, sc0 + (unsigned long long)(t + 1), A));
@@ -2871,64 +2995,92 @@ DN_DEV void step_many_rp_body(const DnParams &p, const DnStepIO &io0, const int 
         }
     } else if (role == 3) {
         // ---- E: everything that reads the new attitude, one step behind A
-        __builtin_amdgcn_s_setprio(1);
-        block_lds_barrier();                                               // P
+        block_lds_barrier(); MW_EDGE(1);                                   // P
 #pragma clang loop unroll(disable)
         for (int t = 0; t <= k_steps; ++t) {
+            RP_TAKE_TURNS();
             if (t > 0) {
                 const int u = t - 1;
                 const RMailA<R> &ma = maila[u & 1];
+                const RMailL<R> &ml = maill[u & 1];
                 Flight<R> fl;
                 fl.qx = ma.q[0][lane]; fl.qy = ma.q[1][lane]; fl.qz = ma.q[2][lane]; fl.qw = ma.q[3][lane];
                 const float4 wn = ma.w[lane];
                 fl.wx = wn.x; fl.wy = wn.y; fl.wz = wn.z;
+                fl.px = ml.f64[0][lane]; fl.py = ml.f64[1][lane]; fl.pz = ml.f64[2][lane];
+                const int fb = __float_as_int(ml.f32[lane].w);
+                fl.idx_e = fb & 0xFF;
                 attitude_phase<R>(fl);
                 float o[DN_OBS_DIM];
                 observe_columns_att<R>(fl, o);
+                const int ori = reward_orientation<R>(p, s_tab, fl, ((fb >> 12) & 1) != 0, fl.idx_e + 1 == p.num_waypoints);
                 RMailE<R> &me = maile[u & 1];
-                me.fw[0][lane] = fl.fwx; me.fw[1][lane] = fl.fwy; me.fw[2][lane] = fl.fwz;
                 me.oa[lane] = make_float4(o[3], o[4], o[5], o[9]);
-                me.ob[lane] = make_float2(o[10], o[11]);
+                me.ob[lane] = make_float4(o[10], o[11], __int_as_float(ori), 0.0f);
             }
             MW_BARRIER();                                                  // barrier t
         }
     } else if (role == 4) {
-        // ---- Q: the columns and reward terms that read the linear state and the entry state, one step behind L
-        __builtin_amdgcn_s_setprio(1);
+        // ---- Q: the distance bookkeeping and everything that reads it, one step behind L.  State: d, d_prev (float32 words), just_found,
+        // copies of the gate index / step counter (for the meta word), the entry velocity, prev_vel / prev_ang_v.
         float4 P4 = b.g4[li], P5 = b.g5[li];                               // .xyz: prev_vel, prev_ang_v
-        block_lds_barrier();                                               // P
-        int s3p = 2;                                                       // (t - 1) % 3
+        const float4 G0 = b.g0[li], G2 = b.g2[li], G3 = b.g3[li];
+        float d = G0.w, dprev = G2.w, vex = G2.x, vey = G2.y, vez = G2.z;
+        int steps = unpack_meta(G3.w).steps, idx = unpack_meta(G3.w).idx, jf = unpack_meta(G3.w).just_found;
+        block_lds_barrier(); MW_EDGE(1);                                   // P
 #pragma clang loop unroll(disable)
         for (int t = 0; t <= k_steps; ++t) {
+            RP_TAKE_TURNS();
             if (t > 0) {
                 const int u = t - 1;
-                const MailL<R> &ml = maill[s3p];
+                const RMailL<R> &ml = maill[u & 1];
                 Flight<R> fl;
                 fl.px = ml.f64[0][lane]; fl.py = ml.f64[1][lane]; fl.pz = ml.f64[2][lane];
-                const float4 a0 = ml.f32[0][lane], a1 = ml.f32[1][lane];
-                fl.vx = a0.x; fl.vy = a0.y; fl.vz = a0.z; fl.d_e = a0.w;
-                fl.vex = a1.x; fl.vey = a1.y; fl.vez = a1.z; fl.dprev_e = a1.w;
-                const int fb = ml.flags[lane];
-                fl.idx_e = fb & 0xFF; fl.just_found_e = (fb >> 8) & 1; fl.truncated = (fb >> 9) & 1;
-                const bool terminated = ((fb >> 11) & 1) != 0;
+                const R d2n = ml.f64[3][lane], d2r = ml.f64[4][lane];
+                const float4 a0 = ml.f32[lane];
+                const int fb = __float_as_int(a0.w);
+                fl.vx = a0.x; fl.vy = a0.y; fl.vz = a0.z;
+                fl.d_e = d; fl.dprev_e = dprev; fl.just_found_e = jf;
+                fl.vex = vex; fl.vey = vey; fl.vez = vez;
+                fl.idx_e = fb & 0xFF; fl.truncated = (fb >> 9) & 1;
+                const bool coll1 = ((fb >> 10) & 1) != 0, terminated = ((fb >> 11) & 1) != 0, found_now = ((fb >> 12) & 1) != 0;
+                const bool done = terminated || fl.truncated != 0;
                 const float4 we = maila[u & 1].we[lane];
                 fl.aex = we.x; fl.aey = we.y; fl.aez = we.z;
                 float o[DN_OBS_DIM];
                 observe_columns_lin<R>(p, c, fl, o);
                 const RewardPre<R> pre = reward_entry<R>(p, c, fl, P4, P5);
+                // rules_verdict / rules_commit's distance bookkeeping (the roots of L's squared distances)
+                const bool last_gate = fl.idx_e + 1 == p.num_waypoints;
+                R d_post = (R)d;                                           // Verdict.d_obs: what the reset observation shows (quirk Q2)
+                if (!terminated) { d_post = FM<R>::sqrt0(d2n); steps += 1; }
+                if (!coll1) {
+                    dprev = d;
+                    if (found_now) { idx += 1; if (!last_gate) jf = 1; } else jf = 0;
+                }
+                d = (float)d_post;
+                if (__ballot(done) != 0ull) {
+                    if (done) {
+                        d = (float)FM<R>::sqrt0(d2r);                      // :651
+                        dprev = d;                                         // :652
+                        idx = 0; steps = 0; jf = 0;
+                    }
+                }
                 RMailC<R> &mc = mailc[u & 1];
-                mc.r[0][lane] = pre.r0; mc.r[1][lane] = pre.s_lin; mc.r[2][lane] = pre.s_ang;
+                mc.r[0][lane] = pre.r0; mc.r[1][lane] = pre.s_lin; mc.r[2][lane] = pre.s_ang; mc.r[3][lane] = d_post;
                 mc.oa[lane] = make_float4(o[0], o[1], o[2], o[6]);
-                mc.ob[lane] = make_float4(o[7], o[8], o[12], __int_as_float((int)pre.pen_lin | ((int)pre.pen_ang << 1)));
+                mc.ob[lane] = make_float4(o[7], o[8], o[12], __int_as_float(fb | ((int)pre.pen_lin << 16) | ((int)pre.pen_ang << 17)));
                 // prev_vel / prev_ang_v: _update_state_post_step (skipped on a terminated step, quirk Q5), zero after a reset
                 if (!terminated) { P4 = make_float4(fl.vex, fl.vey, fl.vez, 0.0f); P5 = make_float4(fl.aex, fl.aey, fl.aez, 0.0f); }
-                if (terminated || fl.truncated) P4 = P5 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (done) P4 = P5 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                vex = done ? 0.0f : fl.vx; vey = done ? 0.0f : fl.vy; vez = done ? 0.0f : fl.vz;      // the next step's entry velocity
             }
-            s3p = s3p == 2 ? 0 : s3p + 1;
             MW_BARRIER();                                                  // barrier t
         }
         if (active) {
+            float *g0 = reinterpret_cast<float *>(b.g0 + li), *g2 = reinterpret_cast<float *>(b.g2 + li), *g3 = reinterpret_cast<float *>(b.g3 + li);
             float *g4 = reinterpret_cast<float *>(b.g4 + li), *g5 = reinterpret_cast<float *>(b.g5 + li);
+            g0[3] = d; g2[3] = dprev; g3[3] = pack_meta(steps, idx, jf);
             g4[0] = P4.x; g4[1] = P4.y; g4[2] = P4.z; g5[0] = P5.x; g5[1] = P5.y; g5[2] = P5.z;
         }
     } else if (role == 5) {
@@ -2937,44 +3089,40 @@ DN_DEV void step_many_rp_body(const DnParams &p, const DnStepIO &io0, const int 
         StatAcc acc;
         Rms rms;                                                           // never touched here
         RewNorm rn = {0.0, 0.0, 1.0, 1e-4};
-        block_lds_barrier();                                               // P
-        int s3q = 1;                                                       // (t - 2) % 3
+        block_lds_barrier(); MW_EDGE(1);                                   // P
 #pragma clang loop unroll(disable)
         for (int t = 0; t <= k_steps + 1; ++t) {
+            RP_TAKE_TURNS();
             if (t > 1) {
                 const int u = t - 2;
-                const MailL<R> &ml = maill[s3q];
                 const RMailE<R> &me = maile[u & 1];
                 const RMailC<R> &mc = mailc[u & 1];
                 Flight<R> fl;
                 Verdict<R> v;
-                fl.px = ml.f64[0][lane]; fl.py = ml.f64[1][lane]; fl.pz = ml.f64[2][lane]; v.d_obs = ml.f64[3][lane];
-                fl.d_e = ml.f32[0][lane].w;
-                const int fb = ml.flags[lane];
-                fl.idx_e = fb & 0xFF; fl.just_found_e = (fb >> 8) & 1; fl.truncated = (fb >> 9) & 1;
-                v.coll1 = (fb >> 10) & 1; v.terminated = (fb >> 11) & 1;
-                fl.fwx = me.fw[0][lane]; fl.fwy = me.fw[1][lane]; fl.fwz = me.fw[2][lane];
-                const float4 cb = mc.ob[lane];
+                const float4 cb = mc.ob[lane], eb = me.ob[lane];
+                const int fb = __float_as_int(cb.w);
+                fl.idx_e = fb & 0xFF; fl.truncated = (fb >> 9) & 1;
+                v.coll1 = (fb >> 10) & 1; v.terminated = (fb >> 11) & 1; v.d_obs = R(0.0);
+                const bool found_now = ((fb >> 12) & 1) != 0;
+                // report_scalars re-forms found_now from the entry distance: hand it one that decides the same way
+                fl.d_e = found_now ? 0.0f : FLT_MAX;
                 RewardPre<R> pre;
                 pre.r0 = mc.r[0][lane]; pre.s_lin = mc.r[1][lane]; pre.s_ang = mc.r[2][lane];
-                const int pb = __float_as_int(cb.w);
-                pre.pen_lin = (pb & 1) != 0; pre.pen_ang = (pb & 2) != 0;
-                pre.found_now = (R)fl.d_e <= c.threshold;                  // as reward_entry forms them
+                pre.pen_lin = ((fb >> 16) & 1) != 0; pre.pen_ang = ((fb >> 17) & 1) != 0;
+                pre.found_now = found_now;
                 pre.last_gate = fl.idx_e + 1 == p.num_waypoints;
                 R r_normal;
                 float r_found32;
-                reward_pose<R>(p, s_tab, fl, pre, r_normal, r_found32);
+                reward_assemble<R>(pre, __float_as_int(eb.z), r_normal, r_found32);
                 fl.vex = fl.vey = fl.vez = fl.aex = fl.aey = fl.aez = 0.0f;    // prev_vel / prev_ang_v live on Q
                 const StepOut out = block_out(io0, tile_base, (long long)u * n, (long long)u * words);
                 report_scalars<R, false>(p, c, out, fl, v, r_normal, r_found32, li, lane, active, G4, G5, acc, rn);
                 if (!NORM) {
                     const float4 ea = me.oa[lane], ca = mc.oa[lane];
-                    const float2 eb = me.ob[lane];
                     float o[DN_OBS_DIM] = {ca.x, ca.y, ca.z, ea.x, ea.y, ea.z, ca.w, cb.x, cb.y, ea.w, eb.x, eb.y, cb.z};
-                    report_obs_cols<R, false, 0, DN_OBS_DIM>(p, c, out, v.terminated != 0 || fl.truncated != 0, v.d_obs, o, li, active, rms);
+                    report_obs_cols<R, false, 0, DN_OBS_DIM>(p, c, out, v.terminated != 0 || fl.truncated != 0, mc.r[3][lane], o, li, active, rms);
                 }
             }
-            s3q = s3q == 2 ? 0 : s3q + 1;
             if (t <= k_steps) MW_BARRIER();                                // barrier t
         }
         flush_stats(p, acc, sc0 + (unsigned long long)k_steps, lane);
@@ -2986,22 +3134,20 @@ DN_DEV void step_many_rp_body(const DnParams &p, const DnStepIO &io0, const int 
         // ---- N1: columns 0..6 of step t - 2 through the normaliser and out
         Rms rms;
         load_rms_cols<0, 7>(p, tile_base, li, rms);
-        block_lds_barrier();                                               // P
-        int s3q = 1;
+        block_lds_barrier(); MW_EDGE(1);                                   // P
 #pragma clang loop unroll(disable)
         for (int t = 0; t <= k_steps + 1; ++t) {
+            RP_TAKE_TURNS();
             if (t > 1) {
                 const int u = t - 2;
-                const MailL<R> &ml = maill[s3q];
-                const int fb = ml.flags[lane];
-                const R d_obs = ml.f64[3][lane];
-                const float4 ea = maile[u & 1].oa[lane], ca = mailc[u & 1].oa[lane];
+                const RMailC<R> &mc = mailc[u & 1];
+                const int fb = __float_as_int(mc.ob[lane].w);
+                const float4 ea = maile[u & 1].oa[lane], ca = mc.oa[lane];
                 float o[DN_OBS_DIM] = {ca.x, ca.y, ca.z, ea.x, ea.y, ea.z, ca.w, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
                 normalize_obs_cols<0, 7>(rms, o);                          // the step observation (= terminal_observation)
                 const StepOut out = block_out(io0, tile_base, (long long)u * n, (long long)u * words);
-                report_obs_cols<R, true, 0, 7>(p, c, out, (((fb >> 9) | (fb >> 11)) & 1) != 0, d_obs, o, li, active, rms);
+                report_obs_cols<R, true, 0, 7>(p, c, out, (((fb >> 9) | (fb >> 11)) & 1) != 0, R(0.0), o, li, active, rms);
             }
-            s3q = s3q == 2 ? 0 : s3q + 1;
             if (t <= k_steps) MW_BARRIER();                                // barrier t
         }
         if (active) store_rms_cols<0, 7, true>(p, tile_base, li, rms);
@@ -3009,27 +3155,27 @@ DN_DEV void step_many_rp_body(const DnParams &p, const DnStepIO &io0, const int 
         // ---- N2: columns 7..12
         Rms rms;
         load_rms_cols<7, DN_OBS_DIM>(p, tile_base, li, rms);
-        block_lds_barrier();                                               // P
-        int s3q = 1;
+        block_lds_barrier(); MW_EDGE(1);                                   // P
 #pragma clang loop unroll(disable)
         for (int t = 0; t <= k_steps + 1; ++t) {
+            RP_TAKE_TURNS();
             if (t > 1) {
                 const int u = t - 2;
-                const MailL<R> &ml = maill[s3q];
-                const int fb = ml.flags[lane];
-                const R d_obs = ml.f64[3][lane];
-                const float4 ea = maile[u & 1].oa[lane], cb = mailc[u & 1].ob[lane];
-                const float2 eb = maile[u & 1].ob[lane];
+                const RMailC<R> &mc = mailc[u & 1];
+                const float4 cb = mc.ob[lane];
+                const int fb = __float_as_int(cb.w);
+                const R d_obs = mc.r[3][lane];
+                const float4 ea = maile[u & 1].oa[lane], eb = maile[u & 1].ob[lane];
                 float o[DN_OBS_DIM] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, cb.x, cb.y, ea.w, eb.x, eb.y, cb.z};
                 normalize_obs_cols<7, DN_OBS_DIM>(rms, o);
                 const StepOut out = block_out(io0, tile_base, (long long)u * n, (long long)u * words);
                 report_obs_cols<R, true, 7, DN_OBS_DIM>(p, c, out, (((fb >> 9) | (fb >> 11)) & 1) != 0, d_obs, o, li, active, rms);
             }
-            s3q = s3q == 2 ? 0 : s3q + 1;
             if (t <= k_steps) MW_BARRIER();                                // barrier t
         }
         if (active) store_rms_cols<7, DN_OBS_DIM, false>(p, tile_base, li, rms);
     }
+    MW_EDGE(3);
 }
 
 // sixteen waves of two tiles on four SIMDs: four waves a SIMD, 128 registers a wave
@@ -3583,6 +3729,11 @@ hipError_t dn_launch_step_many_mw(const DnParams &p, const DnStepIO &io, int k, 
     return hipGetLastError();
 }
 #ifdef DN_MW_STAMP
+extern "C" int dn_debug_mw_edges(long long *out)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mw_edge), sizeof(long long) * 64) == hipSuccess ? 0 : 1;
+}
 extern "C" int dn_debug_mw_stamps(long long *out)
 {
     if (hipDeviceSynchronize() != hipSuccess) return 1;

@@ -45,4 +45,15 @@ print("release skew between roles (cycles, mean over iterations):", (rel[ok].max
 arr = v[:NR, :, 0][ok]
 last = arr.argmax(axis=0)
 print("last role to arrive, histogram:", {names[int(np.flatnonzero(ok)[k])]: int((last == k).sum()) for k in range(ok.sum())})
+if hasattr(raw, "dn_debug_mw_edges"):
+    eb = (C.c_longlong * 64)()
+    assert raw.dn_debug_mw_edges(eb) == 0
+    e = np.array(list(eb), dtype=np.int64).reshape(8, 8)
+    print(f"last launch, per role: cycles entry -> barrier P -> exit, and the role's wall time in the kernel (100 MHz counter)")
+    for r in range(NR):
+        if e[r, 0] == 0:
+            continue
+        print(f"  role {r} {names[r]}: prologue {e[r, 1] - e[r, 0]:6d}  loop+epilogue {e[r, 3] - e[r, 1]:7d}  wall {(e[r, 5] - e[r, 4]) * 10} ns")
+    w0, w1 = e[:NR, 4][e[:NR, 4] > 0].min(), e[:NR, 5].max()
+    print(f"  tile wall time in the kernel {(w1 - w0) * 10} ns for {K} steps = {(w1 - w0) * 10 / K / 1000:.3f} us per step; eager launch-to-launch above")
 env.close()
