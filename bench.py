@@ -53,6 +53,10 @@ def algo_bytes_per_launch(n, steps_per_launch, norm):
 
 def kernel_name(waves, dtype, norm, fused):
     r, nm = ("double" if dtype == "float64" else "float"), ("true" if norm else "false")
+    if waves == 8 and fused:
+        return f"dn_step_many_rp8_kernel<{r}>"
+    if waves == 6 and fused:
+        return f"dn_step_many_rp6_kernel<{r}>"
     if waves == 5 and fused:
         return f"dn_step_many_5w_kernel<{r}, false>"
     if waves == 4 and fused:
@@ -82,6 +86,15 @@ def traffic_per_launch(track, n, dtype, norm, fused_steps, waves):
         if model:
             return int(n * (model["per_step"] * fused_steps + model["per_launch"])), f"model:{base} ({model['per_step']} B x K + {model['per_launch']} B per drone, fitted to {model['fitted_on']})"
     return None, f"no PMC pass for {key}"
+
+
+def issue_evidence(kernel):
+    """The committed instruction-mix counters of the kernel that was actually timed (profiles/instmix.json), or None."""
+    try:
+        ev = json.load(open(os.path.join(ROOT, "profiles", "instmix.json"))).get(kernel)
+    except Exception:  # noqa: BLE001
+        return None
+    return dict(ev, kernel=kernel) if ev else None
 
 
 def parse():
@@ -200,6 +213,7 @@ def mlp_kernel_leg(torch, dev, name, fn, n, macs_mfma, macs, nets, passes):
     mfma_flop = 2.0 * macs_mfma * n * nets * passes
     return {"kernel": name, "avg_us": round(us, 2), "mfma_flop": mfma_flop, "useful_flop": 2.0 * macs * n * nets,
             "mfma_tflops": round(mfma_flop / (us * 1e-6) / 1e12, 1), "mfma_frac": round(mfma_flop / (us * 1e-6) / MFMA_PEAK_FLOPS, 4),
+            "useful_tflops": round(2.0 * macs * n * nets / (us * 1e-6) / 1e12, 1),
             "passes": passes, "what": "200 launches of this kernel alone replayed from one hipGraph between two HIP events; mfma_frac = MFMA flop issued "
                                       "(padded tiles; x3 for the split-bf16 float32 grade) / time / 2.5 PFLOP/s dense peak"}
 
@@ -281,15 +295,17 @@ def ppo_rollout(pkg, track, n, max_steps, dev, rank):
         env.close()
     except Exception as exc:  # noqa: BLE001
         kernels["error"] = f"{type(exc).__name__}: {exc}"
-    return {"value": round(res["fused_graph"], 1), "unit": "env-steps/s", "kernels": kernels,
-            "policy": "fused MFMA MLP (dn_mlp_forward, bf16 weights/activations, float32 accumulate) + dn_step_sampled "
+    return {"value": round(res["fused_graph_fp32"], 1), "unit": "env-steps/s", "kernels": kernels,
+            "policy": "the reference's float32 networks (PBDroneSimulator.py:251-286) as fused MFMA MLPs at float32 grade (dn_mlp_forward grade 1: "
+                      "split-bf16 operands, three MFMAs per product; <= 1e-4 on the action mean against the float32 torch network) + dn_step_sampled "
                       "(Gaussian sample + step): two launches per step, the truncation bootstrap as one masked critic pass per rollout, hipGraph replay",
+            "value_bf16_grade": round(res["fused_graph"], 1),
+            "policy_bf16_grade": "the same loop with bf16 weights / activations, float32 accumulate (narrower arithmetic than the reference's networks: "
+                                 "~9e-3 on the action mean): a named variant, never `value`",
             "value_fp16_grade": round(res["fused_graph_fp16"], 1),
             "policy_fp16_grade": "the same loop with float16 weights and activations (dn_mlp_forward grade 2): the bf16 grade's speed at an eighth "
-                                 "of its rounding error (~1e-3 on the action mean against the float32 torch network; bf16: ~9e-3)",
+                                 "of its rounding error (~1e-3 on the action mean against the float32 torch network)",
             "value_fp32_grade": round(res["fused_graph_fp32"], 1),
-            "policy_fp32_grade": "the same loop with the networks at the reference's float32 precision (dn_mlp_forward grade 1: split-bf16 "
-                                 "operands, three MFMAs per product; <= 1e-4 on the action mean against the float32 torch network)",
             "variants": {"torch fp32 eager": round(res["eager"], 1), "torch fp32 hipGraph": round(res["graph"], 1),
                          "torch bf16 trunks hipGraph": round(res["graph_bf16"], 1),
                          "fused MFMA policy, torch glue, eager": round(res["eager_mfma"], 1),
@@ -434,6 +450,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
+        # one line per rank on stderr BEFORE the first collective: a mis-launched scaling run (N ranks on one device, a rank that sees
+        # fewer devices than WORLD_SIZE) is then diagnosable from the driver's tail even if the rendezvous hangs
+        print(f"bench.py: rank {rank}/{world} local_rank {local_rank} -> cuda:{local_rank} of {torch.cuda.device_count()} visible device(s), "
+              f"rccl_world_size {world}, MASTER {os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}", file=sys.stderr, flush=True)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import drl_dronenavigation_amd as pkg
@@ -639,35 +659,51 @@ def main():
 
     # where HBM IS the bound: the same step kernel over a fleet that fills the chip many times over (one wave per 64 drones,
     # 32768 workgroups), one control step per launch -- the regime the byte model of SURVEY 8(d) describes
-    large = None
+    def hbm_bound_leg(norm_l):
+        nl = 2097152
+        env_l = pkg.DroneVecEnv(track, nl, max_steps=max_steps, normalize_obs=norm_l, compute_dtype=args.compute_dtype, device=dev)
+        env_l.reset_tensor()
+        gl = torch.Generator(device="cpu").manual_seed(7)
+        acts_l = (torch.rand((2, nl, 4), generator=gl, dtype=torch.float32) * 2 - 1).to(dev)
+        for t in range(20):
+            env_l.step_tensor(acts_l[t & 1])
+        e0_, e1_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(dev)
+        e0_.record(stream)
+        reps_l = 200
+        for t in range(reps_l):
+            env_l.step_tensor(acts_l[t & 1])
+        e1_.record(stream)
+        torch.cuda.synchronize(dev)
+        us_l = e0_.elapsed_time(e1_) * 1e3 / reps_l
+        bytes_l = (ALGO_BYTES_PER_ENV_STEP + (ALGO_BYTES_NORMALISER if norm_l else 0)) * nl
+        wv_l = env_l.kernel_waves(fused=False)
+        traffic_l, src_l = traffic_per_launch(args.track, nl, args.compute_dtype, norm_l, 0, wv_l)
+        d = {"num_envs": nl, "kernel": kernel_name(wv_l, args.compute_dtype, norm_l, False),
+             "us_per_vector_step": round(us_l, 3), "value": round(nl / (us_l * 1e-6), 1), "unit": "env-steps/s",
+             "algorithmic_bytes_per_launch": bytes_l, "achieved_GBps": round(bytes_l / (us_l * 1e-6) / 1e9, 1),
+             "frac": round(bytes_l / (us_l * 1e-6) / 1e9 / HBM_PEAK_GBPS, 5),
+             "traffic": traffic_l, "traffic_source": src_l,
+             "traffic_ratio": (round(traffic_l / bytes_l, 4) if traffic_l else None),
+             "what": ("2 097 152 drones, one control step per launch, per-drone NormalizeObservation ON as the reference runs it "
+                      "(PBDroneSimulator.py:181): 288 + 432 = 720 B per drone-step, the regime in which the step IS bandwidth bound"
+                      if norm_l else
+                      "2 097 152 drones, one control step per launch, normaliser off (288 B per drone-step; the reference never runs it this way)")}
+        env_l.close()
+        del acts_l
+        return d
+
+    large = large_norm = None
     if world == 1 and not args.profile_lite:
-        try:
-            nl = 2097152
-            env_l = pkg.DroneVecEnv(track, nl, max_steps=max_steps, normalize_obs=False, compute_dtype=args.compute_dtype, device=dev)
-            env_l.reset_tensor()
-            gl = torch.Generator(device="cpu").manual_seed(7)
-            acts_l = (torch.rand((2, nl, 4), generator=gl, dtype=torch.float32) * 2 - 1).to(dev)
-            for t in range(20):
-                env_l.step_tensor(acts_l[t & 1])
-            e0_, e1_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            torch.cuda.synchronize(dev)
-            e0_.record(stream)
-            reps_l = 200
-            for t in range(reps_l):
-                env_l.step_tensor(acts_l[t & 1])
-            e1_.record(stream)
-            torch.cuda.synchronize(dev)
-            us_l = e0_.elapsed_time(e1_) * 1e3 / reps_l
-            bytes_l = ALGO_BYTES_PER_ENV_STEP * nl
-            large = {"num_envs": nl, "kernel": kernel_name(env_l.kernel_waves(fused=False), args.compute_dtype, False, False),
-                     "us_per_vector_step": round(us_l, 3), "value": round(nl / (us_l * 1e-6), 1), "unit": "env-steps/s",
-                     "algorithmic_bytes_per_launch": bytes_l, "achieved_GBps": round(bytes_l / (us_l * 1e-6) / 1e9, 1),
-                     "frac": round(bytes_l / (us_l * 1e-6) / 1e9 / HBM_PEAK_GBPS, 5),
-                     "what": "2 097 152 drones, one control step per launch: the fleet size at which the step IS bandwidth bound"}
-            env_l.close()
-            del acts_l
-        except Exception as exc:  # noqa: BLE001
-            large = {"error": f"{type(exc).__name__}: {exc}"}
+        for norm_l in (True, False):
+            try:
+                d_l = hbm_bound_leg(norm_l)
+            except Exception as exc:  # noqa: BLE001
+                d_l = {"error": f"{type(exc).__name__}: {exc}"}
+            if norm_l:
+                large_norm = d_l
+            else:
+                large = d_l
 
     # a measured stream-copy ceiling of THIS box beside the nominal 8 TB/s (a device-to-device copy of 1 GiB: read + write)
     copy_ceiling = None
@@ -675,18 +711,27 @@ def main():
         try:
             src = torch.empty(1 << 28, dtype=torch.float32, device=dev).fill_(1.0)
             dst = torch.empty_like(src)
-            for _ in range(3):
-                dst.copy_(src)
-            e0_, e1_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            torch.cuda.synchronize(dev)
-            e0_.record(stream)
-            for _ in range(20):
-                dst.copy_(src)
-            e1_.record(stream)
-            torch.cuda.synchronize(dev)
-            gbps = 2.0 * src.numel() * 4 * 20 / (e0_.elapsed_time(e1_) * 1e-3) / 1e9
+
+            def time_copy(fn):
+                for _ in range(3):
+                    fn()
+                e0_, e1_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize(dev)
+                e0_.record(stream)
+                for _ in range(20):
+                    fn()
+                e1_.record(stream)
+                torch.cuda.synchronize(dev)
+                return 2.0 * src.numel() * 4 * 20 / (e0_.elapsed_time(e1_) * 1e-3) / 1e9
+            gbps = time_copy(lambda: pkg.stream_copy(dst, src))
+            gbps_torch = time_copy(lambda: dst.copy_(src))
             copy_ceiling = {"GBps": round(gbps, 1), "frac_of_nominal": round(gbps / HBM_PEAK_GBPS, 4),
-                            "what": "torch device-to-device copy of 1 GiB float32 (1 GiB read + 1 GiB written per copy), 20 copies between two HIP events"}
+                            "what": "dn_stream_copy: hand-written float4 copy kernel (one 16-byte load + store per lane, one lane per 16 bytes: the fastest of "
+                                    "the forms swept in profiles/r04_copy_sweep.txt) over 1 GiB float32 -- 1 GiB read + 1 GiB written per copy, 20 copies "
+                                    "between two HIP events",
+                            "torch_copy_GBps": round(gbps_torch, 1),
+                            "guide_float4_copy_GBps": 6290,
+                            "guide_source": "/opt/skills/guides/MI355X_MICROARCH.md (float4 copy, 6.29 TB/s)"}
             del src, dst
         except Exception as exc:  # noqa: BLE001
             copy_ceiling = {"error": f"{type(exc).__name__}: {exc}"}
@@ -745,18 +790,14 @@ def main():
                                                      + (f" + {ALGO_BYTES_NORMALISER} B statistics" if args.normalize_obs else "")
                                                      + " per drone and launch (SURVEY 8(d) split into per-step I/O and per-launch state)"),
                          "avg_launch_us": round(launch_us, 4), "us_per_vector_step": round(step_us, 4),
-                         "note": "at 32768 drones neither launch shape is bandwidth bound: the fused launch runs at the pace of the wave (role) with the most "
-                                 "instructions per step -- a wave issues one instruction per ~7.5 cycles however idle its SIMD is (profiles/r03_valu_rates.txt) -- "
-                                 "which is why the step is cut into four / five role waves per 64 drones; the single-step launch is bound by load + launch "
-                                 "latency (DESIGN.md 4, profiles/r03_pqx_stamps.txt)",
-                         "issue_bound_evidence": {"source": "profiles/r02_f_instmix_4w.txt (rocprofv3 --pmc SQ_* passes of the four-wave kernel; recipe profiles/instmix.sh)",
-                                                  "valu_instructions_per_64_drone_step": 813, "salu_instructions_per_64_drone_step": 192,
-                                                  "simd_issue_busy": 0.95,
-                                                  "what": "four-wave kernel, normaliser off, two 64-drone tiles (eight waves) per CU: SQ_ACTIVE_INST_ANY covers 95 % of the "
-                                                          "step time (quad-cycle granularity); the same step at 2 097 152 drones, one step per launch, is the HBM-bound "
-                                                          "case (hbm_bound_fleet)"}},
+                         "note": "at 32768 drones neither launch shape is bandwidth bound: with two tiles per CU the fused launch is bound by the vector ALUs "
+                                 "(float64 instructions occupy a SIMD's ALU 4 cycles each; ~1 100 vector instructions per tile-step: issue_bound_evidence, "
+                                 "profiles/r04_notes.md), with one tile per CU by the role with the longest instruction stream; the single-step launch is "
+                                 "bound by load + launch latency (DESIGN.md 4, profiles/r03_pqx_stamps.txt)",
+                         "issue_bound_evidence": issue_evidence(kernel_name(wv, args.compute_dtype, args.normalize_obs, args.mode == "many"))},
             "single_step": single_step,
             ("normalize_obs_on" if other_norm else "normalize_obs_off"): norm_leg,
+            "hbm_bound_fleet_norm": large_norm,
             "hbm_bound_fleet": large,
             "hbm_copy_ceiling": copy_ceiling,
             "other_launch_shapes": others,

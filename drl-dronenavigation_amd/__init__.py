@@ -11,13 +11,13 @@ from ._capi import DroneNavError, DroneNavLibraryError  # noqa: F401
 from .tracks import Track  # noqa: F401
 
 __all__ = ["DroneVecEnv", "Track", "tracks", "gae", "DroneNavError", "DroneNavLibraryError", "make_config",
-           "RolloutCollector", "ShardPlan", "all_gather_rollout", "preprocess_action", "MlpActorCritic", "SacActor", "FusedSacActor"]
+           "RolloutCollector", "ShardPlan", "all_gather_rollout", "preprocess_action", "stream_copy", "MlpActorCritic", "SacActor", "FusedSacActor"]
 
 
 def __getattr__(name):
     # vec_env imports torch; keep `import drl_dronenavigation_amd` light for tools that only build.
     import importlib
-    if name in ("DroneVecEnv", "gae", "make_config", "vec_env", "preprocess_action"):
+    if name in ("DroneVecEnv", "gae", "make_config", "vec_env", "preprocess_action", "stream_copy"):
         vec_env = importlib.import_module(__name__ + ".vec_env")
         return vec_env if name == "vec_env" else getattr(vec_env, name)
     if name in ("collector", "RolloutCollector", "ShardPlan", "all_gather_rollout", "ReplayBuffer", "RingReplayBuffer", "OffPolicyCollector",

@@ -11,7 +11,7 @@ from . import build as _build
 MAX_WAYPOINTS = 64
 OBS_DIM = 13
 ACT_DIM = 4
-ABI_VERSION = 6
+ABI_VERSION = 7
 GROUND_CONTACT_AUTO = 2
 
 DN_OK = 0
@@ -84,6 +84,7 @@ PROTOTYPES = {
     "dn_step_many": (_I32, [_VP, _I64] + [_VP] * 11),
     "dn_eval_kinematics": (_I32, [_VP] * 11),
     "dn_compact_done": (_I32, [_VP, _I64, _VP, _VP, _I32, _VP]),
+    "dn_stream_copy": (_I32, [_VP, _VP, _I64, _I32, _VP]),
     "dn_get_state": (_I32, [_VP, _VP, _I64]),
     "dn_set_state": (_I32, [_VP, _VP, _I64]),
     "dn_get_stats": (_I32, [_VP, C.POINTER(DnStats), _VP]),

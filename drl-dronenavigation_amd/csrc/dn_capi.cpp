@@ -176,6 +176,10 @@ int32_t validate(const dn_config *c)
 bool ground_contact_reachable(const dn_config &c)
 {
     if (!c.cylinder) return true;                                      // no corridor: nothing else keeps a drone off the floor
+    // random_spawn: segment 0 then starts at this episode's drawn spawn point (rules_commit / dn_reset_kernel), which may sit up to 0.1
+    // below the lowest waypoint -- the bound below, on the fixed spawn, does not cover it.  The option is dormant in the reference
+    // (PBDroneEnv.py:622-627); keep the term, as the reference does.
+    if (c.random_spawn) return true;
     const double z_contact = DN_CONTACT_MARGIN + std::sqrt(0.25 * DN_COLL_H * DN_COLL_H + DN_COLL_R * DN_COLL_R);
     double z_min;                                                       // lowest z inside any corridor
     if (c.circle) z_min = 1.0 - c.threshold;                            // torus around the unit circle at z = 1 (:723-741)
@@ -582,6 +586,18 @@ int32_t dn_mlp_step_sampled(dn_env *env, const dn_mlp_net *nets, int32_t num_net
             return fail(DN_ERR_INVALID_ARGUMENT, "net %d: packed weights must be 16-byte aligned", k);
     }
     if (nets[0].out_dim != DN_ACT_DIM) return fail(DN_ERR_INVALID_ARGUMENT, "nets[0] must be the actor (out_dim 4)");
+    {   // one launch: the critic's workgroups and later actor workgroups still READ policy_obs while earlier actor tails already WRITE obs
+        // and the networks' outputs -- overlapping buffers would be a silent data race, so they are refused
+        const long long nn = c.num_envs;
+        const uintptr_t pb = (uintptr_t)policy_obs, pe = pb + (uintptr_t)nn * obs_dim * sizeof(float);
+        const uintptr_t ob = (uintptr_t)obs, oe = ob + (uintptr_t)nn * DN_OBS_DIM * sizeof(float);
+        if (pb < oe && ob < pe) return fail(DN_ERR_INVALID_ARGUMENT, "policy_obs must not overlap obs (the launch reads one while it writes the other)");
+        for (int k = 0; k < num_nets; ++k) {
+            const uintptr_t nb = (uintptr_t)nets[k].out, ne = nb + (uintptr_t)nn * nets[k].out_dim * sizeof(float);
+            if ((nb < pe && pb < ne) || (nb < oe && ob < ne))
+                return fail(DN_ERR_INVALID_ARGUMENT, "net %d: out must not overlap policy_obs or obs", k);
+        }
+    }
     // the tail is the three-wave single step: the plain configuration dn_step_sampled covers, without noise and without the
     // ground-contact term, on fleets for which dn_create picked that shape; whole workgroups of the policy kernel only
     if (c.clip_rew || c.norm_rew || c.physics != 0 || c.action_type != 0 || c.random_spawn || c.zero_damping || c.ground_contact ||
@@ -655,6 +671,17 @@ int32_t dn_compact_done(const uint64_t *done_mask, int64_t num_envs, int32_t *in
         return fail(DN_ERR_INVALID_ARGUMENT, "done_mask, indices, count are required and num_envs >= 1");
     DN_HIP(hipSetDevice(device_id));
     DN_HIP(dn_launch_compact((const unsigned long long *)done_mask, num_envs, indices, count, (hipStream_t)stream));
+    return DN_OK;
+}
+
+int32_t dn_stream_copy(void *dst, const void *src, int64_t bytes, int32_t device_id, void *stream)
+{
+    if (!dst || !src || bytes < 16 || (bytes & 15) || ((uintptr_t)dst & 15) || ((uintptr_t)src & 15))
+        return fail(DN_ERR_INVALID_ARGUMENT, "dst, src: 16-byte aligned device pointers; bytes: a positive multiple of 16");
+    DN_HIP(hipSetDevice(device_id));
+    int cus = 256;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) != hipSuccess || cus < 1) cus = 256;
+    DN_HIP(dn_launch_stream_copy(dst, src, bytes / 16, cus, (hipStream_t)stream));
     return DN_OK;
 }
 

@@ -134,6 +134,7 @@ hipError_t dn_launch_mlp(const dn_mlp_net *nets, int num_nets, const float *obs,
                          hipStream_t stream);
 hipError_t dn_launch_mlp_step(const DnParams &p, const DnStepIO &io, const dn_mlp_net *nets, int num_nets, const float *obs, int obs_dim,
                               hipStream_t stream);                                                                             // dn_fused.hip
+hipError_t dn_launch_stream_copy(void *dst, const void *src, long long n16, int num_cus, hipStream_t stream);
 hipError_t dn_launch_compact(const unsigned long long *mask, long long n, int32_t *indices, int32_t *count,
                              hipStream_t stream);
 

@@ -3613,6 +3613,16 @@ __global__ __launch_bounds__(256) void dn_fill4_kernel(float4 *dst, float4 v, lo
 {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) dst[i] = v;
 }
+// The copy ceiling of the box (dn_stream_copy): ONE 16-byte load and one 16-byte store per lane, no loop -- the form that measured
+// fastest on MI355X (profiles/r04_copy_sweep.txt: 6 237 GB/s read + write over 1 GiB, against 4 100-5 200 for grid-stride loops of
+// 4-64 workgroups per CU with or without non-temporal hints, 5 300-5 750 for a contiguous chunk per workgroup, 4 689 for hipMemcpyAsync
+// and ~5 500 for torch's copy_): the dispatcher streams workgroups onto CUs as they drain, and every wave has exactly one load in flight.
+typedef float dn_v4f __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void dn_stream_copy_kernel(const float4 *__restrict__ src4, float4 *__restrict__ dst4, long long n16)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) reinterpret_cast<dn_v4f *>(dst4)[i] = reinterpret_cast<const dn_v4f *>(src4)[i];
+}
 __global__ __launch_bounds__(256) void dn_filld_kernel(double *dst, double v, long long n)
 {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) dst[i] = v;
@@ -3626,6 +3636,17 @@ hipError_t dn_launch_fill4(float4 *dst, float4 v, long long n, hipStream_t strea
     if (n <= 0) return hipSuccess;
     const unsigned grid = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
     hipLaunchKernelGGL(dn_fill4_kernel, dim3(grid), dim3(256), 0, stream, dst, v, n);
+    return hipGetLastError();
+}
+
+hipError_t dn_launch_stream_copy(void *dst, const void *src, long long n16, int num_cus, hipStream_t stream)
+{
+    (void)num_cus;
+    const long long per = 256ll * 0x40000000ll;                  // grid.x <= 2^30 workgroups per launch
+    for (long long off = 0; off < n16; off += per) {
+        const long long m = n16 - off < per ? n16 - off : per;
+        hipLaunchKernelGGL(dn_stream_copy_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, stream, (const float4 *)src + off, (float4 *)dst + off, m);
+    }
     return hipGetLastError();
 }
 

@@ -567,6 +567,19 @@ def preprocess_action(actions, normalize_actions=True):
     return rpm, forces, zt
 
 
+def stream_copy(dst, src):
+    """dn_stream_copy: the hand-written float4 copy kernel bench.py quotes as the HBM copy ceiling of the box.  `dst`, `src`:
+    contiguous CUDA tensors of the same byte size (a multiple of 16)."""
+    dev = src.device
+    nbytes = src.numel() * src.element_size()
+    if dev.type != "cuda" or dst.device != dev or dst.numel() * dst.element_size() != nbytes or not (src.is_contiguous() and dst.is_contiguous()):
+        raise ValueError("stream_copy: two contiguous CUDA tensors of the same byte size on one device")
+    with torch.cuda.device(dev):
+        _capi.check(_capi.load().dn_stream_copy(dst.data_ptr(), src.data_ptr(), nbytes, dev.index,
+                                                C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    return dst
+
+
 def gae(rewards, values, dones, last_values, last_dones, gamma=0.99, gae_lambda=0.95):
     """Generalised advantage estimation on the GPU (dn_gae).  Tensors laid out [n_steps, n_envs];
     `dones[t]` is the episode-start flag of step t (cleanRLPPO.py:207-248)."""

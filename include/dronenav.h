@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define DN_ABI_VERSION 6
+#define DN_ABI_VERSION 7
 #define DN_MAX_WAYPOINTS 64
 #define DN_OBS_DIM 13      /* 12 kinematic + distance, PBDroneEnv._computeObs, PBDroneEnv.py:296-336 */
 #define DN_ACT_DIM 4       /* four rotor thrust commands, PBDroneEnv._actionSpace, PBDroneEnv.py:225-243 */
@@ -207,6 +207,12 @@ int32_t dn_eval_kinematics(dn_env *env, const double *kinematics, float *obs, fl
  * without scanning N flags).  indices: device int32[N]; count: device int32[1]. */
 int32_t dn_compact_done(const uint64_t *done_mask, int64_t num_envs, int32_t *indices, int32_t *count,
                         int32_t device_id, void *stream);
+
+/* Measurement helper ("a measured stream-copy ceiling on the box"): a hand-written float4 copy of `bytes` bytes
+ * (a multiple of 16, both pointers 16-byte aligned, device memory) -- one 16-byte load and one 16-byte store per lane, one lane per
+ * 16 bytes (the form that measured fastest: profiles/r04_copy_sweep.txt) -- enqueued on `stream`.  What bench.py quotes as `hbm_copy_ceiling` beside the
+ * nominal 8 TB/s; it replaces no reference code. */
+int32_t dn_stream_copy(void *dst, const void *src, int64_t bytes, int32_t device_id, void *stream);
 
 /* Host <-> device copies of the whole persistent state (synchronous).  states: host array [N]. */
 int32_t dn_get_state(dn_env *env, dn_env_state *states, int64_t count);

@@ -10,13 +10,20 @@ OUT="$ROOT/gpurun_out/instmix_$TAG"
 mkdir -p "$OUT"
 cd /tmp
 i=0
+FAILED=""
 for pair in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU" "SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS" "SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
             "SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_LDS SQ_INSTS_BRANCH" "SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64" "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_CVT" \
             "SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_TRANS_F32"; do
     i=$((i+1))
-    rocprofv3 --kernel-trace --pmc $pair -d "$OUT/p$i" -o p$i -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-ppo-rollout --profile-lite "$@" > "$OUT/bench_p$i.log" 2>&1 || true
+    rocprofv3 --kernel-trace --pmc $pair -d "$OUT/p$i" -o p$i -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-ppo-rollout --profile-lite "$@" > "$OUT/bench_p$i.log" 2>&1 || FAILED="$FAILED p$i($pair)"
 done
 cd "$ROOT"
 python3 profiles/instmix.py "$OUT" > "$ROOT/gpurun_out/instmix_$TAG.txt"
-rm -rf "$OUT"          # the raw databases exceed what gpurun copies back (TAG is non-empty: set -u / the usage check above)
+if [ -n "$FAILED" ]; then
+    echo "# FAILED passes (logs kept under gpurun_out/instmix_$TAG/): $FAILED -- this summary is incomplete" >> "$ROOT/gpurun_out/instmix_$TAG.txt"
+    find "$OUT" -name "*.db" -delete
+else
+    rm -rf "$OUT"      # the raw databases exceed what gpurun copies back (TAG is non-empty: set -u / the usage check above)
+fi
 cat "$ROOT/gpurun_out/instmix_$TAG.txt"
+[ -z "$FAILED" ] || exit 1

@@ -16,9 +16,10 @@ rm -rf "$OUT"; mkdir -p "$OUT"
 SCRIPT="$1"; shift
 cd /tmp
 i=0
+FAILED=""
 for grp in "${GROUPS_[@]}"; do
     i=$((i+1))
-    rocprofv3 --kernel-trace --pmc $grp -d "$OUT/p$i" -o p$i -- python3 "$ROOT/$SCRIPT" "$@" > "$OUT/run_p$i.log" 2>&1 || true
+    rocprofv3 --kernel-trace --pmc $grp -d "$OUT/p$i" -o p$i -- python3 "$ROOT/$SCRIPT" "$@" > "$OUT/run_p$i.log" 2>&1 || FAILED="$FAILED p$i($grp)"
 done
 cd "$ROOT"
 python3 - "$OUT" > "$ROOT/gpurun_out/pmc_$TAG.txt" <<'PY'
@@ -39,5 +40,11 @@ for k in sorted({k for k, _ in rows}):
         if kk == k:
             print(f"  {c:32s} {avg:18.1f} per dispatch   (x{n})")
 PY
-rm -rf "$OUT"
+if [ -n "$FAILED" ]; then
+    echo "# FAILED passes (logs kept under gpurun_out/pmc_$TAG/): $FAILED -- this summary is incomplete" >> "$ROOT/gpurun_out/pmc_$TAG.txt"
+    find "$OUT" -name "*.db" -delete
+else
+    rm -rf "$OUT"
+fi
 cat "$ROOT/gpurun_out/pmc_$TAG.txt"
+[ -z "$FAILED" ] || exit 1

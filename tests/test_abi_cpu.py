@@ -67,7 +67,7 @@ int main(void) {
     assert got == [C.sizeof(K.DnConfig), C.sizeof(K.DnEnvState), C.sizeof(K.DnStats), C.sizeof(K.DnMlpNet),
                    K.DnConfig.random_spawn.offset, K.DnConfig.seed.offset, K.DnEnvState.pid.offset,
                    K.DnEnvState.rms_mean.offset, K.ABI_VERSION], got
-    assert pkg._capi.load().dn_abi_version() == pkg._capi.ABI_VERSION == 6
+    assert pkg._capi.load().dn_abi_version() == pkg._capi.ABI_VERSION == 7
 
 
 def test_config_defaults_follow_the_driver(pkg):
@@ -97,6 +97,8 @@ def test_ground_contact_auto_is_on_wherever_the_term_can_fire(pkg):
         assert resolved(tracks.REGISTRY[name]()) == 0, name
     for name in ("up", "half_up_forward", "up_circle", "up_sharp_back_turn"):
         assert resolved(tracks.REGISTRY[name]()) == 1, name
+    # random_spawn: segment 0 starts at a drawn point up to 0.1 below the lowest waypoint, which the fixed-spawn bound does not cover
+    assert resolved(tracks.reaching(), random_spawn=True) == 1
     assert resolved(tracks.reaching(), cylinder=False) == 1             # no corridor: nothing else keeps a drone off the floor
     assert resolved(tracks.circle(1, 4, 1), threshold=0.95) == 1        # a torus fat enough to reach the floor
     assert resolved(tracks.reaching(), ground_contact=True) == 1 and resolved(tracks.up(), ground_contact=False) == 0
@@ -115,6 +117,15 @@ def test_ground_contact_auto_is_on_wherever_the_term_can_fire(pkg):
     cfg = make_config(num_envs=8, target_points=t.targets(), initial_xyzs=t.initial_xyzs, aviary_dim=t.aviary_dim)
     cfg.ground_contact = 3
     assert lib.dn_resolve_ground_contact(C.byref(cfg)) == -1
+
+
+def test_stream_copy_refuses_what_it_cannot_copy(pkg):
+    """dn_stream_copy (the hand-written copy ceiling of bench.py) validates before it touches the device."""
+    lib = pkg._capi.load()
+    assert lib.dn_stream_copy(None, None, 1024, 0, None) == -1
+    assert lib.dn_stream_copy(C.c_void_p(4096), C.c_void_p(8192), 1000, 0, None) == -1      # not a multiple of 16
+    assert lib.dn_stream_copy(C.c_void_p(4100), C.c_void_p(8192), 1024, 0, None) == -1      # misaligned
+    assert b"16" in lib.dn_last_error()
 
 
 def test_sparse_info_dicts_answer_the_reference_callbacks():

@@ -400,6 +400,25 @@ def test_fused_policy_step_refuses_what_it_is_not_built_for():
         assert rc == -1, (n, kw)
         col.collect()                                         # ... and the collector quietly takes the two-launch path
         env.close()
+    # aliasing buffers (an in-place observation buffer as DroneVecEnv keeps): the one launch reads policy_obs while it writes obs
+    n = 256
+    env = pkg.DroneVecEnv(tracks.reaching(), n, device=dev)
+    pol = pkg.FusedMlpPolicy(net, n, dev)
+    z = lambda *s, dt=torch.float32: torch.zeros(s, dtype=dt, device=dev)          # noqa: E731
+    both, mean, val = z(n, 13), z(n, 4), z(n, 1)
+
+    def call(policy_obs, obs, nets):
+        return lib.dn_mlp_step_sampled(env._handle, C.cast(nets, C.c_void_p), 2, policy_obs.data_ptr(), 13, (C.c_float * 4)(0, 0, 0, 0), 1, 0,
+                                       z(n, 4).data_ptr(), z(n).data_ptr(), obs.data_ptr(), z(n).data_ptr(), z(n, dt=torch.uint8).data_ptr(),
+                                       z(n, dt=torch.uint8).data_ptr(), z(n, dt=torch.int32).data_ptr(), None, None, None, None, None)
+    ok_nets = (_capi.DnMlpNet * 2)(_net_struct(pol.pi, mean), _net_struct(pol.vf, val))
+    assert call(both, both, ok_nets) == -1 and b"overlap" in lib.dn_last_error()
+    bad_nets = (_capi.DnMlpNet * 2)(_net_struct(pol.pi, mean), _net_struct(pol.vf, val))
+    bad_nets[0].out = both.data_ptr()                         # the actor's output inside the observation buffer
+    assert call(z(n, 13), both, bad_nets) == -1 and b"overlap" in lib.dn_last_error()
+    assert call(z(n, 13), z(n, 13), ok_nets) == 0             # distinct buffers: accepted
+    torch.cuda.synchronize()
+    env.close()
 
 
 @pytest.mark.parametrize("norm", [False, True])
