@@ -84,6 +84,7 @@ PROTOTYPES = {
     "dn_step_many": (_I32, [_VP, _I64] + [_VP] * 11),
     "dn_eval_kinematics": (_I32, [_VP] * 11),
     "dn_compact_done": (_I32, [_VP, _I64, _VP, _VP, _I32, _VP]),
+    "dn_pack_done": (_I32, [_VP, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I32, _VP]),
     "dn_stream_copy": (_I32, [_VP, _VP, _I64, _I32, _VP]),
     "dn_get_state": (_I32, [_VP, _VP, _I64]),
     "dn_set_state": (_I32, [_VP, _VP, _I64]),

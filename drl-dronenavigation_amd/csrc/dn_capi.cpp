@@ -674,6 +674,18 @@ int32_t dn_compact_done(const uint64_t *done_mask, int64_t num_envs, int32_t *in
     return DN_OK;
 }
 
+int32_t dn_pack_done(const uint64_t *done_mask, int64_t num_envs, const float *terminal_obs, const float *ep_return, const int32_t *ep_length,
+                     const uint8_t *truncated, const int32_t *found_targets, int32_t *indices, int32_t *count, float *packed,
+                     int32_t device_id, void *stream)
+{
+    if (!done_mask || !terminal_obs || !ep_return || !ep_length || !truncated || !found_targets || !indices || !count || !packed || num_envs < 1)
+        return fail(DN_ERR_INVALID_ARGUMENT, "every pointer is required and num_envs >= 1");
+    DN_HIP(hipSetDevice(device_id));
+    DN_HIP(dn_launch_compact_pack((const unsigned long long *)done_mask, num_envs, terminal_obs, ep_return, ep_length, truncated, found_targets,
+                                  indices, count, packed, (hipStream_t)stream));
+    return DN_OK;
+}
+
 int32_t dn_stream_copy(void *dst, const void *src, int64_t bytes, int32_t device_id, void *stream)
 {
     if (!dst || !src || bytes < 16 || (bytes & 15) || ((uintptr_t)dst & 15) || ((uintptr_t)src & 15))

@@ -134,6 +134,9 @@ hipError_t dn_launch_mlp(const dn_mlp_net *nets, int num_nets, const float *obs,
                          hipStream_t stream);
 hipError_t dn_launch_mlp_step(const DnParams &p, const DnStepIO &io, const dn_mlp_net *nets, int num_nets, const float *obs, int obs_dim,
                               hipStream_t stream);                                                                             // dn_fused.hip
+hipError_t dn_launch_compact_pack(const unsigned long long *mask, long long n, const float *terminal_obs, const float *ep_return,
+                                  const int32_t *ep_length, const uint8_t *truncated, const int32_t *found, int32_t *indices, int32_t *count,
+                                  float *packed, hipStream_t stream);
 hipError_t dn_launch_stream_copy(void *dst, const void *src, long long n16, int num_cus, hipStream_t stream);
 hipError_t dn_launch_compact(const unsigned long long *mask, long long n, int32_t *indices, int32_t *count,
                              hipStream_t stream);

@@ -3527,6 +3527,55 @@ __global__ __launch_bounds__(1024) void dn_compact_kernel(const unsigned long lo
     if (threadIdx.x == 1023 && blockIdx.x == gridDim.x - 1) *count = base + incl;
 }
 
+// dn_pack_done: the compaction above with, next to every index, the episode-end record of that drone as ONE 64-byte row --
+// terminal_observation (13), Monitor return, Monitor length (int bits), TimeLimit.truncated | found_targets << 8 (int bits) -- so that
+// the NumPy step() brings the few finished drones' records to the host in one short copy instead of four whole per-drone arrays.
+__global__ __launch_bounds__(1024) void dn_compact_pack_kernel(const unsigned long long *__restrict__ mask, long long n,
+                                                               const float *__restrict__ terminal_obs, const float *__restrict__ ep_return,
+                                                               const int32_t *__restrict__ ep_length, const uint8_t *__restrict__ truncated,
+                                                               const int32_t *__restrict__ found, int32_t *__restrict__ indices,
+                                                               int32_t *__restrict__ count, float *__restrict__ packed)
+{
+    __shared__ int s_wave[16], s_before[16];
+    const long long words = (n + 63) / 64;
+    const long long w_base = (long long)blockIdx.x * 1024;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int before = 0;
+    for (long long w = threadIdx.x; w < w_base; w += 1024) before += __popcll(mask[w]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) before += __shfl_xor(before, off);
+    const long long w = w_base + threadIdx.x;
+    unsigned long long mword = w < words ? mask[w] : 0ull;
+    const int mine = __popcll(mword);
+    int incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        int v = __shfl_up(incl, off);
+        if (lane >= off) incl += v;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    if (lane == 0) s_before[wave] = before;
+    __syncthreads();
+    int base = 0;
+    for (int k = 0; k < 16; ++k) base += s_before[k];
+    for (int k = 0; k < wave; ++k) base += s_wave[k];
+    int pos = base + incl - mine;
+    while (mword) {
+        const int b = __ffsll((long long)mword) - 1;
+        const long long i = w * 64 + b;
+        indices[pos] = (int32_t)i;
+        float *row = packed + (long long)pos * 16;
+#pragma unroll
+        for (int k = 0; k < DN_OBS_DIM; ++k) row[k] = terminal_obs[i * DN_OBS_DIM + k];
+        row[13] = ep_return[i];
+        row[14] = __int_as_float(ep_length[i]);
+        row[15] = __int_as_float((int)truncated[i] | (found[i] << 8));
+        ++pos;
+        mword &= mword - 1;
+    }
+    if (threadIdx.x == 1023 && blockIdx.x == gridDim.x - 1) *count = base + incl;
+}
+
 // A1-A3 on their own (dn_preprocess_action): N x PBDroneEnv._preprocessAction + the force/torque lines of
 // BaseAviary._physics, so the float32 chain can be checked bit for bit against the reference's golden vectors.
 __global__ __launch_bounds__(256) void dn_action_chain_kernel(const float4 *__restrict__ actions, long long n, int normalize_actions,
@@ -3912,6 +3961,15 @@ hipError_t dn_launch_compact(const unsigned long long *mask, long long n, int32_
 {
     const unsigned blocks = (unsigned)(((n + 63) / 64 + 1023) / 1024);
     hipLaunchKernelGGL(dn_compact_kernel, dim3(blocks), dim3(1024), 0, stream, mask, n, indices, count);
+    return hipGetLastError();
+}
+hipError_t dn_launch_compact_pack(const unsigned long long *mask, long long n, const float *terminal_obs, const float *ep_return,
+                                  const int32_t *ep_length, const uint8_t *truncated, const int32_t *found, int32_t *indices, int32_t *count,
+                                  float *packed, hipStream_t stream)
+{
+    const unsigned blocks = (unsigned)(((n + 63) / 64 + 1023) / 1024);
+    hipLaunchKernelGGL(dn_compact_pack_kernel, dim3(blocks), dim3(1024), 0, stream, mask, n, terminal_obs, ep_return, ep_length, truncated, found,
+                       indices, count, packed);
     return hipGetLastError();
 }
 #ifdef DN_PQX_STAMP

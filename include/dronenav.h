@@ -208,6 +208,15 @@ int32_t dn_eval_kinematics(dn_env *env, const double *kinematics, float *obs, fl
 int32_t dn_compact_done(const uint64_t *done_mask, int64_t num_envs, int32_t *indices, int32_t *count,
                         int32_t device_id, void *stream);
 
+/* dn_compact_done plus, for every finished drone in index order, its episode-end record as one row of 16 float32 words:
+ * terminal_observation[13] (SubprocVecEnv's info["terminal_observation"]), Monitor's episode return, its length (int32 bits) and
+ * TimeLimit.truncated | found_targets << 8 (int32 bits) -- what SubprocVecEnv's worker puts into `info` when an episode ends
+ * (PBDroneSimulator.py:653-666 with Monitor, :196).  The host copies count x 64 bytes instead of four whole per-drone arrays.
+ * Inputs: the buffers the last dn_step wrote.  indices: device int32[N]; count: device int32[1]; packed: device float[N x 16]. */
+int32_t dn_pack_done(const uint64_t *done_mask, int64_t num_envs, const float *terminal_obs, const float *ep_return, const int32_t *ep_length,
+                     const uint8_t *truncated, const int32_t *found_targets, int32_t *indices, int32_t *count, float *packed,
+                     int32_t device_id, void *stream);
+
 /* Measurement helper ("a measured stream-copy ceiling on the box"): a hand-written float4 copy of `bytes` bytes
  * (a multiple of 16, both pointers 16-byte aligned, device memory) -- one 16-byte load and one 16-byte store per lane, one lane per
  * 16 bytes (the form that measured fastest: profiles/r04_copy_sweep.txt) -- enqueued on `stream`.  What bench.py quotes as `hbm_copy_ceiling` beside the

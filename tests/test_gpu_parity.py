@@ -472,6 +472,39 @@ def test_sparse_info_mode_matches_full():
     full.close(); sparse.close()
 
 
+def test_step_with_reused_host_buffers_and_a_mass_finish():
+    """fresh_arrays=False hands out views of two alternating pinned mirrors: the arrays of step t must still hold step t's values after
+    step t + 1 returned (SB3 reads `_last_obs` once more then), and equal what the default (fresh copies) returns.  max_steps is
+    small, so the time limit ends every drone's episode in the same step: more finished drones than the first host copy carries
+    packed records for (dn_pack_done's second copy)."""
+    pkg = _gpu()
+    track = _tracks().reaching()
+    n = 5000                                              # the first copy carries 312 records
+    fresh = pkg.DroneVecEnv(track, n, device="cuda:0", max_steps=9)
+    reuse = pkg.DroneVecEnv(track, n, device="cuda:0", max_steps=9, fresh_arrays=False)
+    assert fresh._pack_prefix < n and np.array_equal(fresh.reset(), reuse.reset())
+    rng = np.random.default_rng(3)
+    held = None
+    mass = 0
+    for t in range(40):
+        a = (0.0922 + 0.002 * rng.standard_normal((n, 4))).astype(np.float32)      # hover: nobody crashes before the time limit
+        of, rf, df, inf_f = fresh.step(a)
+        orr, rr, dr, inf_r = reuse.step(a)
+        assert np.array_equal(of, orr) and np.array_equal(rf, rr) and np.array_equal(df, dr)
+        if held is not None:                              # step t - 1's arrays, untouched by this step
+            assert np.array_equal(held[0], held[1]) and np.array_equal(held[2], held[3])
+        held = (orr, of.copy(), rr, rf.copy())
+        k = int(df.sum())
+        mass = max(mass, k)
+        for i in np.flatnonzero(df):
+            assert inf_r[i]["episode"] == {**inf_f[i]["episode"], "t": inf_r[i]["episode"]["t"]}
+            assert inf_r[i]["TimeLimit.truncated"] == inf_f[i]["TimeLimit.truncated"] and inf_r[i]["found_targets"] == inf_f[i]["found_targets"]
+            assert np.array_equal(inf_r[i]["terminal_observation"], inf_f[i]["terminal_observation"])
+        assert np.array_equal(reuse.done_indices(), np.flatnonzero(df))
+    assert mass > fresh._pack_prefix                      # the second copy ran
+    fresh.close(); reuse.close()
+
+
 def test_full_size_properties():
     """BASELINE size (32768 drones, race track): size-independent properties -- determinism, unit
     quaternions, reset rows, the done ballot words vs the byte flags vs the compacted index list, and the
