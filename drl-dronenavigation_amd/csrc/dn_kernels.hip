@@ -199,7 +199,7 @@ DN_DEV void philox4x32(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsig
     }
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
-// Box-Muller on one pair of Philox words, float64 throughout, every operation spelled out (no libm call: the device
+// The EXACT form (draws that feed the dynamics: action noise, the policies' sampling, random spawn): Box-Muller on one pair of Philox words, float64 throughout, every operation spelled out (no libm call: the device
 // library's log / sin / cos carry argument-reduction paths for inputs that cannot occur here and cost ~300 instructions
 // a pair; this is ~80).  u = (r + 0.5) / 2^32 lies strictly inside (0, 1).
 //   ln u1:  u1 = m 2^e, m in [sqrt(1/2), sqrt(2)),  ln m = 2 atanh(s) = 2 s (1 + s^2/3 + ... + s^14/15),  s = (m-1)/(m+1),
@@ -207,7 +207,7 @@ DN_DEV void philox4x32(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsig
 //   angle:  2 pi u2 = k pi/2 + theta, k = rint(4 u2), theta = 2 pi (u2 - k/4) in [-pi/4, pi/4] (the subtraction is
 //           exact), sin / cos Taylor to theta^13 / theta^14 (2e-14), quadrant fix-up by k.
 // Equal to the libm form (log, sqrt, cos, sin of the C library) to ~1e-13 before the float32 cast.
-DN_DEV void box_muller_pair(unsigned ra, unsigned rb, float &z0, float &z1)
+DN_DEV void box_muller_pair64(unsigned ra, unsigned rb, float &z0, float &z1)
 {
     const double u1 = ((double)ra + 0.5) * (1.0 / 4294967296.0);
     const double u2 = ((double)rb + 0.5) * (1.0 / 4294967296.0);
@@ -260,15 +260,42 @@ DN_DEV void box_muller_pair(unsigned ra, unsigned rb, float &z0, float &z1)
     z0 = (float)(rad * cosv);
     z1 = (float)(rad * sinv);
 }
+// The FLOAT32 form (observation noise: 13 of the 17 draws of a config-5 step, 26 when an episode ends): the same Box-Muller on the
+// hardware transcendentals, ~25 instructions a pair instead of ~80.  Observation noise is added to a float32 output and feeds nothing
+// back inside the environment, so an error of 1e-6 in z is 1e-8 in the observation; the draws that DO feed the dynamics keep the exact
+// form above, because the action chain rounds in float32 and the near-cancelling rotor torques of a hovering drone turn a last-bit
+// difference in one thrust into 1e-4 in the unit angular-velocity columns (seen when the action noise was tried in this form).
+// Care is taken where float32 would lose the draw:
+//   ln u1:  for u1 < 1/2 the float32 value of u1 carries it to 2^-24 relative; for u1 >= 1/2 it does not (u1 -> 1 rounds to 1 and the
+//           radius to 0), so the COMPLEMENT w = 1 - u1 = (~word + 0.5) / 2^32 is formed from the integer (exact to 2^-24 relative)
+//           and -ln(1 - w) taken as w (1 + w/2 + w^2/3) below w = 2^-9 (next term: 2e-9 relative) and as -ln2 log2(1 - w) above;
+//   angle:  v_sin_f32 / v_cos_f32 take their argument in revolutions, i.e. u2 itself: no 2 pi product to round.
+// Against the float64 libm form of the oracle (orc_noise4) the draws differ by at most a few 1e-7 absolute (measured over 1.3e8 draws:
+// tests/test_gpu_parity.py::test_observation_noise_draws_match_their_definition); sigma z enters the state at sigma <= 1e-2.
+DN_DEV void box_muller_pair32(unsigned ra, unsigned rb, float &z0, float &z1)
+{
+    const bool upper = ra >= 0x80000000u;
+    const float u1 = __builtin_fmaf((float)ra, 2.3283064365386963e-10f, 1.1641532182693481e-10f);          // (ra + 0.5) 2^-32
+    const float w = __builtin_fmaf((float)(~ra), 2.3283064365386963e-10f, 1.1641532182693481e-10f);        // 1 - u1, exact to 2^-24 relative
+    const float arg = upper ? 1.0f - w : u1;
+    float L = -0.69314718055994530942f * __builtin_amdgcn_logf(arg);                                          // -ln(arg); v_log_f32 = log2
+    const float series = w * __builtin_fmaf(w, __builtin_fmaf(w, 0.33333333333333333f, 0.5f), 1.0f);
+    L = (upper && w < 0.001953125f) ? series : L;
+    const float rad = __builtin_amdgcn_sqrtf(L + L);
+    const float u2 = __builtin_fmaf((float)rb, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
+    z0 = rad * __builtin_amdgcn_cosf(u2);                                                                    // cos(2 pi u2)
+    z1 = rad * __builtin_amdgcn_sinf(u2);
+}
 // Philox counter = (drone id lo, drone id hi, vector step lo, stream | vector step hi << 8): the 64-bit vector-step counter
 // enters whole, so the streams do not repeat when its low word wraps (2^32 vector steps = hours of fused stepping);
 // stream ids are below 256.
+template <bool EXACT = true>
 DN_DEV void noise4(unsigned long long seed, unsigned long long gid, unsigned long long step, unsigned stream, float z[4])
 {
     unsigned r[4];
     philox4x32((unsigned)gid, (unsigned)(gid >> 32), (unsigned)step, stream | ((unsigned)(step >> 32) << 8), (unsigned)seed, (unsigned)(seed >> 32), r);
-    box_muller_pair(r[0], r[1], z[0], z[1]);
-    box_muller_pair(r[2], r[3], z[2], z[3]);
+    if (EXACT) { box_muller_pair64(r[0], r[1], z[0], z[1]); box_muller_pair64(r[2], r[3], z[2], z[3]); }
+    else { box_muller_pair32(r[0], r[1], z[0], z[1]); box_muller_pair32(r[2], r[3], z[2], z[3]); }
 }
 DN_DEV void add_act_noise(const DnParams &p, unsigned long long gid, unsigned long long step, float a[4])
 {   // float32, unfused (its own function: the fused-multiply-add licence of step_body must not reach it)
@@ -294,7 +321,7 @@ DN_DEV void add_obs_noise(const DnParams &p, unsigned long long gid, unsigned lo
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
         float z[4];
-        noise4(p.seed, gid, step, stream0 + (unsigned)b, z);
+        noise4<false>(p.seed, gid, step, stream0 + (unsigned)b, z);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             if (4 * b + j < DN_OBS_DIM) {
@@ -326,7 +353,7 @@ DN_DEV void draw_obs_noise_across(const DnParams &p, const unsigned long long gi
         philox4x32((unsigned)gid, (unsigned)(gid >> 32), (unsigned)step, (stream0 + (pr >> 1)) | ((unsigned)(step >> 32) << 8), (unsigned)p.seed,
                    (unsigned)(p.seed >> 32), r);
         float z0, z1;
-        box_muller_pair((pr & 1u) ? r[2] : r[0], (pr & 1u) ? r[3] : r[1], z0, z1);
+        box_muller_pair32((pr & 1u) ? r[2] : r[0], (pr & 1u) ? r[3] : r[1], z0, z1);
         if (work) {
             scratch[(2u * pr) * DN_BLOCK + d] = z0;
             scratch[(2u * pr + 1u) * DN_BLOCK + d] = z1;
@@ -3311,8 +3338,8 @@ DN_DEV void pqx_step(const DnParams &p, const DnStepIO &io0, PqxShared<R> &sh, c
             // and B3 -- where the observation exists -- their seven Box-Muller pairs were ~1.7 us of the tile's critical path; here
             // P (columns 8..12) and Q (columns 0..7) draw them while X draws the action's and computes the thrust.
             float z[4], z4[4];
-            noise4(p.seed, gid, sc0, 3u, z);
-            noise4(p.seed, gid, sc0, 4u, z4);
+            noise4<false>(p.seed, gid, sc0, 3u, z);
+            noise4<false>(p.seed, gid, sc0, 4u, z4);
 #pragma unroll
             for (int j = 0; j < 4; ++j) sh.zmail[j][lane] = z[j];
             sh.zmail[4][lane] = z4[0];
@@ -3352,7 +3379,7 @@ DN_DEV void pqx_step(const DnParams &p, const DnStepIO &io0, PqxShared<R> &sh, c
         Rms rms;
         if (NORM) load_rms(p, i, rms);
         float zn[DN_OBS_DIM];
-        if (obs_noise) { noise4(p.seed, gid, sc0, 1u, zn); noise4(p.seed, gid, sc0, 2u, zn + 4); }    // columns 0..7 (see P)
+        if (obs_noise) { noise4<false>(p.seed, gid, sc0, 1u, zn); noise4<false>(p.seed, gid, sc0, 2u, zn + 4); }    // columns 0..7 (see P)
         PQX_MARK(1); block_lds_barrier(); PQX_MARK(2);                    // B1
         const R tx = tmail.v[1][lane], ty = tmail.v[2][lane], zt = tmail.v[3][lane];
         const Ang<R> ang = physics_angular<R>(G1, G3, tx, ty, zt);

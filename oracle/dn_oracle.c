@@ -837,6 +837,12 @@ void orc_noise4(uint64_t seed, uint64_t env_id, uint64_t step, uint32_t stream, 
     }
 }
 
+/* The same for n consecutive drones (tests: the device draws against this definition over millions of draws). */
+void orc_noise4_many(uint64_t seed, uint64_t env_id0, int64_t n, uint64_t step, uint32_t stream, float *out)
+{
+    for (int64_t i = 0; i < n; ++i) orc_noise4(seed, env_id0 + (uint64_t)i, step, stream, out + 4 * i);
+}
+
 static void add_obs_noise(const orc_config *c, uint64_t env_id, uint64_t step, uint32_t stream0, float obs[ORC_OBS_DIM])
 {
     if (!(c->obs_noise_sigma > 0.0f)) return;

@@ -195,6 +195,7 @@ void orc_gae(const float *rewards, const float *values, const uint8_t *dones,
 void orc_philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                     uint32_t k0, uint32_t k1, uint32_t out[4]);
 void orc_noise4(uint64_t seed, uint64_t env_id, uint64_t step, uint32_t stream, float out[4]);
+void orc_noise4_many(uint64_t seed, uint64_t env_id0, int64_t n, uint64_t step, uint32_t stream, float *out);   /* [n][4] */
 
 int32_t orc_sizeof_env(void);
 int32_t orc_sizeof_config(void);

@@ -144,6 +144,8 @@ def lib():
     L.orc_gae.argtypes = [C.c_void_p] * 5 + [C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
     L.orc_philox4x32.argtypes = [C.c_uint32] * 6 + [C.POINTER(C.c_uint32)]
     L.orc_noise4.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, fp]
+    L.orc_noise4_many.argtypes = [C.c_uint64, C.c_uint64, C.c_int64, C.c_uint64, C.c_uint32, fp]
+    L.orc_noise4_many.restype = None
     for name in ("orc_sizeof_env", "orc_sizeof_config", "orc_max_threads"):
         getattr(L, name).restype = C.c_int32
     assert L.orc_sizeof_env() == C.sizeof(OrcEnv) == ENV_DTYPE.itemsize, \
