@@ -346,8 +346,9 @@ int32_t dn_create(const dn_config *cfg, dn_env **out)
     const bool rp_ok = plain && !cfg->ground_contact && !noisy;
     if (rp_ok && cfg->normalize_obs && (e->blocks <= e->num_cus || (e->blocks > 2 * e->num_cus && e->blocks <= DN_ROLE_PIPE_TILES_PER_CU * e->num_cus)))
         e->waves_fused = 8;
-    // dn_step (one control step per launch) is latency bound: ~2.9 us of launch-to-launch floor that an empty kernel
-    // already pays (profiles/r02_dispatch_floor.txt) plus the dependent instruction stream of the step.  Cutting the step
+    // dn_step (one control step per launch) is latency bound: 1.65 us of kernel boundary that an empty kernel already pays
+    // (profiles/r03_dispatch_floor.txt; the 2.9 us of round 2 was the host's eager launch cadence), a ~1.2 us memory round trip
+    // with nothing to overlap it, plus the dependent instruction stream of the step.  Cutting the step
     // by dependency over three waves (dn_step_pqx_kernel) shortens that stream while the chip has idle SIMDs; built for the
     // plain configuration without the ground-contact term.  DN_WAVES_SINGLE=1|3 overrides the pick (sweeps).
     // Measured (profiles/r02_sweep_single.txt, us per step, one wave / three waves): 32768 drones 6.4 / 4.7, 65536: 7.7 / 6.8,

@@ -1,6 +1,6 @@
 // dn_kernels.hip -- hand-written HIP kernels (gfx950 / CDNA4) for the drone-navigation environment step.
 //
-// One drone per lane, 64 drones (one tile) per workgroup, one to four 64-lane waves per tile (the step cut by data
+// One drone per lane, 64 drones (one tile) per workgroup, one to eight 64-lane waves per tile (the step cut by data
 // dependency over waves that exchange LDS mail).  The whole reference step
 //   PBDroneEnv.step -> BaseAviary.step -> p.stepSimulation -> obs / reward / done -> post-step
 //   -> SubprocVecEnv auto-reset + Monitor (+ optional per-drone NormalizeObservation)
@@ -1103,9 +1103,23 @@ DN_DEV AttCol<R> attitude_column(const float4 G1)
     c.r02 = F(qx, t.zs, t.wys); c.r12 = F(qy, t.zs, -t.wxs); c.r22 = R(1.0) - F(qx, t.xs, t.yy);
     return c;
 }
+// physics_linear in two parts, like physics_angular: the damping products of the entry velocity (no thrust needed) | the rest.
+template <typename R> struct LinPre {
+    R vkx, vky, kl;        // vx kl, vy kl, kl = c + c |v|
+};
 template <typename R>
-DN_DEV Lin<R> physics_linear_col(const float4 G0, const float4 G2, const AttCol<R> col, const R fz, const R dax, const R day, const R daz,
-                                 const bool extra, const R damp = K<R>::LIN_DAMP)
+DN_DEV LinPre<R> physics_linear_pre(const float4 G2, const R damp = K<R>::LIN_DAMP)
+{
+    LinPre<R> l;
+    const R vx = G2.x, vy = G2.y, vz = G2.z;
+    // the damping norms enter the velocity update at dt * 0.04: a float32 root moves it by 1e-12 relative
+    l.kl = F(damp, (R)__builtin_amdgcn_sqrtf((float)F(vz, vz, F(vy, vy, vx * vx))), damp);
+    l.vkx = vx * l.kl; l.vky = vy * l.kl;
+    return l;
+}
+template <typename R>
+DN_DEV Lin<R> physics_linear_post(const float4 G0, const float4 G2, const AttCol<R> col, const LinPre<R> &l, const R fz, const R dax, const R day,
+                                  const R daz, const bool extra)
 {
     Lin<R> o;
     R px = G0.x, py = G0.y, pz = G0.z;
@@ -1113,10 +1127,8 @@ DN_DEV Lin<R> physics_linear_col(const float4 G0, const float4 G2, const AttCol<
     const R dt = K<R>::DT;
     const R r02 = col.r02, r12 = col.r12, r22 = col.r22;
     // linear: a = R[:,2] fz/M - (0,0,G) - v (c + c|v|)
-    // the damping norms enter the velocity update at dt * 0.04: a float32 root moves it by 1e-12 relative
-    const R kl = F(damp, (R)__builtin_amdgcn_sqrtf((float)F(vz, vz, F(vy, vy, vx * vx))), damp);
     const R fm = fz * K<R>::INV_M;
-    R awx = F(r02, fm, -(vx * kl)), awy = F(r12, fm, -(vy * kl)), awz = F(-vz, kl, F(r22, fm, -K<R>::G));
+    R awx = F(r02, fm, -l.vkx), awy = F(r12, fm, -l.vky), awz = F(-vz, l.kl, F(r22, fm, -K<R>::G));
     if (extra) { awx += dax; awy += day; awz += daz; }
     vx = F(awx, dt, vx); vy = F(awy, dt, vy); vz = F(awz, dt, vz);       // applyDeltaVeeMultiDof
     const R mv = K<R>::MAX_COORD_VEL;
@@ -1128,6 +1140,12 @@ DN_DEV Lin<R> physics_linear_col(const float4 G0, const float4 G2, const AttCol<
     return o;
 }
 template <typename R>
+DN_DEV Lin<R> physics_linear_col(const float4 G0, const float4 G2, const AttCol<R> col, const R fz, const R dax, const R day, const R daz,
+                                 const bool extra, const R damp = K<R>::LIN_DAMP)
+{
+    return physics_linear_post<R>(G0, G2, col, physics_linear_pre<R>(G2, damp), fz, dax, day, daz, extra);
+}
+template <typename R>
 DN_DEV Lin<R> physics_linear(const float4 G0, const float4 G1, const float4 G2, const R fz, const R dax, const R day, const R daz,
                              const bool extra, const R damp = K<R>::LIN_DAMP)
 {
@@ -1137,25 +1155,42 @@ template <typename R> struct Ang {
     R qx, qy, qz, qw;      // new attitude (unit quaternion)
     R wx, wy, wz;          // new angular velocity
 };
+// physics_angular in two parts: everything that reads only the entry state (rotation matrix, body rates, gyroscopic and damping
+// terms) and everything from the torques on.  A single-step kernel evaluates the first part while the thrust is still being computed
+// on another wave; physics_angular = the two back to back, the same expressions in the same order.
+template <typename R> struct AngPre {
+    R qx, qy, qz, qw, wx, wy, wz;
+    R r00, r01, r02, r10, r11, r12, r20, r21, r22;
+    R ka, Iwx, Iwy, Iwz, gx, gy, gz;
+};
 template <typename R>
-DN_DEV Ang<R> physics_angular(const float4 G1, const float4 G3, const R tx, const R ty, const R ztq, const R damp = K<R>::ANG_DAMP)
+DN_DEV AngPre<R> physics_angular_pre(const float4 G1, const float4 G3, const R damp = K<R>::ANG_DAMP)
+{
+    AngPre<R> a;
+    const R qx = G1.x, qy = G1.y, qz = G1.z, qw = G1.w;
+    const R wx = G3.x, wy = G3.y, wz = G3.z;
+    const QuatTerms<R> t = quat_terms<R>(qx, qy, qz, qw);
+    a.r00 = R(1.0) - F(qy, t.ys, t.zz); a.r01 = F(qx, t.ys, -t.wzs); a.r02 = F(qx, t.zs, t.wys);
+    a.r10 = F(qx, t.ys, t.wzs); a.r11 = R(1.0) - F(qx, t.xs, t.zz); a.r12 = F(qy, t.zs, -t.wxs);
+    a.r20 = F(qx, t.zs, -t.wys); a.r21 = F(qy, t.zs, t.wxs); a.r22 = R(1.0) - F(qx, t.xs, t.yy);
+    // angular, in the body frame: I dw = tau - w x (I w) - I w (c + c|w|)
+    const R wbx = F(a.r20, wz, F(a.r10, wy, a.r00 * wx)), wby = F(a.r21, wz, F(a.r11, wy, a.r01 * wx)), wbz = F(a.r22, wz, F(a.r12, wy, a.r02 * wx));
+    a.ka = F(damp, (R)__builtin_amdgcn_sqrtf((float)F(wz, wz, F(wy, wy, wx * wx))), damp);
+    a.Iwx = K<R>::IXX * wbx; a.Iwy = K<R>::IYY * wby; a.Iwz = K<R>::IZZ * wbz;
+    a.gx = F(wby, a.Iwz, -(wbz * a.Iwy)); a.gy = F(wbz, a.Iwx, -(wbx * a.Iwz)); a.gz = F(wbx, a.Iwy, -(wby * a.Iwx));
+    a.qx = qx; a.qy = qy; a.qz = qz; a.qw = qw; a.wx = wx; a.wy = wy; a.wz = wz;
+    return a;
+}
+template <typename R>
+DN_DEV Ang<R> physics_angular_post(const AngPre<R> &a, const R tx, const R ty, const R ztq)
 {
     Ang<R> o;
-    const R qx = G1.x, qy = G1.y, qz = G1.z, qw = G1.w;
-    R wx = G3.x, wy = G3.y, wz = G3.z;
+    const R qx = a.qx, qy = a.qy, qz = a.qz, qw = a.qw;
+    R wx = a.wx, wy = a.wy, wz = a.wz;
     const R dt = K<R>::DT;
-    const QuatTerms<R> t = quat_terms<R>(qx, qy, qz, qw);
-    const R r00 = R(1.0) - F(qy, t.ys, t.zz), r01 = F(qx, t.ys, -t.wzs), r02 = F(qx, t.zs, t.wys);
-    const R r10 = F(qx, t.ys, t.wzs), r11 = R(1.0) - F(qx, t.xs, t.zz), r12 = F(qy, t.zs, -t.wxs);
-    const R r20 = F(qx, t.zs, -t.wys), r21 = F(qy, t.zs, t.wxs), r22 = R(1.0) - F(qx, t.xs, t.yy);
-    // angular, in the body frame: I dw = tau - w x (I w) - I w (c + c|w|)
-    const R wbx = F(r20, wz, F(r10, wy, r00 * wx)), wby = F(r21, wz, F(r11, wy, r01 * wx)), wbz = F(r22, wz, F(r12, wy, r02 * wx));
-    const R ka = F(damp, (R)__builtin_amdgcn_sqrtf((float)F(wz, wz, F(wy, wy, wx * wx))), damp);
-    const R Iwx = K<R>::IXX * wbx, Iwy = K<R>::IYY * wby, Iwz = K<R>::IZZ * wbz;
-    const R gx = F(wby, Iwz, -(wbz * Iwy)), gy = F(wbz, Iwx, -(wbx * Iwz)), gz = F(wbx, Iwy, -(wby * Iwx));
-    const R dbx = F(-Iwx, ka, tx - gx) * K<R>::INV_IXX, dby = F(-Iwy, ka, ty - gy) * K<R>::INV_IYY,
-            dbz = F(-Iwz, ka, ztq - gz) * K<R>::INV_IZZ;
-    const R dwx = F(r02, dbz, F(r01, dby, r00 * dbx)), dwy = F(r12, dbz, F(r11, dby, r10 * dbx)), dwz = F(r22, dbz, F(r21, dby, r20 * dbx));
+    const R dbx = F(-a.Iwx, a.ka, tx - a.gx) * K<R>::INV_IXX, dby = F(-a.Iwy, a.ka, ty - a.gy) * K<R>::INV_IYY,
+            dbz = F(-a.Iwz, a.ka, ztq - a.gz) * K<R>::INV_IZZ;
+    const R dwx = F(a.r02, dbz, F(a.r01, dby, a.r00 * dbx)), dwy = F(a.r12, dbz, F(a.r11, dby, a.r10 * dbx)), dwz = F(a.r22, dbz, F(a.r21, dby, a.r20 * dbx));
     wx = F(dwx, dt, wx); wy = F(dwy, dt, wy); wz = F(dwz, dt, wz);       // applyDeltaVeeMultiDof
     const R mv = K<R>::MAX_COORD_VEL;
     if (__builtin_expect(fmax(fmax(fabs(wx), fabs(wy)), fabs(wz)) > mv, 0)) {
@@ -1180,6 +1215,11 @@ DN_DEV Ang<R> physics_angular(const float4 G1, const float4 G3, const R tx, cons
     o.qx = nx * inv; o.qy = ny * inv; o.qz = nz * inv; o.qw = nw_ * inv;
     o.wx = wx; o.wy = wy; o.wz = wz;
     return o;
+}
+template <typename R>
+DN_DEV Ang<R> physics_angular(const float4 G1, const float4 G3, const R tx, const R ty, const R ztq, const R damp = K<R>::ANG_DAMP)
+{
+    return physics_angular_post<R>(physics_angular_pre<R>(G1, G3, damp), tx, ty, ztq);
 }
 
 template <typename R, typename TH = Thrust, bool XOPT = false>
@@ -2717,6 +2757,7 @@ __global__ __launch_bounds__(4 * DN_BLOCK, 2) void dn_step_many_4w_kernel(const 
     step_many_4w_body<R, NORM, NOISE, 4>(p, io0, k_steps);
 }
 // five waves: two tiles per CU are ten waves on four SIMDs, i.e. FOUR waves on one of them -- 128 registers a wave
+// (three tiles, where noise keeps this shape selected: fifteen waves, four on three of the SIMDs, at the same 128 registers)
 template <typename R, bool NOISE>
 __global__ __launch_bounds__(5 * DN_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void dn_step_many_5w_kernel(const DnParams p, const DnStepIO io0, const int k_steps)
 {
@@ -3344,11 +3385,16 @@ DN_DEV void pqx_step(const DnParams &p, const DnStepIO &io0, PqxShared<R> &sh, c
             for (int j = 0; j < 4; ++j) sh.zmail[j][lane] = z[j];
             sh.zmail[4][lane] = z4[0];
         }
+        // everything of the linear step that does not read the thrust, while X still computes it (this wave's loads are back
+        // ~400-700 cycles before B1 releases: profiles/r03_pqx_stamps.txt)
+        AttCol<R> col = attitude_column<R>(G1);
+        LinPre<R> lpre = physics_linear_pre<R>(G2);
+        pin(col.r02); pin(col.r12); pin(col.r22); pin(lpre.kl); pin(lpre.vkx); pin(lpre.vky);
         PQX_MARK(1); block_lds_barrier(); PQX_MARK(2);                    // B1
         const GateRow<R> row_e = load_gate_row<R>(s_tab, unpack_meta(G3.w).idx);
         const R wp0[3] = {s_tab[DN_T_WP], s_tab[DN_T_WP + 1], s_tab[DN_T_WP + 2]};
         const R fz = tmail.v[0][lane];
-        const Lin<R> lin = physics_linear<R>(G0, G1, G2, fz, R(0.0), R(0.0), R(0.0), false);
+        const Lin<R> lin = physics_linear_post<R>(G0, G2, col, lpre, fz, R(0.0), R(0.0), R(0.0), false);
         Flight<R> fl;
         flight_entry<R>(fl, G0, G2, G3, p.max_steps);
         fl.px = lin.px; fl.py = lin.py; fl.pz = lin.pz;
@@ -3380,9 +3426,14 @@ DN_DEV void pqx_step(const DnParams &p, const DnStepIO &io0, PqxShared<R> &sh, c
         if (NORM) load_rms(p, i, rms);
         float zn[DN_OBS_DIM];
         if (obs_noise) { noise4<false>(p.seed, gid, sc0, 1u, zn); noise4<false>(p.seed, gid, sc0, 2u, zn + 4); }    // columns 0..7 (see P)
+        // the part of the angular step that reads only the entry state (rotation matrix, body rates, gyroscopic and damping terms:
+        // ~75 of its ~170 instructions), while X still computes the thrust
+        AngPre<R> apre = physics_angular_pre<R>(G1, G3);
+        pin(apre.r00); pin(apre.r01); pin(apre.r02); pin(apre.r10); pin(apre.r11); pin(apre.r12); pin(apre.r20); pin(apre.r21); pin(apre.r22);
+        pin(apre.ka); pin(apre.Iwx); pin(apre.Iwy); pin(apre.Iwz); pin(apre.gx); pin(apre.gy); pin(apre.gz);
         PQX_MARK(1); block_lds_barrier(); PQX_MARK(2);                    // B1
         const R tx = tmail.v[1][lane], ty = tmail.v[2][lane], zt = tmail.v[3][lane];
-        const Ang<R> ang = physics_angular<R>(G1, G3, tx, ty, zt);
+        const Ang<R> ang = physics_angular_post<R>(apre, tx, ty, zt);
         qmail[0][lane] = ang.qx; qmail[1][lane] = ang.qy; qmail[2][lane] = ang.qz; qmail[3][lane] = ang.qw;
         PQX_MARK(3); block_lds_barrier(); PQX_MARK(4);                    // B2
         Flight<R> fl;

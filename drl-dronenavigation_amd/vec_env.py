@@ -557,8 +557,10 @@ class DroneVecEnv(_VecEnvBase):
 
     def kernel_waves(self, fused=False):
         """Kernel shape of dn_step (fused=False: 3 = three waves cut by dependency, 1 = one wave) / dn_step_many (fused=True:
-        4 = linear | angular | observation | report waves, 3 = flight | report | aux, 2 = flight | report, 1 = one wave) per
-        64-drone tile (dn_get_kernel_waves; the crossovers are tiles per CU of this device, `num_cus`)."""
+        8 = the role-pipelined kernel (normaliser on: up to 1 tile per CU and at 2-3 tiles per CU), 5 = linear | angular |
+        observation | report | normaliser waves (normaliser on, 1-2 tiles per CU), 4 = the same without the normaliser's wave,
+        3 = flight | report | aux, 2 = flight | report, 1 = one wave) per 64-drone tile (dn_get_kernel_waves; the crossovers are
+        tiles per CU of this device, `num_cus`)."""
         return int(self._lib.dn_get_kernel_waves(self._handle, int(bool(fused))))
 
     @property
