@@ -2505,6 +2505,14 @@ __device__ long long g_mw_stamp[8][48][2];
 #define MW_MARK(k) do { } while (0)
 #endif
 #define MW_BARRIER() do { MW_MARK(0); block_lds_barrier(); MW_MARK(1); } while (0)
+#ifdef DN_MW_STAMP
+__device__ long long g_mw_edge[8][8];    // per role: cycles at entry, after barrier P, --, at exit; wall clock (100 MHz) at entry / exit; HW_ID
+#define MW_EDGE(k) do { if (lane == 0 && blockIdx.x == DN_MW_STAMP) { g_mw_edge[role][k] = (long long)__builtin_readcyclecounter(); \
+        if ((k) == 0) { g_mw_edge[role][4] = (long long)wall_clock64(); g_mw_edge[role][6] = (long long)__builtin_amdgcn_s_getreg(63492); } \
+        if ((k) == 3) g_mw_edge[role][5] = (long long)wall_clock64(); } } while (0)
+#else
+#define MW_EDGE(k) do { } while (0)
+#endif
 
 template <typename R, bool NORM, bool NOISE, int NW>
 DN_DEV void step_many_4w_body(const DnParams &p, const DnStepIO &io0, const int k_steps)
@@ -2556,6 +2564,7 @@ DN_DEV void step_many_4w_body(const DnParams &p, const DnStepIO &io0, const int 
     const DnConsts<R> &c = consts<R>(p);
     const long long n = p.n, words = (p.n + 63) / 64;
     const unsigned long long sc0 = p.st.stats[blockIdx.x].step_count;
+    MW_EDGE(0);
     stage_table<R>(p, s_tab);
     // every wave passes barrier P and the barriers of iterations 0 .. k_steps (k_steps + 1 of them)
     if (role == 0) {
@@ -2749,6 +2758,7 @@ DN_DEV void step_many_4w_body(const DnParams &p, const DnStepIO &io0, const int 
             reinterpret_cast<float *>(b.g5 + li)[3] = G5.w;
         }
     }
+    MW_EDGE(3);
 }
 
 template <typename R, bool NORM, bool NOISE>
@@ -2875,13 +2885,6 @@ DN_DEV void report_obs_cols(const DnParams &p, const DnConsts<R> &c, const StepO
         __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(2); } while (0)
 #else
 #define RP_TAKE_TURNS() do { } while (0)
-#endif
-#ifdef DN_MW_STAMP
-__device__ long long g_mw_edge[8][8];    // per role: cycles at entry, after barrier P, at the end of the loop, at exit; wall clock (100 MHz) at entry / exit
-#define MW_EDGE(k) do { if (lane == 0 && blockIdx.x == DN_MW_STAMP) { g_mw_edge[role][k] = (long long)__builtin_readcyclecounter(); \
-        if ((k) == 0) g_mw_edge[role][4] = (long long)wall_clock64(); if ((k) == 3) g_mw_edge[role][5] = (long long)wall_clock64(); } } while (0)
-#else
-#define MW_EDGE(k) do { } while (0)
 #endif
 template <typename R, bool NORM>
 DN_DEV void step_many_rp_body(const DnParams &p, const DnStepIO &io0, const int k_steps)
