@@ -2873,6 +2873,9 @@ DN_DEV void report_obs_cols(const DnParams &p, const DnConsts<R> &c, const StepO
 #ifndef DN_RP_PRIO
 #define DN_RP_PRIO "33211000"            // s_setprio of the roles L A T E Q X N1 N2
 #endif
+#ifndef DN_RP_PRIO_B
+#define DN_RP_PRIO_B DN_RP_PRIO          // ... in the workgroup that arrives second on its CU (the SIMD arbiter favours the older one)
+#endif
 // Two tiles share a CU, and the SIMD arbiter picks by priority, then AGE: left alone, the workgroup that arrived first runs at its
 // uncontended pace and the second one on what is left (stamps: 2 150 against 3 300-5 400 cycles per iteration), finishes long after it and
 // runs its tail alone with the SIMDs mostly idle.  The two tiles therefore take turns at the higher priority, in slices of the shader
@@ -2918,8 +2921,8 @@ DN_DEV void step_many_rp_body(const DnParams &p, const DnStepIO &io0, const int 
     const bool seg_track = p.cylinder && !p.circle;
     MW_EDGE(0);
     {
-        constexpr char pr[9] = DN_RP_PRIO;
-        switch (pr[role] - '0') {                                          // s_setprio takes an immediate
+        constexpr char pra[9] = DN_RP_PRIO, prb[9] = DN_RP_PRIO_B;
+        switch ((second_tile ? prb[role] : pra[role]) - '0') {             // s_setprio takes an immediate
         case 1: __builtin_amdgcn_s_setprio(1); break;
         case 2: __builtin_amdgcn_s_setprio(2); break;
         case 3: __builtin_amdgcn_s_setprio(3); break;
