@@ -2778,7 +2778,7 @@ __global__ __launch_bounds__(5 * DN_BLOCK) __attribute__((amdgpu_waves_per_eu(4,
 // Role-pipelined kernel (round 4; fused launches of the plain configuration without noise, <= 2 tiles per CU): six roles, eight with the
 // normaliser.
 //
-// Per-role stamps of the four- / five-wave kernels (profiles/mw_stamps.py, profiles/r04_stamps.txt) showed what paces them: not the
+// Per-role stamps of the four- / five-wave kernels (profiles/mw_stamps.py, profiles/r04_stamps_5w_4w.txt, r04_stamps_rp8.txt) showed what paces them: not the
 // recurrence waves L and A but Q (thrust of step t + 1, observation row and reward candidates of step t - 1: busy 2 450 cycles of a
 // 2 620-cycle iteration at one tile per CU, 3 000-3 400 at two), then N and L.  Here the step is cut into EIGHT roles, and the one that
 // carries the rules keeps only what the NEXT step's flags need:
