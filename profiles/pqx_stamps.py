@@ -1,6 +1,6 @@
 # per-role timeline of one tile of the three-wave single step (timing build: scratch/r3/build_kvariant.sh <name> -DDN_PQX_STAMP=<tile>)
 import os, sys, ctypes as C
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import drl_dronenavigation_amd as pkg
 from drl_dronenavigation_amd import tracks
