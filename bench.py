@@ -153,18 +153,25 @@ def cpu_baseline(track, num_envs, max_steps, seconds):
         per = max(time.perf_counter() - t0, 1e-6)
         k = max(2, int(budget / per))
         t0 = time.perf_counter()
+        done = 0
         for t in range(k):
             env.step(acts[t % len(acts)])
+            done += 1
+            if done >= 2 and time.perf_counter() - t0 > 1.5 * budget:      # a team that slowed down after its first step: stay inside the budget
+                break
         dt = time.perf_counter() - t0
-        return dict(value=num_envs * k / dt, steps=k, seconds=dt, threads=threads)
+        return dict(value=num_envs * done / dt, steps=done, seconds=dt, threads=threads)
 
     # The visible CPU count can exceed what the container may actually use (a cgroup quota makes a 256-thread
     # OpenMP team slower than one thread), so probe a ladder of team sizes briefly and time the fastest one.
     ladder = sorted({t for t in (1, 2, 4, 8, 16, 32, 64, 128, 256, usable) if t <= usable})
     probe = {t: rate(t, 0.04 * seconds)["value"] for t in ladder}
-    best = max(probe, key=probe.get)
+    # a short probe can flatter an oversubscribed team (128 threads: 186 M in the probe, 15 M sustained on a shared host): the two best of
+    # the ladder are both timed for a quarter of the budget and the better SUSTAINED rate is the baseline
+    ranked = sorted(probe, key=probe.get, reverse=True)
     one = rate(1, 0.2 * seconds)
-    top = rate(best, 0.5 * seconds) if best != 1 else one
+    cands = [rate(t, 0.25 * seconds) if t != 1 else one for t in ranked[:2]]
+    top = max(cands, key=lambda d: d["value"])
     return {"value": round(top["value"], 1), "unit": "env-steps/s", "cores": top["threads"],
             "kind": "port",
             "sample": f"{num_envs} drones x {top['steps']} vector steps ({top['seconds']:.1f} s) of the same "
