@@ -473,3 +473,47 @@ def test_noise_draws_shared_out_over_the_waves_equal_the_per_drone_draws(norm, m
         assert np.ascontiguousarray(sa[k]).tobytes() == np.ascontiguousarray(sb[k]).tobytes(), k
     single.close()
     fused.close()
+
+
+def test_stream_copy_and_pack_done_entry_points():
+    """The two C-ABI entry points of round 4 on their own.  dn_stream_copy (the copy ceiling bench.py quotes): byte-exact over sizes
+    that are and are not multiples of its 4 KiB workgroup span.  dn_pack_done: the ordered list of finished drones and one 64-byte
+    record each (terminal_observation, Monitor return / length, TimeLimit.truncated | found_targets << 8) against the same step's
+    whole-fleet arrays."""
+    pkg = _pkg()
+    from drl_dronenavigation_amd import tracks
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(3)
+    for n_bytes in (16, 4096, 4096 * 7 + 16 * 5, 1 << 22):
+        src = torch.randint(0, 255, (n_bytes,), dtype=torch.uint8, generator=g).to(dev)
+        dst = torch.zeros_like(src)
+        pkg.stream_copy(dst, src)
+        assert torch.equal(dst, src), n_bytes
+    n = 3000                                              # ragged: 46 tiles + 56 drones
+    env = pkg.DroneVecEnv(tracks.reaching(), n, device=dev, max_steps=7)
+    env.reset_tensor()
+    lib = pkg._capi.load()
+    idx = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    packed = torch.zeros((n, 16), dtype=torch.float32, device=dev)
+    seen = 0
+    for t in range(30):
+        a = (torch.rand((n, 4), generator=g) * 2 - 1).to(dev)
+        obs, rew, done, info = env.step_tensor(a)
+        pkg._capi.check(lib.dn_pack_done(info["done_mask"].data_ptr(), n, info["terminal_obs"].data_ptr(), info["ep_return"].data_ptr(),
+                                         info["ep_length"].data_ptr(), info["truncated"].data_ptr(), info["found_targets"].data_ptr(),
+                                         idx.data_ptr(), cnt.data_ptr(), packed.data_ptr(), 0, env._stream()))
+        torch.cuda.synchronize()
+        want = torch.nonzero(done).flatten().to(torch.int32)
+        k = int(cnt.item())
+        assert k == want.numel() and torch.equal(idx[:k], want)
+        if k:
+            w = want.long()
+            rec = packed[:k]
+            assert torch.equal(rec[:, :13], info["terminal_obs"][w]) and torch.equal(rec[:, 13], info["ep_return"][w])
+            bits = rec[:, 14:16].contiguous().view(torch.int32)
+            assert torch.equal(bits[:, 0], info["ep_length"][w])
+            assert torch.equal(bits[:, 1], info["truncated"][w].to(torch.int32) | (info["found_targets"][w] << 8))
+        seen += k
+    assert seen > n                                       # the time limit ended every episode at least once
+    env.close()
