@@ -668,6 +668,7 @@ def main():
     # 32768 workgroups), one control step per launch -- the regime the byte model of SURVEY 8(d) describes
     def hbm_bound_leg(norm_l):
         nl = 2097152
+        torch.cuda.empty_cache()                              # 1.7 GB of buffers for this leg: from a compact allocator state, not from the holes the earlier legs left
         env_l = pkg.DroneVecEnv(track, nl, max_steps=max_steps, normalize_obs=norm_l, compute_dtype=args.compute_dtype, device=dev)
         env_l.reset_tensor()
         gl = torch.Generator(device="cpu").manual_seed(7)
