@@ -1414,7 +1414,7 @@ def test_nan_actions_propagate_like_numpy():
 
 
 @pytest.mark.parametrize("waves", ["3", "4", "5", "6", "8"])
-@pytest.mark.parametrize("n,K", [(12, 2), (64, 3), (100, 5), (4096, 2)])
+@pytest.mark.parametrize("n,K", [(12, 2), (64, 3), (100, 5), (4096, 2), (100, 1), (4096, 1)])
 def test_three_wave_kernel_short_rollouts_and_ragged_tiles(n, K, waves, monkeypatch):
     """The three- and four-wave kernels trail their report wave two steps behind the flight wave(s): rollouts shorter than
     the skew, a single ragged tile and one drone short of a tile must still match the one-wave kernel bit for bit."""
