@@ -570,8 +570,12 @@ def main():
     e0.record(stream)                                     # a torch event creates its hipEvent on first use (~30 us, measured):
     e1.record(stream)                                     # not inside a timed region that is one 31 us launch
     torch.cuda.synchronize(dev)
-    e0.record(stream)                                     # the roofline's HIP event; the stream is idle, so it completes at once and is not
-    t0 = time.perf_counter()                              # part of the K steps the wall clock brackets
+    # The roofline's HIP events bracket the timed region on the launch stream (two marker packets; measured: they cost the wall clock
+    # nothing, 13.05-13.43 against 13.15-13.53 G env-steps/s without them).  Attaching them to the kernel's own dispatch INSIDE the region
+    # (dn_set_launch_events -> hipExtLaunchKernelGGL) was tried and costs the host 6-15 us of launch path (8.2-10.7 G): that form times one
+    # more launch after the region instead (`kernel_only` below).
+    e0.record(stream)                                     # the stream is idle: it completes at once
+    t0 = time.perf_counter()
     ta = t0
     run(K)
     tb = time.perf_counter()
@@ -585,6 +589,20 @@ def main():
     if os.environ.get("DN_BENCH_DEBUG"):
         print(f"timed region: rec0 {(ta - t0) * 1e6:.1f} run {(tb - ta) * 1e6:.1f} rec1 {(tc - tb) * 1e6:.1f} sync {(td - tc) * 1e6:.1f} us", file=sys.stderr)
     gpu_ms = e0.elapsed_time(e1)                          # HIP events on the launch stream, timed region only
+    kernel_only_us = None
+    if args.mode == "many" and K <= A:
+        # the same K-step launch once more, OUTSIDE the region the wall clock brackets, with its own dispatch's begin / end stamps: the kernel's
+        # duration as rocprofv3 --kernel-trace reports it (the markers above also see the ~1 us between a marker and the kernel)
+        k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        k0.record(stream); k1.record(stream)
+        torch.cuda.synchronize(dev)
+        reps_ = []
+        for _ in range(5):
+            pkg._capi.check(lib.dn_set_launch_events(h, C.c_void_p(k0.cuda_event), C.c_void_p(k1.cuda_event)))
+            run(K)
+            torch.cuda.synchronize(dev)
+            reps_.append(k0.elapsed_time(k1) * 1e3)
+        kernel_only_us = sorted(reps_)[len(reps_) // 2]
     if dist is not None:
         tw = torch.tensor([wall, gpu_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
@@ -808,6 +826,12 @@ def main():
                                                      + (f" + {ALGO_BYTES_NORMALISER} B statistics" if args.normalize_obs else "")
                                                      + " per drone and launch (SURVEY 8(d) split into per-step I/O and per-launch state)"),
                          "avg_launch_us": round(launch_us, 4), "us_per_vector_step": round(step_us, 4),
+                         "timed_with": "HIP events recorded on the launch stream around the timed region (marker to kernel gaps included)",
+                         "kernel_only": ({"launch_us": round(kernel_only_us, 3),
+                                          "frac": round(algo_launch / (kernel_only_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 5),
+                                          "what": "median of 5 identical launches right after the timed region, each timed by HIP events attached to "
+                                                  "its own dispatch (dn_set_launch_events -> hipExtLaunchKernelGGL): the kernel's duration as "
+                                                  "rocprofv3 --kernel-trace reports it"} if kernel_only_us else None),
                          "note": "at 32768 drones neither launch shape is bandwidth bound: with two tiles per CU the fused launch is bound by the vector ALUs "
                                  "(float64 instructions occupy a SIMD's ALU 4 cycles each; ~1 100 vector instructions per tile-step: issue_bound_evidence, "
                                  "profiles/r04_notes.md), with one tile per CU by the role with the longest instruction stream; the single-step launch is "

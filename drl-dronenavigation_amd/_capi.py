@@ -11,7 +11,7 @@ from . import build as _build
 MAX_WAYPOINTS = 64
 OBS_DIM = 13
 ACT_DIM = 4
-ABI_VERSION = 7
+ABI_VERSION = 8
 GROUND_CONTACT_AUTO = 2
 
 DN_OK = 0
@@ -102,6 +102,7 @@ PROTOTYPES = {
     "dn_mlp_forward": (_I32, [_VP, _I32, _VP, _VP, _I64, _I32, _I32, _VP]),
     "dn_mlp_step_sampled": (_I32, [_VP, _VP, _I32, _VP, _I32, C.POINTER(C.c_float), C.c_uint64, _I32] + [_VP] * 12),
     "dn_gae": (_I32, [_VP] * 5 + [_I64, _I64, C.c_double, C.c_double, _VP, _VP, _I32, _VP]),
+    "dn_set_launch_events": (_I32, [_VP, _VP, _VP]),
     "dn_state_bytes": (_I64, [_I64, _I32]),
 }
 

@@ -63,6 +63,15 @@ struct dn_env {
     int num_cus = (int)DN_CALIBRATION_CUS;   // hipDeviceProp_t.multiProcessorCount of cfg.device_id
     int waves_fused = 2;        // kernel shape of dn_step_many (k > 1), see dn_launch_step_many
     int waves_single = 1;       // kernel shape of dn_step (k == 1)
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;   // dn_set_launch_events: attached to the next step kernel's dispatch, then cleared
+};
+
+thread_local hipEvent_t dn_tl_ev_start = nullptr, dn_tl_ev_stop = nullptr;
+
+// arms the dispatch-attached events of dn_set_launch_events for the one launch issued inside its scope
+struct LaunchEvents {
+    explicit LaunchEvents(dn_env *e) { dn_tl_ev_start = e->ev_start; dn_tl_ev_stop = e->ev_stop; e->ev_start = e->ev_stop = nullptr; }
+    ~LaunchEvents() { dn_tl_ev_start = dn_tl_ev_stop = nullptr; }
 };
 
 namespace {
@@ -512,6 +521,7 @@ int32_t dn_step(dn_env *env, const float *actions, float *obs, float *reward, ui
     io.found_targets = found_targets; io.terminal_obs = terminal_obs; io.ep_return = ep_return;
     io.ep_length = ep_length; io.done_mask = (unsigned long long *)done_mask;
     io.mean = nullptr; io.act_out = nullptr; io.logp_out = nullptr; io.sample_squash = 0;
+    const LaunchEvents armed(env);
     DN_HIP(dn_launch_step_many(env->p, io, 1, env->cfg.compute_f32 != 0, env->waves_single, (hipStream_t)stream));
     return DN_OK;
 }
@@ -661,7 +671,16 @@ int32_t dn_step_many(dn_env *env, int64_t k, const float *actions, float *obs, f
     io.found_targets = found_targets; io.terminal_obs = terminal_obs; io.ep_return = ep_return;
     io.ep_length = ep_length; io.done_mask = (unsigned long long *)done_mask;
     io.mean = nullptr; io.act_out = nullptr; io.logp_out = nullptr; io.sample_squash = 0;
+    const LaunchEvents armed(env);
     DN_HIP(dn_launch_step_many(env->p, io, (int)k, env->cfg.compute_f32 != 0, env->waves_fused, (hipStream_t)stream));
+    return DN_OK;
+}
+
+int32_t dn_set_launch_events(dn_env *env, void *start_event, void *stop_event)
+{
+    if (!env) return fail(DN_ERR_INVALID_ARGUMENT, "env is NULL");
+    env->ev_start = (hipEvent_t)start_event;
+    env->ev_stop = (hipEvent_t)stop_event;
     return DN_OK;
 }
 

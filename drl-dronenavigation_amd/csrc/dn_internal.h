@@ -3,6 +3,7 @@
 #define DN_INTERNAL_H
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "../../include/dronenav.h"
@@ -111,6 +112,17 @@ struct DnParams {
     DnConsts<double> c64;
     DnConsts<float> c32;
 };
+
+// dn_set_launch_events (ABI 8): the step kernel of the next dn_step / dn_step_many launch is dispatched with these two hipEvents attached to
+// its own dispatch packet (hipExtLaunchKernelGGL) -- they time the kernel itself, like a profiler's kernel trace, where a pair of
+// hipEventRecord around the call would also time the host's launch path and add two marker packets to the stream.  One shot: the
+// C ABI clears them after the launch.  Thread-local: a dn_env is driven from one host thread at a time (include/dronenav.h).
+extern thread_local hipEvent_t dn_tl_ev_start, dn_tl_ev_stop;
+#define DN_KLAUNCH(kern, grid, blk, shm, stream, ...)                                                                                   \
+    do {                                                                                                                                \
+        if (dn_tl_ev_start || dn_tl_ev_stop) hipExtLaunchKernelGGL(kern, grid, blk, shm, stream, dn_tl_ev_start, dn_tl_ev_stop, 0, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kern, grid, blk, shm, stream, __VA_ARGS__);                                                             \
+    } while (0)
 
 hipError_t dn_launch_step_many(const DnParams &p, const DnStepIO &io, int k, bool f32, int waves, hipStream_t stream);
 hipError_t dn_launch_step_many_mw(const DnParams &p, const DnStepIO &io, int k, bool f32, int waves, hipStream_t stream);   // dn_kernels_mw.hip

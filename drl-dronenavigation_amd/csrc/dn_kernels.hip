@@ -3805,9 +3805,9 @@ hipError_t dn_launch_filld(double *dst, double v, long long n, hipStream_t strea
 #define DN_LAUNCH3(R, NORM, NOISE, ONE, XOPT)                                                                           \
     do {                                                                                                                \
         if (two_wave)                                                                                                   \
-            hipLaunchKernelGGL((dn_step_many_2w_kernel<R, NORM, NOISE, ONE, XOPT>), dim3(grid), dim3(2 * DN_BLOCK), 0, stream, p, io, k); \
+            DN_KLAUNCH((dn_step_many_2w_kernel<R, NORM, NOISE, ONE, XOPT>), dim3(grid), dim3(2 * DN_BLOCK), 0, stream, p, io, k); \
         else                                                                                                            \
-            hipLaunchKernelGGL((dn_step_many_1w_kernel<R, NORM, NOISE, ONE, XOPT>), dim3(grid), dim3(DN_BLOCK), 0, stream, p, io, k);     \
+            DN_KLAUNCH((dn_step_many_1w_kernel<R, NORM, NOISE, ONE, XOPT>), dim3(grid), dim3(DN_BLOCK), 0, stream, p, io, k);     \
     } while (0)
 #define DN_LAUNCH2(R, NORM, NOISE, ONE)                                                                                 \
     do {                                                                                                                \
@@ -3828,22 +3828,22 @@ hipError_t dn_launch_step_many_mw(const DnParams &p, const DnStepIO &io, int k, 
     const bool rew = p.clip_rew != 0 || p.norm_rew != 0 || p.gnd != 0 || p.drag != 0 || p.rpm_actions != 0 || p.pid_mode != 0 || p.random_spawn != 0 || p.zero_damping != 0;
     if ((waves == 8 || waves == 6) && k > 1 && !noise && !rew) {   // role-pipelined kernel (round 4): eight roles with the normaliser, six without
         if (p.normalize_obs) {
-            if (f32) hipLaunchKernelGGL((dn_step_many_rp8_kernel<float>), dim3(grid), dim3(8 * DN_BLOCK), 0, stream, p, io, k);
-            else hipLaunchKernelGGL((dn_step_many_rp8_kernel<double>), dim3(grid), dim3(8 * DN_BLOCK), 0, stream, p, io, k);
+            if (f32) DN_KLAUNCH((dn_step_many_rp8_kernel<float>), dim3(grid), dim3(8 * DN_BLOCK), 0, stream, p, io, k);
+            else DN_KLAUNCH((dn_step_many_rp8_kernel<double>), dim3(grid), dim3(8 * DN_BLOCK), 0, stream, p, io, k);
         } else {
-            if (f32) hipLaunchKernelGGL((dn_step_many_rp6_kernel<float>), dim3(grid), dim3(6 * DN_BLOCK), 0, stream, p, io, k);
-            else hipLaunchKernelGGL((dn_step_many_rp6_kernel<double>), dim3(grid), dim3(6 * DN_BLOCK), 0, stream, p, io, k);
+            if (f32) DN_KLAUNCH((dn_step_many_rp6_kernel<float>), dim3(grid), dim3(6 * DN_BLOCK), 0, stream, p, io, k);
+            else DN_KLAUNCH((dn_step_many_rp6_kernel<double>), dim3(grid), dim3(6 * DN_BLOCK), 0, stream, p, io, k);
         }
         return hipGetLastError();
     }
     if (waves == 5 && k > 1) {                             // four waves + the normaliser's: fused launches of the plain configuration, normaliser on
         const dim3 blk(5 * DN_BLOCK);
         if (f32) {
-            if (noise) hipLaunchKernelGGL((dn_step_many_5w_kernel<float, true>), dim3(grid), blk, 0, stream, p, io, k);
-            else hipLaunchKernelGGL((dn_step_many_5w_kernel<float, false>), dim3(grid), blk, 0, stream, p, io, k);
+            if (noise) DN_KLAUNCH((dn_step_many_5w_kernel<float, true>), dim3(grid), blk, 0, stream, p, io, k);
+            else DN_KLAUNCH((dn_step_many_5w_kernel<float, false>), dim3(grid), blk, 0, stream, p, io, k);
         } else {
-            if (noise) hipLaunchKernelGGL((dn_step_many_5w_kernel<double, true>), dim3(grid), blk, 0, stream, p, io, k);
-            else hipLaunchKernelGGL((dn_step_many_5w_kernel<double, false>), dim3(grid), blk, 0, stream, p, io, k);
+            if (noise) DN_KLAUNCH((dn_step_many_5w_kernel<double, true>), dim3(grid), blk, 0, stream, p, io, k);
+            else DN_KLAUNCH((dn_step_many_5w_kernel<double, false>), dim3(grid), blk, 0, stream, p, io, k);
         }
         return hipGetLastError();
     }
@@ -3852,8 +3852,8 @@ hipError_t dn_launch_step_many_mw(const DnParams &p, const DnStepIO &io, int k, 
         const bool norm = p.normalize_obs != 0;
 #define DN_L4(R, NORM)                                                                                                      \
         do {                                                                                                                \
-            if (noise) hipLaunchKernelGGL((dn_step_many_4w_kernel<R, NORM, true>), dim3(grid), blk, 0, stream, p, io, k);    \
-            else hipLaunchKernelGGL((dn_step_many_4w_kernel<R, NORM, false>), dim3(grid), blk, 0, stream, p, io, k);         \
+            if (noise) DN_KLAUNCH((dn_step_many_4w_kernel<R, NORM, true>), dim3(grid), blk, 0, stream, p, io, k);    \
+            else DN_KLAUNCH((dn_step_many_4w_kernel<R, NORM, false>), dim3(grid), blk, 0, stream, p, io, k);         \
         } while (0)
         if (f32) { if (norm) DN_L4(float, true); else DN_L4(float, false); }
         else { if (norm) DN_L4(double, true); else DN_L4(double, false); }
@@ -3865,8 +3865,8 @@ hipError_t dn_launch_step_many_mw(const DnParams &p, const DnStepIO &io, int k, 
         const bool norm = p.normalize_obs != 0;
 #define DN_L3X(R, NORM, NOISE)                                                                                              \
         do {                                                                                                                \
-            if (rew) hipLaunchKernelGGL((dn_step_many_3w_kernel<R, NORM, NOISE, true>), dim3(grid), blk, 0, stream, p, io, k);   \
-            else hipLaunchKernelGGL((dn_step_many_3w_kernel<R, NORM, NOISE, false>), dim3(grid), blk, 0, stream, p, io, k);      \
+            if (rew) DN_KLAUNCH((dn_step_many_3w_kernel<R, NORM, NOISE, true>), dim3(grid), blk, 0, stream, p, io, k);   \
+            else DN_KLAUNCH((dn_step_many_3w_kernel<R, NORM, NOISE, false>), dim3(grid), blk, 0, stream, p, io, k);      \
         } while (0)
 #define DN_L3(R, NORM)                                                                                                      \
         do {                                                                                                                \
@@ -3901,7 +3901,7 @@ hipError_t dn_launch_step_many(const DnParams &p, const DnStepIO &io, int k, boo
     if (io.mean && waves == 3) {            // dn_step_sampled on three waves
         const unsigned grid = (unsigned)((p.n + DN_BLOCK - 1) / DN_BLOCK);
         const bool noise = p.act_noise_sigma > 0.0f || p.obs_noise_sigma > 0.0f;
-#define DN_LPS(R, NORM, NOISE) hipLaunchKernelGGL((dn_step_pqx_kernel<R, NORM, NOISE, true>), dim3(grid), dim3(3 * DN_BLOCK), 0, stream, p, io)
+#define DN_LPS(R, NORM, NOISE) DN_KLAUNCH((dn_step_pqx_kernel<R, NORM, NOISE, true>), dim3(grid), dim3(3 * DN_BLOCK), 0, stream, p, io)
         if (f32) {
             if (norm) { if (noise) DN_LPS(float, true, true); else DN_LPS(float, true, false); }
             else { if (noise) DN_LPS(float, false, true); else DN_LPS(float, false, false); }
@@ -3915,7 +3915,7 @@ hipError_t dn_launch_step_many(const DnParams &p, const DnStepIO &io, int k, boo
     if (io.mean) {                          // dn_step_sampled: one-wave single-step kernels with the sampler compiled in
         const unsigned grid = (unsigned)((p.n + DN_BLOCK - 1) / DN_BLOCK);
         const bool noise = p.act_noise_sigma > 0.0f || p.obs_noise_sigma > 0.0f;
-#define DN_LS(R, NORM, NOISE) hipLaunchKernelGGL((dn_step_many_1w_kernel<R, NORM, NOISE, true, false, true>), dim3(grid), dim3(DN_BLOCK), 0, stream, p, io, 1)
+#define DN_LS(R, NORM, NOISE) DN_KLAUNCH((dn_step_many_1w_kernel<R, NORM, NOISE, true, false, true>), dim3(grid), dim3(DN_BLOCK), 0, stream, p, io, 1)
         if (f32) {
             if (norm) { if (noise) DN_LS(float, true, true); else DN_LS(float, true, false); }
             else { if (noise) DN_LS(float, false, true); else DN_LS(float, false, false); }
@@ -3929,7 +3929,7 @@ hipError_t dn_launch_step_many(const DnParams &p, const DnStepIO &io, int k, boo
     if (waves == 3 && k == 1) {             // dn_step on three waves cut by dependency (plain configuration; the caller checked)
         const unsigned grid = (unsigned)((p.n + DN_BLOCK - 1) / DN_BLOCK);
         const bool noise = p.act_noise_sigma > 0.0f || p.obs_noise_sigma > 0.0f;
-#define DN_LP(R, NORM, NOISE) hipLaunchKernelGGL((dn_step_pqx_kernel<R, NORM, NOISE, false>), dim3(grid), dim3(3 * DN_BLOCK), 0, stream, p, io)
+#define DN_LP(R, NORM, NOISE) DN_KLAUNCH((dn_step_pqx_kernel<R, NORM, NOISE, false>), dim3(grid), dim3(3 * DN_BLOCK), 0, stream, p, io)
         if (f32) {
             if (norm) { if (noise) DN_LP(float, true, true); else DN_LP(float, true, false); }
             else { if (noise) DN_LP(float, false, true); else DN_LP(float, false, false); }

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define DN_ABI_VERSION 7
+#define DN_ABI_VERSION 8
 #define DN_MAX_WAYPOINTS 64
 #define DN_OBS_DIM 13      /* 12 kinematic + distance, PBDroneEnv._computeObs, PBDroneEnv.py:296-336 */
 #define DN_ACT_DIM 4       /* four rotor thrust commands, PBDroneEnv._actionSpace, PBDroneEnv.py:225-243 */
@@ -354,6 +354,14 @@ int32_t dn_mlp_step_sampled(dn_env *env, const dn_mlp_net *nets, int32_t num_net
                             const float *log_std, uint64_t seed, int32_t deterministic, float *actions_out, float *log_prob_out,
                             float *obs, float *reward, uint8_t *done, uint8_t *truncated, int32_t *found_targets, float *terminal_obs,
                             float *ep_return, int32_t *ep_length, uint64_t *done_mask, void *stream);
+
+/* Measurement hook (ABI 8).  The step kernel of the NEXT dn_step / dn_step_many call on `env` is dispatched with these two hipEvents
+ * (hipEvent_t passed as void *, created with timing enabled; either may be NULL) attached to its own dispatch packet
+ * (hipExtLaunchKernelGGL): hipEventElapsedTime(start, stop) is then the duration of that kernel alone -- what a profiler's kernel trace
+ * reports -- where a pair of hipEventRecord around the call also times the host's launch path and puts two marker packets on the
+ * stream.  One shot: cleared by the launch it was armed for.  It stands where the reference wraps its training loop in cProfile
+ * (Sol/Utilities/Profiler.py:5-16), at the granularity this path has: one launch.  Used by bench.py's roofline figure. */
+int32_t dn_set_launch_events(dn_env *env, void *start_event, void *stop_event);
 
 /* Bytes of HBM the persistent state of `num_envs` drones occupies (capacity planning). */
 int64_t dn_state_bytes(int64_t num_envs, int32_t normalize_obs);
