@@ -55,8 +55,6 @@ def kernel_name(waves, dtype, norm, fused):
     r, nm = ("double" if dtype == "float64" else "float"), ("true" if norm else "false")
     if waves == 8 and fused:
         return f"dn_step_many_rp8_kernel<{r}>"
-    if waves == 6 and fused:
-        return f"dn_step_many_rp6_kernel<{r}>"
     if waves == 5 and fused:
         return f"dn_step_many_5w_kernel<{r}, false>"
     if waves == 4 and fused:
@@ -131,8 +129,10 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(track, num_envs, max_steps, seconds):
-    """Time the CPU oracle (test infrastructure used here only as the reported baseline) on all host cores."""
+def cpu_baseline(track, num_envs, max_steps, seconds, normalize_obs=True):
+    """Time the CPU oracle (test infrastructure used here only as the reported baseline) on all host cores, in the HEADLINE's
+    configuration: the per-drone NormalizeObservation on or off as the timed GPU line has it (the reference always wraps it,
+    PBDroneSimulator.py:181).  The other setting is reported beside it (`other_normaliser_setting`)."""
     import numpy as np
     from oracle import oracle as O
     try:
@@ -140,11 +140,13 @@ def cpu_baseline(track, num_envs, max_steps, seconds):
     except AttributeError:  # pragma: no cover
         usable = os.cpu_count() or 1
     cfg = O.make_config(track.targets(), track.initial_xyzs, track.aviary_dim, circle=track.is_circle,
-                        max_steps=max_steps, normalize_obs=False)
+                        max_steps=max_steps, normalize_obs=normalize_obs)
+    cfg_other = O.make_config(track.targets(), track.initial_xyzs, track.aviary_dim, circle=track.is_circle,
+                              max_steps=max_steps, normalize_obs=not normalize_obs)
     rng = np.random.default_rng(1)
     acts = rng.uniform(-1, 1, (16, num_envs, 4)).astype(np.float32)
 
-    def rate(threads, budget):
+    def rate(threads, budget, cfg=cfg):
         env = O.OracleVecEnv(cfg, num_envs, threads=threads)
         env.reset()
         env.step(acts[0])
@@ -172,11 +174,16 @@ def cpu_baseline(track, num_envs, max_steps, seconds):
     one = rate(1, 0.2 * seconds)
     cands = [rate(t, 0.25 * seconds) if t != 1 else one for t in ranked[:2]]
     top = max(cands, key=lambda d: d["value"])
+    other = rate(top["threads"], 0.1 * seconds, cfg_other)
     return {"value": round(top["value"], 1), "unit": "env-steps/s", "cores": top["threads"],
             "kind": "port",
             "sample": f"{num_envs} drones x {top['steps']} vector steps ({top['seconds']:.1f} s) of the same "
-                      f"workload through oracle/dn_oracle.c (OpenMP team of {top['threads']}, float64); "
+                      f"workload (race track, U(-1,1)^4 actions, per-drone NormalizeObservation {'ON' if normalize_obs else 'OFF'} as in the "
+                      f"timed GPU line) through oracle/dn_oracle.c (OpenMP team of {top['threads']}, float64); "
                       f"{usable} CPUs visible to the process",
+            "normalize_obs": bool(normalize_obs),
+            "other_normaliser_setting": {"normalize_obs": (not normalize_obs), "value": round(other["value"], 1), "cores": other["threads"],
+                                         "steps": other["steps"]},
             "single_thread_value": round(one["value"], 1),
             "thread_ladder": {str(t): round(v, 1) for t, v in probe.items()}}
 
@@ -856,7 +863,7 @@ def main():
                 line["sac_collect"] = {"error": f"{type(exc).__name__}: {exc}"}
         if world == 1 and not args.no_cpu_baseline:
             try:
-                line["cpu_baseline"] = cpu_baseline(track, n, max_steps, args.cpu_baseline_seconds)
+                line["cpu_baseline"] = cpu_baseline(track, n, max_steps, args.cpu_baseline_seconds, args.normalize_obs)
             except Exception as exc:  # noqa: BLE001
                 line["cpu_baseline"] = {"error": f"{type(exc).__name__}: {exc}"}
     # BASELINE configs[3]: the one collective of the design (RCCL all-gather of advantages / returns per rollout), timed on every rank

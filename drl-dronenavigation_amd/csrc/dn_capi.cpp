@@ -351,7 +351,7 @@ int32_t dn_create(const dn_config *cfg, dn_env **out)
     // 1.11 | 0.99, 16 384 1.18 | 1.05, 20 480 1.52 | 1.53, 24 576 1.53 | 1.57, 32 768 1.63 | 1.66, 40 960 2.79 | 2.37, 49 152 2.98 | 2.47
     // -> eight roles up to one tile per CU and from two to three tiles per CU (where two of its workgroups fit a CU and the third tile
     // follows), five waves in between, where sixteen waves saturate the vector ALUs either way.  Without the normaliser the six-role form
-    // (rp6) loses to the four-wave kernel at every size (32 768 drones: 1.68 against 1.40) and is built for DN_WAVES=6 only.
+    // lost to the four-wave kernel at every size (32 768 drones: 1.68 against 1.40) and was removed in round 5.
     const bool rp_ok = plain && !cfg->ground_contact && !noisy;
     if (rp_ok && cfg->normalize_obs && (e->blocks <= e->num_cus || (e->blocks > 2 * e->num_cus && e->blocks <= DN_ROLE_PIPE_TILES_PER_CU * e->num_cus)))
         e->waves_fused = 8;
@@ -377,8 +377,8 @@ int32_t dn_create(const dn_config *cfg, dn_env **out)
         } else if (w[0] == '5') {                              // + the normaliser on a fifth wave (normaliser on only)
             e->waves_fused = pqx_ok ? (cfg->normalize_obs ? 5 : 4) : 3;
             e->waves_single = pqx_ok ? 3 : 1;
-        } else if (w[0] == '6' || w[0] == '8') {               // the role-pipelined kernel (six roles, eight with the normaliser)
-            e->waves_fused = rp_ok ? (cfg->normalize_obs ? 8 : 6) : (pqx_ok ? (cfg->normalize_obs ? 5 : 4) : 3);
+        } else if (w[0] == '8') {                              // the role-pipelined kernel (eight roles; normaliser on, no noise)
+            e->waves_fused = rp_ok && cfg->normalize_obs ? 8 : (pqx_ok ? (cfg->normalize_obs ? 5 : 4) : 3);
             e->waves_single = pqx_ok ? 3 : 1;
         }
     }

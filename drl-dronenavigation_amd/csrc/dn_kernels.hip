@@ -2775,8 +2775,7 @@ __global__ __launch_bounds__(5 * DN_BLOCK) __attribute__((amdgpu_waves_per_eu(4,
 }
 
 // -----------------------------------------------------------------------------------------------------
-// Role-pipelined kernel (round 4; fused launches of the plain configuration without noise, <= 2 tiles per CU): six roles, eight with the
-// normaliser.
+// Role-pipelined kernel (round 4; fused launches of the plain configuration with the normaliser and without noise): eight roles.
 //
 // Per-role stamps of the four- / five-wave kernels (profiles/mw_stamps.py, profiles/r04_stamps_5w_4w.txt, r04_stamps_rp8.txt) showed what paces them: not the
 // recurrence waves L and A but Q (thrust of step t + 1, observation row and reward candidates of step t - 1: busy 2 450 cycles of a
@@ -2866,10 +2865,6 @@ DN_DEV void report_obs_cols(const DnParams &p, const DnConsts<R> &c, const StepO
 #define DN_RP_ORDER_A "LAEQTXMN"
 #define DN_RP_ORDER_B "EQLAMNTX"
 #endif
-#ifndef DN_RP6_ORDER_A
-#define DN_RP6_ORDER_A "LAEQTX"
-#define DN_RP6_ORDER_B "EQLXAT"
-#endif
 #ifndef DN_RP_PRIO
 #define DN_RP_PRIO "33211000"            // s_setprio of the roles L A T E Q X N1 N2
 #endif
@@ -2889,9 +2884,11 @@ DN_DEV void report_obs_cols(const DnParams &p, const DnConsts<R> &c, const StepO
 #else
 #define RP_TAKE_TURNS() do { } while (0)
 #endif
-template <typename R, bool NORM>
+template <typename R>
 DN_DEV void step_many_rp_body(const DnParams &p, const DnStepIO &io0, const int k_steps)
 {
+    constexpr bool NORM = true;                            // the eight-role cut exists with the normaliser only (a six-role form without it lost to
+                                                           // the four-wave kernel at every fleet size, 32 768 drones: 1.68 against 1.40 us per step, and was removed)
     __shared__ R s_tab[DN_MAX_WAYPOINTS * DN_T_STRIDE];
     __shared__ __attribute__((aligned(16))) RMailL<R> maill[2];
     __shared__ __attribute__((aligned(16))) RMailA<R> maila[2];
@@ -2904,8 +2901,8 @@ DN_DEV void step_many_rp_body(const DnParams &p, const DnStepIO &io0, const int 
     const int second_tile = (int)((blockIdx.x / (unsigned)p.num_cus) & 1u);
     // roles: 0 L, 1 A, 2 T, 3 E, 4 Q, 5 X, 6 N1 ('M'), 7 N2 ('N').  A workgroup's waves go to the SIMDs round-robin (wave w -> SIMD w % 4), so
     // SIMD s carries waves s and s + 4 of both tiles of its CU; the second tile takes another order so that the heavy pairs spread out.
-    constexpr char oa[9] = DN_RP_ORDER_A, ob[9] = DN_RP_ORDER_B, oa6[9] = DN_RP6_ORDER_A, ob6[9] = DN_RP6_ORDER_B;
-    const char ch = NORM ? (second_tile ? ob[wv0] : oa[wv0]) : (second_tile ? ob6[wv0] : oa6[wv0]);
+    constexpr char oa[9] = DN_RP_ORDER_A, ob[9] = DN_RP_ORDER_B;
+    const char ch = second_tile ? ob[wv0] : oa[wv0];
     const int role = ch == 'L' ? 0 : ch == 'A' ? 1 : ch == 'T' ? 2 : ch == 'E' ? 3 : ch == 'Q' ? 4 : ch == 'X' ? 5 : ch == 'M' ? 6 : 7;
     const long long tile_base = (long long)blockIdx.x * DN_BLOCK;
     const long long left = p.n - tile_base;
@@ -3191,11 +3188,6 @@ DN_DEV void step_many_rp_body(const DnParams &p, const DnStepIO &io0, const int 
                 fl.vex = fl.vey = fl.vez = fl.aex = fl.aey = fl.aez = 0.0f;    // prev_vel / prev_ang_v live on Q
                 const StepOut out = block_out(io0, tile_base, (long long)u * n, (long long)u * words);
                 report_scalars<R, false>(p, c, out, fl, v, r_normal, r_found32, li, lane, active, G4, G5, acc, rn);
-                if (!NORM) {
-                    const float4 ea = me.oa[lane], ca = mc.oa[lane];
-                    float o[DN_OBS_DIM] = {ca.x, ca.y, ca.z, ea.x, ea.y, ea.z, ca.w, cb.x, cb.y, ea.w, eb.x, eb.y, cb.z};
-                    report_obs_cols<R, false, 0, DN_OBS_DIM>(p, c, out, v.terminated != 0 || fl.truncated != 0, mc.r[3][lane], o, li, active, rms);
-                }
             }
             if (t <= k_steps) MW_BARRIER();                                // barrier t
         }
@@ -3256,12 +3248,7 @@ DN_DEV void step_many_rp_body(const DnParams &p, const DnStepIO &io0, const int 
 template <typename R>
 __global__ __launch_bounds__(8 * DN_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void dn_step_many_rp8_kernel(const DnParams p, const DnStepIO io0, const int k_steps)
 {
-    step_many_rp_body<R, true>(p, io0, k_steps);
-}
-template <typename R>
-__global__ __launch_bounds__(6 * DN_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 4))) void dn_step_many_rp6_kernel(const DnParams p, const DnStepIO io0, const int k_steps)
-{
-    step_many_rp_body<R, false>(p, io0, k_steps);
+    step_many_rp_body<R>(p, io0, k_steps);
 }
 
 // -----------------------------------------------------------------------------------------------------
@@ -3826,14 +3813,9 @@ hipError_t dn_launch_step_many_mw(const DnParams &p, const DnStepIO &io, int k, 
     const bool noise = p.act_noise_sigma > 0.0f || p.obs_noise_sigma > 0.0f;
     // the rarely used options share one set of instantiations (runtime switches inside): reward wrappers, N4 physics terms
     const bool rew = p.clip_rew != 0 || p.norm_rew != 0 || p.gnd != 0 || p.drag != 0 || p.rpm_actions != 0 || p.pid_mode != 0 || p.random_spawn != 0 || p.zero_damping != 0;
-    if ((waves == 8 || waves == 6) && k > 1 && !noise && !rew) {   // role-pipelined kernel (round 4): eight roles with the normaliser, six without
-        if (p.normalize_obs) {
-            if (f32) DN_KLAUNCH((dn_step_many_rp8_kernel<float>), dim3(grid), dim3(8 * DN_BLOCK), 0, stream, p, io, k);
-            else DN_KLAUNCH((dn_step_many_rp8_kernel<double>), dim3(grid), dim3(8 * DN_BLOCK), 0, stream, p, io, k);
-        } else {
-            if (f32) DN_KLAUNCH((dn_step_many_rp6_kernel<float>), dim3(grid), dim3(6 * DN_BLOCK), 0, stream, p, io, k);
-            else DN_KLAUNCH((dn_step_many_rp6_kernel<double>), dim3(grid), dim3(6 * DN_BLOCK), 0, stream, p, io, k);
-        }
+    if (waves == 8 && k > 1 && !noise && !rew && p.normalize_obs) {   // role-pipelined kernel (round 4): eight roles, normaliser on
+        if (f32) DN_KLAUNCH((dn_step_many_rp8_kernel<float>), dim3(grid), dim3(8 * DN_BLOCK), 0, stream, p, io, k);
+        else DN_KLAUNCH((dn_step_many_rp8_kernel<double>), dim3(grid), dim3(8 * DN_BLOCK), 0, stream, p, io, k);
         return hipGetLastError();
     }
     if (waves == 5 && k > 1) {                             // four waves + the normaliser's: fused launches of the plain configuration, normaliser on

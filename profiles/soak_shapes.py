@@ -33,7 +33,7 @@ while time.time() < t_end:
     os.environ["DN_WAVES"] = "1"
     ref = pkg.DroneVecEnv(tracks.REGISTRY[trk](), n, device=dev, **kw)
     del os.environ["DN_WAVES"]
-    forced = str(rng.choice(["", "", "2", "3", "4", "5", "8", "8", "6"]))  # the library's own pick, or a forced shape (5: five waves where the normaliser is on; 8 / 6: the role-pipelined kernel where it applies)
+    forced = str(rng.choice(["", "", "2", "3", "4", "5", "8", "8"]))  # the library's own pick, or a forced shape (5: five waves where the normaliser is on; 8: the role-pipelined kernel where it applies)
     if forced:
         os.environ["DN_WAVES"] = forced
     env = pkg.DroneVecEnv(tracks.REGISTRY[trk](), n, device=dev, **kw)

@@ -683,13 +683,13 @@ def test_kernel_shapes_are_bit_identical(norm, noise, monkeypatch):
     n, K = 1000, 70                       # ragged last tile on purpose
     kw = dict(normalize_obs=norm, max_steps=30, obs_noise_sigma=noise, act_noise_sigma=noise / 10, seed=5)
     envs = {}
-    rp = ("8" if norm else "6",) if noise == 0.0 else ()
+    rp = ("8",) if norm and noise == 0.0 else ()
     for shape in ("1", "2", "3", "4") + (("5",) if norm else ()) + rp:
         monkeypatch.setenv("DN_WAVES", shape)
         envs[shape] = pkg.DroneVecEnv(track, n, device="cuda:0", **kw)
         envs[shape].reset()
         # three waves: flight / report / aux; four: linear + rules / angular + attitude / observation / thrust + report (fused launches);
-        # five: the normaliser and the observation rows on a wave of their own; six / eight: the role-pipelined kernel (no noise)
+        # five: the normaliser and the observation rows on a wave of their own; eight: the role-pipelined kernel (normaliser on, no noise)
         assert envs[shape].kernel_waves(fused=True) == int(shape)
     monkeypatch.delenv("DN_WAVES")
     rng = np.random.default_rng(21)
@@ -1042,45 +1042,79 @@ def _step_mismatch(out, ref, obs_atol, rew_atol):
     return bad
 
 
-@pytest.mark.parametrize("norm,K", [(False, 64), (True, 20), (True, 64)])
-def test_baseline_full_size_fused_launch_matches_oracle(norm, K, monkeypatch):
-    """The bench's own launches -- 32768 drones, race track, K steps of U(-1,1)^4 actions in ONE dn_step_many, with the
-    normaliser on (the reference's configuration: the headline kernel, K = 20 is the driver's launch and 64 the default
-    line's) and off -- against the oracle, every drone, every step, every output; then the mixed stream.
+def _expected_fused_waves(env, n, norm):
+    """dn_create's pick for the plain configuration without noise (dn_capi.cpp): tiles per CU of THIS device decide."""
+    tiles, cus = (n + 63) // 64, env.num_cus
+    if not norm:
+        return 4 if tiles <= 3 * cus else None
+    if tiles <= cus or 2 * cus < tiles <= 3 * cus:
+        return 8                                          # the role-pipelined kernel: up to one tile per CU and from two to three
+    return 5 if tiles <= 3 * cus else None
 
-    Free-running: both sides keep their own float32 state, so a drone whose yaw or roll sits within rounding of +-pi comes out
-    on the other side of the atan2 branch cut (observation column +1 against -1: about one drone-step in 3e6) and the two copies of
-    THAT drone part ways, with the normaliser for the rest of the run.  Such drones are counted and dropped from the lockstep
-    comparison; at most 8 of the 32768 may go that way, every other drone has to match on every step."""
+
+@pytest.mark.parametrize("n,norm,K", [(32768, False, 64), (32768, True, 20), (32768, True, 64),
+                                      (4096, True, 64), (16384, True, 20), (16384, True, 64), (49152, True, 20), (49152, True, 64)])
+def test_baseline_full_size_fused_launch_matches_oracle(n, norm, K, monkeypatch):
+    """The bench's own launches -- race track, K steps of U(-1,1)^4 actions in ONE dn_step_many (K = 20 is the driver's launch, 64 the
+    default line's) -- against the oracle, every drone, every step, every output; then the mixed stream.  32 768 drones: the headline
+    size (five waves with the normaliser, four without); 4 096 / 16 384 / 49 152 drones with the normaliser: the sizes at which
+    dn_create picks the eight-role kernel, met here by the oracle DIRECTLY (long runs: the register-resident _current_position, second
+    episodes inside one launch), not only through bit-identity with the one-wave kernel.
+
+    Free-running: both sides keep their own float32 state, so a drone whose yaw or roll sits within rounding of +-pi comes out on the
+    other side of the atan2 branch cut (observation column +1 against -1: about one drone-step in 3e6) and the two copies of THAT drone
+    part ways, with the normaliser for the rest of the run.  A drone may leave the lockstep comparison ONLY for that cause: at its first
+    mismatch the oracle's raw roll or yaw column (an un-normalised twin of the oracle is stepped beside it for this) must sit within
+    1e-5 of +-1, or its pitch column within 1e-2 of +-1/2: within 1.8 degrees of the gimbal-lock attitude roll and yaw are atan2 of two
+    numbers of size cos(pitch) < 0.03, so a one-ulp difference in the stored quaternion comes out > 30 times larger in those columns
+    (seen: pitch column 0.4966, yaw off by 1e-4 after the normaliser's 1 / std).  Any other first mismatch fails the test, and at most 8
+    drones in 32 768 may go that way."""
     monkeypatch.delenv("DN_WAVES", raising=False)         # the bench's shape is the library's own pick
     track = _tracks().reaching()
-    n = 32768
     env, ora = make_pair(track, n, f32_state=True, max_steps=4096, normalize_obs=norm)
-    assert env.kernel_waves(fused=True) == _bench_fused_waves(norm)
+    want = _expected_fused_waves(env, n, norm)
+    assert want is not None and env.kernel_waves(fused=True) == want, (env.kernel_waves(fused=True), want, env.num_cus)
+    if n == 32768:
+        assert want == _bench_fused_waves(norm)           # the headline's kernel
+    raw = ora
+    if norm:                                              # the un-normalised twin: same dynamics (the normaliser feeds nothing back), raw angle columns
+        env_r, raw = make_pair(track, n, f32_state=True, max_steps=4096, normalize_obs=False)
+        env_r.close()
+        raw.reset()
     np.testing.assert_allclose(env.reset_tensor().cpu().numpy(), ora.reset(), rtol=0, atol=1e-6)
     rng = np.random.default_rng(64)
     dev = torch.device("cuda:0")
     n_done = 0
     lock = np.ones(n, bool)                               # drones still in lockstep
-    for stream, launches in (("uniform", -(-100 // K)), ("mixed", 1)):     # >= 100 uniform steps: crashes, resets, second episodes
+    gpu_episodes = 0
+    for stream, launches in (("uniform", -(-160 // K)), ("mixed", 1)):     # >= 160 uniform steps: crashes, resets, second episodes
         for rep in range(launches):
             acts = np.stack([rng.uniform(-1, 1, (n, 4)).astype(np.float32) if stream == "uniform" else actions_mixed(rng, n)
                              for _ in range(K)])
             out = env.rollout_tensor(torch.from_numpy(acts).to(dev), want_terminal=True)
             torch.cuda.synchronize()
+            gpu_episodes += int(out["done"].sum())
             for t in range(K):
                 info = dict(truncated=out["truncated"][t], found_targets=out["found_targets"][t], terminal_obs=out["terminal_obs"][t],
                             ep_length=out["ep_length"][t], ep_return=out["ep_return"][t])
                 ref = ora.step(acts[t])
+                ref_raw = raw.step(acts[t]) if norm else ref
                 # a one-ulp difference in a stored attitude is amplified by a tumbling drone, one observation in 4e5 reaches
                 # 1.3e-5 -- the per-step bar (1e-5) is the teacher-forced tests'
                 bad = _step_mismatch((out["obs"][t], out["reward"][t], out["done"][t], info), ref, obs_atol=1e-4, rew_atol=2e-4)
+                first = bad & lock
+                if first.any():
+                    row = np.where(ref_raw["done"].astype(bool)[:, None], ref_raw["terminal_obs"], ref_raw["obs"])[first].astype(np.float64)
+                    at_cut = (np.abs(np.abs(row[:, 3]) - 1.0) <= 1e-5) | (np.abs(np.abs(row[:, 5]) - 1.0) <= 1e-5) | \
+                             (np.abs(np.abs(row[:, 4]) - 0.5) <= 1e-2)
+                    assert at_cut.all(), (f"fused n={n} norm={norm} {stream} launch {rep} t={t}: drones {np.flatnonzero(first)[~at_cut][:8]} left lockstep "
+                                          f"away from an atan2 branch cut (raw roll / pitch / yaw columns {row[~at_cut][:4, 3:6]})")
                 lock &= ~bad
-                assert (~lock).sum() <= 8, f"fused full-size norm={norm} {stream} launch {rep} t={t}: {int((~lock).sum())} drones out of lockstep"
+                assert (~lock).sum() <= max(8, n // 4096), f"fused n={n} norm={norm} {stream} launch {rep} t={t}: {int((~lock).sum())} drones out of lockstep"
                 n_done += int((ref["done"].astype(bool) & lock).sum())
-    assert n_done > n // 8
-    assert abs(env.stats()["episodes"] - n_done) <= 40 * int((~lock).sum())
-    print(f"fused full-size norm={norm} K={K}: {n_done} episodes compared, {int((~lock).sum())} drones dropped at a branch cut")
+    assert n_done > n // 2
+    assert env.stats()["episodes"] == gpu_episodes       # the statistics slot counts exactly the done flags the launches returned
+    print(f"fused n={n} norm={norm} K={K}: {n_done} episodes compared, {int((~lock).sum())} drones dropped at a branch cut")
     env.close()
 
 
@@ -1413,14 +1447,14 @@ def test_nan_actions_propagate_like_numpy():
     env.close()
 
 
-@pytest.mark.parametrize("waves", ["3", "4", "5", "6", "8"])
+@pytest.mark.parametrize("waves", ["3", "4", "5", "8"])
 @pytest.mark.parametrize("n,K", [(12, 2), (64, 3), (100, 5), (4096, 2), (100, 1), (4096, 1)])
 def test_three_wave_kernel_short_rollouts_and_ragged_tiles(n, K, waves, monkeypatch):
     """The three- and four-wave kernels trail their report wave two steps behind the flight wave(s): rollouts shorter than
     the skew, a single ragged tile and one drone short of a tile must still match the one-wave kernel bit for bit."""
     pkg = _gpu()
     track = _tracks().reaching()
-    kw = dict(normalize_obs=waves in ("5", "8"), max_steps=4)    # the fifth wave is the normaliser's; eight roles: with it, six: without
+    kw = dict(normalize_obs=waves in ("5", "8"), max_steps=4)    # the fifth wave is the normaliser's; the eight roles exist with it only
     monkeypatch.setenv("DN_WAVES", "1")
     ref = pkg.DroneVecEnv(track, n, device="cuda:0", **kw)
     monkeypatch.setenv("DN_WAVES", waves)
