@@ -95,6 +95,30 @@ def issue_evidence(kernel):
     return dict(ev, kernel=kernel) if ev else None
 
 
+SHADER_CLOCK_GHZ_UNDER_LOAD = 2.14      # shader clock while the fused step runs: 74 504 cycles (s_memtime) in 34.84 us of the 100 MHz wall clock,
+                                        # stamped build of the five-wave kernel (profiles/r05_notes.md section 4)
+
+
+def valu_bound(kernel, n, steps_per_launch, us_per_step, num_cus=256):
+    """The bound that governs the fused step at 32 768 drones, from the committed SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU pass of the
+    kernel that was timed (profiles/instmix.json, re-keyed every round): instructions per 64-drone tile-step x ALU cycles per
+    instruction x tiles per CU / 4 SIMDs / shader clock = the time a step would take if the vector ALUs never idled."""
+    ev = issue_evidence(kernel)
+    if not ev or "alu_cycles_per_valu_instruction" not in ev:
+        return None
+    src = ev.get("driver_launch_k20") if steps_per_launch == 20 and ev.get("driver_launch_k20") else ev
+    insts = src["valu_instructions_per_64_drone_step"]
+    cyc = src["alu_cycles_per_valu_instruction"]
+    tiles_per_cu = ((n + 63) // 64) / num_cus
+    floor_us = tiles_per_cu * insts * cyc / 4.0 / (SHADER_CLOCK_GHZ_UNDER_LOAD * 1e3)
+    return {"valu_insts_per_tile_step": insts, "valu_cycles_per_inst": cyc, "tiles_per_cu": round(tiles_per_cu, 3),
+            "shader_clock_ghz": SHADER_CLOCK_GHZ_UNDER_LOAD,
+            "valu_floor_us_per_step": round(floor_us, 4), "valu_frac": round(floor_us / us_per_step, 4),
+            "counters_from": ("profiles/r05_instmix_k20.txt (the driver's own 20-step launch)" if src is not ev else ev.get("source")),
+            "what": "vector-ALU floor = tiles per CU x instructions per tile-step x ALU cycles per instruction / 4 SIMDs / shader clock; "
+                    "valu_frac = floor / measured time per step (the fraction of the step during which the vector ALUs are busy)"}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -689,55 +713,6 @@ def main():
         except Exception as exc:  # noqa: BLE001
             norm_leg = {"error": f"{type(exc).__name__}: {exc}"}
 
-    # where HBM IS the bound: the same step kernel over a fleet that fills the chip many times over (one wave per 64 drones,
-    # 32768 workgroups), one control step per launch -- the regime the byte model of SURVEY 8(d) describes
-    def hbm_bound_leg(norm_l):
-        nl = 2097152
-        torch.cuda.empty_cache()                              # 1.7 GB of buffers for this leg: from a compact allocator state, not from the holes the earlier legs left
-        env_l = pkg.DroneVecEnv(track, nl, max_steps=max_steps, normalize_obs=norm_l, compute_dtype=args.compute_dtype, device=dev)
-        env_l.reset_tensor()
-        gl = torch.Generator(device="cpu").manual_seed(7)
-        acts_l = (torch.rand((2, nl, 4), generator=gl, dtype=torch.float32) * 2 - 1).to(dev)
-        for t in range(20):
-            env_l.step_tensor(acts_l[t & 1])
-        e0_, e1_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize(dev)
-        e0_.record(stream)
-        reps_l = 200
-        for t in range(reps_l):
-            env_l.step_tensor(acts_l[t & 1])
-        e1_.record(stream)
-        torch.cuda.synchronize(dev)
-        us_l = e0_.elapsed_time(e1_) * 1e3 / reps_l
-        bytes_l = (ALGO_BYTES_PER_ENV_STEP + (ALGO_BYTES_NORMALISER if norm_l else 0)) * nl
-        wv_l = env_l.kernel_waves(fused=False)
-        traffic_l, src_l = traffic_per_launch(args.track, nl, args.compute_dtype, norm_l, 0, wv_l)
-        d = {"num_envs": nl, "kernel": kernel_name(wv_l, args.compute_dtype, norm_l, False),
-             "us_per_vector_step": round(us_l, 3), "value": round(nl / (us_l * 1e-6), 1), "unit": "env-steps/s",
-             "algorithmic_bytes_per_launch": bytes_l, "achieved_GBps": round(bytes_l / (us_l * 1e-6) / 1e9, 1),
-             "frac": round(bytes_l / (us_l * 1e-6) / 1e9 / HBM_PEAK_GBPS, 5),
-             "traffic": traffic_l, "traffic_source": src_l,
-             "traffic_ratio": (round(traffic_l / bytes_l, 4) if traffic_l else None),
-             "what": ("2 097 152 drones, one control step per launch, per-drone NormalizeObservation ON as the reference runs it "
-                      "(PBDroneSimulator.py:181): 288 + 432 = 720 B per drone-step, the regime in which the step IS bandwidth bound"
-                      if norm_l else
-                      "2 097 152 drones, one control step per launch, normaliser off (288 B per drone-step; the reference never runs it this way)")}
-        env_l.close()
-        del acts_l
-        return d
-
-    large = large_norm = None
-    if world == 1 and not args.profile_lite:
-        for norm_l in (True, False):
-            try:
-                d_l = hbm_bound_leg(norm_l)
-            except Exception as exc:  # noqa: BLE001
-                d_l = {"error": f"{type(exc).__name__}: {exc}"}
-            if norm_l:
-                large_norm = d_l
-            else:
-                large = d_l
-
     # a measured stream-copy ceiling of THIS box beside the nominal 8 TB/s (a device-to-device copy of 1 GiB: read + write)
     copy_ceiling = None
     if world == 1 and not args.profile_lite:
@@ -768,6 +743,65 @@ def main():
             del src, dst
         except Exception as exc:  # noqa: BLE001
             copy_ceiling = {"error": f"{type(exc).__name__}: {exc}"}
+
+    # where HBM IS the bound: the same step kernel over a fleet that fills the chip many times over (one wave per 64 drones,
+    # 32768 workgroups), one control step per launch -- the regime the byte model of SURVEY 8(d) describes
+    def hbm_bound_leg(norm_l):
+        nl = 2097152
+        torch.cuda.empty_cache()                              # 1.7 GB of buffers for this leg: from a compact allocator state, not from the holes the earlier legs left
+        env_l = pkg.DroneVecEnv(track, nl, max_steps=max_steps, normalize_obs=norm_l, compute_dtype=args.compute_dtype, device=dev)
+        env_l.reset_tensor()
+        gl = torch.Generator(device="cpu").manual_seed(7)
+        acts_l = (torch.rand((2, nl, 4), generator=gl, dtype=torch.float32) * 2 - 1).to(dev)
+        for t in range(20):
+            env_l.step_tensor(acts_l[t & 1])
+        e0_, e1_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(dev)
+        e0_.record(stream)
+        reps_l = 100
+        for t in range(reps_l):
+            env_l.step_tensor(acts_l[t & 1])
+        e1_.record(stream)
+        torch.cuda.synchronize(dev)
+        us_python = e0_.elapsed_time(e1_) * 1e3 / reps_l      # eager Python loop: the host's launch gaps are inside (side key only)
+        flip = [0]
+
+        def one_step():
+            flip[0] ^= 1
+            env_l.step_tensor(acts_l[flip[0]])
+        us_l = time_launches(torch, dev, one_step, reps=100, warm=4)   # the DEVICE timeline: 100 dn_step launches replayed from one hipGraph
+        bytes_l = (ALGO_BYTES_PER_ENV_STEP + (ALGO_BYTES_NORMALISER if norm_l else 0)) * nl
+        wv_l = env_l.kernel_waves(fused=False)
+        traffic_l, src_l = traffic_per_launch(args.track, nl, args.compute_dtype, norm_l, 0, wv_l)
+        d = {"num_envs": nl, "kernel": kernel_name(wv_l, args.compute_dtype, norm_l, False),
+             "us_per_vector_step": round(us_l, 3), "value": round(nl / (us_l * 1e-6), 1), "unit": "env-steps/s",
+             "algorithmic_bytes_per_launch": bytes_l, "achieved_GBps": round(bytes_l / (us_l * 1e-6) / 1e9, 1),
+             "frac": round(bytes_l / (us_l * 1e-6) / 1e9 / HBM_PEAK_GBPS, 5),
+             "frac_of_copy_ceiling": (round(bytes_l / (us_l * 1e-6) / 1e9 / copy_ceiling["GBps"], 4)
+                                      if copy_ceiling and "GBps" in copy_ceiling else None),
+             "timed_with": "100 dn_step launches captured once into a hipGraph and replayed between two HIP events (device timeline; best of 3)",
+             "python_loop_us_per_vector_step": round(us_python, 3),
+             "traffic": traffic_l, "traffic_source": src_l,
+             "traffic_ratio": (round(traffic_l / bytes_l, 4) if traffic_l else None),
+             "what": ("2 097 152 drones, one control step per launch, per-drone NormalizeObservation ON as the reference runs it "
+                      "(PBDroneSimulator.py:181): 288 + 432 = 720 B per drone-step, the regime in which the step IS bandwidth bound"
+                      if norm_l else
+                      "2 097 152 drones, one control step per launch, normaliser off (288 B per drone-step; the reference never runs it this way)")}
+        env_l.close()
+        del acts_l
+        return d
+
+    large = large_norm = None
+    if world == 1 and not args.profile_lite:
+        for norm_l in (True, False):
+            try:
+                d_l = hbm_bound_leg(norm_l)
+            except Exception as exc:  # noqa: BLE001
+                d_l = {"error": f"{type(exc).__name__}: {exc}"}
+            if norm_l:
+                large_norm = d_l
+            else:
+                large = d_l
 
     # the SB3 NumPy surface (PCIe-inclusive: H2D actions, D2H obs/reward/done/found, N info dicts built in Python);
     # host bound, reported for the record only
@@ -840,9 +874,11 @@ def main():
                                                   "its own dispatch (dn_set_launch_events -> hipExtLaunchKernelGGL): the kernel's duration as "
                                                   "rocprofv3 --kernel-trace reports it"} if kernel_only_us else None),
                          "note": "at 32768 drones neither launch shape is bandwidth bound: with two tiles per CU the fused launch is bound by the vector ALUs "
-                                 "(float64 instructions occupy a SIMD's ALU 4 cycles each; ~1 100 vector instructions per tile-step: issue_bound_evidence, "
-                                 "profiles/r04_notes.md), with one tile per CU by the role with the longest instruction stream; the single-step launch is "
-                                 "bound by load + launch latency (DESIGN.md 4, profiles/r03_pqx_stamps.txt)",
+                                 "(`valu`: ~1 100 vector instructions per tile-step at 4.3 ALU cycles each, and a SIMD with 2.5 waves delivers 70-80 % of its "
+                                 "float64 rate: profiles/r05_notes.md, profiles/r05_valu_throughput.txt), with one tile per CU by the role with the longest "
+                                 "instruction stream; the single-step launch is bound by load + launch latency (DESIGN.md 4, profiles/r03_pqx_stamps.txt)",
+                         "valu": (valu_bound(kernel_name(wv, args.compute_dtype, args.normalize_obs, args.mode == "many"), n, steps_per_launch,
+                                             (kernel_only_us / K) if kernel_only_us else step_us, env.num_cus) if args.mode == "many" else None),
                          "issue_bound_evidence": issue_evidence(kernel_name(wv, args.compute_dtype, args.normalize_obs, args.mode == "many"))},
             "single_step": single_step,
             ("normalize_obs_on" if other_norm else "normalize_obs_off"): norm_leg,

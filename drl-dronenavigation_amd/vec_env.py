@@ -79,6 +79,22 @@ class _SparseInfo(dict):
     def __len__(self):
         return len(self.keys())
 
+    # A caller that KEEPS an info (copy, deepcopy, pickle into a replay buffer or across a process boundary) gets a plain dict with
+    # every key materialised -- a snapshot of this step -- and never the live view, whose answers change with the next step and
+    # whose `_env` reaches the whole DroneVecEnv (ctypes handle, CUDA tensors).
+    def copy(self):
+        return {k: self[k] for k in self.keys()}
+
+    def __copy__(self):
+        return self.copy()
+
+    def __deepcopy__(self, memo):
+        import copy as _copy
+        return {k: _copy.deepcopy(self[k], memo) for k in self.keys()}
+
+    def __reduce__(self):
+        return (dict, (self.copy(),))
+
 
 # enums.Physics / enums.ActionType values of the reference (Sol/PyBullet/enums.py:12-21, :36-44) -> dn_config codes.
 # The reference only ever runs "pyb" + "thrust" (BaseAviary.py:411 pins the physics); the others are its dormant options.
@@ -137,7 +153,14 @@ def make_config(*, num_envs, target_points, initial_xyzs, aviary_dim, threshold=
 
 
 class DroneVecEnv(_VecEnvBase):
-    """N drones on one MI355X behind the SB3 VecEnv API."""
+    """N drones on one MI355X behind the SB3 VecEnv API.
+
+    `info_mode="sparse"` (the default): step() returns ONE persistent list of per-drone info views that answer `found_targets` and
+    `TimeLimit.truncated` from the CURRENT step's host arrays and are refilled by the next step -- an `infos[i]` kept across steps
+    changes under its holder; `infos[i].copy()`, `copy.deepcopy(infos[i])` and pickling give a plain dict snapshot of the step.
+    `info_mode="full"` builds a fresh plain dict per drone and step, exactly what SubprocVecEnv returns (6-10x the host time at
+    32 768 drones).  Observation noise (obs_noise_sigma > 0; the reference has none) is drawn with hardware float32 transcendentals:
+    reproducible on one GPU generation, not part of the bit-exact contract (include/dronenav.h)."""
 
     metadata = {"render_modes": []}
 
@@ -226,28 +249,17 @@ class DroneVecEnv(_VecEnvBase):
                 total += (int(np.prod(shape)) * torch.empty((), dtype=dt).element_size() + 255) // 256 * 256
             self._out_blob = torch.zeros(total, dtype=torch.uint8, device=dev)
             self._front_bytes = offs["_packed"] + self._pack_prefix * 64
-            host_bytes = offs["_term_obs"]                     # the mirror covers the front part and all packed rows
-            self._mirrors = []
-            for _ in range(1 if self.fresh_arrays else 2):
-                try:
-                    blob = torch.zeros(host_bytes, dtype=torch.uint8, pin_memory=True)
-                except RuntimeError:                           # no pinned memory to be had: a pageable mirror still works
-                    blob = torch.zeros(host_bytes, dtype=torch.uint8)
-                views = {"blob": blob}
-                for name, shape, dt in fields:
-                    off = offs[name]
-                    nbytes = int(np.prod(shape)) * torch.empty((), dtype=dt).element_size()
-                    if off < host_bytes:
-                        views["_h" + name] = blob[off:off + nbytes].view(dt).view(shape).numpy()
-                views["_h_packed_i32"] = views["_h_packed"].view(np.int32)
-                self._mirrors.append(views)
+            # the pinned host mirrors of the front part (+ all packed rows) belong to the NumPy surface only: they are allocated by the first
+            # step_async() (_ensure_mirrors), so that the tensor API -- bench.py's 2 M-drone legs, the collectors -- never pays for them
+            # (2 097 152 drones: 260 MB of pinned memory, twice that with fresh_arrays=False)
+            self._mirror_layout = (fields, offs, offs["_term_obs"])
+            self._mirrors = None
             for name, shape, dt in fields:
                 off = offs[name]
                 nbytes = int(np.prod(shape)) * torch.empty((), dtype=dt).element_size()
                 setattr(self, name, self._out_blob[off:off + nbytes].view(dt).view(shape))
             self._packed_off = offs["_packed"]
             self._mirror_i = 0
-            self._use_mirror(0)
             self._done_mask = torch.zeros((n + 63) // 64, dtype=torch.int64, device=dev)
         self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self._ptrs = ((self._obs.data_ptr(), self._reward.data_ptr(), self._done.data_ptr(), self._trunc.data_ptr(),
@@ -260,6 +272,26 @@ class DroneVecEnv(_VecEnvBase):
         self._infos = None                     # sparse info mode: one persistent list of _SparseInfo, built on first use
         self._dirty = []                       # sparse info mode: the dicts filled by the previous step
         self._closed = False
+
+    def _ensure_mirrors(self):
+        if self._mirrors is not None:
+            return
+        fields, offs, host_bytes = self._mirror_layout
+        self._mirrors = []
+        for _ in range(1 if self.fresh_arrays else 2):
+            try:
+                blob = torch.zeros(host_bytes, dtype=torch.uint8, pin_memory=True)
+            except RuntimeError:                               # no pinned memory to be had: a pageable mirror still works
+                blob = torch.zeros(host_bytes, dtype=torch.uint8)
+            views = {"blob": blob}
+            for name, shape, dt in fields:
+                off = offs[name]
+                nbytes = int(np.prod(shape)) * torch.empty((), dtype=dt).element_size()
+                if off < host_bytes:
+                    views["_h" + name] = blob[off:off + nbytes].view(dt).view(shape).numpy()
+            views["_h_packed_i32"] = views["_h_packed"].view(np.int32)
+            self._mirrors.append(views)
+        self._use_mirror(0)
 
     def _use_mirror(self, i):
         self._mirror_i = i
@@ -366,6 +398,7 @@ class DroneVecEnv(_VecEnvBase):
         return obs
 
     def step_async(self, actions):
+        self._ensure_mirrors()
         a = np.ascontiguousarray(actions, dtype=np.float32).reshape(self.num_envs, ACT_DIM)
         self._actions.copy_(torch.from_numpy(a), non_blocking=False)
         self._launch(self._actions)

@@ -234,14 +234,19 @@ int32_t dn_reset_stats(dn_env *env, void *stream);
 /* Kernel shape chosen for this environment's launches (fused != 0: dn_step_many with k > 1; fused == 0: dn_step), as waves
  * per 64-drone tile.  Fused: 8 = the role-pipelined kernel (thrust | linear + flags | angular | attitude | distance bookkeeping +
  * reward terms | scalars | the normaliser's two column halves; plain configuration with normalize_obs, no noise: up to 1 tile per CU
- * and from 2 to 3 tiles per CU), 6 = the same without the normaliser's roles (DN_WAVES=6 only: it loses to 4), 5 = the four-wave shape
+ * and from 2 to 3 tiles per CU), 5 = the four-wave shape
  * with the observation normaliser on a wave of its own (normalize_obs in the plain configuration, 1 to 2 tiles per CU -- 32 768 drones
  * on 256 CUs -- and with noise up to 3), 4 = the recurrence itself on two waves (linear + rules | angular + attitude) plus an observation
  * and a report wave (plain configuration up to 3 tiles per CU), 3 = flight + report + aux wave, 2 = a flight wave + a report wave
  * (mid-size fleets with the optional terms, where more waves cost occupancy), 1 = one wave.
  * Single step: 3 = three waves cut by dependency (dn_step_pqx_kernel, plain configuration up to 4 tiles per CU), 1 = one wave.
  * The multi-wave shapes win while the tiles alone leave SIMDs idle; crossovers are tiles per CU (dn_get_num_cus).  All shapes
- * produce identical bits.  Environment variables DN_WAVES=1|2|3|4|5|6|8 and DN_WAVES_SINGLE=1|3 (read by dn_create) force a shape. */
+ * produce identical bits -- on one device: the observation-noise draws (obs_noise_sigma > 0; 13 of a noisy step's 17 normals) use the
+ * hardware's float32 log2 / sqrt / sin / cos (within 1.2e-6 of the float64 definition, tests/test_gpu_parity.py::
+ * test_observation_noise_draws_match_their_definition), so noisy runs are bit-reproducible across kernel shapes, launches and shards
+ * of one GPU generation, not across generations or against a CPU evaluation; everything that feeds the dynamics (action noise, policy
+ * sampling, random spawn) and the whole noise-free configuration is exact arithmetic.
+ * Environment variables DN_WAVES=1|2|3|4|5|8 and DN_WAVES_SINGLE=1|3 (read by dn_create) force a shape. */
 int32_t dn_get_kernel_waves(const dn_env *env, int32_t fused);
 
 /* Vector-step counter: the Philox counter word of the noise streams and the source of dn_stats.env_steps.  It

@@ -13,7 +13,7 @@ i=0
 FAILED=""
 for pair in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU" "SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS" "SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
             "SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_LDS SQ_INSTS_BRANCH" "SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64" "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_CVT" \
-            "SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_TRANS_F32"; do
+            "SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_TRANS_F32" "SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VMEM_WR" "GRBM_GUI_ACTIVE GRBM_COUNT"; do
     i=$((i+1))
     rocprofv3 --kernel-trace --pmc $pair -d "$OUT/p$i" -o p$i -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-ppo-rollout --profile-lite "$@" > "$OUT/bench_p$i.log" 2>&1 || FAILED="$FAILED p$i($pair)"
 done
