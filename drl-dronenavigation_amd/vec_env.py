@@ -291,6 +291,15 @@ class DroneVecEnv(_VecEnvBase):
                     views["_h" + name] = blob[off:off + nbytes].view(dt).view(shape).numpy()
             views["_h_packed_i32"] = views["_h_packed"].view(np.int32)
             self._mirrors.append(views)
+        # the actions' way in: one pinned staging buffer, filled by a host memcpy and sent with an asynchronous copy on the step's stream (a
+        # copy from the caller's pageable array goes through the runtime's own staging and blocks; measured: 195 against 204 us per step with
+        # reused host buffers at 32 768 drones, nothing with fresh arrays);
+        # step_wait() synchronises the stream before the next step_async() can overwrite it
+        try:
+            self._h_actions = torch.zeros((self.num_envs, ACT_DIM), dtype=torch.float32, pin_memory=True)
+        except RuntimeError:
+            self._h_actions = torch.zeros((self.num_envs, ACT_DIM), dtype=torch.float32)
+        self._h_actions_np = self._h_actions.numpy()
         self._use_mirror(0)
 
     def _use_mirror(self, i):
@@ -399,8 +408,9 @@ class DroneVecEnv(_VecEnvBase):
 
     def step_async(self, actions):
         self._ensure_mirrors()
-        a = np.ascontiguousarray(actions, dtype=np.float32).reshape(self.num_envs, ACT_DIM)
-        self._actions.copy_(torch.from_numpy(a), non_blocking=False)
+        np.copyto(self._h_actions_np, np.asarray(actions, dtype=np.float32).reshape(self.num_envs, ACT_DIM))
+        with torch.cuda.device(self.device):
+            self._actions.copy_(self._h_actions, non_blocking=True)
         self._launch(self._actions)
         with torch.cuda.device(self.device):                   # finished drones: ordered indices + one 64-byte record each
             _capi.check(self._lib.dn_pack_done(self._done_mask.data_ptr(), self.num_envs, self._term_obs.data_ptr(), self._ep_ret.data_ptr(),
