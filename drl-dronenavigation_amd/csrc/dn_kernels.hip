@@ -2506,10 +2506,11 @@ __device__ long long g_mw_stamp[8][48][2];
 #endif
 #define MW_BARRIER() do { MW_MARK(0); block_lds_barrier(); MW_MARK(1); } while (0)
 #ifdef DN_MW_STAMP
-__device__ long long g_mw_edge[8][8];    // per role: cycles at entry, after barrier P, --, at exit; wall clock (100 MHz) at entry / exit; HW_ID
-#define MW_EDGE(k) do { if (lane == 0 && blockIdx.x == DN_MW_STAMP) { g_mw_edge[role][k] = (long long)__builtin_readcyclecounter(); \
-        if ((k) == 0) { g_mw_edge[role][4] = (long long)wall_clock64(); g_mw_edge[role][6] = (long long)__builtin_amdgcn_s_getreg(63492); } \
-        if ((k) == 3) g_mw_edge[role][5] = (long long)wall_clock64(); } } while (0)
+__device__ long long g_mw_edge[16][8];    // per role: cycles at entry, after barrier P, --, at exit; wall clock (100 MHz) at entry / exit; HW_ID
+#define MW_EDGE(k) do { if (lane == 0 && (blockIdx.x == DN_MW_STAMP || blockIdx.x == DN_MW_STAMP + 256)) { const int r_ = role + (blockIdx.x == DN_MW_STAMP ? 0 : 8); \
+        g_mw_edge[r_][k] = (long long)__builtin_readcyclecounter(); \
+        if ((k) == 0) { g_mw_edge[r_][4] = (long long)wall_clock64(); g_mw_edge[r_][6] = (long long)__builtin_amdgcn_s_getreg(63492); } \
+        if ((k) == 3) g_mw_edge[r_][5] = (long long)wall_clock64(); } } while (0)
 #else
 #define MW_EDGE(k) do { } while (0)
 #endif
@@ -3868,7 +3869,7 @@ hipError_t dn_launch_step_many_mw(const DnParams &p, const DnStepIO &io, int k, 
 extern "C" int dn_debug_mw_edges(long long *out)
 {
     if (hipDeviceSynchronize() != hipSuccess) return 1;
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mw_edge), sizeof(long long) * 64) == hipSuccess ? 0 : 1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mw_edge), sizeof(long long) * 128) == hipSuccess ? 0 : 1;
 }
 extern "C" int dn_debug_mw_stamps(long long *out)
 {
