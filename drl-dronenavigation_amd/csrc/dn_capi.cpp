@@ -427,6 +427,10 @@ int32_t dn_create(const dn_config *cfg, dn_env **out)
     p.pid_mode = pid_mode;
     p.random_spawn = cfg->random_spawn != 0;
     p.zero_damping = cfg->zero_damping != 0;
+    {   // DN_EXACT_OBS_NOISE=1: observation noise in the exact float64 Box-Muller form (reproducible across GPU generations; ~10 % slower noisy steps)
+        const char *x = getenv("DN_EXACT_OBS_NOISE");
+        p.exact_obs_noise = (x && x[0] == '1') ? 1 : 0;
+    }
     p.act_noise_sigma = cfg->act_noise_sigma; p.obs_noise_sigma = cfg->obs_noise_sigma;
     p.seed = cfg->seed; p.env_id_offset = cfg->env_id_offset;
     build_consts<double>(*cfg, p.c64);

@@ -105,6 +105,7 @@ struct DnParams {
     int random_spawn;               // N4: episodes start at a Philox-drawn point around a random track line
     int zero_damping;               // N4: changeDynamics(linearDamping=0, angularDamping=0), BaseAviary.py:571-573 (commented out there)
     float act_noise_sigma, obs_noise_sigma;
+    int exact_obs_noise;            // DN_EXACT_OBS_NOISE=1 (read by dn_create): the observation-noise draws in the exact float64 form as well
     unsigned long long seed;
     long long env_id_offset;
     const double *tab64;   // [W][DN_T_STRIDE] float64 table

@@ -297,6 +297,20 @@ DN_DEV void noise4(unsigned long long seed, unsigned long long gid, unsigned lon
     if (EXACT) { box_muller_pair64(r[0], r[1], z[0], z[1]); box_muller_pair64(r[2], r[3], z[2], z[3]); }
     else { box_muller_pair32(r[0], r[1], z[0], z[1]); box_muller_pair32(r[2], r[3], z[2], z[3]); }
 }
+// The observation noise's draws: the float32 form, or -- DN_EXACT_OBS_NOISE=1, for runs that must replay bit for bit on another GPU generation
+// or against the CPU definition -- the exact form the dynamics-feeding draws always use (one wave-uniform branch; ~3x the instructions a pair).
+DN_DEV void obs_pair(const DnParams &p, const unsigned ra, const unsigned rb, float &z0, float &z1)
+{
+    if (p.exact_obs_noise) box_muller_pair64(ra, rb, z0, z1);
+    else box_muller_pair32(ra, rb, z0, z1);
+}
+DN_DEV void obs_noise4(const DnParams &p, unsigned long long gid, unsigned long long step, unsigned stream, float z[4])
+{
+    unsigned r[4];
+    philox4x32((unsigned)gid, (unsigned)(gid >> 32), (unsigned)step, stream | ((unsigned)(step >> 32) << 8), (unsigned)p.seed, (unsigned)(p.seed >> 32), r);
+    obs_pair(p, r[0], r[1], z[0], z[1]);
+    obs_pair(p, r[2], r[3], z[2], z[3]);
+}
 DN_DEV void add_act_noise(const DnParams &p, unsigned long long gid, unsigned long long step, float a[4])
 {   // float32, unfused (its own function: the fused-multiply-add licence of step_body must not reach it)
     float z[4];
@@ -321,7 +335,7 @@ DN_DEV void add_obs_noise(const DnParams &p, unsigned long long gid, unsigned lo
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
         float z[4];
-        noise4<false>(p.seed, gid, step, stream0 + (unsigned)b, z);
+        obs_noise4(p, gid, step, stream0 + (unsigned)b, z);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             if (4 * b + j < DN_OBS_DIM) {
@@ -353,7 +367,7 @@ DN_DEV void draw_obs_noise_across(const DnParams &p, const unsigned long long gi
         philox4x32((unsigned)gid, (unsigned)(gid >> 32), (unsigned)step, (stream0 + (pr >> 1)) | ((unsigned)(step >> 32) << 8), (unsigned)p.seed,
                    (unsigned)(p.seed >> 32), r);
         float z0, z1;
-        box_muller_pair32((pr & 1u) ? r[2] : r[0], (pr & 1u) ? r[3] : r[1], z0, z1);
+        obs_pair(p, (pr & 1u) ? r[2] : r[0], (pr & 1u) ? r[3] : r[1], z0, z1);
         if (work) {
             scratch[(2u * pr) * DN_BLOCK + d] = z0;
             scratch[(2u * pr + 1u) * DN_BLOCK + d] = z1;
@@ -3373,8 +3387,8 @@ DN_DEV void pqx_step(const DnParams &p, const DnStepIO &io0, PqxShared<R> &sh, c
             // and B3 -- where the observation exists -- their seven Box-Muller pairs were ~1.7 us of the tile's critical path; here
             // P (columns 8..12) and Q (columns 0..7) draw them while X draws the action's and computes the thrust.
             float z[4], z4[4];
-            noise4<false>(p.seed, gid, sc0, 3u, z);
-            noise4<false>(p.seed, gid, sc0, 4u, z4);
+            obs_noise4(p, gid, sc0, 3u, z);
+            obs_noise4(p, gid, sc0, 4u, z4);
 #pragma unroll
             for (int j = 0; j < 4; ++j) sh.zmail[j][lane] = z[j];
             sh.zmail[4][lane] = z4[0];
@@ -3419,7 +3433,7 @@ DN_DEV void pqx_step(const DnParams &p, const DnStepIO &io0, PqxShared<R> &sh, c
         Rms rms;
         if (NORM) load_rms(p, i, rms);
         float zn[DN_OBS_DIM];
-        if (obs_noise) { noise4<false>(p.seed, gid, sc0, 1u, zn); noise4<false>(p.seed, gid, sc0, 2u, zn + 4); }    // columns 0..7 (see P)
+        if (obs_noise) { obs_noise4(p, gid, sc0, 1u, zn); obs_noise4(p, gid, sc0, 2u, zn + 4); }    // columns 0..7 (see P)
         // the part of the angular step that reads only the entry state (rotation matrix, body rates, gyroscopic and damping terms:
         // ~75 of its ~170 instructions), while X still computes the thrust
         AngPre<R> apre = physics_angular_pre<R>(G1, G3);

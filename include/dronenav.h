@@ -245,7 +245,8 @@ int32_t dn_reset_stats(dn_env *env, void *stream);
  * hardware's float32 log2 / sqrt / sin / cos (within 1.2e-6 of the float64 definition, tests/test_gpu_parity.py::
  * test_observation_noise_draws_match_their_definition), so noisy runs are bit-reproducible across kernel shapes, launches and shards
  * of one GPU generation, not across generations or against a CPU evaluation; everything that feeds the dynamics (action noise, policy
- * sampling, random spawn) and the whole noise-free configuration is exact arithmetic.
+ * sampling, random spawn) and the whole noise-free configuration is exact arithmetic.  DN_EXACT_OBS_NOISE=1 (read by dn_create) draws the
+ * observation noise in the exact form as well (bit-equal to the float64 definition for > 99.99 % of draws, one float32 ulp otherwise).
  * Environment variables DN_WAVES=1|2|3|4|5|8 and DN_WAVES_SINGLE=1|3 (read by dn_create) force a shape. */
 int32_t dn_get_kernel_waves(const dn_env *env, int32_t fused);
 
