@@ -551,6 +551,7 @@ int32_t dn_step_sampled(dn_env *env, const float *mean, const float *log_std, ui
     for (int j = 0; j < 4; ++j) io.log_std[j] = log_std[j];
     io.sample_seed = seed; io.sample_deterministic = deterministic != 0; io.sample_squash = 0;
     // the sampling lives in the single-step kernels (one wave, or three waves cut by dependency)
+    const LaunchEvents armed(env);                         // dn_set_launch_events: this launch takes the hook as well
     DN_HIP(dn_launch_step_many(env->p, io, 1, env->cfg.compute_f32 != 0, env->waves_single == 3 ? 3 : 1, (hipStream_t)stream));
     return DN_OK;
 }
@@ -574,6 +575,7 @@ int32_t dn_step_squashed(dn_env *env, const float *mu_log_std, uint64_t seed, in
     io.mean = mu_log_std; io.act_out = actions_out; io.logp_out = log_prob_out;
     for (int j = 0; j < 4; ++j) io.log_std[j] = 0.0f;
     io.sample_seed = seed; io.sample_deterministic = deterministic != 0; io.sample_squash = 1;
+    const LaunchEvents armed(env);                         // dn_set_launch_events: this launch takes the hook as well
     DN_HIP(dn_launch_step_many(env->p, io, 1, env->cfg.compute_f32 != 0, env->waves_single == 3 ? 3 : 1, (hipStream_t)stream));
     return DN_OK;
 }

@@ -361,7 +361,7 @@ int32_t dn_mlp_step_sampled(dn_env *env, const dn_mlp_net *nets, int32_t num_net
                             float *obs, float *reward, uint8_t *done, uint8_t *truncated, int32_t *found_targets, float *terminal_obs,
                             float *ep_return, int32_t *ep_length, uint64_t *done_mask, void *stream);
 
-/* Measurement hook (ABI 8).  The step kernel of the NEXT dn_step / dn_step_many call on `env` is dispatched with these two hipEvents
+/* Measurement hook (ABI 8).  The step kernel of the NEXT dn_step / dn_step_many / dn_step_sampled / dn_step_squashed call on `env` is dispatched with these two hipEvents
  * (hipEvent_t passed as void *, created with timing enabled; either may be NULL) attached to its own dispatch packet
  * (hipExtLaunchKernelGGL): hipEventElapsedTime(start, stop) is then the duration of that kernel alone -- what a profiler's kernel trace
  * reports -- where a pair of hipEventRecord around the call also times the host's launch path and puts two marker packets on the
