@@ -879,7 +879,13 @@ def main():
                                  "instruction stream; the single-step launch is bound by load + launch latency (DESIGN.md 4, profiles/r03_pqx_stamps.txt)",
                          "valu": (valu_bound(kernel_name(wv, args.compute_dtype, args.normalize_obs, args.mode == "many"), n, steps_per_launch,
                                              (kernel_only_us / K) if kernel_only_us else step_us, env.num_cus) if args.mode == "many" else None),
-                         "issue_bound_evidence": issue_evidence(kernel_name(wv, args.compute_dtype, args.normalize_obs, args.mode == "many"))},
+                         "issue_bound_evidence": issue_evidence(kernel_name(wv, args.compute_dtype, args.normalize_obs, args.mode == "many")),
+                         # the regime in which HBM IS the bound, beside the headline's own fraction (full legs: hbm_bound_fleet[_norm] below)
+                         "hbm_bound_regime": ({"num_envs": 2097152, "timed_with": "100 dn_step launches replayed from one hipGraph",
+                                               "normaliser_on": {k_: large_norm.get(k_) for k_ in ("us_per_vector_step", "achieved_GBps", "frac", "frac_of_copy_ceiling", "traffic_ratio")},
+                                               "normaliser_off": {k_: large.get(k_) for k_ in ("us_per_vector_step", "achieved_GBps", "frac", "frac_of_copy_ceiling", "traffic_ratio")},
+                                               "copy_ceiling_GBps": (copy_ceiling or {}).get("GBps")}
+                                              if isinstance(large_norm, dict) and isinstance(large, dict) and "frac" in large_norm and "frac" in large else None)},
             "single_step": single_step,
             ("normalize_obs_on" if other_norm else "normalize_obs_off"): norm_leg,
             "hbm_bound_fleet_norm": large_norm,
