@@ -3,6 +3,9 @@
 // iteration (distinct registers), 4000 iterations.  Output: ns per wave-instruction per SIMD and, at the clock the
 // chip reports, cycles; plus a single wave's own issue interval.
 // Build: hipcc --offload-arch=gfx950 -O3 -o valu_throughput valu_throughput.hip
+// Run:   ./valu_throughput            the instruction kinds of the step kernels (profiles/r05_valu_throughput.txt, first part)
+//        PART2=1 ./valu_throughput    v_cndmask forms, integer / bit operations, scalar adds, pairs of kinds (second part)
+//        PART3=1 ./valu_throughput    one kind with different register patterns and dependency distances (third part)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
