@@ -95,28 +95,51 @@ def issue_evidence(kernel):
     return dict(ev, kernel=kernel) if ev else None
 
 
-SHADER_CLOCK_GHZ_UNDER_LOAD = 2.14      # shader clock while the fused step runs: 74 504 cycles (s_memtime) in 34.84 us of the 100 MHz wall clock,
-                                        # stamped build of the five-wave kernel (profiles/r05_notes.md section 4)
+SHADER_CLOCK_GHZ_ASSUMED = 2.14         # fallback only: 74 504 cycles (s_memtime) in 34.84 us of the 100 MHz wall clock, stamped build of the five-wave
+                                        # kernel in round 5.  The committed counter passes carry their own clock (GRBM_GUI_ACTIVE / kernel duration).
 
 
-def valu_bound(kernel, n, steps_per_launch, us_per_step, num_cus=256):
+def valu_bound(kernel, n, steps_per_launch, us_per_step, num_cus=256, regime=None):
     """The bound that governs the fused step at 32 768 drones, from the committed SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU pass of the
     kernel that was timed (profiles/instmix.json, re-keyed every round): instructions per 64-drone tile-step x ALU cycles per
-    instruction x tiles per CU / 4 SIMDs / shader clock = the time a step would take if the vector ALUs never idled."""
+    instruction x tiles per CU / 4 SIMDs / shader clock = the time a step would take if the vector ALUs never idled.  The shader
+    clock is the one of the counter pass itself (GRBM_GUI_ACTIVE cycles / the kernel's duration in that pass) when the pass has it;
+    otherwise an assumed figure, labelled as such.  `regime`: a named sub-entry of the kernel's record (e.g. "hover_band_k20")."""
     ev = issue_evidence(kernel)
     if not ev or "alu_cycles_per_valu_instruction" not in ev:
         return None
-    src = ev.get("driver_launch_k20") if steps_per_launch == 20 and ev.get("driver_launch_k20") else ev
+    if regime:
+        src = ev.get(regime)
+        if not src:
+            return None
+    else:
+        src = ev.get("driver_launch_k20") if steps_per_launch == 20 and ev.get("driver_launch_k20") else ev
     insts = src["valu_instructions_per_64_drone_step"]
     cyc = src["alu_cycles_per_valu_instruction"]
+    clock = src.get("shader_clock_ghz")
+    clock_src = src.get("shader_clock_source", "GRBM_GUI_ACTIVE / kernel duration of the counter pass") if clock else "ASSUMED (round 5's stamped build); no GRBM_GUI_ACTIVE in the committed pass"
+    clock = clock or SHADER_CLOCK_GHZ_ASSUMED
     tiles_per_cu = ((n + 63) // 64) / num_cus
-    floor_us = tiles_per_cu * insts * cyc / 4.0 / (SHADER_CLOCK_GHZ_UNDER_LOAD * 1e3)
+    floor_us = tiles_per_cu * insts * cyc / 4.0 / (clock * 1e3)
     return {"valu_insts_per_tile_step": insts, "valu_cycles_per_inst": cyc, "tiles_per_cu": round(tiles_per_cu, 3),
-            "shader_clock_ghz": SHADER_CLOCK_GHZ_UNDER_LOAD,
+            "shader_clock_ghz": clock, "shader_clock_source": clock_src,
             "valu_floor_us_per_step": round(floor_us, 4), "valu_frac": round(floor_us / us_per_step, 4),
-            "counters_from": ("profiles/r05_instmix_k20.txt (the driver's own 20-step launch)" if src is not ev else ev.get("source")),
+            "counters_from": src.get("source") or ev.get("source"),
             "what": "vector-ALU floor = tiles per CU x instructions per tile-step x ALU cycles per instruction / 4 SIMDs / shader clock; "
                     "valu_frac = floor / measured time per step (the fraction of the step during which the vector ALUs are busy)"}
+
+
+# csrc/dn_action_sat.h: outside (ACT_SAT_LO, ACT_SAT_HI) the rescaled action is clipped to a thrust bound (rotor_force_sat's fast path)
+ACT_SAT_LO, ACT_SAT_HI = 0.0899437964, 0.0971653908
+
+
+def fast_path_hit_rate(torch, acts):
+    """Fraction of (64-drone tile, rotor, step) groups of the resident action batches in which EVERY lane is saturated, i.e. in which the
+    wave skips the float32 thrust chain (rotor_force_sat).  acts: [A, n, 4] float32 on the device."""
+    a_, n_ = acts.shape[0], acts.shape[1]
+    m = n_ // 64 * 64
+    sat = (acts[:, :m] <= ACT_SAT_LO) | (acts[:, :m] >= ACT_SAT_HI)
+    return float(sat.view(a_, m // 64, 64, 4).all(dim=2).float().mean().item())
 
 
 def parse():
@@ -136,6 +159,11 @@ def parse():
     ap.add_argument("--mode", default="many", choices=["many", "single", "graph"],
                     help="many: one dn_step_many call; single: K python-level dn_step calls; graph: hipGraph replay")
     ap.add_argument("--action-batches", type=int, default=64, help="distinct resident action batches cycled")
+    ap.add_argument("--actions", default="uniform", choices=["uniform", "hover"],
+                    help="action distribution of the timed region (SURVEY 8(d) C2): uniform = U(-1,1)^4, BASELINE's stream (99.6 %% of actions saturate a "
+                         "thrust bound; episodes of ~130 steps); hover = 0.0922 + 0.003 N(0,1), the un-saturated band a trained policy lives in (long "
+                         "flights, every wave evaluates the float32 thrust chain).  The default run times uniform as `value` and hover as the "
+                         "`hover_band` leg; --actions hover makes hover the timed region (the counter passes of that regime)")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ppo-rollout", action="store_true", help="skip the policy-in-the-loop rollout measurement")
@@ -506,7 +534,12 @@ def main():
     # synthetic actions resident in HBM before the timed region: U(-1,1)^4 float32, seeded per global drone id
     A = max(1, min(args.action_batches, K))
     g = torch.Generator(device="cpu").manual_seed(1 + rank)
-    acts = (torch.rand((A, n, 4), generator=g, dtype=torch.float32) * 2 - 1).to(dev)
+
+    def draw_actions(kind, gen):
+        if kind == "hover":                                # hover is a = 0.092227
+            return (0.0922 + 0.003 * torch.randn((A, n, 4), generator=gen, dtype=torch.float32)).to(dev)
+        return (torch.rand((A, n, 4), generator=gen, dtype=torch.float32) * 2 - 1).to(dev)
+    acts = draw_actions(args.actions, g)
     lib = pkg._capi.load()
     stream = torch.cuda.current_stream(dev)
     sptr = C.c_void_p(stream.cuda_stream)
@@ -620,20 +653,23 @@ def main():
     if os.environ.get("DN_BENCH_DEBUG"):
         print(f"timed region: rec0 {(ta - t0) * 1e6:.1f} run {(tb - ta) * 1e6:.1f} rec1 {(tc - tb) * 1e6:.1f} sync {(td - tc) * 1e6:.1f} us", file=sys.stderr)
     gpu_ms = e0.elapsed_time(e1)                          # HIP events on the launch stream, timed region only
-    kernel_only_us = None
-    if args.mode == "many" and K <= A:
-        # the same K-step launch once more, OUTSIDE the region the wall clock brackets, with its own dispatch's begin / end stamps: the kernel's
-        # duration as rocprofv3 --kernel-trace reports it (the markers above also see the ~1 us between a marker and the kernel)
+    def kernel_only(handle, fn, k):
+        """The same k-step launch with its own dispatch's begin / end stamps (dn_set_launch_events -> hipExtLaunchKernelGGL): the kernel's
+        duration as rocprofv3 --kernel-trace reports it (marker events also see the ~1 us between a marker and the kernel).  Median of 5."""
         k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         k0.record(stream); k1.record(stream)
         torch.cuda.synchronize(dev)
         reps_ = []
         for _ in range(5):
-            pkg._capi.check(lib.dn_set_launch_events(h, C.c_void_p(k0.cuda_event), C.c_void_p(k1.cuda_event)))
-            run(K)
+            pkg._capi.check(lib.dn_set_launch_events(handle, C.c_void_p(k0.cuda_event), C.c_void_p(k1.cuda_event)))
+            fn(k)
             torch.cuda.synchronize(dev)
             reps_.append(k0.elapsed_time(k1) * 1e3)
-        kernel_only_us = sorted(reps_)[len(reps_) // 2]
+        return sorted(reps_)[len(reps_) // 2]
+
+    kernel_only_us = None
+    if args.mode == "many" and K <= A and not args.profile_lite:      # (not in the counter passes: these launches take another dispatch path)
+        kernel_only_us = kernel_only(h, run, K)                       # OUTSIDE the region the wall clock brackets
     if dist is not None:
         tw = torch.tensor([wall, gpu_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
@@ -712,6 +748,52 @@ def main():
             env_n.close()
         except Exception as exc:  # noqa: BLE001
             norm_leg = {"error": f"{type(exc).__name__}: {exc}"}
+
+    # SURVEY 8(d) C2's second action distribution, the same launch: a = 0.0922 + 0.003 N(0,1), the un-saturated band around hover.  The
+    # headline's U(-1,1) saturates 99.6 % of actions, which rotor_force_sat turns into two selects per rotor on 79 % of (tile, rotor)
+    # evaluations; here every wave evaluates the float32 chain and episodes are long (no reset pass on most tile-steps) -- the regime a
+    # trained policy lives in, timed so that the fast path cannot be read as tuning to the benchmark.
+    hover_leg = None
+    if world == 1 and not args.profile_lite and args.mode == "many":
+        try:
+            other_kind = "hover" if args.actions == "uniform" else "uniform"
+            env_h = pkg.DroneVecEnv(track, n, max_steps=max_steps, normalize_obs=args.normalize_obs, compute_dtype=args.compute_dtype,
+                                    env_id_offset=rank * n, device=dev)
+            env_h.reset_tensor()
+            hh = env_h._handle
+            acts_h = draw_actions(other_kind, torch.Generator(device="cpu").manual_seed(101 + rank))
+
+            def many_h(k):
+                done = 0
+                while done < k:
+                    c = min(A, k - done)
+                    pkg._capi.check(lib.dn_step_many(hh, c, acts_h.data_ptr(), o["obs"].data_ptr(), o["reward"].data_ptr(),
+                                                     o["done"].data_ptr(), o["trunc"].data_ptr(), o["found"].data_ptr(),
+                                                     None, None, None, None, sptr))
+                    done += c
+            t_h = time.perf_counter()
+            while time.perf_counter() - t_h < 0.25:            # into the regime's steady state (episodes of up to max_steps steps)
+                many_h(64 * A)
+                torch.cuda.synchronize(dev)
+            wv_h = env_h.kernel_waves(fused=True)
+            hover_leg = leg("many", many_h, k_many, A, args.normalize_obs, wv_h)
+            ko_h = kernel_only(hh, many_h, A)
+            st_h = env_h.stats()
+            hover_leg.update({
+                "actions": ("0.0922 + 0.003 N(0,1) (hover band, SURVEY 8(d) C2)" if other_kind == "hover" else "U(-1,1)^4"),
+                "fast_path_hit_rate": round(fast_path_hit_rate(torch, acts_h), 4),
+                "episodes_finished": st_h["episodes"], "env_steps": st_h.get("env_steps"),
+                "kernel_only_launch_us": round(ko_h, 3), "kernel_only_us_per_vector_step": round(ko_h / A, 4),
+                "kernel_only_frac": round(algo_bytes_per_launch(n, A, args.normalize_obs) / (ko_h * 1e-6) / 1e9 / HBM_PEAK_GBPS, 5),
+                "valu": valu_bound(kernel_name(wv_h, args.compute_dtype, args.normalize_obs, True), n, A, ko_h / A, env.num_cus,
+                                   regime=("hover_band_k20" if other_kind == "hover" else None)),
+                "what": "the headline's launch (same kernel, same K, same fleet size, normaliser as in the headline) under the OTHER action "
+                        "distribution of SURVEY 8(d) C2; us_per_vector_step = HIP events around back-to-back launches (dispatch gaps included), "
+                        "kernel_only_* = the kernel's own duration (dn_set_launch_events, median of 5)"})
+            env_h.close()
+            del acts_h
+        except Exception as exc:  # noqa: BLE001
+            hover_leg = {"error": f"{type(exc).__name__}: {exc}"}
 
     # a measured stream-copy ceiling of THIS box beside the nominal 8 TB/s (a device-to-device copy of 1 GiB: read + write)
     copy_ceiling = None
@@ -840,12 +922,52 @@ def main():
         wv = waves if args.mode == "many" else waves_single
         traffic, tsrc = traffic_per_launch(args.track, n, args.compute_dtype, args.normalize_obs,
                                            steps_per_launch if args.mode == "many" else 0, wv)
+        kname = kernel_name(wv, args.compute_dtype, args.normalize_obs, args.mode == "many")
+        valu = (valu_bound(kname, n, steps_per_launch, (kernel_only_us / K) if kernel_only_us else step_us, env.num_cus,
+                           regime=("hover_band_k20" if args.actions == "hover" else None)) if args.mode == "many" else None)
+        ln_ok = isinstance(large_norm, dict) and "frac" in large_norm
+        l_ok = isinstance(large, dict) and "frac" in large
+        hv_ok = isinstance(hover_leg, dict) and "kernel_only_us_per_vector_step" in hover_leg
+        # Every fraction DESIGN.md section 5 quotes, as SCALAR fields of the roofline object (nested objects do not survive every
+        # reader of this line): the bound that governs the headline, the kernel's own duration, the other launch shape, the other action
+        # regime, and the regime in which HBM IS the bound -- each with the place its inputs come from.
+        flat = {
+            "valu_frac": valu and valu["valu_frac"], "valu_floor_us_per_step": valu and valu["valu_floor_us_per_step"],
+            "valu_insts_per_tile_step": valu and valu["valu_insts_per_tile_step"], "valu_cycles_per_inst": valu and valu["valu_cycles_per_inst"],
+            "valu_shader_clock_ghz": valu and valu["shader_clock_ghz"],
+            "valu_source": valu and f"{valu['counters_from']}; clock: {valu['shader_clock_source']}",
+            "governing_bound": ("valu" if valu and valu["valu_frac"] > achieved / HBM_PEAK_GBPS else "hbm"),
+            "kernel_only_us": kernel_only_us and round(kernel_only_us, 3),
+            "kernel_only_frac": kernel_only_us and round(algo_launch / (kernel_only_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 5),
+            "kernel_only_source": "dn_set_launch_events on 5 launches right after the timed region (median); rocprofv3 twin: profiles/r06_a_bench32k_k20.txt",
+            "single_step_us": single_step.get("us_per_vector_step"), "single_step_frac": single_step.get("frac"),
+            "single_step_source": "single_step leg of this line (dn_step launches replayed from a hipGraph, 288 + 432 B per drone)",
+            "fast_path_hit_rate": round(fast_path_hit_rate(torch, acts), 4),
+            "hover_us_per_step": hover_leg["kernel_only_us_per_vector_step"] if hv_ok else None,
+            "hover_frac": hover_leg["kernel_only_frac"] if hv_ok else None,
+            "hover_fast_path_hit_rate": hover_leg["fast_path_hit_rate"] if hv_ok else None,
+            "hover_valu_insts_per_tile_step": (hover_leg["valu"] or {}).get("valu_insts_per_tile_step") if hv_ok else None,
+            "hover_valu_frac": (hover_leg["valu"] or {}).get("valu_frac") if hv_ok else None,
+            "hover_source": "hover_band leg of this line (same launch, actions 0.0922 + 0.003 N(0,1)); counters: profiles/instmix.json hover_band_k20",
+            "hbm_bound_num_envs": 2097152 if ln_ok else None,
+            "hbm_bound_us": large_norm["us_per_vector_step"] if ln_ok else None,
+            "hbm_bound_frac": large_norm["frac"] if ln_ok else None,
+            "hbm_bound_frac_of_copy": large_norm["frac_of_copy_ceiling"] if ln_ok else None,
+            "hbm_bound_traffic_ratio": large_norm.get("traffic_ratio") if ln_ok else None,
+            "hbm_bound_nonorm_us": large["us_per_vector_step"] if l_ok else None,
+            "hbm_bound_nonorm_frac": large["frac"] if l_ok else None,
+            "hbm_bound_nonorm_frac_of_copy": large["frac_of_copy_ceiling"] if l_ok else None,
+            "hbm_copy_GBps": (copy_ceiling or {}).get("GBps"),
+            "hbm_bound_source": "hbm_bound_fleet_norm / hbm_bound_fleet / hbm_copy_ceiling legs of this line (2 097 152 drones, one dn_step per launch, "
+                                "100 launches replayed from one hipGraph; copy kernel measured in the same process)",
+        }
         line = {
             "metric": "env_steps_per_sec", "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world,
             "steps": K, "warmup": W, "ms_per_step": round(wall * 1e3 / K, 6), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": "f64" if args.compute_dtype == "float64" else "f32", "data": "synthetic",
-            "config": {"workload": f"{n} drones/GPU, 8-gate race track (Waypoints.reaching), U(-1,1)^4 actions resident in HBM, "
+            "config": {"workload": f"{n} drones/GPU, 8-gate race track (Waypoints.reaching), "
+                                   f"{'U(-1,1)^4' if args.actions == 'uniform' else '0.0922 + 0.003 N(0,1) hover-band'} actions resident in HBM, "
                                    f"norm_rew off, obs normaliser {'on' if args.normalize_obs else 'off'}, auto-reset on",
                        "num_envs_per_gpu": n, "global_num_envs": n * world, "track": args.track,
                        "state_dtype": "f32", "launch_mode": args.mode, "parallelism": f"env-shard x{world} (no data-path collective)",
@@ -859,7 +981,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": tsrc,
                          "traffic_frac": (round(traffic / (launch_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 5) if traffic else None),
-                         "kernel": kernel_name(wv, args.compute_dtype, args.normalize_obs, args.mode == "many"),
+                         **flat,
+                         "kernel": kname,
                          "waves_per_64_drones": wv,
                          "env_steps_per_launch": n * steps_per_launch, "vector_steps_per_launch": steps_per_launch,
                          "algorithmic_bytes_per_launch": algo_launch,
@@ -874,12 +997,11 @@ def main():
                                                   "its own dispatch (dn_set_launch_events -> hipExtLaunchKernelGGL): the kernel's duration as "
                                                   "rocprofv3 --kernel-trace reports it"} if kernel_only_us else None),
                          "note": "at 32768 drones neither launch shape is bandwidth bound: with two tiles per CU the fused launch is bound by the vector ALUs "
-                                 "(`valu`: ~1 100 vector instructions per tile-step at 4.3 ALU cycles each, and a SIMD with 2.5 waves delivers 70-80 % of its "
-                                 "float64 rate: profiles/r05_notes.md, profiles/r05_valu_throughput.txt), with one tile per CU by the role with the longest "
+                                 "(`valu_*`: vector instructions per tile-step x ALU cycles each, and a SIMD with 2.5 waves delivers 70-80 % of its "
+                                 "float64 rate: profiles/r06_notes.md, profiles/r05_valu_throughput.txt), with one tile per CU by the role with the longest "
                                  "instruction stream; the single-step launch is bound by load + launch latency (DESIGN.md 4, profiles/r03_pqx_stamps.txt)",
-                         "valu": (valu_bound(kernel_name(wv, args.compute_dtype, args.normalize_obs, args.mode == "many"), n, steps_per_launch,
-                                             (kernel_only_us / K) if kernel_only_us else step_us, env.num_cus) if args.mode == "many" else None),
-                         "issue_bound_evidence": issue_evidence(kernel_name(wv, args.compute_dtype, args.normalize_obs, args.mode == "many")),
+                         "valu": valu,
+                         "issue_bound_evidence": issue_evidence(kname),
                          # the regime in which HBM IS the bound, beside the headline's own fraction (full legs: hbm_bound_fleet[_norm] below)
                          "hbm_bound_regime": ({"num_envs": 2097152, "timed_with": "100 dn_step launches replayed from one hipGraph",
                                                "normaliser_on": {k_: large_norm.get(k_) for k_ in ("us_per_vector_step", "achieved_GBps", "frac", "frac_of_copy_ceiling", "traffic_ratio")},
@@ -887,6 +1009,7 @@ def main():
                                                "copy_ceiling_GBps": (copy_ceiling or {}).get("GBps")}
                                               if isinstance(large_norm, dict) and isinstance(large, dict) and "frac" in large_norm and "frac" in large else None)},
             "single_step": single_step,
+            "hover_band": hover_leg,
             ("normalize_obs_on" if other_norm else "normalize_obs_off"): norm_leg,
             "hbm_bound_fleet_norm": large_norm,
             "hbm_bound_fleet": large,

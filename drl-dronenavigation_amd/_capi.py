@@ -11,7 +11,7 @@ from . import build as _build
 MAX_WAYPOINTS = 64
 OBS_DIM = 13
 ACT_DIM = 4
-ABI_VERSION = 8
+ABI_VERSION = 9
 GROUND_CONTACT_AUTO = 2
 
 DN_OK = 0
@@ -78,6 +78,7 @@ PROTOTYPES = {
     "dn_num_envs": (_I64, [_VP]),
     "dn_get_config": (_I32, [_VP, C.POINTER(DnConfig)]),
     "dn_get_num_cus": (_I32, [_VP]),
+    "dn_get_exact_flags": (_I32, [_VP]),
     "dn_resolve_ground_contact": (_I32, [C.POINTER(DnConfig)]),
     "dn_reset": (_I32, [_VP, _VP, _VP]),
     "dn_step": (_I32, [_VP] * 12),
@@ -109,9 +110,17 @@ PROTOTYPES = {
 _lib = None
 
 
+def _truthy(name):
+    """An on / off environment switch, spelt as dn_create accepts it (anything else is left for dn_create to refuse)."""
+    return os.environ.get(name, "").strip().lower() in ("1", "true", "on", "yes")
+
+
 def library_path():
-    # DN_LIB_PATH: an alternative build of the same ABI (A/B measurements of kernel variants); default = the in-tree library
-    return os.environ.get("DN_LIB_PATH") or _build.LIB_PATH
+    # DN_LIB_PATH: an alternative build of the same ABI (A/B measurements of kernel variants).  DN_EXACT_NORM=1: the build with the
+    # normaliser's float64 output stage (libdronenav_exact.so, include/dronenav.h DN_EXACT_FLAG_NORM).  Default = the in-tree library.
+    if os.environ.get("DN_LIB_PATH"):
+        return os.environ["DN_LIB_PATH"]
+    return _build.LIB_PATH_EXACT if _truthy("DN_EXACT_NORM") else _build.LIB_PATH
 
 
 def load():

@@ -10,8 +10,13 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libdronenav.so")
+# The same ABI with the observation normaliser's OUTPUT stage in float64 (-DDN_NORM_EXACT=1, dn_kernels.hip normalize_obs_cols): the
+# float32 nearest to the float64 evaluation instead of <= 3 float32 ulp.  A build of its own because the form is a compile-time one (as a
+# run-time switch it costs the fused kernels ~100 spilled registers); DN_EXACT_NORM=1 makes _capi.load() take this library.
+LIB_PATH_EXACT = os.path.join(CSRC, "libdronenav_exact.so")
 SOURCES = ["dn_kernels.hip", "dn_kernels_mw.hip", "dn_mlp.hip", "dn_fused.hip", "dn_capi.cpp"]
-HEADERS = ["dn_internal.h", os.path.join("..", "..", "include", "dronenav.h")]
+STEP_SOURCES = ["dn_kernels.hip", "dn_kernels_mw.hip", "dn_fused.hip"]      # the translation units that inline the normaliser
+HEADERS = ["dn_internal.h", "dn_action_sat.h", os.path.join("..", "..", "include", "dronenav.h")]
 # -ffp-contract=off: no multiply-add is fused BY LICENCE -- the float32 action chain rounds every operation as numpy does, and the
 # float64 part writes its fused multiply-adds out explicitly so that every kernel shape produces the same bits.
 # Correctly rounded float32 divide/sqrt is hipcc's default; stated explicitly because parity relies on it.
@@ -37,34 +42,44 @@ def hipcc():
 
 
 def is_stale():
-    if not os.path.exists(LIB_PATH):
-        return True
-    t = os.path.getmtime(LIB_PATH)
     deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
-    return any(os.path.getmtime(d) > t for d in deps)
+    for lib in (LIB_PATH, LIB_PATH_EXACT):
+        if not os.path.exists(lib):
+            return True
+        t = os.path.getmtime(lib)
+        if any(os.path.getmtime(d) > t for d in deps):
+            return True
+    return False
 
 
 def build_library(force=False, verbose=False):
-    """Compile csrc/*.{hip,cpp} -> csrc/libdronenav.so.  Returns the library path."""
+    """Compile csrc/*.{hip,cpp} -> csrc/libdronenav.so and csrc/libdronenav_exact.so.  Returns the path of the default library."""
     if not force and not is_stale():
         return LIB_PATH
-    objs, cmds = [], []
+    objs, objs_exact, cmds = [], [], []
     for src in SOURCES:
-        obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
-        cmd = [hipcc()] + FLAGS + FLAGS_OF.get(src, NO_LICM) + EXTRA + ["-c", os.path.join(CSRC, src), "-o", obj]
-        if verbose:
-            print(" ".join(cmd))
-        objs.append(obj)
-        cmds.append(cmd)
+        stem = os.path.join(CSRC, os.path.splitext(src)[0])
+        base = [hipcc()] + FLAGS + FLAGS_OF.get(src, NO_LICM) + EXTRA
+        cmds.append(base + ["-c", os.path.join(CSRC, src), "-o", stem + ".o"])
+        objs.append(stem + ".o")
+        if src in STEP_SOURCES:
+            cmds.append(base + ["-DDN_NORM_EXACT=1", "-c", os.path.join(CSRC, src), "-o", stem + ".exact.o"])
+            objs_exact.append(stem + ".exact.o")
+        else:
+            objs_exact.append(stem + ".o")
+    if verbose:
+        for c in cmds:
+            print(" ".join(c))
     procs = [subprocess.Popen(c) for c in cmds]              # the translation units are independent: compile them side by side
     codes = [p.wait() for p in procs]
     for c, rc in zip(cmds, codes):
         if rc != 0:
             raise subprocess.CalledProcessError(rc, c)
-    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    for lib, ob in ((LIB_PATH, objs), (LIB_PATH_EXACT, objs_exact)):
+        cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + ob
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
     return LIB_PATH
 
 

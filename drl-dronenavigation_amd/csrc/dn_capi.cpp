@@ -50,6 +50,21 @@ constexpr double DN_COLL_R = 0.06, DN_COLL_H = 0.025;   // base_link collision c
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// An on / off environment switch read by dn_create: 1 / 0, or -1 for a value that is neither (the create then fails: a typo
+// must not silently select the other arithmetic).  Unset or empty = off.
+int env_switch(const char *name)
+{
+    const char *x = getenv(name);
+    if (!x || !x[0]) return 0;
+    char b[8] = "";
+    size_t k = 0;
+    for (; x[k] && k < sizeof b - 1; ++k) b[k] = (char)((x[k] >= 'A' && x[k] <= 'Z') ? x[k] - 'A' + 'a' : x[k]);
+    if (x[k]) return -1;
+    if (!strcmp(b, "1") || !strcmp(b, "true") || !strcmp(b, "on") || !strcmp(b, "yes")) return 1;
+    if (!strcmp(b, "0") || !strcmp(b, "false") || !strcmp(b, "off") || !strcmp(b, "no")) return 0;
+    return -1;
+}
+
 }  // namespace
 
 struct dn_env {
@@ -68,11 +83,32 @@ struct dn_env {
 
 thread_local hipEvent_t dn_tl_ev_start = nullptr, dn_tl_ev_stop = nullptr;
 
-// arms the dispatch-attached events of dn_set_launch_events for the one launch issued inside its scope
+// Takes the events dn_set_launch_events armed: constructed FIRST THING in every step-family entry point, so that the call they were
+// armed for consumes them (the hooked launches) or drops them (a validation failure, an entry point without the hook) -- they never
+// survive into a later call, whose caller may have destroyed them by then.  Nests (dn_step_many(k = 1) -> dn_step).
+thread_local int dn_tl_ev_depth = 0;
 struct LaunchEvents {
-    explicit LaunchEvents(dn_env *e) { dn_tl_ev_start = e->ev_start; dn_tl_ev_stop = e->ev_stop; e->ev_start = e->ev_stop = nullptr; }
-    ~LaunchEvents() { dn_tl_ev_start = dn_tl_ev_stop = nullptr; }
+    explicit LaunchEvents(dn_env *e)
+    {
+        if (dn_tl_ev_depth++ == 0) { dn_tl_ev_start = e->ev_start; dn_tl_ev_stop = e->ev_stop; }
+        e->ev_start = e->ev_stop = nullptr;
+    }
+    ~LaunchEvents() { if (--dn_tl_ev_depth == 0) dn_tl_ev_start = dn_tl_ev_stop = nullptr; }
+    LaunchEvents(const LaunchEvents &) = delete;
+    LaunchEvents &operator=(const LaunchEvents &) = delete;
 };
+// an armed launch inside a stream capture would record the events into the graph (undefined on replay): refused
+static bool armed_while_capturing(hipStream_t stream)
+{
+    if (!dn_tl_ev_start && !dn_tl_ev_stop) return false;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    return hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+}
+#define DN_REFUSE_ARMED_CAPTURE(stream)                                                                                           \
+    do {                                                                                                                          \
+        if (armed_while_capturing((hipStream_t)(stream)))                                                                         \
+            return fail(DN_ERR_INVALID_ARGUMENT, "dn_set_launch_events: an armed launch cannot be captured into a hipGraph");     \
+    } while (0)
 
 namespace {
 
@@ -428,8 +464,19 @@ int32_t dn_create(const dn_config *cfg, dn_env **out)
     p.random_spawn = cfg->random_spawn != 0;
     p.zero_damping = cfg->zero_damping != 0;
     {   // DN_EXACT_OBS_NOISE=1: observation noise in the exact float64 Box-Muller form (reproducible across GPU generations; ~10 % slower noisy steps)
-        const char *x = getenv("DN_EXACT_OBS_NOISE");
-        p.exact_obs_noise = (x && x[0] == '1') ? 1 : 0;
+        // DN_EXACT_NORM=1: the normaliser's output stage in float64 (the float32 nearest to the float64 evaluation instead of <= 3 ulp) -- a
+        // compile-time form (dn_kernels.hip, normalize_obs_cols) that lives in libdronenav_exact.so: here the request is only CHECKED against the build.
+        // Both are readable back through dn_get_exact_flags; a value that is neither a yes nor a no fails the create.
+        int v = env_switch("DN_EXACT_OBS_NOISE");
+        if (v < 0) { (void)hipFree(e->arena); delete e; return fail(DN_ERR_INVALID_ARGUMENT, "DN_EXACT_OBS_NOISE=%s: expected 1 | true | on | yes or 0 | false | off | no", getenv("DN_EXACT_OBS_NOISE")); }
+        p.exact_obs_noise = v;
+        v = env_switch("DN_EXACT_NORM");
+        if (v < 0) { (void)hipFree(e->arena); delete e; return fail(DN_ERR_INVALID_ARGUMENT, "DN_EXACT_NORM=%s: expected 1 | true | on | yes or 0 | false | off | no", getenv("DN_EXACT_NORM")); }
+        if (v == 1 && !dn_norm_exact_compiled_in()) {
+            (void)hipFree(e->arena); delete e;
+            return fail(DN_ERR_INVALID_ARGUMENT, "DN_EXACT_NORM=1 asks for the normaliser's float64 output stage, which is a build of its own: load "
+                                                 "libdronenav_exact.so (the Python package does when the variable is set) instead of this library");
+        }
     }
     p.act_noise_sigma = cfg->act_noise_sigma; p.obs_noise_sigma = cfg->obs_noise_sigma;
     p.seed = cfg->seed; p.env_id_offset = cfg->env_id_offset;
@@ -495,6 +542,12 @@ int32_t dn_get_config(const dn_env *env, dn_config *out)
 
 int32_t dn_get_num_cus(const dn_env *env) { return env ? env->num_cus : 0; }
 
+int32_t dn_get_exact_flags(const dn_env *env)
+{
+    if (!env) return 0;
+    return (env->p.exact_obs_noise ? DN_EXACT_FLAG_OBS_NOISE : 0) | (dn_norm_exact_compiled_in() ? DN_EXACT_FLAG_NORM : 0);
+}
+
 int32_t dn_resolve_ground_contact(const dn_config *cfg)
 {
     const int32_t rc = validate(cfg);
@@ -516,16 +569,17 @@ int32_t dn_step(dn_env *env, const float *actions, float *obs, float *reward, ui
                 uint64_t *done_mask, void *stream)
 {
     if (!env) return fail(DN_ERR_INVALID_ARGUMENT, "env is NULL");
+    const LaunchEvents armed(env);                         // dn_set_launch_events: consumed by this call, or dropped if it fails below
     if (!actions || !obs || !reward || !done || !truncated || !found_targets)
         return fail(DN_ERR_INVALID_ARGUMENT, "actions, obs, reward, done, truncated and found_targets are required");
     if (((uintptr_t)actions & 15u) || ((uintptr_t)obs & 15u))
         return fail(DN_ERR_INVALID_ARGUMENT, "actions and obs must be 16-byte aligned");
+    DN_REFUSE_ARMED_CAPTURE(stream);
     DnStepIO io;
     io.actions = actions; io.obs = obs; io.reward = reward; io.done = done; io.truncated = truncated;
     io.found_targets = found_targets; io.terminal_obs = terminal_obs; io.ep_return = ep_return;
     io.ep_length = ep_length; io.done_mask = (unsigned long long *)done_mask;
     io.mean = nullptr; io.act_out = nullptr; io.logp_out = nullptr; io.sample_squash = 0;
-    const LaunchEvents armed(env);
     DN_HIP(dn_launch_step_many(env->p, io, 1, env->cfg.compute_f32 != 0, env->waves_single, (hipStream_t)stream));
     return DN_OK;
 }
@@ -536,6 +590,7 @@ int32_t dn_step_sampled(dn_env *env, const float *mean, const float *log_std, ui
                         uint64_t *done_mask, void *stream)
 {
     if (!env) return fail(DN_ERR_INVALID_ARGUMENT, "env is NULL");
+    const LaunchEvents armed(env);                         // dn_set_launch_events: this launch takes the hook as well
     if (!mean || !log_std || !actions_out || !log_prob_out || !obs || !reward || !done || !truncated || !found_targets)
         return fail(DN_ERR_INVALID_ARGUMENT, "mean, log_std, actions_out, log_prob_out, obs, reward, done, truncated and found_targets are required");
     if (((uintptr_t)mean & 15u) || ((uintptr_t)actions_out & 15u) || ((uintptr_t)obs & 15u))
@@ -551,7 +606,7 @@ int32_t dn_step_sampled(dn_env *env, const float *mean, const float *log_std, ui
     for (int j = 0; j < 4; ++j) io.log_std[j] = log_std[j];
     io.sample_seed = seed; io.sample_deterministic = deterministic != 0; io.sample_squash = 0;
     // the sampling lives in the single-step kernels (one wave, or three waves cut by dependency)
-    const LaunchEvents armed(env);                         // dn_set_launch_events: this launch takes the hook as well
+    DN_REFUSE_ARMED_CAPTURE(stream);
     DN_HIP(dn_launch_step_many(env->p, io, 1, env->cfg.compute_f32 != 0, env->waves_single == 3 ? 3 : 1, (hipStream_t)stream));
     return DN_OK;
 }
@@ -561,6 +616,7 @@ int32_t dn_step_squashed(dn_env *env, const float *mu_log_std, uint64_t seed, in
                          float *terminal_obs, float *ep_return, int32_t *ep_length, uint64_t *done_mask, void *stream)
 {
     if (!env) return fail(DN_ERR_INVALID_ARGUMENT, "env is NULL");
+    const LaunchEvents armed(env);                         // dn_set_launch_events: this launch takes the hook as well
     if (!mu_log_std || !actions_out || !obs || !reward || !done || !truncated || !found_targets)
         return fail(DN_ERR_INVALID_ARGUMENT, "mu_log_std, actions_out, obs, reward, done, truncated and found_targets are required");
     if (((uintptr_t)mu_log_std & 15u) || ((uintptr_t)actions_out & 15u) || ((uintptr_t)obs & 15u))
@@ -575,7 +631,7 @@ int32_t dn_step_squashed(dn_env *env, const float *mu_log_std, uint64_t seed, in
     io.mean = mu_log_std; io.act_out = actions_out; io.logp_out = log_prob_out;
     for (int j = 0; j < 4; ++j) io.log_std[j] = 0.0f;
     io.sample_seed = seed; io.sample_deterministic = deterministic != 0; io.sample_squash = 1;
-    const LaunchEvents armed(env);                         // dn_set_launch_events: this launch takes the hook as well
+    DN_REFUSE_ARMED_CAPTURE(stream);
     DN_HIP(dn_launch_step_many(env->p, io, 1, env->cfg.compute_f32 != 0, env->waves_single == 3 ? 3 : 1, (hipStream_t)stream));
     return DN_OK;
 }
@@ -586,6 +642,8 @@ int32_t dn_mlp_step_sampled(dn_env *env, const dn_mlp_net *nets, int32_t num_net
                             float *ep_return, int32_t *ep_length, uint64_t *done_mask, void *stream)
 {
     if (!env) return fail(DN_ERR_INVALID_ARGUMENT, "env is NULL");
+    const LaunchEvents dropped(env);                       // no hook on this launch: armed events are dropped here, not left for a later call
+    dn_tl_ev_start = dn_tl_ev_stop = nullptr;
     if (!nets || !policy_obs || !log_std || !actions_out || !log_prob_out || !obs || !reward || !done || !truncated || !found_targets)
         return fail(DN_ERR_INVALID_ARGUMENT, "nets, policy_obs, log_std, actions_out, log_prob_out, obs, reward, done, truncated and found_targets are required");
     if (num_nets < 1 || num_nets > 2) return fail(DN_ERR_INVALID_ARGUMENT, "num_nets must be 1 (actor) or 2 (actor, critic)");
@@ -639,6 +697,8 @@ int32_t dn_eval_kinematics(dn_env *env, const double *kinematics, float *obs, fl
                            int32_t *found_targets, float *terminal_obs, float *ep_return, int32_t *ep_length, void *stream)
 {
     if (!env) return fail(DN_ERR_INVALID_ARGUMENT, "env is NULL");
+    const LaunchEvents dropped(env);                       // no hook on this launch: armed events are dropped here, not left for a later call
+    dn_tl_ev_start = dn_tl_ev_stop = nullptr;
     if (!kinematics || !obs || !reward || !done || !truncated || !found_targets)
         return fail(DN_ERR_INVALID_ARGUMENT, "kinematics, obs, reward, done, truncated and found_targets are required");
     if (((uintptr_t)kinematics & 7u) || ((uintptr_t)obs & 15u))
@@ -660,6 +720,7 @@ int32_t dn_step_many(dn_env *env, int64_t k, const float *actions, float *obs, f
                      int32_t *ep_length, uint64_t *done_mask, void *stream)
 {
     if (!env) return fail(DN_ERR_INVALID_ARGUMENT, "env is NULL");
+    const LaunchEvents armed(env);                         // dn_set_launch_events: consumed by this call, or dropped if it fails below
     if (k < 1) return fail(DN_ERR_INVALID_ARGUMENT, "k must be >= 1 (got %lld)", (long long)k);
     const long long n = env->cfg.num_envs;
     if (k > 1 && (n & 3)) return fail(DN_ERR_INVALID_ARGUMENT, "dn_step_many needs num_envs %% 4 == 0 (got %lld)", n);
@@ -677,7 +738,7 @@ int32_t dn_step_many(dn_env *env, int64_t k, const float *actions, float *obs, f
     io.found_targets = found_targets; io.terminal_obs = terminal_obs; io.ep_return = ep_return;
     io.ep_length = ep_length; io.done_mask = (unsigned long long *)done_mask;
     io.mean = nullptr; io.act_out = nullptr; io.logp_out = nullptr; io.sample_squash = 0;
-    const LaunchEvents armed(env);
+    DN_REFUSE_ARMED_CAPTURE(stream);
     DN_HIP(dn_launch_step_many(env->p, io, (int)k, env->cfg.compute_f32 != 0, env->waves_fused, (hipStream_t)stream));
     return DN_OK;
 }

@@ -125,6 +125,7 @@ extern thread_local hipEvent_t dn_tl_ev_start, dn_tl_ev_stop;
         else hipLaunchKernelGGL(kern, grid, blk, shm, stream, __VA_ARGS__);                                                             \
     } while (0)
 
+int dn_norm_exact_compiled_in();      // 1 in libdronenav_exact.so (-DDN_NORM_EXACT=1: the normaliser's float64 output stage), else 0
 hipError_t dn_launch_step_many(const DnParams &p, const DnStepIO &io, int k, bool f32, int waves, hipStream_t stream);
 hipError_t dn_launch_step_many_mw(const DnParams &p, const DnStepIO &io, int k, bool f32, int waves, hipStream_t stream);   // dn_kernels_mw.hip
 hipError_t dn_launch_reset(const DnParams &p, float *obs, bool f32, hipStream_t stream);

@@ -21,6 +21,7 @@
 //   PBDroneEnv.py = Sol/Model/Environments/PBDroneEnv.py, BaseAviary.py = Sol/PyBullet/BaseAviary.py,
 //   env_utils.py = Sol/Model/env_utils.py, normalize.py = Sol/Model/Environments/normalize.py.
 #include "dn_internal.h"
+#include "dn_action_sat.h"
 
 #ifndef DN_TU
 #define DN_TU 1      // see dn_launch_step_many: 1 = this file as such, 2 = through dn_kernels_mw.hip
@@ -124,6 +125,28 @@ DN_DEV float rotor_force_from_cmd(float cmd, float a, float &torque, float *rpm_
 DN_DEV float rotor_force_from_action(float a, bool normalize_actions, float &torque, float *rpm_out = nullptr, bool nan_check = true)
 {
     return rotor_force_from_cmd(normalize_actions ? rescale_unclipped32(a) : a, a, torque, rpm_out, nan_check);
+}
+// The saturation fast path (round 6).  The thrust clip of rotor_force_from_cmd is the chain's ONLY read of the command, so every
+// command <= a_low yields the force / torque of a_low and every command >= a_high those of a_high; rescale_action is monotone in
+// the action, so in raw-action space that is two float32 thresholds (csrc/dn_action_sat.h; tests/tools/check_action_chain_exact.c
+// proves thresholds and constants against the literal numpy-order chain for all 2^32 - 2^24 non-NaN actions).  99.6 % of U(-1,1)
+// actions -- and of a sigma = 1 Gaussian policy's -- lie outside the 0.0072-wide band in between: per rotor the WAVE takes the chain
+// only if one of its lanes is inside the band (or NaN: both compares false), 21 % of rotor evaluations at U(-1,1); then every
+// lane takes it, and a saturated lane's chain returns the same two constants: bit-exact by construction either way.
+constexpr float ACT_SAT_LO32 = __builtin_bit_cast(float, DN_ACT_SAT_LO_BITS), ACT_SAT_HI32 = __builtin_bit_cast(float, DN_ACT_SAT_HI_BITS);
+constexpr float F_LO32 = __builtin_bit_cast(float, DN_F_LO_BITS), F_HI32 = __builtin_bit_cast(float, DN_F_HI_BITS);
+constexpr float TQ_LO32 = __builtin_bit_cast(float, DN_TQ_LO_BITS), TQ_HI32 = __builtin_bit_cast(float, DN_TQ_HI_BITS);
+static_assert(__builtin_bit_cast(unsigned, A_LOW32) == DN_A_LOW_BITS && __builtin_bit_cast(unsigned, A_HIGH32) == DN_A_HIGH_BITS,
+              "dn_action_sat.h was derived for other action bounds");
+DN_DEV float rotor_force_sat(const float a, const bool normalize_actions, float &torque)
+{
+    const float t_lo = normalize_actions ? ACT_SAT_LO32 : A_LOW32, t_hi = normalize_actions ? ACT_SAT_HI32 : A_HIGH32;   // wave-uniform
+    const bool hi = a >= t_hi, lo = a <= t_lo;
+    float f = hi ? F_HI32 : F_LO32;
+    torque = hi ? TQ_HI32 : TQ_LO32;
+    if (__ballot(!(hi || lo)) != 0ull)            // wave-uniform: a lane inside the band, or a NaN (np.clip / sqrt propagate it: the chain's own select)
+        f = rotor_force_from_cmd(normalize_actions ? rescale_unclipped32(a) : a, a, torque, nullptr, true);
+    return f;
 }
 
 DN_DEV float z_torque32(const float tq[4])
@@ -417,6 +440,19 @@ DN_DEV double rcp_f64(double x)
 }
 // Columns [K0, K1) only: a kernel may give the columns of one drone to two waves (each then holds its columns' statistics and a
 // copy of the count).  The shared quantities (tot, inv, cw) and every per-column expression are the same whatever the range.
+//
+// The OUTPUT stage (round 6).  The statistics are float64 and updated exactly as above whatever the build; the normalised value
+// leaves as a float32, and by default it is formed there: float32(x - new_mean) * v_rsq_f32(float32(new_var) + 1e-8f) -- four
+// float32-rate instructions instead of v_rsq_f64 + a Newton step + a float64 product (8 float64-rate ones, 37.6 -> 24 ns of a SIMD per
+// column; the normaliser is a third of the fused step's vector-ALU time).  The result is within 3 float32 ulp (3.6e-7 relative) of
+// the correctly rounded float64 evaluation, against the 1e-5 bar of the parity contract; nothing is fed back (the statistics never
+// read the output).  -DDN_NORM_EXACT=1 keeps the float64 output stage -- the float32 nearest to the float64 evaluation (1/2 ulp) --
+// and is what libdronenav_exact.so is built with (build.py; DN_EXACT_NORM=1 selects that library, dn_get_exact_flags reports it).
+// A compile-time switch: as a run-time one (tried first) both forms sit in every normaliser pass and the five-wave kernel spills 159
+// registers instead of 48.
+#ifndef DN_NORM_EXACT
+#define DN_NORM_EXACT 0
+#endif
 template <int K0, int K1>
 DN_DEV void normalize_obs_cols(Rms &r, float o[DN_OBS_DIM])
 {   // explicit fused multiply-adds, no contraction licence (one arithmetic sequence for every kernel that inlines this)
@@ -431,12 +467,16 @@ DN_DEV void normalize_obs_cols(Rms &r, float o[DN_OBS_DIM])
         const double new_var = __builtin_fma(delta * delta, inv, r.var[k]) * cw;
         r.mean[k] = new_mean;
         r.var[k] = new_var;
+#if DN_NORM_EXACT
         const double s = new_var + 1e-8;
         double y = __builtin_amdgcn_rsq(s);
-#ifndef DN_NORM_RAW_RSQ
         y = __builtin_fma(y, __builtin_fma(-(0.5 * s * y), y, 0.5), y);
-#endif
         o[k] = (float)((x - new_mean) * y);
+#else
+        const float e32 = (float)(x - new_mean);
+        const float s32 = (float)new_var + 1e-8f;
+        o[k] = e32 * __builtin_amdgcn_rsqf(s32);
+#endif
     }
     r.count = tot;
 }
@@ -1021,22 +1061,14 @@ DN_DEV Thrust thrust_phase(const DnParams &p, unsigned long long gid, unsigned l
     if (NOISE && p.act_noise_sigma > 0.0f) add_act_noise(p, gid, step_count, a);
     Thrust t;
     float tq[4];
-    float cmd[4];
-    if (p.normalize_actions) {                         // one wave-uniform branch for the four rotors
+    const bool norm_act = p.normalize_actions != 0;
+#ifdef DN_NO_SAT_FASTPATH                              // ablation switch (profiles/r06_notes.md): the chain for every rotor of every lane
 #pragma unroll
-        for (int j = 0; j < 4; ++j) cmd[j] = rescale_unclipped32(a[j]);
-    } else {
+    for (int j = 0; j < 4; ++j) t.f[j] = rotor_force_from_action(a[j], norm_act, tq[j], nullptr, true);
+#else
 #pragma unroll
-        for (int j = 0; j < 4; ++j) cmd[j] = a[j];
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) t.f[j] = rotor_force_from_cmd(cmd[j], a[j], tq[j], nullptr, false);
-    // np.clip / sqrt propagate NaN, the v_med3 clips do not: one test per wave, the selects only where it fires
-    if (__builtin_expect(__ballot(__builtin_isunordered(a[0], a[1]) || __builtin_isunordered(a[2], a[3])) != 0ull, 0)) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (a[j] != a[j]) { t.f[j] = a[j]; tq[j] = a[j]; }
-    }
+    for (int j = 0; j < 4; ++j) t.f[j] = rotor_force_sat(a[j], norm_act, tq[j]);
+#endif
     t.zt = z_torque32(tq);                             // BaseAviary.py:780
     return t;
 }
@@ -3674,7 +3706,11 @@ __global__ __launch_bounds__(256) void dn_action_chain_kernel(const float4 *__re
     const float a[4] = {A.x, A.y, A.z, A.w};
     float tq[4], f[4], r[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) f[j] = rotor_force_from_action(a[j], normalize_actions != 0, tq[j], &r[j]);
+    for (int j = 0; j < 4; ++j) {
+        float tq_chain;
+        rotor_force_from_action(a[j], normalize_actions != 0, tq_chain, &r[j]);          // the rpm output: the chain itself
+        f[j] = rotor_force_sat(a[j], normalize_actions != 0, tq[j]);                     // forces / torque: the path the step kernels take
+    }
     if (rpm) rpm[i] = make_float4(r[0], r[1], r[2], r[3]);
     if (forces) forces[i] = make_float4(f[0], f[1], f[2], f[3]);
     if (z_torque) z_torque[i] = z_torque32(tq);
@@ -3766,6 +3802,8 @@ __global__ __launch_bounds__(256) void dn_filld_kernel(double *dst, double v, lo
 }  // namespace
 
 #if DN_TU == 1
+int dn_norm_exact_compiled_in() { return DN_NORM_EXACT; }
+
 hipError_t dn_launch_fill4(float4 *dst, float4 v, long long n, hipStream_t stream)
 {
     if (n <= 0) return hipSuccess;

@@ -407,6 +407,10 @@ class DroneVecEnv(_VecEnvBase):
         return obs
 
     def step_async(self, actions):
+        if self._pending:
+            # a second step_async would overwrite the pinned action staging buffer while the first copy may still be in flight, and step
+            # the fleet twice for one step_wait (SubprocVecEnv raises AlreadySteppingError here)
+            raise RuntimeError("step_async() while a step is already pending: call step_wait() first")
         self._ensure_mirrors()
         np.copyto(self._h_actions_np, np.asarray(actions, dtype=np.float32).reshape(self.num_envs, ACT_DIM))
         with torch.cuda.device(self.device):

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define DN_ABI_VERSION 8
+#define DN_ABI_VERSION 9
 #define DN_MAX_WAYPOINTS 64
 #define DN_OBS_DIM 13      /* 12 kinematic + distance, PBDroneEnv._computeObs, PBDroneEnv.py:296-336 */
 #define DN_ACT_DIM 4       /* four rotor thrust commands, PBDroneEnv._actionSpace, PBDroneEnv.py:225-243 */
@@ -250,6 +250,21 @@ int32_t dn_reset_stats(dn_env *env, void *stream);
  * Environment variables DN_WAVES=1|2|3|4|5|8 and DN_WAVES_SINGLE=1|3 (read by dn_create) force a shape. */
 int32_t dn_get_kernel_waves(const dn_env *env, int32_t fused);
 
+/* The arithmetic switches dn_create resolved from the process environment (ABI 9), as a bit mask: a checkpoint or a shard restored in a
+ * process with another setting would otherwise replay other observation noise / other last bits silently -- compare this value.
+ *   DN_EXACT_FLAG_OBS_NOISE  DN_EXACT_OBS_NOISE=1: observation noise in the exact float64 Box-Muller form (see above).
+ *   DN_EXACT_FLAG_NORM       DN_EXACT_NORM=1: the observation normaliser's OUTPUT stage in float64.  The running statistics are float64
+ *                            and updated by the same expressions either way (normalize.py:34-47); the normalised value
+ *                            (obs - mean) / sqrt(var + 1e-8) (normalize.py:94-97) leaves as a float32, and by default it is formed in
+ *                            float32 on the hardware reciprocal square root: within 3 float32 ulp (3.6e-7 relative) of the float64
+ *                            evaluation, 30x inside the 1e-5 parity bar, for a third less vector-ALU time in the normaliser.  With the
+ *                            switch the output is the float32 nearest to the float64 evaluation (1/2 ulp).
+ * Accepted values: 1 | true | on | yes and 0 | false | off | no (any case; unset or empty = off); anything else fails dn_create with
+ * DN_ERR_INVALID_ARGUMENT. */
+#define DN_EXACT_FLAG_OBS_NOISE 1
+#define DN_EXACT_FLAG_NORM 2
+int32_t dn_get_exact_flags(const dn_env *env);
+
 /* Vector-step counter: the Philox counter word of the noise streams and the source of dn_stats.env_steps.  It
  * lives on the device and is advanced by the step kernels themselves, so dn_step / dn_step_many launches captured
  * into a hipGraph keep counting when the graph is replayed.  Both calls synchronise the device. */
@@ -361,11 +376,13 @@ int32_t dn_mlp_step_sampled(dn_env *env, const dn_mlp_net *nets, int32_t num_net
                             float *obs, float *reward, uint8_t *done, uint8_t *truncated, int32_t *found_targets, float *terminal_obs,
                             float *ep_return, int32_t *ep_length, uint64_t *done_mask, void *stream);
 
-/* Measurement hook (ABI 8).  The step kernel of the NEXT dn_step / dn_step_many / dn_step_sampled / dn_step_squashed call on `env` is dispatched with these two hipEvents
+/* Measurement hook (ABI 8; lifetime rules ABI 9).  The step kernel of the NEXT dn_step / dn_step_many / dn_step_sampled / dn_step_squashed call on `env` is dispatched with these two hipEvents
  * (hipEvent_t passed as void *, created with timing enabled; either may be NULL) attached to its own dispatch packet
  * (hipExtLaunchKernelGGL): hipEventElapsedTime(start, stop) is then the duration of that kernel alone -- what a profiler's kernel trace
  * reports -- where a pair of hipEventRecord around the call also times the host's launch path and puts two marker packets on the
- * stream.  One shot: cleared by the launch it was armed for.  It stands where the reference wraps its training loop in cProfile
+ * stream.  One shot: consumed by the next step-family call on `env` whatever its outcome -- a call that fails validation, dn_eval_kinematics
+ * and dn_mlp_step_sampled (no hook) DROP the events instead of leaving them armed for a later launch.  An armed launch cannot be
+ * captured into a hipGraph (DN_ERR_INVALID_ARGUMENT if the stream is capturing).  It stands where the reference wraps its training loop in cProfile
  * (Sol/Utilities/Profiler.py:5-16), at the granularity this path has: one launch.  Used by bench.py's roofline figure. */
 int32_t dn_set_launch_events(dn_env *env, void *start_event, void *stop_event);
 

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Instruction-mix counters of the fused step kernel (run on the GPU box through gpurun):   profiles/instmix.sh <tag>
 # One rocprofv3 pass per counter pair (kernel trace only; --pmc is never combined with other trace domains), the bench in
-# --profile-lite mode; profiles/instmix.py <dir> prints per-launch and per 64-drone-step values.
+# --profile-lite mode; profiles/instmix.py <dir> prints per-launch and (DN_IM_K=<steps per launch> DN_IM_N=<drones>) per 64-drone-step values.
 set -eu
 TAG=${1:?usage: profiles/instmix.sh <tag> [bench args]}; shift
 export TMPDIR=/tmp
@@ -18,7 +18,7 @@ for pair in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_V
     rocprofv3 --kernel-trace --pmc $pair -d "$OUT/p$i" -o p$i -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-ppo-rollout --profile-lite "$@" > "$OUT/bench_p$i.log" 2>&1 || FAILED="$FAILED p$i($pair)"
 done
 cd "$ROOT"
-python3 profiles/instmix.py "$OUT" > "$ROOT/gpurun_out/instmix_$TAG.txt"
+python3 profiles/instmix.py "$OUT" ${DN_IM_K:-0} ${DN_IM_N:-32768} > "$ROOT/gpurun_out/instmix_$TAG.txt"
 if [ -n "$FAILED" ]; then
     echo "# FAILED passes (logs kept under gpurun_out/instmix_$TAG/): $FAILED -- this summary is incomplete" >> "$ROOT/gpurun_out/instmix_$TAG.txt"
     find "$OUT" -name "*.db" -delete

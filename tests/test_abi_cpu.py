@@ -67,7 +67,7 @@ int main(void) {
     assert got == [C.sizeof(K.DnConfig), C.sizeof(K.DnEnvState), C.sizeof(K.DnStats), C.sizeof(K.DnMlpNet),
                    K.DnConfig.random_spawn.offset, K.DnConfig.seed.offset, K.DnEnvState.pid.offset,
                    K.DnEnvState.rms_mean.offset, K.ABI_VERSION], got
-    assert pkg._capi.load().dn_abi_version() == pkg._capi.ABI_VERSION == 8
+    assert pkg._capi.load().dn_abi_version() == pkg._capi.ABI_VERSION == 9
 
 
 def test_config_defaults_follow_the_driver(pkg):

@@ -1,7 +1,8 @@
 """The short float32 sequences of the HIP action chain (Markstein division by a constant, one-ulp sqrt fix-up;
 csrc/dn_kernels.hip rotor_force_from_action) are proven bit-identical to IEEE divide / sqrt by enumerating every
-float32 input that can reach them (tests/tools/check_action_chain_exact.c).  CPU only; the exhaustive run takes a
-couple of seconds on 8 cores."""
+float32 input that can reach them (tests/tools/check_action_chain_exact.c), and the saturation fast path's constants
+(csrc/dn_action_sat.h: two raw-action thresholds, two force / torque pairs) are proven against the literal chain for
+EVERY float32 action, with and without rescale_action.  CPU only; the exhaustive run takes a few seconds on 8 cores."""
 import json
 import os
 import subprocess
@@ -12,9 +13,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_short_division_and_sqrt_are_correctly_rounded(tmp_path):
     exe = str(tmp_path / "check_exact")
     src = os.path.join(ROOT, "tests", "tools", "check_action_chain_exact.c")
-    subprocess.check_call(["gcc", "-O2", "-mfma", "-fopenmp", "-ffp-contract=off", src, "-o", exe, "-lm"])
+    inc = os.path.join(ROOT, "drl-dronenavigation_amd", "csrc")          # dn_action_sat.h: the constants the kernel itself compiles in
+    subprocess.check_call(["gcc", "-O2", "-mfma", "-fopenmp", "-ffp-contract=off", "-I" + inc, src, "-o", exe, "-lm"])
     out = subprocess.run([exe, "1"], capture_output=True, text=True, timeout=600)
     res = json.loads(out.stdout)
     assert out.returncode == 0, res
     assert res["den"][1] > 2e9 and res["kf"][1] > 1e7 and res["scale"][1] > 5e6 and res["sqrt"][1] > 3e7
     assert res["den"][0] == res["kf"][0] == res["scale"][0] == res["sqrt"][0] == 0
+    # every non-NaN float32 action x {rescaled, raw command}: 2 x (2^32 - 2^24 + 2)
+    assert res["sat"] == [0, 2 * (2 ** 32 - 2 ** 24 + 2)], res
+    assert res["sat_constants_bad"] == 0 and res["sat_not_tight"] == 0
+    assert res["sat_band"] == 969265            # float32 actions strictly inside the unsaturated band

@@ -1,0 +1,283 @@
+"""Round 6: the saturation fast path of the float32 action chain, the float32 output stage of the observation normaliser (and the
+build that keeps the float64 one), the arithmetic switches of ABI 9 and the lifetime of armed launch events.  All through the C ABI /
+DroneVecEnv on a real MI355X (`-m gpu`)."""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from oracle import oracle as O  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU: the HIP path has no CPU fallback")
+    import drl_dronenavigation_amd as pkg
+    return pkg
+
+
+def _bits(x):
+    return np.ascontiguousarray(x, np.float32).view(np.uint32)
+
+
+# the constants of csrc/dn_action_sat.h (proven exhaustively on the CPU by tests/test_action_chain_exact.py)
+SAT_LO, SAT_HI = np.uint32(0x3DB83474).view(np.float32), np.uint32(0x3DC6FEA6).view(np.float32)
+A_LOW, A_HIGH = np.uint32(0x3CE6B357).view(np.float32), np.uint32(0x3E17E6D2).view(np.float32)
+
+
+def chain_numpy(a, normalize):
+    """The reference's float32 action chain, literally, in numpy float32 as the reference evaluates it: PBDroneEnv.rescale_action
+    (PBDroneEnv.py:949-971), _preprocessAction (:872-895), env_utils.cmd2pwm / pwm2rpm (env_utils.py:8-59), BaseAviary._physics
+    (BaseAviary.py:776-780).  Returns (forces [N,4], z_torque [N]) float32."""
+    f = np.float32
+    a = np.asarray(a, f)
+    kf, km, scale, const = f(3.16e-10), f(7.94e-12), f(0.2685), f(4070.3)
+    with np.errstate(all="ignore"):
+        cmd = a
+        if normalize:
+            cmd = np.clip(f(-1.0) + f(2.0) * ((a - A_LOW) / (A_HIGH - A_LOW)), f(-1.0), f(1.0))
+        thrust = np.clip(cmd, A_LOW, A_HIGH)
+        pwm = (np.sqrt(np.maximum(thrust, f(0)) / f(1) / kf) - const) / scale
+        pwm = np.clip(pwm, f(20000.0), f(65535.0))
+        rpm = scale * pwm + const
+        sq = rpm * rpm
+        force, tq = sq * kf, sq * km
+        z = -tq[:, 0]
+        z = z + tq[:, 1]
+        z = z - tq[:, 2]
+        z = z + tq[:, 3]
+    return force.astype(f), z.astype(f)
+
+
+def test_saturation_fast_path_is_the_chain_bit_for_bit():
+    """rotor_force_sat (csrc/dn_kernels.hip): a wave takes the chain for a rotor only if one of its 64 lanes is inside the unsaturated band
+    (or NaN); otherwise every lane selects one of two constant pairs.  Waves built to take each path -- all lanes saturated, one lane inside
+    the band, lanes exactly ON the two thresholds and one float32 inside them, infinities, a NaN among saturated lanes -- against the
+    reference's chain evaluated literally in numpy float32: forces and yaw torque bit for bit, both action modes."""
+    pkg = _gpu()
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(6)
+    up = lambda x: np.nextafter(np.float32(x), np.float32(np.inf), dtype=np.float32)      # noqa: E731
+    dn = lambda x: np.nextafter(np.float32(x), np.float32(-np.inf), dtype=np.float32)     # noqa: E731
+    for normalize in (True, False):
+        lo, hi = (SAT_LO, SAT_HI) if normalize else (A_LOW, A_HIGH)
+        sat = lambda m: np.where(rng.random((m, 4)) < 0.5, rng.uniform(-1.0, float(lo), (m, 4)),      # noqa: E731
+                                 rng.uniform(float(hi), 1.0, (m, 4))).astype(np.float32)
+        waves = []
+        for _ in range(64):                                     # every lane of every rotor saturated: the fast path alone
+            waves.append(sat(64))
+        for k in range(64):                                     # one lane of one rotor inside the band: that rotor's chain for the whole wave
+            w = sat(64)
+            w[rng.integers(64), k % 4] = np.float32(rng.uniform(float(up(lo)), float(dn(hi))))
+            waves.append(w)
+        edge = [lo, up(lo), dn(lo), hi, dn(hi), up(hi), np.float32(np.inf), np.float32(-np.inf), np.float32(-0.0), np.float32(0.0),
+                np.float32(1.0), np.float32(-1.0), np.float32(3e38), np.float32(-3e38), np.float32(1e-45)]
+        for e in edge:                                          # the edge value on one lane, then on all of them
+            w = sat(64)
+            w[5, 2] = e
+            waves.append(w)
+            waves.append(np.full((64, 4), e, np.float32))
+        w = sat(64)
+        w[9, 1] = np.float32(np.nan)                            # np.clip / sqrt propagate NaN: force and torque of that rotor are NaN
+        waves.append(w)
+        a = np.concatenate(waves)
+        _, forces, zt = pkg.preprocess_action(torch.from_numpy(a).to(dev), normalize_actions=normalize)
+        f_ref, z_ref = chain_numpy(a, normalize)
+        f_gpu, z_gpu = forces.cpu().numpy(), zt.cpu().numpy()
+        nan_f, nan_z = np.isnan(f_ref), np.isnan(z_ref)
+        assert nan_f.sum() == 1 and nan_z.sum() == 1
+        assert np.array_equal(np.isnan(f_gpu), nan_f) and np.array_equal(np.isnan(z_gpu), nan_z)
+        assert np.array_equal(_bits(f_gpu)[~nan_f], _bits(f_ref)[~nan_f]), f"forces, normalize_actions={normalize}"
+        assert np.array_equal(_bits(z_gpu)[~nan_z], _bits(z_ref)[~nan_z]), f"z torque, normalize_actions={normalize}"
+        # the two constant pairs are what the saturated lanes carry
+        assert set(np.unique(_bits(f_gpu[:64 * 64]))) == {0x3CE6B357, 0x3E17E6D2}
+
+
+def test_fused_step_with_the_fast_path_equals_the_oracle_in_both_action_regimes():
+    """The step kernels take the same function: 20 fused steps from reset at BASELINE's 32 768 drones under U(-1,1) (99.6 % of actions
+    saturated: the fast path) and under the hover band 0.0922 + 0.003 N(0,1) (SURVEY 8(d) C2's second distribution: every wave takes the
+    chain), each against the oracle stepping the same actions -- flags exact, observations 1e-5, rewards 1e-4 (free-running)."""
+    pkg = _gpu()
+    from drl_dronenavigation_amd import tracks
+    dev = torch.device("cuda:0")
+    n, K = 32768, 20
+    track = tracks.reaching()
+    for name in ("uniform", "hover"):
+        rng = np.random.default_rng(3)
+        acts = (rng.uniform(-1, 1, (K, n, 4)) if name == "uniform" else 0.0922 + 0.003 * rng.standard_normal((K, n, 4))).astype(np.float32)
+        env = pkg.DroneVecEnv(track, n, normalize_obs=True, max_steps=4096, device=dev)
+        ora = O.OracleVecEnv(O.make_config(track.targets(), track.initial_xyzs, track.aviary_dim, circle=False, max_steps=4096,
+                                           f32_state=True, normalize_obs=True, ground_contact=env.ground_contact), n, threads=8)
+        np.testing.assert_allclose(env.reset(), ora.reset(), rtol=0, atol=1e-5)
+        out = env.rollout_tensor(torch.from_numpy(acts).to(dev))
+        torch.cuda.synchronize()
+        assert env.kernel_waves(fused=True) == 5
+        for t in range(K):
+            ref = ora.step(acts[t])
+            assert np.array_equal(out["done"][t].cpu().numpy().astype(bool), ref["done"].astype(bool)), (name, t)
+            assert np.array_equal(out["truncated"][t].cpu().numpy().astype(bool), ref["truncated"].astype(bool)), (name, t)
+            assert np.array_equal(out["found_targets"][t].cpu().numpy(), ref["found_targets"]), (name, t)
+            np.testing.assert_allclose(out["obs"][t].cpu().numpy(), ref["obs"], rtol=1e-5, atol=1e-5, err_msg=f"{name} t={t}")
+            np.testing.assert_allclose(out["reward"][t].cpu().numpy(), ref["reward"], rtol=1e-5, atol=1e-4, err_msg=f"{name} t={t}")
+        env.close()
+
+
+_CHILD = r"""
+import json, os, sys
+import numpy as np
+import torch
+sys.path.insert(0, {root!r})
+import drl_dronenavigation_amd as pkg
+from drl_dronenavigation_amd import tracks
+dev = torch.device("cuda:0")
+n, K = 4096, 96
+env = pkg.DroneVecEnv(tracks.reaching(), n, normalize_obs=True, max_steps=60, device=dev)
+flags = int(pkg._capi.load().dn_get_exact_flags(env._handle))
+env.reset_tensor()
+acts = torch.from_numpy(np.load({acts!r})).to(dev)
+out = env.rollout_tensor(acts)
+torch.cuda.synchronize()
+np.savez({dst!r}, obs=out["obs"].cpu().numpy(), done=out["done"].cpu().numpy(), reward=out["reward"].cpu().numpy(),
+         rms_mean=env.get_state()["rms_mean"], rms_var=env.get_state()["rms_var"], flags=flags, lib=pkg._capi.library_path())
+env.close()
+"""
+
+
+def test_float32_output_stage_against_the_exact_build(tmp_path):
+    """The default library forms the normalised observation in float32 (v_rsq_f32): within 3 float32 ulp of libdronenav_exact.so
+    (DN_EXACT_NORM=1: the float64 output stage), which in turn is the oracle's float64 evaluation rounded to float32 (1/2 ulp + what the
+    raw float32 observation itself differs by).  Statistics, flags and rewards are IDENTICAL between the two builds: only the output
+    stage differs.  dn_get_exact_flags reports which build is loaded."""
+    pkg = _gpu()
+    from drl_dronenavigation_amd import tracks
+    assert os.path.exists(pkg.build.LIB_PATH_EXACT), "libdronenav_exact.so must be built next to libdronenav.so"
+    rng = np.random.default_rng(11)
+    n, K = 4096, 96
+    acts = np.stack([np.where((np.arange(n) % 2 == 0)[:, None], rng.uniform(-1, 1, (n, 4)),
+                              0.0922 + 0.003 * rng.standard_normal((n, 4))).astype(np.float32) for _ in range(K)])
+    np.save(tmp_path / "acts.npy", acts)
+    res = {}
+    for name, val in (("fast", "0"), ("exact", "1")):
+        env_ = dict(os.environ, DN_EXACT_NORM=val)
+        env_.pop("DN_LIB_PATH", None)
+        dst = str(tmp_path / f"{name}.npz")
+        code = _CHILD.format(root=ROOT, acts=str(tmp_path / "acts.npy"), dst=dst)
+        subprocess.run([sys.executable, "-c", code], check=True, env=env_, timeout=600)
+        res[name] = np.load(dst)
+    assert int(res["fast"]["flags"]) & 2 == 0 and int(res["exact"]["flags"]) & 2 == 2
+    assert str(res["exact"]["lib"]).endswith("libdronenav_exact.so") and str(res["fast"]["lib"]).endswith("libdronenav.so")
+    assert np.array_equal(res["fast"]["done"], res["exact"]["done"])
+    assert np.array_equal(_bits(res["fast"]["reward"]), _bits(res["exact"]["reward"]))
+    assert np.array_equal(res["fast"]["rms_mean"], res["exact"]["rms_mean"]) and np.array_equal(res["fast"]["rms_var"], res["exact"]["rms_var"])
+    fo, eo = res["fast"]["obs"].astype(np.float64), res["exact"]["obs"].astype(np.float64)
+    ulp = np.spacing(np.abs(res["exact"]["obs"]).astype(np.float32)).astype(np.float64)
+    err_ulp = np.abs(fo - eo) / np.maximum(ulp, np.float64(np.spacing(np.float32(1e-30))))
+    assert err_ulp.max() <= 3.0, f"float32 output stage off by {err_ulp.max():.2f} float32 ulp"
+    assert res["fast"]["done"].sum() > n, "episodes must end (the reset observation's second pass) in this run"
+    print(f"float32 output stage: max {err_ulp.max():.2f} ulp, mean {err_ulp.mean():.3f} ulp over {fo.size} normalised values; "
+          f"|obs| max {np.abs(eo).max():.2f}")
+    # the exact build against the oracle's float64 evaluation on the same actions
+    track = tracks.reaching()
+    ora = O.OracleVecEnv(O.make_config(track.targets(), track.initial_xyzs, track.aviary_dim, circle=False, max_steps=60,
+                                       f32_state=True, normalize_obs=True, ground_contact=False), n, threads=8)
+    ora.reset()
+    worst = 0.0
+    for t in range(K):
+        ref = ora.step(acts[t])
+        assert np.array_equal(res["exact"]["done"][t].astype(bool), ref["done"].astype(bool))
+        np.testing.assert_allclose(res["exact"]["obs"][t], ref["obs"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(res["fast"]["obs"][t], ref["obs"], rtol=1e-5, atol=1e-5)
+        worst = max(worst, float(np.abs(res["fast"]["obs"][t].astype(np.float64) - ref["obs"]).max()))
+    print(f"default build against the oracle: max |obs err| = {worst:.2e}")
+
+
+def test_arithmetic_switches_are_checked_not_guessed(monkeypatch):
+    """DN_EXACT_OBS_NOISE / DN_EXACT_NORM accept 1 | true | on | yes and 0 | false | off | no; anything else fails dn_create
+    (a typo must not silently select the other arithmetic), a request for the exact normaliser on the default build fails loudly, and
+    dn_get_exact_flags returns what was resolved."""
+    pkg = _gpu()
+    from drl_dronenavigation_amd import tracks
+    lib = pkg._capi.load()
+    for val, want in (("1", 1), ("TRUE", 1), ("on", 1), ("yes", 1), ("0", 0), ("off", 0), ("", 0)):
+        monkeypatch.setenv("DN_EXACT_OBS_NOISE", val)
+        env = pkg.DroneVecEnv(tracks.reaching(), 64, obs_noise_sigma=0.01, device="cuda:0")
+        assert int(lib.dn_get_exact_flags(env._handle)) & 1 == want, val
+        env.close()
+    monkeypatch.setenv("DN_EXACT_OBS_NOISE", "maybe")
+    with pytest.raises(pkg.DroneNavError, match="DN_EXACT_OBS_NOISE"):
+        pkg.DroneVecEnv(tracks.reaching(), 64, device="cuda:0")
+    monkeypatch.delenv("DN_EXACT_OBS_NOISE")
+    # this process loaded the default build: asking IT for the exact normaliser is refused (the loader would have picked the other library)
+    monkeypatch.setenv("DN_EXACT_NORM", "1")
+    with pytest.raises(pkg.DroneNavError, match="libdronenav_exact.so"):
+        pkg.DroneVecEnv(tracks.reaching(), 64, device="cuda:0")
+    monkeypatch.setenv("DN_EXACT_NORM", "2")
+    with pytest.raises(pkg.DroneNavError, match="DN_EXACT_NORM"):
+        pkg.DroneVecEnv(tracks.reaching(), 64, device="cuda:0")
+
+
+def test_armed_launch_events_never_outlive_the_next_call():
+    """events armed by dn_set_launch_events are consumed by the next step-family call whatever its outcome.  A call that fails
+    validation drops them; so does dn_eval_kinematics (no hook): a later launch must not record into them.  An armed launch inside a
+    stream capture is refused."""
+    pkg = _gpu()
+    from drl_dronenavigation_amd import tracks
+    dev = torch.device("cuda:0")
+    n = 4096
+    env = pkg.DroneVecEnv(tracks.reaching(), n, normalize_obs=True, device=dev)
+    env.reset_tensor()
+    lib, h = pkg._capi.load(), env._handle
+    stream = torch.cuda.current_stream(dev)
+    acts = torch.rand((8, n, 4), device=dev) * 2 - 1
+    k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    k0.record(stream); k1.record(stream)
+    torch.cuda.synchronize()
+    env.rollout_tensor(acts)
+    pkg._capi.check(lib.dn_set_launch_events(h, C.c_void_p(k0.cuda_event), C.c_void_p(k1.cuda_event)))
+    env.rollout_tensor(acts)
+    torch.cuda.synchronize()
+    first = k0.elapsed_time(k1)
+    assert first > 0.0
+    # armed, then a call that fails validation (k = 0): the events are dropped, the next good launch leaves them untouched
+    pkg._capi.check(lib.dn_set_launch_events(h, C.c_void_p(k0.cuda_event), C.c_void_p(k1.cuda_event)))
+    rc = lib.dn_step_many(h, 0, acts.data_ptr(), None, None, None, None, None, None, None, None, None, C.c_void_p(stream.cuda_stream))
+    assert rc == -1
+    env.rollout_tensor(acts)
+    torch.cuda.synchronize()
+    assert k0.elapsed_time(k1) == first
+    # armed, then a capture: refused (and dropped)
+    pkg._capi.check(lib.dn_set_launch_events(h, C.c_void_p(k0.cuda_event), C.c_void_p(k1.cuda_event)))
+    ptrs = _scratch_ptrs(n, dev)                           # allocated BEFORE the capture
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(stream)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            rc = lib.dn_step(h, acts[0].data_ptr(), *ptrs, None, None, None, None, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    assert rc == -1 and "hipGraph" in lib.dn_last_error().decode()
+    stream.wait_stream(side)
+    env.rollout_tensor(acts)
+    torch.cuda.synchronize()
+    assert k0.elapsed_time(k1) == first
+    env.close()
+
+
+_SCRATCH = {}
+
+
+def _scratch_ptrs(n, dev):
+    """obs, reward, done, truncated, found_targets device buffers for a raw dn_step call."""
+    if n not in _SCRATCH:
+        _SCRATCH[n] = (torch.empty((n, 13), device=dev), torch.empty(n, device=dev), torch.empty(n, dtype=torch.uint8, device=dev),
+                       torch.empty(n, dtype=torch.uint8, device=dev), torch.empty(n, dtype=torch.int32, device=dev))
+    return tuple(t.data_ptr() for t in _SCRATCH[n])

@@ -7,14 +7,20 @@
  *   division by a constant c:   q0 = a * RN(1/c);  r = fma(-q0, c, a);  q = fma(r, RN(1/c), q0)      vs   a / c
  *   square root:                s = approx;  one ulp below / above tested with fma residuals          vs   sqrtf
  *
+ *   saturation fast path:       raw action <= DN_ACT_SAT_LO -> (F_LO, TQ_LO),  >= DN_ACT_SAT_HI -> (F_HI, TQ_HI)
+ *                               (csrc/dn_action_sat.h, rotor_force_sat in csrc/dn_kernels.hip)                 vs   the literal chain
+ *   for EVERY float32 action (all 2^32 bit patterns but the NaNs), with and without rescale_action.
+ *
  * Usage: check_action_chain_exact [stride]   (stride 1 = exhaustive, default; larger = subsample for quick runs)
- * Build: gcc -O2 -mfma -fopenmp -ffp-contract=off check_action_chain_exact.c -lm
+ * Build: gcc -O2 -mfma -fopenmp -ffp-contract=off -I<repo>/drl-dronenavigation_amd/csrc check_action_chain_exact.c -lm
  */
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+
+#include "dn_action_sat.h"
 
 static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
@@ -35,6 +41,41 @@ static inline float sqrt_fix(float x, float s)
     if (rm <= 0.0f) out = sm;
     if (rp > 0.0f) out = sp;
     return out;
+}
+
+/* np.clip = minimum(maximum(x, lo), hi) */
+static inline float clipf(float x, float lo, float hi)
+{
+    if (x < lo) return lo;
+    if (x > hi) return hi;
+    return x;
+}
+/* PBDroneEnv.rescale_action (PBDroneEnv.py:949-971), float32, numpy's operation order, IEEE divide */
+static inline float rescale_literal(float a, float a_low, float a_high)
+{
+    float num = a - a_low;
+    float den = a_high - a_low;
+    float q = num / den;
+    float m = 2.0f * q;                    /* (high - low) = 1 - (-1) */
+    float r = -1.0f + m;
+    return clipf(r, -1.0f, 1.0f);
+}
+/* everything after PBDroneEnv._preprocessAction's clip (PBDroneEnv.py:889): cmd2pwm / pwm2rpm (env_utils.py:8-59) and the force /
+ * torque lines of BaseAviary._physics (BaseAviary.py:776-777), float32, numpy's operation order, IEEE divide and sqrt */
+static inline void force_of_thrust_literal(float thrust, float *f, float *tq)
+{
+    const float KF = (float)3.16e-10, KM = (float)7.94e-12, SCALE = (float)0.2685, CONST_ = (float)4070.3;
+    if (thrust < 0.0f) thrust = 0.0f;
+    float t = thrust / 1.0f;
+    t = t / KF;
+    float s = sqrtf(t);
+    float pwm = (s - CONST_) / SCALE;
+    pwm = clipf(pwm, 20000.0f, 65535.0f);
+    float r0 = SCALE * pwm;
+    float rpm = r0 + CONST_;
+    float sq = rpm * rpm;
+    *f = sq * KF;
+    *tq = sq * KM;
 }
 
 int main(int argc, char **argv)
@@ -80,7 +121,43 @@ int main(int argc, char **argv)
         if (f2u(div_const(num, SCALE, ySCALE)) != f2u(num / SCALE)) ++bad_scale;
         ++n3;
     }
-    printf("{\"stride\": %u, \"den\": [%lld, %lld], \"kf\": [%lld, %lld], \"scale\": [%lld, %lld], \"sqrt\": [%lld, %lld]}\n",
-           stride, bad_den, n1, bad_kf, n2, bad_scale, n3, bad_sqrt, n4);
-    return (bad_den || bad_kf || bad_scale || bad_sqrt) ? 1 : 0;
+    /* The saturation fast path (csrc/dn_action_sat.h).  The force / torque are a pure function of the clipped thrust, so the literal
+     * chain is evaluated up to the clip for every action and beyond it only where the thrust is not one of the two bounds. */
+    long long bad_sat = 0, n5 = 0, n_band = 0, bad_const = 0, bad_tight = 0;
+    {
+        const float SAT_LO = u2f(DN_ACT_SAT_LO_BITS), SAT_HI = u2f(DN_ACT_SAT_HI_BITS);
+        const uint32_t FLO = DN_F_LO_BITS, TLO = DN_TQ_LO_BITS, FHI = DN_F_HI_BITS, THI = DN_TQ_HI_BITS;
+        float f, tq;
+        if (f2u(A_LOW) != DN_A_LOW_BITS || f2u(A_HIGH) != DN_A_HIGH_BITS) ++bad_const;
+        force_of_thrust_literal(A_LOW, &f, &tq);
+        if (f2u(f) != FLO || f2u(tq) != TLO) ++bad_const;
+        force_of_thrust_literal(A_HIGH, &f, &tq);
+        if (f2u(f) != FHI || f2u(tq) != THI) ++bad_const;
+        /* the thresholds are tight: one float32 inside the band the thrust is no longer a bound */
+        if (clipf(rescale_literal(u2f(DN_ACT_SAT_LO_BITS + 1u), A_LOW, A_HIGH), A_LOW, A_HIGH) == A_LOW) ++bad_tight;
+        if (clipf(rescale_literal(u2f(DN_ACT_SAT_HI_BITS - 1u), A_LOW, A_HIGH), A_LOW, A_HIGH) == A_HIGH) ++bad_tight;
+#pragma omp parallel for reduction(+ : bad_sat, n5, n_band) schedule(static)
+        for (long long k = 0; k <= 0xFFFFFFFFll; k += stride) {
+            const float a = u2f((uint32_t)k);
+            if (a != a) continue;                                  /* NaN: the kernel's slow path (np.clip / sqrt propagate it) */
+            for (int normalize = 0; normalize < 2; ++normalize) {
+                const float cmd = normalize ? rescale_literal(a, A_LOW, A_HIGH) : a;
+                const float thrust = clipf(cmd, A_LOW, A_HIGH);    /* PBDroneEnv.py:889 */
+                const float lo = normalize ? SAT_LO : A_LOW, hi = normalize ? SAT_HI : A_HIGH;
+                /* what rotor_force_sat's fast path returns, or "the chain itself" (-1) */
+                const int fast = a >= hi ? 1 : (a <= lo ? 0 : -1);
+                const int lit = thrust == A_HIGH ? 1 : (thrust == A_LOW ? 0 : -1);
+                if (fast != -1 && fast != lit) ++bad_sat;          /* a fast-path action whose literal thrust is not that bound */
+                if (normalize && fast == -1) {
+                    ++n_band;
+                    if (lit != -1) ++bad_sat;                      /* inside the band the thrust must be strictly between the bounds (tightness) */
+                }
+                ++n5;
+            }
+        }
+    }
+    printf("{\"stride\": %u, \"den\": [%lld, %lld], \"kf\": [%lld, %lld], \"scale\": [%lld, %lld], \"sqrt\": [%lld, %lld], "
+           "\"sat\": [%lld, %lld], \"sat_band\": %lld, \"sat_constants_bad\": %lld, \"sat_not_tight\": %lld}\n",
+           stride, bad_den, n1, bad_kf, n2, bad_scale, n3, bad_sqrt, n4, bad_sat, n5, n_band, bad_const, bad_tight);
+    return (bad_den || bad_kf || bad_scale || bad_sqrt || bad_sat || bad_const || bad_tight) ? 1 : 0;
 }
