@@ -185,6 +185,7 @@ void build_consts(const dn_config &c, DnConsts<R> &k)
     k.reset_obs[4] = (R)-0.0 / pi;
     k.reset_obs[5] = (R)0.0 / pi;
     for (int j = 6; j < 12; ++j) k.reset_obs[j] = (R)0.0;
+    for (int j = 0; j < 12; ++j) k.reset_obs32[j] = (float)k.reset_obs[j];
 }
 
 int32_t validate(const dn_config *c)

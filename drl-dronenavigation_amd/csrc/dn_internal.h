@@ -91,6 +91,8 @@ struct DnConsts {
     R inv_max_target_dist;
     R inv_dim[3];       // 1 / (x_high, y_high, z_high): position normalisation as a multiply
     R reset_obs[12];    // observation of the freshly spawned body (BaseAviary.reset, BaseAviary.py:318)
+    float reset_obs32[12];   // ... as the float32 words the observation row carries (what the kernels read: half the scalar registers of
+                             // the R values, and no float64 -> float32 conversion per column in the reset observation's normaliser pass)
 };
 
 struct DnParams {

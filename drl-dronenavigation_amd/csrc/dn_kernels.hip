@@ -544,14 +544,20 @@ template <> struct FM<double> {
         double e = __builtin_fma(-(0.5 * x * y), y, 0.5);
         return __builtin_fma(y, e, y);
     }
-    static DN_DEV double sqrt0(double x)        // x >= 0, exact 0 allowed
+    static DN_DEV double rcp_f32grade(double x)   // one Newton step on the 2^-23 seed: ~2^-46, for results that leave as float32
+    {
+        double r = __builtin_amdgcn_rcp(x);
+        double e = __builtin_fma(-x, r, 1.0);
+        return __builtin_fma(r, e, r);
+    }
+    // x >= 0, exact 0 allowed.  One coupled Newton step on the 2^-23 seed (g ~ sqrt x, h ~ 1 / (2 sqrt x): 2^-45) and the residual
+    // correction g += (x - g^2) h, which squares that again: the double nearest to the root or its neighbour (round 6; a second
+    // coupled step in front of the correction bought nothing but three instructions).
+    static DN_DEV double sqrt0(double x)
     {
         double y = __builtin_amdgcn_rsq(x);
         double g = x * y, h = 0.5 * y;
         double r = __builtin_fma(-h, g, 0.5);
-        g = __builtin_fma(g, r, g);
-        h = __builtin_fma(h, r, h);
-        r = __builtin_fma(-h, g, 0.5);
         g = __builtin_fma(g, r, g);
         h = __builtin_fma(h, r, h);
         const double d = __builtin_fma(-g, g, x);
@@ -564,6 +570,7 @@ template <> struct FM<float> {                  // speed option (compute_f32): h
     static DN_DEV float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
     static DN_DEV float rsq(float x) { return __builtin_amdgcn_rsqf(x); }
     static DN_DEV float rsq_f32grade(float x) { return __builtin_amdgcn_rsqf(x); }
+    static DN_DEV float rcp_f32grade(float x) { return __builtin_amdgcn_rcpf(x); }
     static DN_DEV float sqrt0(float x) { return __builtin_amdgcn_sqrtf(x); }
     static DN_DEV float fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 };
@@ -825,7 +832,7 @@ template <typename R>
 DN_DEV void reset_obs(const DnParams &p, const DnConsts<R> &c, R d_last, float o[DN_OBS_DIM])
 {
 #pragma unroll
-    for (int k = 0; k < 12; ++k) o[k] = (float)c.reset_obs[k];
+    for (int k = 0; k < 12; ++k) o[k] = c.reset_obs32[k];
     o[12] = p.include_distance ? (float)(d_last * c.inv_max_target_dist) : 0.0f;
 }
 
@@ -1066,8 +1073,25 @@ DN_DEV Thrust thrust_phase(const DnParams &p, unsigned long long gid, unsigned l
 #pragma unroll
     for (int j = 0; j < 4; ++j) t.f[j] = rotor_force_from_action(a[j], norm_act, tq[j], nullptr, true);
 #else
+    // Per rotor: two selects, and the chain only if a lane of the wave is inside the band.  The four chains sit in four branches and
+    // cannot interleave, so where EVERY rotor of the wave needs its chain (a policy in the hover band: always; U(-1,1): 0.2 % of
+    // wave-steps) they are evaluated side by side as before -- four independent dependency chains for the scheduler to overlap.  That
+    // test is made only once rotor 0 is known to need its chain (U(-1,1): one wave-step in five), so the saturated regime does not pay
+    // for it on the role every barrier waits for (measured: the four ballots up front cost the U(-1,1) launch 2 %).
+    const float t_lo = norm_act ? ACT_SAT_LO32 : A_LOW32, t_hi = norm_act ? ACT_SAT_HI32 : A_HIGH32;      // wave-uniform
+    bool side_by_side = false;
+    if (__ballot(!(a[0] >= t_hi || a[0] <= t_lo)) != 0ull) {
+        side_by_side = true;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) t.f[j] = rotor_force_sat(a[j], norm_act, tq[j]);
+        for (int j = 1; j < 4; ++j) side_by_side = side_by_side && __ballot(!(a[j] >= t_hi || a[j] <= t_lo)) != 0ull;
+    }
+    if (side_by_side) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t.f[j] = rotor_force_from_action(a[j], norm_act, tq[j], nullptr, true);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t.f[j] = rotor_force_sat(a[j], norm_act, tq[j]);
+    }
 #endif
     t.zt = z_torque32(tq);                             // BaseAviary.py:780
     return t;
@@ -1125,7 +1149,8 @@ template <typename R> struct QuatTerms {
 template <typename R> DN_DEV QuatTerms<R> quat_terms(const R qx, const R qy, const R qz, const R qw)
 {   // btMatrix3x3::setRotation: s = 2 / |q|^2
     QuatTerms<R> t;
-    const R s = R(2.0) * FM<R>::rcp(F(qw, qw, F(qz, qz, F(qy, qy, qx * qx))));
+    // (one Newton step on the reciprocal: 2^-46 relative in a matrix whose products leave as float32 state words)
+    const R s = R(2.0) * FM<R>::rcp_f32grade(F(qw, qw, F(qz, qz, F(qy, qy, qx * qx))));
     t.xs = qx * s; t.ys = qy * s; t.zs = qz * s;
     t.wxs = qw * t.xs; t.wys = qw * t.ys; t.wzs = qw * t.zs;
     t.yy = qy * t.ys; t.zz = qz * t.zs;
@@ -1141,13 +1166,25 @@ template <typename R> struct AttCol {
     R r02, r12, r22;
 };
 template <typename R>
-DN_DEV AttCol<R> attitude_column(const float4 G1)
+DN_DEV AttCol<R> attitude_column_terms(const float4 G1, const QuatTerms<R> &t)
 {
-    const R qx = G1.x, qy = G1.y, qz = G1.z, qw = G1.w;
-    const QuatTerms<R> t = quat_terms<R>(qx, qy, qz, qw);
+    const R qx = G1.x, qy = G1.y;
     AttCol<R> c;
     c.r02 = F(qx, t.zs, t.wys); c.r12 = F(qy, t.zs, -t.wxs); c.r22 = R(1.0) - F(qx, t.xs, t.yy);
     return c;
+}
+template <typename R>
+DN_DEV AttCol<R> attitude_column(const float4 G1)
+{
+    const R qx = G1.x, qy = G1.y, qz = G1.z, qw = G1.w;
+    return attitude_column_terms<R>(G1, quat_terms<R>(qx, qy, qz, qw));
+}
+// quat_terms of the identity attitude (a freshly reset body): s = 2, every product with x, y, z vanishes
+template <typename R> DN_DEV QuatTerms<R> quat_terms_identity()
+{
+    QuatTerms<R> t;
+    t.xs = t.ys = t.zs = t.wxs = t.wys = t.wzs = t.yy = t.zz = R(0.0);
+    return t;
 }
 // physics_linear in two parts, like physics_angular: the damping products of the entry velocity (no thrust needed) | the rest.
 template <typename R> struct LinPre {
@@ -1209,13 +1246,22 @@ template <typename R> struct AngPre {
     R r00, r01, r02, r10, r11, r12, r20, r21, r22;
     R ka, Iwx, Iwy, Iwz, gx, gy, gz;
 };
+// ... on quaternion terms the caller already holds: a wave that owns the attitude across the steps of a fused launch forms quat_terms of
+// the NEW attitude once, at the end of a step (for the thrust direction it mails to the linear half), and starts the next step from them.
+template <typename R>
+DN_DEV AngPre<R> physics_angular_pre_terms(const float4 G1, const float4 G3, const QuatTerms<R> &t, const R damp = K<R>::ANG_DAMP);
 template <typename R>
 DN_DEV AngPre<R> physics_angular_pre(const float4 G1, const float4 G3, const R damp = K<R>::ANG_DAMP)
+{
+    const R qx = G1.x, qy = G1.y, qz = G1.z, qw = G1.w;
+    return physics_angular_pre_terms<R>(G1, G3, quat_terms<R>(qx, qy, qz, qw), damp);
+}
+template <typename R>
+DN_DEV AngPre<R> physics_angular_pre_terms(const float4 G1, const float4 G3, const QuatTerms<R> &t, const R damp)
 {
     AngPre<R> a;
     const R qx = G1.x, qy = G1.y, qz = G1.z, qw = G1.w;
     const R wx = G3.x, wy = G3.y, wz = G3.z;
-    const QuatTerms<R> t = quat_terms<R>(qx, qy, qz, qw);
     a.r00 = R(1.0) - F(qy, t.ys, t.zz); a.r01 = F(qx, t.ys, -t.wzs); a.r02 = F(qx, t.zs, t.wys);
     a.r10 = F(qx, t.ys, t.wzs); a.r11 = R(1.0) - F(qx, t.xs, t.zz); a.r12 = F(qy, t.zs, -t.wxs);
     a.r20 = F(qx, t.zs, -t.wys); a.r21 = F(qy, t.zs, t.wxs); a.r22 = R(1.0) - F(qx, t.xs, t.yy);
@@ -1257,7 +1303,7 @@ DN_DEV Ang<R> physics_angular_post(const AngPre<R> &a, const R tx, const R ty, c
     const R ny = F(-ax, qz, F(az, qx, F(ay, qw, aw * qy)));
     const R nz = F(-ay, qx, F(ax, qy, F(az, qw, aw * qz)));
     const R nw_ = F(-az, qz, F(-ay, qy, F(-ax, qx, aw * qw)));
-    const R inv = FM<R>::rsq(F(nw_, nw_, F(nz, nz, F(ny, ny, nx * nx))));
+    const R inv = FM<R>::rsq_f32grade(F(nw_, nw_, F(nz, nz, F(ny, ny, nx * nx))));     // the unit quaternion leaves as four float32 words
     o.qx = nx * inv; o.qy = ny * inv; o.qz = nz * inv; o.qw = nw_ * inv;
     o.wx = wx; o.wy = wy; o.wz = wz;
     return o;
@@ -1583,25 +1629,45 @@ template <typename R> struct RewardPre {
     R s_lin, s_ang;        // |dv|, |dw| where the smoothness penalty applies                  :599-607
     bool pen_lin, pen_ang, found_now, last_gate;
 };
+// smoothness_reward (PBDroneEnv.py:599-607), one of its two terms: -|d| if |d| > limit, d = the entry rate minus its stale post-step
+// copy (quirk Q4).  Its own function so that the wave that OWNS the rate (the balanced four-wave kernel: L the linear one, A the angular
+// one) can form it -- the same expressions, the same bits -- and mail a float and a flag.  The penalty enters the reward at 1/25: a
+// float32 root (1e-7 relative) is far inside the reward's 1e-5 bar.
+template <typename R> struct Smooth {
+    R s;                   // |d| where the penalty applies, else 0 (a float32 value)
+    bool pen;
+};
 template <typename R>
-DN_DEV RewardPre<R> reward_entry(const DnParams &p, const DnConsts<R> &c, const Flight<R> &fl, const float4 G4, const float4 G5)
+DN_DEV Smooth<R> smooth_term(const float ex, const float ey, const float ez, const float4 P, const R lim2)
 {
-    RewardPre<R> q;
+    const R lx = (R)ex - (R)P.x, ly = (R)ey - (R)P.y, lz = (R)ez - (R)P.z;
+    const R a2 = FM<R>::fma(lz, lz, FM<R>::fma(ly, ly, lx * lx));
+    Smooth<R> o;
+    o.pen = a2 > lim2;
+    o.s = R(0.0);
+    if (o.pen) o.s = (R)__builtin_amdgcn_sqrtf((float)a2);
+    return o;
+}
+// the terms of reward_entry that read the distance pair and the gate index only
+template <typename R>
+DN_DEV void reward_entry_core(const DnParams &p, const DnConsts<R> &c, const Flight<R> &fl, RewardPre<R> &q)
+{
     q.found_now = (R)fl.d_e <= c.threshold;
     q.last_gate = fl.idx_e + 1 == p.num_waypoints;
     // :555 3 e^{-2d} (v_exp_f32: 1e-7 rel, 1e-8 in the reward) + :556
     const R gain = fl.just_found_e ? R(0.0) : ((R)fl.dprev_e - (R)fl.d_e) * R(3000.0);
     q.r0 = FM<R>::fma(R(3.0), (R)__builtin_amdgcn_exp2f((float)(R(-2.0 * 1.4426950408889634) * (R)fl.d_e)), gain);
-    // smoothness_reward (:599-607) on the stale post-step copies (quirk Q4): -|dv| if |dv| > 0.7, -|dw| if > 0.3
-    const R lx = (R)fl.vex - (R)G4.x, ly = (R)fl.vey - (R)G4.y, lz = (R)fl.vez - (R)G4.z;
-    const R ax_ = (R)fl.aex - (R)G5.x, ay_ = (R)fl.aey - (R)G5.y, az_ = (R)fl.aez - (R)G5.z;
-    const R la2 = FM<R>::fma(lz, lz, FM<R>::fma(ly, ly, lx * lx)), aa2 = FM<R>::fma(az_, az_, FM<R>::fma(ay_, ay_, ax_ * ax_));
-    // the penalties enter the reward at 1/25: a float32 root (1e-7 relative) is far inside the reward's 1e-5 bar
-    q.pen_lin = la2 > R(0.7) * R(0.7);                                            // needs > 160 m/s^2: rare
-    q.pen_ang = aa2 > R(0.3) * R(0.3);
-    q.s_lin = q.s_ang = R(0.0);
-    if (q.pen_lin) q.s_lin = (R)__builtin_amdgcn_sqrtf((float)la2);
-    if (q.pen_ang) q.s_ang = (R)__builtin_amdgcn_sqrtf((float)aa2);
+}
+template <typename R>
+DN_DEV RewardPre<R> reward_entry(const DnParams &p, const DnConsts<R> &c, const Flight<R> &fl, const float4 G4, const float4 G5)
+{
+    RewardPre<R> q;
+    reward_entry_core<R>(p, c, fl, q);
+    // smoothness_reward (:599-607) on the stale post-step copies (quirk Q4): -|dv| if |dv| > 0.7 (needs > 160 m/s^2: rare), -|dw| if > 0.3
+    const Smooth<R> sl = smooth_term<R>(fl.vex, fl.vey, fl.vez, G4, R(0.7) * R(0.7));
+    const Smooth<R> sa = smooth_term<R>(fl.aex, fl.aey, fl.aez, G5, R(0.3) * R(0.3));
+    q.pen_lin = sl.pen; q.pen_ang = sa.pen;
+    q.s_lin = sl.s; q.s_ang = sa.s;
     return q;
 }
 // reward_pose in two halves: the orientation term against the waypoint the taken branch refers to (reads the pose), and the assembly
@@ -1643,8 +1709,20 @@ DN_DEV Observed<R> observe_phase(const DnParams &p, const DnConsts<R> &c, const 
                                  Rms &rms)
 {
     Observed<R> ob;
+#ifdef DN_EXP_Q_LIGHT                                   // timing experiment only (wrong results): the observation columns and the smoothness terms gone from this wave
+    for (int k = 0; k < DN_OBS_DIM; ++k) ob.o[k] = fl.d_e;
+    {
+        RewardPre<R> q;
+        q.found_now = (R)fl.d_e <= c.threshold; q.last_gate = fl.idx_e + 1 == p.num_waypoints;
+        const R gain = fl.just_found_e ? R(0.0) : ((R)fl.dprev_e - (R)fl.d_e) * R(3000.0);
+        q.r0 = FM<R>::fma(R(3.0), (R)__builtin_amdgcn_exp2f((float)(R(-2.0 * 1.4426950408889634) * (R)fl.d_e)), gain);
+        q.pen_lin = q.pen_ang = false; q.s_lin = q.s_ang = R(0.0);
+        reward_pose<R>(p, s_tab, fl, q, ob.r_normal, ob.r_found32);
+    }
+#else
     observe_columns<R>(p, c, fl, ob.o);
     reward_candidates<R>(p, c, s_tab, fl, G4, G5, ob.r_normal, ob.r_found32);
+#endif
     // sensor noise / per-drone normaliser act on the step observation (which is also terminal_observation)
     if (NOISE && p.obs_noise_sigma > 0.0f) add_obs_noise(p, gid, step_count, 1u, ob.o);
     if (NORM) normalize_obs(rms, ob.o);
@@ -2529,7 +2607,8 @@ template <typename R> struct MailL {      // L -> Q (and its flag word -> A): th
     int flags[DN_BLOCK];                  // idx_e | just_found_e << 8 | truncated << 9 | coll1 << 10 | terminated << 11
 };
 template <typename R> struct MailG {      // A -> L (qnew) and A -> Q (the rest): the angular half and the attitude read-outs
-    float4 qnew[DN_BLOCK];                // the new attitude as the float32 state words (before any reset)
+    R col[3][DN_BLOCK];                   // attitude_column of the new attitude as it goes back to HBM (float32 words), before any reset:
+                                          // all the linear half reads of it (round 6; it used to take the four words and redo quat_terms)
     R fw[3][DN_BLOCK];                    // forward vector of the new pose
     float4 eul[DN_BLOCK];                 // roll_num32, roll_den32, pitch32, yaw32
     float4 w[DN_BLOCK];                   // new angular velocity (float32 state words)
@@ -2551,6 +2630,11 @@ __device__ long long g_mw_stamp[8][48][2];
 #define MW_MARK(k) do { } while (0)
 #endif
 #define MW_BARRIER() do { MW_MARK(0); block_lds_barrier(); MW_MARK(1); } while (0)
+#ifdef DN_ROLE_MARK      // ISA inspection only (profiles/role_isa.sh): a comment line at the top of every role's K-step loop
+#define MW_ROLE_MARK(name) asm volatile("; DN_ROLE_LOOP " name)
+#else
+#define MW_ROLE_MARK(name) do { } while (0)
+#endif
 #ifdef DN_MW_STAMP
 __device__ long long g_mw_edge[16][8];    // per role: cycles at entry, after barrier P, --, at exit; wall clock (100 MHz) at entry / exit; HW_ID
 #define MW_EDGE(k) do { if (lane == 0 && (blockIdx.x == DN_MW_STAMP || blockIdx.x == DN_MW_STAMP + 256)) { const int r_ = role + (blockIdx.x == DN_MW_STAMP ? 0 : 8); \
@@ -2614,22 +2698,36 @@ DN_DEV void step_many_4w_body(const DnParams &p, const DnStepIO &io0, const int 
     MW_EDGE(0);
     stage_table<R>(p, s_tab);
     // every wave passes barrier P and the barriers of iterations 0 .. k_steps (k_steps + 1 of them)
+#ifndef DN_5W_PRIO
+#define DN_5W_PRIO "22311"               // s_setprio of the roles L A Q X N: Q, the role every barrier waits for, first (round 6: 33200 -> 22311 is 3 % of the step)
+#endif
+    {
+        constexpr char pr[6] = DN_5W_PRIO;
+        switch (pr[role] - '0') {                                          // s_setprio takes an immediate
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        case 3: __builtin_amdgcn_s_setprio(3); break;
+        default: break;
+        }
+    }
     if (role == 0) {
-        __builtin_amdgcn_s_setprio(3);
-        float4 G0 = b.g0[li], G1 = b.g1[li], G2 = b.g2[li], G3 = b.g3[li];
+        float4 G0 = b.g0[li], G2 = b.g2[li], G3 = b.g3[li];
+        AttCol<R> col = attitude_column<R>(b.g1[li]);                      // the thrust direction of the entry attitude; from step 1 on A mails it
         block_lds_barrier();                                               // P
         const R wp0[3] = {s_tab[DN_T_WP], s_tab[DN_T_WP + 1], s_tab[DN_T_WP + 2]};
         bool done_prev = false;
 #pragma clang loop unroll(disable)
         for (int t = 0; t <= k_steps; ++t) {
+            MW_ROLE_MARK("L");
             if (t < k_steps) {
-                if (t > 0) {                                               // entry attitude: A's step t-1, reset by my verdict of t-1
-                    const float4 qn = mailg[(t - 1) & 1].qnew[lane];
-                    G1 = done_prev ? make_float4(0.0f, 0.0f, 0.0f, 1.0f) : qn;
+                if (t > 0) {                                               // entry attitude: A's step t-1, level after my reset of t-1
+                    const MailG<R> &mp = mailg[(t - 1) & 1];
+                    const R c0 = mp.col[0][lane], c1 = mp.col[1][lane], c2 = mp.col[2][lane];
+                    col.r02 = done_prev ? R(0.0) : c0; col.r12 = done_prev ? R(0.0) : c1; col.r22 = done_prev ? R(1.0) : c2;
                 }
                 const GateRow<R> row_e = load_gate_row<R>(s_tab, unpack_meta(G3.w).idx);
                 const R fz = tmail[t & 1].v[0][lane];
-                const Lin<R> lin = physics_linear<R>(G0, G1, G2, fz, R(0.0), R(0.0), R(0.0), false);
+                const Lin<R> lin = physics_linear_col<R>(G0, G2, col, fz, R(0.0), R(0.0), R(0.0), false);
                 Flight<R> fl;
                 flight_entry<R>(fl, G0, G2, G3, p.max_steps);
                 fl.px = lin.px; fl.py = lin.py; fl.pz = lin.pz;
@@ -2655,25 +2753,34 @@ DN_DEV void step_many_4w_body(const DnParams &p, const DnStepIO &io0, const int 
             reinterpret_cast<float *>(b.g3 + li)[3] = G3.w;
         }
     } else if (role == 1) {
-        __builtin_amdgcn_s_setprio(3);
         float4 G1 = b.g1[li], G3 = b.g3[li];                               // G3.xyz: angular velocity (the .w belongs to L)
+        // btMatrix3x3::setRotation's terms of the entry attitude: formed ONCE per step, at the end of the step before -- they give the
+        // thrust direction L needs for its next step (mailed) and they start this wave's own next step (same expressions, same bits as
+        // attitude_column / physics_angular_pre on the state word)
+        QuatTerms<R> qt = quat_terms<R>((R)G1.x, (R)G1.y, (R)G1.z, (R)G1.w);
         block_lds_barrier();                                               // P
 #pragma clang loop unroll(disable)
         for (int t = 0; t <= k_steps; ++t) {
+            MW_ROLE_MARK("A");
             if (t > 0) {                                                   // L's verdict of step t-1: a finished drone restarts level, at rest
                 const int fb = maill[(t - 1) & 1].flags[lane];
-                if (((fb >> 9) | (fb >> 11)) & 1) { G1 = make_float4(0.0f, 0.0f, 0.0f, 1.0f); G3.x = G3.y = G3.z = 0.0f; }
+                const bool fin = (((fb >> 9) | (fb >> 11)) & 1) != 0;
+                if (__ballot(fin) != 0ull) {                               // wave-uniform: most wave-steps of a long flight skip the selects
+                    if (fin) { G1 = make_float4(0.0f, 0.0f, 0.0f, 1.0f); G3.x = G3.y = G3.z = 0.0f; qt = quat_terms_identity<R>(); }
+                }
             }
             if (t < k_steps) {
                 const R tx = tmail[t & 1].v[1][lane], ty = tmail[t & 1].v[2][lane], zt = tmail[t & 1].v[3][lane];
-                const Ang<R> ang = physics_angular<R>(G1, G3, tx, ty, zt);
+                const Ang<R> ang = physics_angular_post<R>(physics_angular_pre_terms<R>(G1, G3, qt), tx, ty, zt);
                 Flight<R> fl;
                 fl.qx = ang.qx; fl.qy = ang.qy; fl.qz = ang.qz; fl.qw = ang.qw;
                 attitude_phase<R>(fl);
                 MailG<R> &mg = mailg[t & 1];
                 const float4 qn = make_float4((float)ang.qx, (float)ang.qy, (float)ang.qz, (float)ang.qw);
                 const float4 wn = make_float4((float)ang.wx, (float)ang.wy, (float)ang.wz, 0.0f);
-                mg.qnew[lane] = qn;
+                qt = quat_terms<R>((R)qn.x, (R)qn.y, (R)qn.z, (R)qn.w);   // of the state word, as the next step reads it
+                const AttCol<R> cn = attitude_column_terms<R>(qn, qt);
+                mg.col[0][lane] = cn.r02; mg.col[1][lane] = cn.r12; mg.col[2][lane] = cn.r22;
                 mg.fw[0][lane] = fl.fwx; mg.fw[1][lane] = fl.fwy; mg.fw[2][lane] = fl.fwz;
                 mg.eul[lane] = make_float4(fl.roll_num32, fl.roll_den32, fl.pitch32, fl.yaw32);
                 mg.w[lane] = wn;
@@ -2688,7 +2795,6 @@ DN_DEV void step_many_4w_body(const DnParams &p, const DnStepIO &io0, const int 
             g3[0] = G3.x; g3[1] = G3.y; g3[2] = G3.z;
         }
     } else if (role == 2) {
-        __builtin_amdgcn_s_setprio(2);
         float4 P4 = b.g4[li], P5 = b.g5[li];                               // .xyz: prev_vel, prev_ang_v
         Rms rms;                                                           // never touched here: the observation leaves raw
         // the thrust chain lives here: with it on the report wave (its stores, the episode statistics, the normaliser) that wave was
@@ -2704,6 +2810,7 @@ DN_DEV void step_many_4w_body(const DnParams &p, const DnStepIO &io0, const int 
         block_lds_barrier();                                               // P: table and thrust(0) published
 #pragma clang loop unroll(disable)
         for (int t = 0; t <= k_steps; ++t) {
+            MW_ROLE_MARK("Q");
             if (THRUST_ON_Q && t + 1 < k_steps) {                          // thrust(t+1), for the next iteration of L and A
                 const float4 A_next = (act + (long long)(t + 2 < k_steps ? t + 2 : t + 1) * n)[li];
                 post_thrust<R>(tmail[(t + 1) & 1], lane, thrust_phase<NOISE>(p, gid, sc0 + (unsigned long long)(t + 1), A));
@@ -2722,8 +2829,8 @@ DN_DEV void step_many_4w_body(const DnParams &p, const DnStepIO &io0, const int 
                 const int fb = ml.flags[lane];
                 fl.idx_e = fb & 0xFF; fl.just_found_e = (fb >> 8) & 1; fl.truncated = (fb >> 9) & 1;
                 v.coll1 = (fb >> 10) & 1; v.terminated = (fb >> 11) & 1;
-                const float4 qn = mg.qnew[lane], e = mg.eul[lane], wn = mg.w[lane], we = mg.we[lane];
-                fl.qx = (R)qn.x; fl.qy = (R)qn.y; fl.qz = (R)qn.z; fl.qw = (R)qn.w;      // not read by the observation / reward (attitude came over)
+                const float4 e = mg.eul[lane], wn = mg.w[lane], we = mg.we[lane];
+                fl.qx = fl.qy = fl.qz = R(0.0); fl.qw = R(1.0);            // not read by the observation / reward (the attitude's read-outs came over)
                 fl.fwx = mg.fw[0][lane]; fl.fwy = mg.fw[1][lane]; fl.fwz = mg.fw[2][lane];
                 fl.roll_num32 = e.x; fl.roll_den32 = e.y; fl.pitch32 = e.z; fl.yaw32 = e.w;
                 fl.wx = wn.x; fl.wy = wn.y; fl.wz = wn.z;
@@ -2747,6 +2854,7 @@ DN_DEV void step_many_4w_body(const DnParams &p, const DnStepIO &io0, const int 
         block_lds_barrier();                                               // P
 #pragma clang loop unroll(disable)
         for (int t = 0; t <= k_steps + 1; ++t) {
+            MW_ROLE_MARK("N");
             if (t > 1) {
                 const int u = t - 2;
                 Flight<R> fl;
@@ -2777,6 +2885,7 @@ DN_DEV void step_many_4w_body(const DnParams &p, const DnStepIO &io0, const int 
         block_lds_barrier();                                               // P
 #pragma clang loop unroll(disable)
         for (int t = 0; t <= k_steps + 1; ++t) {
+            MW_ROLE_MARK("X");
             if (!THRUST_ON_Q && t + 1 < k_steps) {                         // thrust(t+1), for the next iteration of L and A
                 const float4 A_next = (act + (long long)(t + 2 < k_steps ? t + 2 : t + 1) * n)[li];
                 post_thrust<R>(tmail[(t + 1) & 1], lane, thrust_phase<NOISE>(p, gid, sc0 + (unsigned long long)(t + 1), A));
@@ -2808,10 +2917,273 @@ DN_DEV void step_many_4w_body(const DnParams &p, const DnStepIO &io0, const int 
     MW_EDGE(3);
 }
 
+// -----------------------------------------------------------------------------------------------------
+// Balanced four-wave kernel (round 6; fused launches of the plain configuration WITH the normaliser, no noise: DN_WAVES=4).
+//
+// Per-role stamps of the five-wave kernel once the thrust chain's fast path and the float32 output stage were in
+// (profiles/r06_notes.md): every role arrives at the barrier within a few hundred cycles of the others -- the launch is bound by the
+// SUM of the roles' instruction streams on SIMDs that hold 2.5 waves, and by its pipeline depth: X and N trail Q, which trails L and A,
+// so a K-step launch runs K + 2 iterations and the driver's K = 20 pays two of them for nothing.  Here the same device functions are
+// dealt to FOUR waves so that every consumer trails its producer by exactly one step:
+//
+//   L  physics_linear(t) on A's thrust direction | rules_verdict, rules_commit | observation columns 0 1 2 6 7 8 12 | linear
+//      smoothness term; owns position, velocity, the distance pair / meta word, _current_position and prev_vel          -> BMailL[t & 1]
+//   A  physics_angular(t) | attitude of the new pose | observation columns 3 4 5 9 10 11 | angular smoothness term | thrust
+//      direction of the new attitude; owns attitude, angular velocity and prev_ang_v                                   -> BMailG[t & 1]
+//   Q  thrust(t + 1) -> tmail | step t - 1: reward terms, orientation term, assembly, A7 select, Monitor, statistics, scalar stores
+//   N  step t - 1: the thirteen columns straight from L's and A's mail -> normaliser -> rows (terminal / reset observation included)
+//                                                                                                  == barrier t ==
+// K + 1 iterations and K + 1 barriers per launch (the five-wave kernel: K + 2), eight waves per CU at two tiles = two per SIMD with
+// 256 registers each (no spills; the five-wave kernel is held to 128 and spills ~50), and nobody re-packs the observation between
+// mails.  Same functions, same typed values across LDS: bit-identical to every other shape.
+// -----------------------------------------------------------------------------------------------------
+template <typename R> struct BMailL {      // L -> Q (pose, distance pair, flags, smoothness), A (flags), N (columns, d_obs, flags)
+    R f64[4][DN_BLOCK];                    // new position (3), Verdict.d_obs
+    float4 oa[DN_BLOCK];                   // o0 o1 o2 o6
+    float4 ob[DN_BLOCK];                   // o7 o8 o12, d_e
+    float4 oc[DN_BLOCK];                   // dprev_e, s_lin, flag word (int bits), --
+};
+// flag word: idx_e [0:8) | just_found_e << 8 | truncated << 9 | coll1 << 10 | terminated << 11 | pen_lin << 16
+template <typename R> struct BMailG {      // A -> L (thrust direction), Q (forward vector, smoothness), N (columns)
+    R col[3][DN_BLOCK];                    // attitude_column of the new attitude as it goes back to HBM (float32 words), before any reset
+    R fw[3][DN_BLOCK];                     // forward vector of the new pose
+    float4 oa[DN_BLOCK];                   // o3 o4 o5 o9
+    float4 ob[DN_BLOCK];                   // o10 o11, s_ang, pen_ang (int bits)
+};
+#ifndef DN_B4_ORDER_A
+#define DN_B4_ORDER_A "LAQN"
+#define DN_B4_ORDER_B "NQAL"             // the second tile of a CU: wave w of both tiles shares SIMD w, heavy roles meet light ones
+#endif
+#ifndef DN_B4_PRIO
+#define DN_B4_PRIO "0000"                // s_setprio of the roles L A Q N
+#endif
+template <typename R>
+DN_DEV void step_many_b4_body(const DnParams &p, const DnStepIO &io0, const int k_steps)
+{
+    __shared__ R s_tab[DN_MAX_WAYPOINTS * DN_T_STRIDE];
+    __shared__ __attribute__((aligned(16))) BMailL<R> maill[2];
+    __shared__ __attribute__((aligned(16))) BMailG<R> mailg[2];
+    __shared__ __attribute__((aligned(16))) ThrustMail<R> tmail[2];
+    constexpr bool NOISE = false;
+    const unsigned lane = threadIdx.x & (DN_BLOCK - 1);
+    const int wv0 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int second_tile = (int)((blockIdx.x / (unsigned)p.num_cus) & 1u);
+    constexpr char oa[5] = DN_B4_ORDER_A, ob[5] = DN_B4_ORDER_B;
+    const char ch = second_tile ? ob[wv0] : oa[wv0];
+    const int role = ch == 'L' ? 0 : ch == 'A' ? 1 : ch == 'Q' ? 2 : 3;      // 0 L, 1 A, 2 Q, 3 N
+    const long long tile_base = (long long)blockIdx.x * DN_BLOCK;
+    const long long left = p.n - tile_base;
+    const unsigned rows = left < DN_BLOCK ? (unsigned)left : DN_BLOCK;
+    const bool active = lane < rows;
+    const unsigned li = active ? lane : rows - 1;
+    __builtin_assume(li < DN_BLOCK);
+    const long long i = tile_base + li;
+    const unsigned long long gid = (unsigned long long)(p.env_id_offset + i);
+    const BlockState b = block_state(p.st, tile_base);
+    const DnConsts<R> &c = consts<R>(p);
+    const long long n = p.n, words = (p.n + 63) / 64;
+    const unsigned long long sc0 = p.st.stats[blockIdx.x].step_count;
+    MW_EDGE(0);
+    stage_table<R>(p, s_tab);
+    {
+        constexpr char pr[5] = DN_B4_PRIO;
+        switch (pr[role] - '0') {                                          // s_setprio takes an immediate
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        case 3: __builtin_amdgcn_s_setprio(3); break;
+        default: break;
+        }
+    }
+    // every wave passes barrier P and the barriers of iterations 0 .. k_steps - 1
+    if (role == 0) {
+        // ---- L
+        float4 G0 = b.g0[li], G2 = b.g2[li], G3 = b.g3[li];
+        float4 P4 = b.g4[li];                                              // .xyz: prev_vel (the .w, Monitor's return, belongs to Q)
+        AttCol<R> col = attitude_column<R>(b.g1[li]);                      // the thrust direction of the entry attitude; from step 1 on A mails it
+        block_lds_barrier(); MW_EDGE(1);                                   // P
+        const R wp0[3] = {s_tab[DN_T_WP], s_tab[DN_T_WP + 1], s_tab[DN_T_WP + 2]};
+        bool done_prev = false;
+#pragma clang loop unroll(disable)
+        for (int t = 0; t < k_steps; ++t) {
+            MW_ROLE_MARK("L");
+            if (t > 0) {                                                   // entry attitude: A's step t-1, level after my reset of t-1
+                const BMailG<R> &mp = mailg[(t - 1) & 1];
+                const R c0 = mp.col[0][lane], c1 = mp.col[1][lane], c2 = mp.col[2][lane];
+                col.r02 = done_prev ? R(0.0) : c0; col.r12 = done_prev ? R(0.0) : c1; col.r22 = done_prev ? R(1.0) : c2;
+            }
+            const GateRow<R> row_e = load_gate_row<R>(s_tab, unpack_meta(G3.w).idx);
+            const R fz = tmail[t & 1].v[0][lane];
+            const Lin<R> lin = physics_linear_col<R>(G0, G2, col, fz, R(0.0), R(0.0), R(0.0), false);
+            Flight<R> fl;
+            flight_entry<R>(fl, G0, G2, G3, p.max_steps);
+            fl.px = lin.px; fl.py = lin.py; fl.pz = lin.pz;
+            fl.vx = (float)lin.vx; fl.vy = (float)lin.vy; fl.vz = (float)lin.vz;
+            fl.qx = fl.qy = fl.qz = R(0.0); fl.qw = R(1.0);                // the attitude belongs to A (no ground-contact term here)
+            fl.wx = fl.wy = fl.wz = 0.0f;
+            RulesMid<R> m;
+            const Verdict<R> v = rules_verdict<R>(p, c, s_tab, row_e, fl, G3, m);
+            float o[DN_OBS_DIM];
+            observe_columns_lin<R>(p, c, fl, o);
+            const Smooth<R> sl = smooth_term<R>(fl.vex, fl.vey, fl.vez, P4, R(0.7) * R(0.7));
+            BMailL<R> &ml = maill[t & 1];
+            ml.f64[0][lane] = fl.px; ml.f64[1][lane] = fl.py; ml.f64[2][lane] = fl.pz; ml.f64[3][lane] = v.d_obs;
+            ml.oa[lane] = make_float4(o[0], o[1], o[2], o[6]);
+            ml.ob[lane] = make_float4(o[7], o[8], o[12], fl.d_e);
+            ml.oc[lane] = make_float4(fl.dprev_e, (float)sl.s,
+                                      __int_as_float(fl.idx_e | (fl.just_found_e << 8) | (fl.truncated << 9) | (v.coll1 << 10) | (v.terminated << 11) |
+                                                     ((int)sl.pen << 16)), 0.0f);
+            float4 S0, S1, S2, S3;
+            rules_commit<R>(c, wp0, fl, m, G0, G3, b.g6, li, active, S0, S1, S2, S3);
+            // prev_vel: _update_state_post_step (skipped on a terminated step, quirk Q5), zero after a reset
+            if (!v.terminated) { P4.x = fl.vex; P4.y = fl.vey; P4.z = fl.vez; }
+            done_prev = v.terminated != 0 || fl.truncated != 0;
+            if (done_prev) P4.x = P4.y = P4.z = 0.0f;
+            G0 = S0; G2 = S2; G3.w = S3.w;
+            MW_BARRIER();                                                  // barrier t
+        }
+        if (active) {
+            b.g0[li] = G0; b.g2[li] = G2;
+            reinterpret_cast<float *>(b.g3 + li)[3] = G3.w;
+            float *g4 = reinterpret_cast<float *>(b.g4 + li);
+            g4[0] = P4.x; g4[1] = P4.y; g4[2] = P4.z;
+        }
+    } else if (role == 1) {
+        // ---- A
+        float4 G1 = b.g1[li], G3 = b.g3[li];                               // G3.xyz: angular velocity (the .w belongs to L)
+        float4 P5 = b.g5[li];                                              // .xyz: prev_ang_v (the .w, Monitor's length word, belongs to Q)
+        QuatTerms<R> qt = quat_terms<R>((R)G1.x, (R)G1.y, (R)G1.z, (R)G1.w);   // formed once per step: see the five-wave kernel's A
+        float wex = 0.0f, wey = 0.0f, wez = 0.0f;                          // entry angular velocity of the step just integrated
+        block_lds_barrier(); MW_EDGE(1);                                   // P
+#pragma clang loop unroll(disable)
+        for (int t = 0; t <= k_steps; ++t) {
+            MW_ROLE_MARK("A");
+            if (t > 0) {                                                   // L's verdict of step t-1
+                const int fb = __float_as_int(maill[(t - 1) & 1].oc[lane].z);
+                // prev_ang_v: _update_state_post_step (skipped on a terminated step, quirk Q5), zero after a reset
+                if (!((fb >> 11) & 1)) { P5.x = wex; P5.y = wey; P5.z = wez; }
+                const bool fin = (((fb >> 9) | (fb >> 11)) & 1) != 0;
+                if (__ballot(fin) != 0ull) {                               // a finished drone restarts level, at rest (wave-uniform skip)
+                    if (fin) {
+                        G1 = make_float4(0.0f, 0.0f, 0.0f, 1.0f); G3.x = G3.y = G3.z = 0.0f; qt = quat_terms_identity<R>();
+                        P5.x = P5.y = P5.z = 0.0f;
+                    }
+                }
+            }
+            if (t < k_steps) {
+                wex = G3.x; wey = G3.y; wez = G3.z;
+                const Smooth<R> sa = smooth_term<R>(wex, wey, wez, P5, R(0.3) * R(0.3));
+                const R tx = tmail[t & 1].v[1][lane], ty = tmail[t & 1].v[2][lane], zt = tmail[t & 1].v[3][lane];
+                const Ang<R> ang = physics_angular_post<R>(physics_angular_pre_terms<R>(G1, G3, qt), tx, ty, zt);
+                const float4 qn = make_float4((float)ang.qx, (float)ang.qy, (float)ang.qz, (float)ang.qw);
+                const float4 wn = make_float4((float)ang.wx, (float)ang.wy, (float)ang.wz, 0.0f);
+                Flight<R> fl;
+                fl.qx = ang.qx; fl.qy = ang.qy; fl.qz = ang.qz; fl.qw = ang.qw;
+                fl.wx = wn.x; fl.wy = wn.y; fl.wz = wn.z;
+                attitude_phase<R>(fl);
+                float o[DN_OBS_DIM];
+                observe_columns_att<R>(fl, o);
+                qt = quat_terms<R>((R)qn.x, (R)qn.y, (R)qn.z, (R)qn.w);   // of the state word, as the next step reads it
+                const AttCol<R> cn = attitude_column_terms<R>(qn, qt);
+                BMailG<R> &mg = mailg[t & 1];
+                mg.col[0][lane] = cn.r02; mg.col[1][lane] = cn.r12; mg.col[2][lane] = cn.r22;
+                mg.fw[0][lane] = fl.fwx; mg.fw[1][lane] = fl.fwy; mg.fw[2][lane] = fl.fwz;
+                mg.oa[lane] = make_float4(o[3], o[4], o[5], o[9]);
+                mg.ob[lane] = make_float4(o[10], o[11], (float)sa.s, __int_as_float((int)sa.pen));
+                G1 = qn; G3.x = wn.x; G3.y = wn.y; G3.z = wn.z;
+                MW_BARRIER();                                              // barrier t
+            }
+        }
+        if (active) {
+            b.g1[li] = G1;
+            float *g3 = reinterpret_cast<float *>(b.g3 + li), *g5 = reinterpret_cast<float *>(b.g5 + li);
+            g3[0] = G3.x; g3[1] = G3.y; g3[2] = G3.z;
+            g5[0] = P5.x; g5[1] = P5.y; g5[2] = P5.z;
+        }
+    } else if (role == 2) {
+        // ---- Q: the action chain one step ahead; reward and scalars one step behind
+        float4 G4 = b.g4[li], G5 = b.g5[li];                               // .w: Monitor return / length
+        StatAcc acc;
+        RewNorm rn = {0.0, 0.0, 1.0, 1e-4};
+        const float4 *act = reinterpret_cast<const float4 *>(io0.actions) + tile_base;
+        float4 A = act[li];
+        {
+            const float4 A1 = (act + (long long)(k_steps > 1 ? 1 : 0) * n)[li];
+            post_thrust<R>(tmail[0], lane, thrust_phase<NOISE>(p, gid, sc0, A));
+            A = A1;
+        }
+        block_lds_barrier(); MW_EDGE(1);                                   // P: table and thrust(0) published
+#pragma clang loop unroll(disable)
+        for (int t = 0; t <= k_steps; ++t) {
+            MW_ROLE_MARK("Q");
+            if (t + 1 < k_steps) {                                         // thrust(t+1), for the next iteration of L and A
+                const float4 A_next = (act + (long long)(t + 2 < k_steps ? t + 2 : t + 1) * n)[li];
+                post_thrust<R>(tmail[(t + 1) & 1], lane, thrust_phase<NOISE>(p, gid, sc0 + (unsigned long long)(t + 1), A));
+                A = A_next;
+            }
+            if (t > 0) {                                                   // the step L and A finished last iteration
+                const int u = t - 1;
+                const BMailL<R> &ml = maill[u & 1];
+                const BMailG<R> &mg = mailg[u & 1];
+                Flight<R> fl;
+                Verdict<R> v;
+                fl.px = ml.f64[0][lane]; fl.py = ml.f64[1][lane]; fl.pz = ml.f64[2][lane];
+                const float4 lc = ml.oc[lane], gb = mg.ob[lane];
+                fl.d_e = ml.ob[lane].w; fl.dprev_e = lc.x;
+                const int fb = __float_as_int(lc.z);
+                fl.idx_e = fb & 0xFF; fl.just_found_e = (fb >> 8) & 1; fl.truncated = (fb >> 9) & 1;
+                v.coll1 = (fb >> 10) & 1; v.terminated = (fb >> 11) & 1; v.d_obs = R(0.0);      // d_obs: N's (the reset observation)
+                fl.fwx = mg.fw[0][lane]; fl.fwy = mg.fw[1][lane]; fl.fwz = mg.fw[2][lane];
+                RewardPre<R> pre;
+                reward_entry_core<R>(p, c, fl, pre);
+                pre.s_lin = (R)lc.y; pre.pen_lin = ((fb >> 16) & 1) != 0;
+                pre.s_ang = (R)gb.z; pre.pen_ang = (__float_as_int(gb.w) & 1) != 0;
+                R r_normal;
+                float r_found32;
+                reward_pose<R>(p, s_tab, fl, pre, r_normal, r_found32);
+                fl.vex = fl.vey = fl.vez = fl.aex = fl.aey = fl.aez = 0.0f;    // prev_vel / prev_ang_v live on L / A
+                const StepOut out = block_out(io0, tile_base, (long long)u * n, (long long)u * words);
+                report_scalars<R, false>(p, c, out, fl, v, r_normal, r_found32, li, lane, active, G4, G5, acc, rn);
+            }
+            if (t < k_steps) MW_BARRIER();                                 // barrier t
+        }
+        flush_stats(p, acc, sc0 + (unsigned long long)k_steps, lane);
+        if (active) {
+            reinterpret_cast<float *>(b.g4 + li)[3] = G4.w;
+            reinterpret_cast<float *>(b.g5 + li)[3] = G5.w;
+        }
+    } else {
+        // ---- N: the observation of step t - 1 from L's and A's mail through the normaliser and out
+        Rms rms;
+        load_rms(p, i, rms);
+        block_lds_barrier(); MW_EDGE(1);                                   // P
+#pragma clang loop unroll(disable)
+        for (int t = 0; t <= k_steps; ++t) {
+            MW_ROLE_MARK("N");
+            if (t > 0) {
+                const int u = t - 1;
+                const BMailL<R> &ml = maill[u & 1];
+                const BMailG<R> &mg = mailg[u & 1];
+                const float4 la = ml.oa[lane], lb = ml.ob[lane], ga = mg.oa[lane], gb = mg.ob[lane];
+                const int fb = __float_as_int(ml.oc[lane].z);
+                Verdict<R> v;
+                v.d_obs = ml.f64[3][lane]; v.coll1 = (fb >> 10) & 1; v.terminated = (fb >> 11) & 1;
+                float o[DN_OBS_DIM] = {la.x, la.y, la.z, ga.x, ga.y, ga.z, la.w, lb.x, lb.y, ga.w, gb.x, gb.y, lb.z};
+                normalize_obs(rms, o);                                     // the step observation (= terminal_observation)
+                const StepOut out = block_out(io0, tile_base, (long long)u * n, (long long)u * words);
+                report_obs<R, true, NOISE, 2>(p, c, nullptr, out, ((fb >> 9) & 1) != 0, v, o, gid, sc0 + (unsigned long long)u, li, lane, rows, active, rms);
+            }
+            if (t < k_steps) MW_BARRIER();                                 // barrier t
+        }
+        if (active) store_rms(p, i, rms);
+    }
+    MW_EDGE(3);
+}
+
 template <typename R, bool NORM, bool NOISE>
 __global__ __launch_bounds__(4 * DN_BLOCK, 2) void dn_step_many_4w_kernel(const DnParams p, const DnStepIO io0, const int k_steps)
 {
-    step_many_4w_body<R, NORM, NOISE, 4>(p, io0, k_steps);
+    if constexpr (NORM && !NOISE) step_many_b4_body<R>(p, io0, k_steps);     // normaliser on, no noise: the balanced cut (round 6)
+    else step_many_4w_body<R, NORM, NOISE, 4>(p, io0, k_steps);
 }
 // five waves: two tiles per CU are ten waves on four SIMDs, i.e. FOUR waves on one of them -- 128 registers a wave
 // (three tiles, where noise keeps this shape selected: fifteen waves, four on three of the SIMDs, at the same 128 registers)
@@ -2889,7 +3261,7 @@ DN_DEV void report_obs_cols(const DnParams &p, const DnConsts<R> &c, const StepO
             }
 #pragma unroll
             for (int k = K0; k < K1; ++k)                                 // reset_obs<R>: BaseAviary.py:318 before :617-658 (Q2)
-                o[k] = k < 12 ? (float)c.reset_obs[k < 12 ? k : 0] : (p.include_distance ? (float)(d_obs * c.inv_max_target_dist) : 0.0f);
+                o[k] = k < 12 ? c.reset_obs32[k < 12 ? k : 0] : (p.include_distance ? (float)(d_obs * c.inv_max_target_dist) : 0.0f);
             if (NORM) normalize_obs_cols<K0, K1>(rms, o);
         }
     }
@@ -3063,21 +3435,26 @@ DN_DEV void step_many_rp_body(const DnParams &p, const DnStepIO &io0, const int 
     } else if (role == 1) {
         // ---- A: the angular half of the recurrence
         float4 G1 = b.g1[li], G3 = b.g3[li];                               // G3.xyz: angular velocity (the .w belongs to Q)
+        QuatTerms<R> qt = quat_terms<R>((R)G1.x, (R)G1.y, (R)G1.z, (R)G1.w);   // formed once per step: see the five-wave kernel's A
         block_lds_barrier(); MW_EDGE(1);                                   // P
 #pragma clang loop unroll(disable)
         for (int t = 0; t <= k_steps; ++t) {
             RP_TAKE_TURNS();
             if (t > 0) {                                                   // L's verdict of step t-1: a finished drone restarts level, at rest
                 const int fb = __float_as_int(maill[(t - 1) & 1].f32[lane].w);
-                if (((fb >> 9) | (fb >> 11)) & 1) { G1 = make_float4(0.0f, 0.0f, 0.0f, 1.0f); G3.x = G3.y = G3.z = 0.0f; }
+                const bool fin = (((fb >> 9) | (fb >> 11)) & 1) != 0;
+                if (__ballot(fin) != 0ull) {
+                    if (fin) { G1 = make_float4(0.0f, 0.0f, 0.0f, 1.0f); G3.x = G3.y = G3.z = 0.0f; qt = quat_terms_identity<R>(); }
+                }
             }
             if (t < k_steps) {
                 const R tx = tmail[t & 1].v[1][lane], ty = tmail[t & 1].v[2][lane], zt = tmail[t & 1].v[3][lane];
-                const Ang<R> ang = physics_angular<R>(G1, G3, tx, ty, zt);
+                const Ang<R> ang = physics_angular_post<R>(physics_angular_pre_terms<R>(G1, G3, qt), tx, ty, zt);
                 RMailA<R> &ma = maila[t & 1];
                 const float4 qn = make_float4((float)ang.qx, (float)ang.qy, (float)ang.qz, (float)ang.qw);
                 const float4 wn = make_float4((float)ang.wx, (float)ang.wy, (float)ang.wz, 0.0f);
-                const AttCol<R> cn = attitude_column<R>(qn);               // what physics_linear(t + 1) reads of the state word
+                qt = quat_terms<R>((R)qn.x, (R)qn.y, (R)qn.z, (R)qn.w);   // of the state word, as the next step reads it
+                const AttCol<R> cn = attitude_column_terms<R>(qn, qt);     // what physics_linear(t + 1) reads of the state word
                 ma.q[0][lane] = ang.qx; ma.q[1][lane] = ang.qy; ma.q[2][lane] = ang.qz; ma.q[3][lane] = ang.qw;
                 ma.col[0][lane] = cn.r02; ma.col[1][lane] = cn.r12; ma.col[2][lane] = cn.r22;
                 ma.w[lane] = wn;
@@ -3205,7 +3582,6 @@ DN_DEV void step_many_rp_body(const DnParams &p, const DnStepIO &io0, const int 
         // ---- X: the scalars of step t - 2 (and, without the normaliser, its observation rows)
         float4 G4 = b.g4[li], G5 = b.g5[li];                               // .w: Monitor return / length
         StatAcc acc;
-        Rms rms;                                                           // never touched here
         RewNorm rn = {0.0, 0.0, 1.0, 1e-4};
         block_lds_barrier(); MW_EDGE(1);                                   // P
 #pragma clang loop unroll(disable)

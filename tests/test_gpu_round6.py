@@ -106,30 +106,41 @@ def test_saturation_fast_path_is_the_chain_bit_for_bit():
 def test_fused_step_with_the_fast_path_equals_the_oracle_in_both_action_regimes():
     """The step kernels take the same function: 20 fused steps from reset at BASELINE's 32 768 drones under U(-1,1) (99.6 % of actions
     saturated: the fast path) and under the hover band 0.0922 + 0.003 N(0,1) (SURVEY 8(d) C2's second distribution: every wave takes the
-    chain), each against the oracle stepping the same actions -- flags exact, observations 1e-5, rewards 1e-4 (free-running)."""
+    chain), normaliser off (four-wave kernel) and on (five-wave kernel, the headline's), each against the oracle stepping the same actions
+    free-running -- flags exact, rewards 1e-4, observations 1e-5 on the raw row.  Both sides keep their own float32 state, which may sit one
+    ulp apart: the unit angular-velocity columns divide by |w| (2e-7 / |w| where a hovering drone barely turns), and with the normaliser
+    on a raw difference reaches the output divided by sqrt(var + 1e-8) of that column -- the bars follow the oracle's own |w| and var."""
     pkg = _gpu()
     from drl_dronenavigation_amd import tracks
     dev = torch.device("cuda:0")
     n, K = 32768, 20
     track = tracks.reaching()
-    for name in ("uniform", "hover"):
-        rng = np.random.default_rng(3)
-        acts = (rng.uniform(-1, 1, (K, n, 4)) if name == "uniform" else 0.0922 + 0.003 * rng.standard_normal((K, n, 4))).astype(np.float32)
-        env = pkg.DroneVecEnv(track, n, normalize_obs=True, max_steps=4096, device=dev)
-        ora = O.OracleVecEnv(O.make_config(track.targets(), track.initial_xyzs, track.aviary_dim, circle=False, max_steps=4096,
-                                           f32_state=True, normalize_obs=True, ground_contact=env.ground_contact), n, threads=8)
-        np.testing.assert_allclose(env.reset(), ora.reset(), rtol=0, atol=1e-5)
-        out = env.rollout_tensor(torch.from_numpy(acts).to(dev))
-        torch.cuda.synchronize()
-        assert env.kernel_waves(fused=True) == 5
-        for t in range(K):
-            ref = ora.step(acts[t])
-            assert np.array_equal(out["done"][t].cpu().numpy().astype(bool), ref["done"].astype(bool)), (name, t)
-            assert np.array_equal(out["truncated"][t].cpu().numpy().astype(bool), ref["truncated"].astype(bool)), (name, t)
-            assert np.array_equal(out["found_targets"][t].cpu().numpy(), ref["found_targets"]), (name, t)
-            np.testing.assert_allclose(out["obs"][t].cpu().numpy(), ref["obs"], rtol=1e-5, atol=1e-5, err_msg=f"{name} t={t}")
-            np.testing.assert_allclose(out["reward"][t].cpu().numpy(), ref["reward"], rtol=1e-5, atol=1e-4, err_msg=f"{name} t={t}")
-        env.close()
+    for norm in (False, True):
+        for name in ("uniform", "hover"):
+            rng = np.random.default_rng(3)
+            acts = (rng.uniform(-1, 1, (K, n, 4)) if name == "uniform" else 0.0922 + 0.003 * rng.standard_normal((K, n, 4))).astype(np.float32)
+            env = pkg.DroneVecEnv(track, n, normalize_obs=norm, max_steps=4096, device=dev)
+            ora = O.OracleVecEnv(O.make_config(track.targets(), track.initial_xyzs, track.aviary_dim, circle=False, max_steps=4096,
+                                               f32_state=True, normalize_obs=norm, ground_contact=env.ground_contact), n, threads=8)
+            np.testing.assert_allclose(env.reset(), ora.reset(), rtol=0, atol=1e-5)
+            out = env.rollout_tensor(torch.from_numpy(acts).to(dev))
+            torch.cuda.synchronize()
+            assert env.kernel_waves(fused=True) == (5 if norm else 4)
+            for t in range(K):
+                ref = ora.step(acts[t])
+                tag = (name, norm, t)
+                assert np.array_equal(out["done"][t].cpu().numpy().astype(bool), ref["done"].astype(bool)), tag
+                assert np.array_equal(out["truncated"][t].cpu().numpy().astype(bool), ref["truncated"].astype(bool)), tag
+                assert np.array_equal(out["found_targets"][t].cpu().numpy(), ref["found_targets"]), tag
+                np.testing.assert_allclose(out["reward"][t].cpu().numpy(), ref["reward"], rtol=1e-5, atol=1e-4, err_msg=str(tag))
+                raw = np.full((n, 13), 2e-7)                          # what a one-ulp state difference moves a raw column of order one by
+                wn = np.linalg.norm(ora.envs["ang_v"], axis=1)
+                raw[:, 9:12] = np.maximum(2e-7, 2e-7 / np.maximum(wn, 1e-30))[:, None]
+                scale = 1.0 / np.sqrt(ora.envs["rms_var"] + 1e-8) if norm else 1.0
+                tol = 1e-5 + 1e-5 * np.abs(ref["obs"]) + raw * scale
+                err = np.abs(out["obs"][t].cpu().numpy().astype(np.float64) - ref["obs"])
+                assert (err <= tol).all(), (tag, float((err - tol).max()), int((err > tol).sum()))
+            env.close()
 
 
 _CHILD = r"""
@@ -281,3 +292,20 @@ def _scratch_ptrs(n, dev):
         _SCRATCH[n] = (torch.empty((n, 13), device=dev), torch.empty(n, device=dev), torch.empty(n, dtype=torch.uint8, device=dev),
                        torch.empty(n, dtype=torch.uint8, device=dev), torch.empty(n, dtype=torch.int32, device=dev))
     return tuple(t.data_ptr() for t in _SCRATCH[n])
+
+
+def test_step_async_twice_is_refused():
+    """a second step_async() before step_wait() would overwrite the pinned action staging buffer under an H2D copy that may
+    still be in flight and step the fleet twice: refused, like SubprocVecEnv's AlreadySteppingError."""
+    pkg = _gpu()
+    from drl_dronenavigation_amd import tracks
+    env = pkg.DroneVecEnv(tracks.reaching(), 256, device="cuda:0")
+    env.reset()
+    a = np.zeros((256, 4), np.float32)
+    env.step_async(a)
+    with pytest.raises(RuntimeError, match="already pending"):
+        env.step_async(a)
+    env.step_wait()
+    env.step_async(a)
+    env.step_wait()
+    env.close()
