@@ -50,6 +50,19 @@ constexpr double DN_COLL_R = 0.06, DN_COLL_H = 0.025;   // base_link collision c
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// dn_set_state: the second moment the device carries for a given RunningMeanStd.var / .count -- the double m nearest to var x count
+// with m / count == var where one exists (so that dn_get_state of what was just set returns the var it was given, and a blob taken
+// with dn_get_state restores to statistics that read back identically).
+double second_moment(double var, double count)
+{
+    const double m = var * count;
+    if (!(count > 0.0) || !std::isfinite(m) || m / count == var) return m;
+    const double lo = std::nextafter(m, -HUGE_VAL), hi = std::nextafter(m, HUGE_VAL);
+    if (lo / count == var) return lo;
+    if (hi / count == var) return hi;
+    return m;
+}
+
 // An on / off environment switch read by dn_create: 1 / 0, or -1 for a value that is neither (the create then fails: a typo
 // must not silently select the other arithmetic).  Unset or empty = off.
 int env_switch(const char *name)
@@ -253,7 +266,7 @@ int32_t init_state_rms(dn_env *e, hipStream_t s)
 {   // normalize.RunningMeanStd.__init__, normalize.py:14-18
     const long long n = e->cfg.num_envs;
     DN_HIP(dn_launch_filld(e->p.st.rms_mean, 0.0, n * DN_OBS_DIM, s));
-    DN_HIP(dn_launch_filld(e->p.st.rms_var, 1.0, n * DN_OBS_DIM, s));
+    DN_HIP(dn_launch_filld(e->p.st.rms_m2, 1.0 * 1e-4, n * DN_OBS_DIM, s));     // var = 1, held as the second moment var x count
     DN_HIP(dn_launch_filld(e->p.st.rms_count, 1e-4, n, s));
     return DN_OK;
 }
@@ -443,7 +456,7 @@ int32_t dn_create(const dn_config *cfg, dn_env **out)
     p.st.g6 = (float4 *)(base + L.off_g[6]);
     p.st.g7 = drag ? (float4 *)(base + L.off_g7) : nullptr;
     p.st.rms_mean = (double *)(base + L.off_mean);
-    p.st.rms_var = (double *)(base + L.off_var);
+    p.st.rms_m2 = (double *)(base + L.off_var);
     p.st.rms_count = (double *)(base + L.off_count);
     p.st.rr = (double *)(base + L.off_rr);
     p.st.pid = pid_mode ? (double *)(base + L.off_pid) : nullptr;
@@ -821,7 +834,7 @@ int32_t dn_get_state(dn_env *env, dn_env_state *states, int64_t count)
     if (env->cfg.normalize_obs) {
         mean.resize((size_t)n * DN_OBS_DIM); var.resize((size_t)n * DN_OBS_DIM); cnt.resize((size_t)n);
         DN_HIP(hipMemcpy(mean.data(), env->p.st.rms_mean, mean.size() * sizeof(double), hipMemcpyDeviceToHost));
-        DN_HIP(hipMemcpy(var.data(), env->p.st.rms_var, var.size() * sizeof(double), hipMemcpyDeviceToHost));
+        DN_HIP(hipMemcpy(var.data(), env->p.st.rms_m2, var.size() * sizeof(double), hipMemcpyDeviceToHost));
         DN_HIP(hipMemcpy(cnt.data(), env->p.st.rms_count, cnt.size() * sizeof(double), hipMemcpyDeviceToHost));
     }
     std::vector<double> rr;
@@ -862,7 +875,7 @@ int32_t dn_get_state(dn_env *env, dn_env_state *states, int64_t count)
         if (s.steps > 0) { s.cur_pos[0] = s.pos[0]; s.cur_pos[1] = s.pos[1]; s.cur_pos[2] = s.pos[2]; }
         else { s.cur_pos[0] = g[6][i].x; s.cur_pos[1] = g[6][i].y; s.cur_pos[2] = g[6][i].z; }
         if (env->cfg.normalize_obs) {
-            for (int k = 0; k < DN_OBS_DIM; ++k) { s.rms_mean[k] = mean[(size_t)k * n + i]; s.rms_var[k] = var[(size_t)k * n + i]; }
+            for (int k = 0; k < DN_OBS_DIM; ++k) { s.rms_mean[k] = mean[(size_t)k * n + i]; s.rms_var[k] = var[(size_t)k * n + i] / cnt[(size_t)i]; }      // the device holds the second moment var x count
             s.rms_count = cnt[(size_t)i];
         }
     }
@@ -907,7 +920,8 @@ int32_t dn_set_state(dn_env *env, const dn_env_state *states, int64_t count)
         g[5][i] = make_float4(s.prev_ang_v[0], s.prev_ang_v[1], s.prev_ang_v[2], flen);
         g[6][i] = make_float4(s.cur_pos[0], s.cur_pos[1], s.cur_pos[2], 0.0f);
         if (env->cfg.normalize_obs) {
-            for (int k = 0; k < DN_OBS_DIM; ++k) { mean[(size_t)k * n + i] = s.rms_mean[k]; var[(size_t)k * n + i] = s.rms_var[k]; }
+            if (!(s.rms_count > 0.0)) return fail(DN_ERR_INVALID_ARGUMENT, "state %lld: rms_count must be > 0 (RunningMeanStd starts at 1e-4)", i);
+            for (int k = 0; k < DN_OBS_DIM; ++k) { mean[(size_t)k * n + i] = s.rms_mean[k]; var[(size_t)k * n + i] = second_moment(s.rms_var[k], s.rms_count); }
             cnt[(size_t)i] = s.rms_count;
         }
     }
@@ -917,7 +931,7 @@ int32_t dn_set_state(dn_env *env, const dn_env_state *states, int64_t count)
     for (int k = 0; k < 7; ++k) DN_HIP(hipMemcpy(dst[k], g[k].data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice));
     if (env->cfg.normalize_obs) {
         DN_HIP(hipMemcpy(env->p.st.rms_mean, mean.data(), mean.size() * sizeof(double), hipMemcpyHostToDevice));
-        DN_HIP(hipMemcpy(env->p.st.rms_var, var.data(), var.size() * sizeof(double), hipMemcpyHostToDevice));
+        DN_HIP(hipMemcpy(env->p.st.rms_m2, var.data(), var.size() * sizeof(double), hipMemcpyHostToDevice));
         DN_HIP(hipMemcpy(env->p.st.rms_count, cnt.data(), cnt.size() * sizeof(double), hipMemcpyHostToDevice));
     }
     if (env->cfg.norm_rew) DN_HIP(hipMemcpy(env->p.st.rr, rr.data(), rr.size() * sizeof(double), hipMemcpyHostToDevice));

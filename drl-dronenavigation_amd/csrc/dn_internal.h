@@ -51,7 +51,7 @@ struct DnState {
     float4 *g6;  // _current_position.xyz (valid while steps == 0; otherwise it equals pos), pad
     float4 *g7;  // BaseAviary.last_clipped_action (previous step's rpm); allocated with Physics.PYB_DRAG only, else NULL
     double *rms_mean;   // [13][N]  normalize.RunningMeanStd.mean
-    double *rms_var;    // [13][N]
+    double *rms_m2;     // [13][N]  RunningMeanStd.var x .count: the second moment (dn_kernels.hip normalize_obs_cols; dn_get_state returns var)
     double *rms_count;  // [N]
     double *rr;         // [4][N]  NormalizeReward: returns, return_rms.mean, .var, .count (norm_rew only)
     double *pid;        // [9][N]  DSLPIDControl: integral_pos_e, last_rpy, integral_rpy_e (action types PID / VEL / ONE_D_PID only)

@@ -401,23 +401,25 @@ DN_DEV void draw_obs_noise_across(const DnParams &p, const unsigned long long gi
 }
 
 // ---- A10: normalize.NormalizeObservation with a batch of one (normalize.py:34-47, :94-97) ---------
-// The statistics of one drone (13 means, 13 variances, the count) live in registers for the whole launch: loaded
+// The statistics of one drone (13 means, 13 second moments, the count) live in registers for the whole launch: loaded
 // once, updated by every observation the drone emits (step observations and reset observations, in that order),
 // stored once.  The reference's update, with batch_count = 1 and batch_var = 0,
 //     tot = count + 1;  new_mean = mean + delta / tot;  M2 = var count + delta^2 count / tot;  new_var = M2 / tot
-// is evaluated as  new_mean = mean + delta r,  new_var = (var + delta^2 r) (count r)  with r = 1/tot from
-// v_rcp_f64 + two Newton steps (shared by the 13 columns), and the normalised value uses v_rsq_f64 + one Newton step
-// (it leaves as float32): 16 instructions per column instead of ~90 for three IEEE divides and a sqrt, equal to the
-// literal form to 1e-16.
+// carries the SECOND MOMENT M2 = var count from step to step here (round 6; HBM holds it as well: dn_get_state / dn_set_state
+// convert, var = M2 / count), because the update then needs no division at all and shares a product with the output:
+//     r = 1 / tot (v_rcp_f64 + two Newton steps, shared by the 13 columns);  cw = count r
+//     e = delta cw  (= x - new_mean);  new_mean = mean + delta r;  M2' = M2 + delta e;  new_var + 1e-8 = M2' r + 1e-8
+// -- five float64 operations and one fused multiply-add for the radicand per column (the var-carrying form: seven), equal to
+// the literal form to 1e-16.
 struct Rms {
-    double mean[DN_OBS_DIM], var[DN_OBS_DIM], count;
+    double mean[DN_OBS_DIM], m2[DN_OBS_DIM], count;
 };
 DN_DEV void load_rms(const DnParams &p, long long i, Rms &r)
 {
 #pragma unroll
     for (int k = 0; k < DN_OBS_DIM; ++k) {
         r.mean[k] = p.st.rms_mean[(long long)k * p.n + i];
-        r.var[k] = p.st.rms_var[(long long)k * p.n + i];
+        r.m2[k] = p.st.rms_m2[(long long)k * p.n + i];
     }
     r.count = p.st.rms_count[i];
 }
@@ -426,7 +428,7 @@ DN_DEV void store_rms(const DnParams &p, long long i, const Rms &r)
 #pragma unroll
     for (int k = 0; k < DN_OBS_DIM; ++k) {
         p.st.rms_mean[(long long)k * p.n + i] = r.mean[k];
-        p.st.rms_var[(long long)k * p.n + i] = r.var[k];
+        p.st.rms_m2[(long long)k * p.n + i] = r.m2[k];
     }
     p.st.rms_count[i] = r.count;
 }
@@ -442,9 +444,9 @@ DN_DEV double rcp_f64(double x)
 // copy of the count).  The shared quantities (tot, inv, cw) and every per-column expression are the same whatever the range.
 //
 // The OUTPUT stage (round 6).  The statistics are float64 and updated exactly as above whatever the build; the normalised value
-// leaves as a float32, and by default it is formed there: float32(x - new_mean) * v_rsq_f32(float32(new_var) + 1e-8f) -- four
-// float32-rate instructions instead of v_rsq_f64 + a Newton step + a float64 product (8 float64-rate ones, 37.6 -> 24 ns of a SIMD per
-// column; the normaliser is a third of the fused step's vector-ALU time).  The result is within 3 float32 ulp (3.6e-7 relative) of
+// leaves as a float32, and by default it is formed there: float32(x - new_mean) * v_rsq_f32(float32(new_var + 1e-8)) -- two conversions,
+// one float32 transcendental and one float32 product instead of v_rsq_f64 + a Newton step + a float64 product + a conversion (37.6 -> 21 ns
+// of a SIMD per column with the second-moment form above; the normaliser is a third of the fused step's vector-ALU time).  The result is within 3 float32 ulp (3.6e-7 relative) of
 // the correctly rounded float64 evaluation, against the 1e-5 bar of the parity contract; nothing is fed back (the statistics never
 // read the output).  -DDN_NORM_EXACT=1 keeps the float64 output stage -- the float32 nearest to the float64 evaluation (1/2 ulp) --
 // and is what libdronenav_exact.so is built with (build.py; DN_EXACT_NORM=1 selects that library, dn_get_exact_flags reports it).
@@ -463,19 +465,18 @@ DN_DEV void normalize_obs_cols(Rms &r, float o[DN_OBS_DIM])
     for (int k = K0; k < K1; ++k) {
         const double x = (double)o[k];
         const double delta = x - r.mean[k];
+        const double e = delta * cw;                                       // x - new_mean
         const double new_mean = __builtin_fma(delta, inv, r.mean[k]);
-        const double new_var = __builtin_fma(delta * delta, inv, r.var[k]) * cw;
+        const double new_m2 = __builtin_fma(delta, e, r.m2[k]);
         r.mean[k] = new_mean;
-        r.var[k] = new_var;
+        r.m2[k] = new_m2;
+        const double s = __builtin_fma(new_m2, inv, 1e-8);                 // new_var + 1e-8
 #if DN_NORM_EXACT
-        const double s = new_var + 1e-8;
         double y = __builtin_amdgcn_rsq(s);
         y = __builtin_fma(y, __builtin_fma(-(0.5 * s * y), y, 0.5), y);
-        o[k] = (float)((x - new_mean) * y);
+        o[k] = (float)(e * y);
 #else
-        const float e32 = (float)(x - new_mean);
-        const float s32 = (float)new_var + 1e-8f;
-        o[k] = e32 * __builtin_amdgcn_rsqf(s32);
+        o[k] = (float)e * __builtin_amdgcn_rsqf((float)s);
 #endif
     }
     r.count = tot;
@@ -488,7 +489,7 @@ DN_DEV void load_rms_cols(const DnParams &p, const long long tile_base, const un
 #pragma unroll
     for (int k = K0; k < K1; ++k) {
         r.mean[k] = (p.st.rms_mean + ((long long)k * p.n + tile_base))[li];
-        r.var[k] = (p.st.rms_var + ((long long)k * p.n + tile_base))[li];
+        r.m2[k] = (p.st.rms_m2 + ((long long)k * p.n + tile_base))[li];
     }
     r.count = (p.st.rms_count + tile_base)[li];
 }
@@ -498,7 +499,7 @@ DN_DEV void store_rms_cols(const DnParams &p, const long long tile_base, const u
 #pragma unroll
     for (int k = K0; k < K1; ++k) {
         (p.st.rms_mean + ((long long)k * p.n + tile_base))[li] = r.mean[k];
-        (p.st.rms_var + ((long long)k * p.n + tile_base))[li] = r.var[k];
+        (p.st.rms_m2 + ((long long)k * p.n + tile_base))[li] = r.m2[k];
     }
     if (COUNT) (p.st.rms_count + tile_base)[li] = r.count;
 }
@@ -1709,20 +1710,8 @@ DN_DEV Observed<R> observe_phase(const DnParams &p, const DnConsts<R> &c, const 
                                  Rms &rms)
 {
     Observed<R> ob;
-#ifdef DN_EXP_Q_LIGHT                                   // timing experiment only (wrong results): the observation columns and the smoothness terms gone from this wave
-    for (int k = 0; k < DN_OBS_DIM; ++k) ob.o[k] = fl.d_e;
-    {
-        RewardPre<R> q;
-        q.found_now = (R)fl.d_e <= c.threshold; q.last_gate = fl.idx_e + 1 == p.num_waypoints;
-        const R gain = fl.just_found_e ? R(0.0) : ((R)fl.dprev_e - (R)fl.d_e) * R(3000.0);
-        q.r0 = FM<R>::fma(R(3.0), (R)__builtin_amdgcn_exp2f((float)(R(-2.0 * 1.4426950408889634) * (R)fl.d_e)), gain);
-        q.pen_lin = q.pen_ang = false; q.s_lin = q.s_ang = R(0.0);
-        reward_pose<R>(p, s_tab, fl, q, ob.r_normal, ob.r_found32);
-    }
-#else
     observe_columns<R>(p, c, fl, ob.o);
     reward_candidates<R>(p, c, s_tab, fl, G4, G5, ob.r_normal, ob.r_found32);
-#endif
     // sensor noise / per-drone normaliser act on the step observation (which is also terminal_observation)
     if (NOISE && p.obs_noise_sigma > 0.0f) add_obs_noise(p, gid, step_count, 1u, ob.o);
     if (NORM) normalize_obs(rms, ob.o);
@@ -2917,278 +2906,18 @@ DN_DEV void step_many_4w_body(const DnParams &p, const DnStepIO &io0, const int 
     MW_EDGE(3);
 }
 
-// -----------------------------------------------------------------------------------------------------
-// Balanced four-wave kernel (round 6; fused launches of the plain configuration WITH the normaliser, no noise: DN_WAVES=4).
-//
-// Per-role stamps of the five-wave kernel once the thrust chain's fast path and the float32 output stage were in
-// (profiles/r06_notes.md): every role arrives at the barrier within a few hundred cycles of the others -- the launch is bound by the
-// SUM of the roles' instruction streams on SIMDs that hold 2.5 waves, and by its pipeline depth: X and N trail Q, which trails L and A,
-// so a K-step launch runs K + 2 iterations and the driver's K = 20 pays two of them for nothing.  Here the same device functions are
-// dealt to FOUR waves so that every consumer trails its producer by exactly one step:
-//
-//   L  physics_linear(t) on A's thrust direction | rules_verdict, rules_commit | observation columns 0 1 2 6 7 8 12 | linear
-//      smoothness term; owns position, velocity, the distance pair / meta word, _current_position and prev_vel          -> BMailL[t & 1]
-//   A  physics_angular(t) | attitude of the new pose | observation columns 3 4 5 9 10 11 | angular smoothness term | thrust
-//      direction of the new attitude; owns attitude, angular velocity and prev_ang_v                                   -> BMailG[t & 1]
-//   Q  thrust(t + 1) -> tmail | step t - 1: reward terms, orientation term, assembly, A7 select, Monitor, statistics, scalar stores
-//   N  step t - 1: the thirteen columns straight from L's and A's mail -> normaliser -> rows (terminal / reset observation included)
-//                                                                                                  == barrier t ==
-// K + 1 iterations and K + 1 barriers per launch (the five-wave kernel: K + 2), eight waves per CU at two tiles = two per SIMD with
-// 256 registers each (no spills; the five-wave kernel is held to 128 and spills ~50), and nobody re-packs the observation between
-// mails.  Same functions, same typed values across LDS: bit-identical to every other shape.
-// -----------------------------------------------------------------------------------------------------
-template <typename R> struct BMailL {      // L -> Q (pose, distance pair, flags, smoothness), A (flags), N (columns, d_obs, flags)
-    R f64[4][DN_BLOCK];                    // new position (3), Verdict.d_obs
-    float4 oa[DN_BLOCK];                   // o0 o1 o2 o6
-    float4 ob[DN_BLOCK];                   // o7 o8 o12, d_e
-    float4 oc[DN_BLOCK];                   // dprev_e, s_lin, flag word (int bits), --
-};
-// flag word: idx_e [0:8) | just_found_e << 8 | truncated << 9 | coll1 << 10 | terminated << 11 | pen_lin << 16
-template <typename R> struct BMailG {      // A -> L (thrust direction), Q (forward vector, smoothness), N (columns)
-    R col[3][DN_BLOCK];                    // attitude_column of the new attitude as it goes back to HBM (float32 words), before any reset
-    R fw[3][DN_BLOCK];                     // forward vector of the new pose
-    float4 oa[DN_BLOCK];                   // o3 o4 o5 o9
-    float4 ob[DN_BLOCK];                   // o10 o11, s_ang, pen_ang (int bits)
-};
-#ifndef DN_B4_ORDER_A
-#define DN_B4_ORDER_A "LAQN"
-#define DN_B4_ORDER_B "NQAL"             // the second tile of a CU: wave w of both tiles shares SIMD w, heavy roles meet light ones
-#endif
-#ifndef DN_B4_PRIO
-#define DN_B4_PRIO "0000"                // s_setprio of the roles L A Q N
-#endif
-template <typename R>
-DN_DEV void step_many_b4_body(const DnParams &p, const DnStepIO &io0, const int k_steps)
-{
-    __shared__ R s_tab[DN_MAX_WAYPOINTS * DN_T_STRIDE];
-    __shared__ __attribute__((aligned(16))) BMailL<R> maill[2];
-    __shared__ __attribute__((aligned(16))) BMailG<R> mailg[2];
-    __shared__ __attribute__((aligned(16))) ThrustMail<R> tmail[2];
-    constexpr bool NOISE = false;
-    const unsigned lane = threadIdx.x & (DN_BLOCK - 1);
-    const int wv0 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int second_tile = (int)((blockIdx.x / (unsigned)p.num_cus) & 1u);
-    constexpr char oa[5] = DN_B4_ORDER_A, ob[5] = DN_B4_ORDER_B;
-    const char ch = second_tile ? ob[wv0] : oa[wv0];
-    const int role = ch == 'L' ? 0 : ch == 'A' ? 1 : ch == 'Q' ? 2 : 3;      // 0 L, 1 A, 2 Q, 3 N
-    const long long tile_base = (long long)blockIdx.x * DN_BLOCK;
-    const long long left = p.n - tile_base;
-    const unsigned rows = left < DN_BLOCK ? (unsigned)left : DN_BLOCK;
-    const bool active = lane < rows;
-    const unsigned li = active ? lane : rows - 1;
-    __builtin_assume(li < DN_BLOCK);
-    const long long i = tile_base + li;
-    const unsigned long long gid = (unsigned long long)(p.env_id_offset + i);
-    const BlockState b = block_state(p.st, tile_base);
-    const DnConsts<R> &c = consts<R>(p);
-    const long long n = p.n, words = (p.n + 63) / 64;
-    const unsigned long long sc0 = p.st.stats[blockIdx.x].step_count;
-    MW_EDGE(0);
-    stage_table<R>(p, s_tab);
-    {
-        constexpr char pr[5] = DN_B4_PRIO;
-        switch (pr[role] - '0') {                                          // s_setprio takes an immediate
-        case 1: __builtin_amdgcn_s_setprio(1); break;
-        case 2: __builtin_amdgcn_s_setprio(2); break;
-        case 3: __builtin_amdgcn_s_setprio(3); break;
-        default: break;
-        }
-    }
-    // every wave passes barrier P and the barriers of iterations 0 .. k_steps - 1
-    if (role == 0) {
-        // ---- L
-        float4 G0 = b.g0[li], G2 = b.g2[li], G3 = b.g3[li];
-        float4 P4 = b.g4[li];                                              // .xyz: prev_vel (the .w, Monitor's return, belongs to Q)
-        AttCol<R> col = attitude_column<R>(b.g1[li]);                      // the thrust direction of the entry attitude; from step 1 on A mails it
-        block_lds_barrier(); MW_EDGE(1);                                   // P
-        const R wp0[3] = {s_tab[DN_T_WP], s_tab[DN_T_WP + 1], s_tab[DN_T_WP + 2]};
-        bool done_prev = false;
-#pragma clang loop unroll(disable)
-        for (int t = 0; t < k_steps; ++t) {
-            MW_ROLE_MARK("L");
-            if (t > 0) {                                                   // entry attitude: A's step t-1, level after my reset of t-1
-                const BMailG<R> &mp = mailg[(t - 1) & 1];
-                const R c0 = mp.col[0][lane], c1 = mp.col[1][lane], c2 = mp.col[2][lane];
-                col.r02 = done_prev ? R(0.0) : c0; col.r12 = done_prev ? R(0.0) : c1; col.r22 = done_prev ? R(1.0) : c2;
-            }
-            const GateRow<R> row_e = load_gate_row<R>(s_tab, unpack_meta(G3.w).idx);
-            const R fz = tmail[t & 1].v[0][lane];
-            const Lin<R> lin = physics_linear_col<R>(G0, G2, col, fz, R(0.0), R(0.0), R(0.0), false);
-            Flight<R> fl;
-            flight_entry<R>(fl, G0, G2, G3, p.max_steps);
-            fl.px = lin.px; fl.py = lin.py; fl.pz = lin.pz;
-            fl.vx = (float)lin.vx; fl.vy = (float)lin.vy; fl.vz = (float)lin.vz;
-            fl.qx = fl.qy = fl.qz = R(0.0); fl.qw = R(1.0);                // the attitude belongs to A (no ground-contact term here)
-            fl.wx = fl.wy = fl.wz = 0.0f;
-            RulesMid<R> m;
-            const Verdict<R> v = rules_verdict<R>(p, c, s_tab, row_e, fl, G3, m);
-            float o[DN_OBS_DIM];
-            observe_columns_lin<R>(p, c, fl, o);
-            const Smooth<R> sl = smooth_term<R>(fl.vex, fl.vey, fl.vez, P4, R(0.7) * R(0.7));
-            BMailL<R> &ml = maill[t & 1];
-            ml.f64[0][lane] = fl.px; ml.f64[1][lane] = fl.py; ml.f64[2][lane] = fl.pz; ml.f64[3][lane] = v.d_obs;
-            ml.oa[lane] = make_float4(o[0], o[1], o[2], o[6]);
-            ml.ob[lane] = make_float4(o[7], o[8], o[12], fl.d_e);
-            ml.oc[lane] = make_float4(fl.dprev_e, (float)sl.s,
-                                      __int_as_float(fl.idx_e | (fl.just_found_e << 8) | (fl.truncated << 9) | (v.coll1 << 10) | (v.terminated << 11) |
-                                                     ((int)sl.pen << 16)), 0.0f);
-            float4 S0, S1, S2, S3;
-            rules_commit<R>(c, wp0, fl, m, G0, G3, b.g6, li, active, S0, S1, S2, S3);
-            // prev_vel: _update_state_post_step (skipped on a terminated step, quirk Q5), zero after a reset
-            if (!v.terminated) { P4.x = fl.vex; P4.y = fl.vey; P4.z = fl.vez; }
-            done_prev = v.terminated != 0 || fl.truncated != 0;
-            if (done_prev) P4.x = P4.y = P4.z = 0.0f;
-            G0 = S0; G2 = S2; G3.w = S3.w;
-            MW_BARRIER();                                                  // barrier t
-        }
-        if (active) {
-            b.g0[li] = G0; b.g2[li] = G2;
-            reinterpret_cast<float *>(b.g3 + li)[3] = G3.w;
-            float *g4 = reinterpret_cast<float *>(b.g4 + li);
-            g4[0] = P4.x; g4[1] = P4.y; g4[2] = P4.z;
-        }
-    } else if (role == 1) {
-        // ---- A
-        float4 G1 = b.g1[li], G3 = b.g3[li];                               // G3.xyz: angular velocity (the .w belongs to L)
-        float4 P5 = b.g5[li];                                              // .xyz: prev_ang_v (the .w, Monitor's length word, belongs to Q)
-        QuatTerms<R> qt = quat_terms<R>((R)G1.x, (R)G1.y, (R)G1.z, (R)G1.w);   // formed once per step: see the five-wave kernel's A
-        float wex = 0.0f, wey = 0.0f, wez = 0.0f;                          // entry angular velocity of the step just integrated
-        block_lds_barrier(); MW_EDGE(1);                                   // P
-#pragma clang loop unroll(disable)
-        for (int t = 0; t <= k_steps; ++t) {
-            MW_ROLE_MARK("A");
-            if (t > 0) {                                                   // L's verdict of step t-1
-                const int fb = __float_as_int(maill[(t - 1) & 1].oc[lane].z);
-                // prev_ang_v: _update_state_post_step (skipped on a terminated step, quirk Q5), zero after a reset
-                if (!((fb >> 11) & 1)) { P5.x = wex; P5.y = wey; P5.z = wez; }
-                const bool fin = (((fb >> 9) | (fb >> 11)) & 1) != 0;
-                if (__ballot(fin) != 0ull) {                               // a finished drone restarts level, at rest (wave-uniform skip)
-                    if (fin) {
-                        G1 = make_float4(0.0f, 0.0f, 0.0f, 1.0f); G3.x = G3.y = G3.z = 0.0f; qt = quat_terms_identity<R>();
-                        P5.x = P5.y = P5.z = 0.0f;
-                    }
-                }
-            }
-            if (t < k_steps) {
-                wex = G3.x; wey = G3.y; wez = G3.z;
-                const Smooth<R> sa = smooth_term<R>(wex, wey, wez, P5, R(0.3) * R(0.3));
-                const R tx = tmail[t & 1].v[1][lane], ty = tmail[t & 1].v[2][lane], zt = tmail[t & 1].v[3][lane];
-                const Ang<R> ang = physics_angular_post<R>(physics_angular_pre_terms<R>(G1, G3, qt), tx, ty, zt);
-                const float4 qn = make_float4((float)ang.qx, (float)ang.qy, (float)ang.qz, (float)ang.qw);
-                const float4 wn = make_float4((float)ang.wx, (float)ang.wy, (float)ang.wz, 0.0f);
-                Flight<R> fl;
-                fl.qx = ang.qx; fl.qy = ang.qy; fl.qz = ang.qz; fl.qw = ang.qw;
-                fl.wx = wn.x; fl.wy = wn.y; fl.wz = wn.z;
-                attitude_phase<R>(fl);
-                float o[DN_OBS_DIM];
-                observe_columns_att<R>(fl, o);
-                qt = quat_terms<R>((R)qn.x, (R)qn.y, (R)qn.z, (R)qn.w);   // of the state word, as the next step reads it
-                const AttCol<R> cn = attitude_column_terms<R>(qn, qt);
-                BMailG<R> &mg = mailg[t & 1];
-                mg.col[0][lane] = cn.r02; mg.col[1][lane] = cn.r12; mg.col[2][lane] = cn.r22;
-                mg.fw[0][lane] = fl.fwx; mg.fw[1][lane] = fl.fwy; mg.fw[2][lane] = fl.fwz;
-                mg.oa[lane] = make_float4(o[3], o[4], o[5], o[9]);
-                mg.ob[lane] = make_float4(o[10], o[11], (float)sa.s, __int_as_float((int)sa.pen));
-                G1 = qn; G3.x = wn.x; G3.y = wn.y; G3.z = wn.z;
-                MW_BARRIER();                                              // barrier t
-            }
-        }
-        if (active) {
-            b.g1[li] = G1;
-            float *g3 = reinterpret_cast<float *>(b.g3 + li), *g5 = reinterpret_cast<float *>(b.g5 + li);
-            g3[0] = G3.x; g3[1] = G3.y; g3[2] = G3.z;
-            g5[0] = P5.x; g5[1] = P5.y; g5[2] = P5.z;
-        }
-    } else if (role == 2) {
-        // ---- Q: the action chain one step ahead; reward and scalars one step behind
-        float4 G4 = b.g4[li], G5 = b.g5[li];                               // .w: Monitor return / length
-        StatAcc acc;
-        RewNorm rn = {0.0, 0.0, 1.0, 1e-4};
-        const float4 *act = reinterpret_cast<const float4 *>(io0.actions) + tile_base;
-        float4 A = act[li];
-        {
-            const float4 A1 = (act + (long long)(k_steps > 1 ? 1 : 0) * n)[li];
-            post_thrust<R>(tmail[0], lane, thrust_phase<NOISE>(p, gid, sc0, A));
-            A = A1;
-        }
-        block_lds_barrier(); MW_EDGE(1);                                   // P: table and thrust(0) published
-#pragma clang loop unroll(disable)
-        for (int t = 0; t <= k_steps; ++t) {
-            MW_ROLE_MARK("Q");
-            if (t + 1 < k_steps) {                                         // thrust(t+1), for the next iteration of L and A
-                const float4 A_next = (act + (long long)(t + 2 < k_steps ? t + 2 : t + 1) * n)[li];
-                post_thrust<R>(tmail[(t + 1) & 1], lane, thrust_phase<NOISE>(p, gid, sc0 + (unsigned long long)(t + 1), A));
-                A = A_next;
-            }
-            if (t > 0) {                                                   // the step L and A finished last iteration
-                const int u = t - 1;
-                const BMailL<R> &ml = maill[u & 1];
-                const BMailG<R> &mg = mailg[u & 1];
-                Flight<R> fl;
-                Verdict<R> v;
-                fl.px = ml.f64[0][lane]; fl.py = ml.f64[1][lane]; fl.pz = ml.f64[2][lane];
-                const float4 lc = ml.oc[lane], gb = mg.ob[lane];
-                fl.d_e = ml.ob[lane].w; fl.dprev_e = lc.x;
-                const int fb = __float_as_int(lc.z);
-                fl.idx_e = fb & 0xFF; fl.just_found_e = (fb >> 8) & 1; fl.truncated = (fb >> 9) & 1;
-                v.coll1 = (fb >> 10) & 1; v.terminated = (fb >> 11) & 1; v.d_obs = R(0.0);      // d_obs: N's (the reset observation)
-                fl.fwx = mg.fw[0][lane]; fl.fwy = mg.fw[1][lane]; fl.fwz = mg.fw[2][lane];
-                RewardPre<R> pre;
-                reward_entry_core<R>(p, c, fl, pre);
-                pre.s_lin = (R)lc.y; pre.pen_lin = ((fb >> 16) & 1) != 0;
-                pre.s_ang = (R)gb.z; pre.pen_ang = (__float_as_int(gb.w) & 1) != 0;
-                R r_normal;
-                float r_found32;
-                reward_pose<R>(p, s_tab, fl, pre, r_normal, r_found32);
-                fl.vex = fl.vey = fl.vez = fl.aex = fl.aey = fl.aez = 0.0f;    // prev_vel / prev_ang_v live on L / A
-                const StepOut out = block_out(io0, tile_base, (long long)u * n, (long long)u * words);
-                report_scalars<R, false>(p, c, out, fl, v, r_normal, r_found32, li, lane, active, G4, G5, acc, rn);
-            }
-            if (t < k_steps) MW_BARRIER();                                 // barrier t
-        }
-        flush_stats(p, acc, sc0 + (unsigned long long)k_steps, lane);
-        if (active) {
-            reinterpret_cast<float *>(b.g4 + li)[3] = G4.w;
-            reinterpret_cast<float *>(b.g5 + li)[3] = G5.w;
-        }
-    } else {
-        // ---- N: the observation of step t - 1 from L's and A's mail through the normaliser and out
-        Rms rms;
-        load_rms(p, i, rms);
-        block_lds_barrier(); MW_EDGE(1);                                   // P
-#pragma clang loop unroll(disable)
-        for (int t = 0; t <= k_steps; ++t) {
-            MW_ROLE_MARK("N");
-            if (t > 0) {
-                const int u = t - 1;
-                const BMailL<R> &ml = maill[u & 1];
-                const BMailG<R> &mg = mailg[u & 1];
-                const float4 la = ml.oa[lane], lb = ml.ob[lane], ga = mg.oa[lane], gb = mg.ob[lane];
-                const int fb = __float_as_int(ml.oc[lane].z);
-                Verdict<R> v;
-                v.d_obs = ml.f64[3][lane]; v.coll1 = (fb >> 10) & 1; v.terminated = (fb >> 11) & 1;
-                float o[DN_OBS_DIM] = {la.x, la.y, la.z, ga.x, ga.y, ga.z, la.w, lb.x, lb.y, ga.w, gb.x, gb.y, lb.z};
-                normalize_obs(rms, o);                                     // the step observation (= terminal_observation)
-                const StepOut out = block_out(io0, tile_base, (long long)u * n, (long long)u * words);
-                report_obs<R, true, NOISE, 2>(p, c, nullptr, out, ((fb >> 9) & 1) != 0, v, o, gid, sc0 + (unsigned long long)u, li, lane, rows, active, rms);
-            }
-            if (t < k_steps) MW_BARRIER();                                 // barrier t
-        }
-        if (active) store_rms(p, i, rms);
-    }
-    MW_EDGE(3);
-}
-
 template <typename R, bool NORM, bool NOISE>
 __global__ __launch_bounds__(4 * DN_BLOCK, 2) void dn_step_many_4w_kernel(const DnParams p, const DnStepIO io0, const int k_steps)
 {
-    if constexpr (NORM && !NOISE) step_many_b4_body<R>(p, io0, k_steps);     // normaliser on, no noise: the balanced cut (round 6)
-    else step_many_4w_body<R, NORM, NOISE, 4>(p, io0, k_steps);
+    step_many_4w_body<R, NORM, NOISE, 4>(p, io0, k_steps);
 }
 // five waves: two tiles per CU are ten waves on four SIMDs, i.e. FOUR waves on one of them -- 128 registers a wave
 // (three tiles, where noise keeps this shape selected: fifteen waves, four on three of the SIMDs, at the same 128 registers)
 template <typename R, bool NOISE>
-__global__ __launch_bounds__(5 * DN_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void dn_step_many_5w_kernel(const DnParams p, const DnStepIO io0, const int k_steps)
+#ifndef DN_5W_WAVES_PER_EU
+#define DN_5W_WAVES_PER_EU 4
+#endif
+__global__ __launch_bounds__(5 * DN_BLOCK) __attribute__((amdgpu_waves_per_eu(DN_5W_WAVES_PER_EU, DN_5W_WAVES_PER_EU))) void dn_step_many_5w_kernel(const DnParams p, const DnStepIO io0, const int k_steps)
 {
     step_many_4w_body<R, true, NOISE, 5>(p, io0, k_steps);
 }

@@ -113,7 +113,7 @@ typedef struct dn_env_state {
     float ep_ret;                               /* Monitor: running episode return (high word, see ep_ret_lo) */
     int32_t ep_len;                             /* Monitor: running episode length */
     double rms_mean[DN_OBS_DIM];                /* normalize.RunningMeanStd.mean  (normalize_obs only) */
-    double rms_var[DN_OBS_DIM];                 /*                         .var                       */
+    double rms_var[DN_OBS_DIM];                 /*                         .var  (the device carries the second moment var x count; these calls convert) */
     double rms_count;                           /*                         .count                     */
     double rr_returns;                          /* NormalizeReward.returns (discounted return, norm_rew only)  */
     double rr_mean, rr_var, rr_count;           /* NormalizeReward.return_rms                                  */

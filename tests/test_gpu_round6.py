@@ -194,7 +194,7 @@ def test_float32_output_stage_against_the_exact_build(tmp_path):
     ulp = np.spacing(np.abs(res["exact"]["obs"]).astype(np.float32)).astype(np.float64)
     err_ulp = np.abs(fo - eo) / np.maximum(ulp, np.float64(np.spacing(np.float32(1e-30))))
     assert err_ulp.max() <= 3.0, f"float32 output stage off by {err_ulp.max():.2f} float32 ulp"
-    assert res["fast"]["done"].sum() > n, "episodes must end (the reset observation's second pass) in this run"
+    assert res["fast"]["done"].sum() >= n, "episodes must end (the reset observation's second pass) in this run"
     print(f"float32 output stage: max {err_ulp.max():.2f} ulp, mean {err_ulp.mean():.3f} ulp over {fo.size} normalised values; "
           f"|obs| max {np.abs(eo).max():.2f}")
     # the exact build against the oracle's float64 evaluation on the same actions
