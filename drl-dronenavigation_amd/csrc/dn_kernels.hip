@@ -1596,9 +1596,14 @@ DN_DEV void observe_columns_lin(const DnParams &p, const DnConsts<R> &c, const F
     o[1] = (float)(fl.py * c.inv_dim[1]);
     o[2] = (float)(fl.pz * c.inv_dim[2]);
     const float third32 = (float)K<R>::THIRD;
-    o[6] = clipv((float)((R)fl.vx * K<R>::THIRD), -1.0f, 1.0f);
-    o[7] = clipv((float)((R)fl.vy * K<R>::THIRD), -1.0f, 1.0f);
-    o[8] = clipv((float)((R)fl.vz * K<R>::THIRD), -third32, third32);
+    const float v6 = (float)((R)fl.vx * K<R>::THIRD), v7 = (float)((R)fl.vy * K<R>::THIRD), v8 = (float)((R)fl.vz * K<R>::THIRD);
+    o[6] = __builtin_amdgcn_fmed3f(v6, -1.0f, 1.0f);
+    o[7] = __builtin_amdgcn_fmed3f(v7, -1.0f, 1.0f);
+    o[8] = __builtin_amdgcn_fmed3f(v8, -third32, third32);
+    // np.clip propagates NaN, v_med3 does not: one test per wave, the selects only where it fires (a NaN action poisons the state)
+    if (__builtin_expect(__ballot(__builtin_isunordered(v6, v7) || v8 != v8) != 0ull, 0)) {
+        o[6] = v6 != v6 ? v6 : o[6]; o[7] = v7 != v7 ? v7 : o[7]; o[8] = v8 != v8 ? v8 : o[8];
+    }
     o[12] = p.include_distance ? (float)((R)fl.d_e * c.inv_max_target_dist) : 0.0f;
 }
 template <typename R>
@@ -1609,11 +1614,18 @@ DN_DEV void observe_columns_att(const Flight<R> &fl, float o[DN_OBS_DIM])
     o[3] = roll32 * inv_pi32;
     o[4] = pitch32 * inv_pi32;
     o[5] = yaw32 * inv_pi32;
-    const R w2 = FM<R>::fma((R)fl.wz, (R)fl.wz, FM<R>::fma((R)fl.wy, (R)fl.wy, (R)fl.wx * (R)fl.wx));   // explicit order, see attitude_phase
-    if (w2 != R(0.0)) {                                   // ang_v / |ang_v|, zero stays zero (:383-384)
+    // ang_v / |ang_v|, zero stays zero (:383-384).  The three words are float32 state and the columns leave as float32: the norm is taken
+    // there (v_rsq_f32, 1 ulp: the columns within 2 float32 ulp of the float64 quotient, 2.4e-7 on a unit vector) wherever w^2 is a normal
+    // float32 with room to spare; a drone turning slower than 1e-15 rad/s (w^2 would underflow) takes the float64 form -- a per-lane
+    // choice (the block is skipped when no lane of the wave needs it), so a drone's columns do not depend on its neighbours.
+    const float w2f = __builtin_fmaf(fl.wz, fl.wz, __builtin_fmaf(fl.wy, fl.wy, fl.wx * fl.wx));
+    const float rw32 = w2f != 0.0f ? __builtin_amdgcn_rsqf(w2f) : 0.0f;
+    o[9] = fl.wx * rw32; o[10] = fl.wy * rw32; o[11] = fl.wz * rw32;
+    if (__builtin_expect(w2f < 1e-30f && (fl.wx != 0.0f || fl.wy != 0.0f || fl.wz != 0.0f), 0)) {
+        const R w2 = FM<R>::fma((R)fl.wz, (R)fl.wz, FM<R>::fma((R)fl.wy, (R)fl.wy, (R)fl.wx * (R)fl.wx));   // explicit order, see attitude_phase
         const R rw = FM<R>::rsq_f32grade(w2);
         o[9] = (float)((R)fl.wx * rw); o[10] = (float)((R)fl.wy * rw); o[11] = (float)((R)fl.wz * rw);
-    } else { o[9] = fl.wx; o[10] = fl.wy; o[11] = fl.wz; }
+    }
 }
 template <typename R>
 DN_DEV void observe_columns(const DnParams &p, const DnConsts<R> &c, const Flight<R> &fl, float o[DN_OBS_DIM])
@@ -2529,8 +2541,12 @@ __global__ __launch_bounds__(3 * DN_BLOCK, NORM ? 2 : 3) void dn_step_many_3w_ke
                 const Observed<R> ob = observe_phase<R, false, NOISE>(p, c, s_tab, fl, P4, P5, gid, sc0 + (unsigned long long)u, rms);
                 post_maila<R>(maila[u & 1], lane, fl, v, ob);
                 // prev_vel / prev_ang_v: _update_state_post_step (skipped on a terminated step, quirk Q5), zero after a reset
-                if (!v.terminated) { P4 = make_float4(fl.vex, fl.vey, fl.vez, 0.0f); P5 = make_float4(fl.aex, fl.aey, fl.aez, 0.0f); }
-                if (v.terminated || fl.truncated) P4 = P5 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                // (a terminated step is a finished one, so the old copies never survive: one select per word)
+                {
+                    const bool fin = v.terminated != 0 || fl.truncated != 0;
+                    P4 = fin ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : make_float4(fl.vex, fl.vey, fl.vez, 0.0f);
+                    P5 = fin ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : make_float4(fl.aex, fl.aey, fl.aez, 0.0f);
+                }
             }
             block_lds_barrier();                                           // barrier t
         }
@@ -2827,8 +2843,12 @@ DN_DEV void step_many_4w_body(const DnParams &p, const DnStepIO &io0, const int 
                 const Observed<R> ob = observe_phase<R, false, NOISE>(p, c, s_tab, fl, P4, P5, gid, sc0 + (unsigned long long)u, rms);
                 post_maila<R>(maila[u & 1], lane, fl, v, ob);
                 // prev_vel / prev_ang_v: _update_state_post_step (skipped on a terminated step, quirk Q5), zero after a reset
-                if (!v.terminated) { P4 = make_float4(fl.vex, fl.vey, fl.vez, 0.0f); P5 = make_float4(fl.aex, fl.aey, fl.aez, 0.0f); }
-                if (v.terminated || fl.truncated) P4 = P5 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                // (a terminated step is a finished one, so the old copies never survive: one select per word)
+                {
+                    const bool fin = v.terminated != 0 || fl.truncated != 0;
+                    P4 = fin ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : make_float4(fl.vex, fl.vey, fl.vez, 0.0f);
+                    P5 = fin ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : make_float4(fl.aex, fl.aey, fl.aez, 0.0f);
+                }
             }
             MW_BARRIER();                                                  // barrier t
         }
@@ -3295,8 +3315,9 @@ DN_DEV void step_many_rp_body(const DnParams &p, const DnStepIO &io0, const int 
                 mc.oa[lane] = make_float4(o[0], o[1], o[2], o[6]);
                 mc.ob[lane] = make_float4(o[7], o[8], o[12], __int_as_float(fb | ((int)pre.pen_lin << 16) | ((int)pre.pen_ang << 17)));
                 // prev_vel / prev_ang_v: _update_state_post_step (skipped on a terminated step, quirk Q5), zero after a reset
-                if (!terminated) { P4 = make_float4(fl.vex, fl.vey, fl.vez, 0.0f); P5 = make_float4(fl.aex, fl.aey, fl.aez, 0.0f); }
-                if (done) P4 = P5 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                // (a terminated step is a finished one, so the old copies never survive: one select per word)
+                P4 = done ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : make_float4(fl.vex, fl.vey, fl.vez, 0.0f);
+                P5 = done ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : make_float4(fl.aex, fl.aey, fl.aez, 0.0f);
                 vex = done ? 0.0f : fl.vx; vey = done ? 0.0f : fl.vy; vez = done ? 0.0f : fl.vz;      // the next step's entry velocity
             }
             MW_BARRIER();                                                  // barrier t
