@@ -2718,7 +2718,7 @@ DN_DEV void step_many_4w_body(const DnParams &p, const DnStepIO &io0, const int 
     if (role == 0) {
         float4 G0 = b.g0[li], G2 = b.g2[li], G3 = b.g3[li];
         AttCol<R> col = attitude_column<R>(b.g1[li]);                      // the thrust direction of the entry attitude; from step 1 on A mails it
-        block_lds_barrier();                                               // P
+        block_lds_barrier(); MW_EDGE(1);                                   // P
         const R wp0[3] = {s_tab[DN_T_WP], s_tab[DN_T_WP + 1], s_tab[DN_T_WP + 2]};
         bool done_prev = false;
 #pragma clang loop unroll(disable)
@@ -2753,6 +2753,7 @@ DN_DEV void step_many_4w_body(const DnParams &p, const DnStepIO &io0, const int 
             }
             MW_BARRIER();                                                  // barrier t
         }
+        MW_EDGE(2);
         if (active) {
             b.g0[li] = G0; b.g2[li] = G2;
             reinterpret_cast<float *>(b.g3 + li)[3] = G3.w;
@@ -2763,7 +2764,7 @@ DN_DEV void step_many_4w_body(const DnParams &p, const DnStepIO &io0, const int 
         // thrust direction L needs for its next step (mailed) and they start this wave's own next step (same expressions, same bits as
         // attitude_column / physics_angular_pre on the state word)
         QuatTerms<R> qt = quat_terms<R>((R)G1.x, (R)G1.y, (R)G1.z, (R)G1.w);
-        block_lds_barrier();                                               // P
+        block_lds_barrier(); MW_EDGE(1);                                   // P
 #pragma clang loop unroll(disable)
         for (int t = 0; t <= k_steps; ++t) {
             MW_ROLE_MARK("A");
@@ -2794,6 +2795,7 @@ DN_DEV void step_many_4w_body(const DnParams &p, const DnStepIO &io0, const int 
             }
             MW_BARRIER();                                                  // barrier t
         }
+        MW_EDGE(2);
         if (active) {
             b.g1[li] = G1;
             float *g3 = reinterpret_cast<float *>(b.g3 + li);
@@ -2812,7 +2814,7 @@ DN_DEV void step_many_4w_body(const DnParams &p, const DnStepIO &io0, const int 
             post_thrust<R>(tmail[0], lane, thrust_phase<NOISE>(p, gid, sc0, A));
             A = A1;
         }
-        block_lds_barrier();                                               // P: table and thrust(0) published
+        block_lds_barrier(); MW_EDGE(1);                                   // P: table and thrust(0) published
 #pragma clang loop unroll(disable)
         for (int t = 0; t <= k_steps; ++t) {
             MW_ROLE_MARK("Q");
@@ -2852,6 +2854,7 @@ DN_DEV void step_many_4w_body(const DnParams &p, const DnStepIO &io0, const int 
             }
             MW_BARRIER();                                                  // barrier t
         }
+        MW_EDGE(2);
         if (active) {
             float *g4 = reinterpret_cast<float *>(b.g4 + li), *g5 = reinterpret_cast<float *>(b.g5 + li);
             g4[0] = P4.x; g4[1] = P4.y; g4[2] = P4.z; g5[0] = P5.x; g5[1] = P5.y; g5[2] = P5.z;
@@ -2860,7 +2863,7 @@ DN_DEV void step_many_4w_body(const DnParams &p, const DnStepIO &io0, const int 
         // ---- N (NW == 5): observation -> normaliser -> rows, the reset observation of a finished drone included
         Rms rms;
         load_rms(p, i, rms);
-        block_lds_barrier();                                               // P
+        block_lds_barrier(); MW_EDGE(1);                                   // P
 #pragma clang loop unroll(disable)
         for (int t = 0; t <= k_steps + 1; ++t) {
             MW_ROLE_MARK("N");
@@ -2876,6 +2879,7 @@ DN_DEV void step_many_4w_body(const DnParams &p, const DnStepIO &io0, const int 
             }
             if (t <= k_steps) MW_BARRIER();                                // barrier t
         }
+        MW_EDGE(2);
         if (active) store_rms(p, i, rms);
     } else {
         float4 G4 = b.g4[li], G5 = b.g5[li];                               // .w: Monitor return / length
@@ -2891,7 +2895,7 @@ DN_DEV void step_many_4w_body(const DnParams &p, const DnStepIO &io0, const int 
             post_thrust<R>(tmail[0], lane, thrust_phase<NOISE>(p, gid, sc0, A));
             A = A1;
         }
-        block_lds_barrier();                                               // P
+        block_lds_barrier(); MW_EDGE(1);                                   // P
 #pragma clang loop unroll(disable)
         for (int t = 0; t <= k_steps + 1; ++t) {
             MW_ROLE_MARK("X");
@@ -2916,6 +2920,7 @@ DN_DEV void step_many_4w_body(const DnParams &p, const DnStepIO &io0, const int 
             }
             if (t <= k_steps) MW_BARRIER();                                // barrier t
         }
+        MW_EDGE(2);
         flush_stats(p, acc, sc0 + (unsigned long long)k_steps, lane);
         if (NORM && NW == 4 && active) store_rms(p, i, rms);
         if (active) {

@@ -54,7 +54,7 @@ if hasattr(raw, "dn_debug_mw_edges"):
         if e[r, 0] == 0:
             continue
         hw = int(e[r, 6])                                   # HW_REG_HW_ID (gfx9): wave_id [3:0], simd_id [5:4], pipe_id [7:6], cu_id [11:8], sh_id [12], se_id [15:13]
-        print(f"  role {r} {names[r]}: prologue {e[r, 1] - e[r, 0]:6d}  loop+epilogue {e[r, 3] - e[r, 1]:7d}  wall {(e[r, 5] - e[r, 4]) * 10} ns   "
+        print(f"  role {r} {names[r]}: prologue {e[r, 1] - e[r, 0]:6d}  loop {e[r, 2] - e[r, 1] if e[r, 2] else -1:7d}  epilogue {e[r, 3] - e[r, 2] if e[r, 2] else -1:6d}  (loop+epilogue {e[r, 3] - e[r, 1]:7d})  wall {(e[r, 5] - e[r, 4]) * 10} ns   "
               f"HW_ID {hw:#010x}: simd {(hw >> 4) & 3} wave slot {hw & 15} cu {(hw >> 8) & 15} sh {(hw >> 12) & 1} se {(hw >> 13) & 7}")
     w0, w1 = e[:NR, 4][e[:NR, 4] > 0].min(), e[:NR, 5].max()
     print(f"  tile wall time in the kernel {(w1 - w0) * 10} ns for {K} steps = {(w1 - w0) * 10 / K / 1000:.3f} us per step; eager launch-to-launch above")

@@ -49,6 +49,6 @@ def test_valu_bound_is_computed_from_the_committed_counter_pass():
         assert v is not None and v["tiles_per_cu"] == 2.0 and 3.5 < v["valu_cycles_per_inst"] < 5.5
         floor = v["tiles_per_cu"] * v["valu_insts_per_tile_step"] * v["valu_cycles_per_inst"] / 4.0 / (v["shader_clock_ghz"] * 1e3)
         assert abs(floor - v["valu_floor_us_per_step"]) < 1e-3 and 0.3 < v["valu_frac"] < 1.0
-    assert "r05_instmix_k20" in v20["counters_from"]              # the driver's launch quotes the pass of the driver's own command
+    assert "r06_instmix_k20" in v20["counters_from"]              # the driver's launch quotes the pass of the driver's own command
     assert v20["valu_insts_per_tile_step"] != v64["valu_insts_per_tile_step"]
     assert b.valu_bound("no such kernel", 32768, 20, 1.0) is None

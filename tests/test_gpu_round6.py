@@ -309,3 +309,68 @@ def test_step_async_twice_is_refused():
     env.step_async(a)
     env.step_wait()
     env.close()
+
+
+def _time_fused(env, acts, launches=50, reps=3):
+    """us per launch of env.rollout_tensor(acts): `launches` launches captured once into a hipGraph, replayed, best of `reps`."""
+    dev = acts.device
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        out = env.rollout_tensor(acts)
+        for _ in range(3):
+            env.rollout_tensor(acts, out=out)
+        side.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            for _ in range(launches):
+                env.rollout_tensor(acts, out=out)
+        g.replay()
+        side.synchronize()
+        best = float("inf")
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(side)
+            g.replay()
+            e1.record(side)
+            side.synchronize()
+            best = min(best, e0.elapsed_time(e1) * 1e3 / launches)
+    torch.cuda.current_stream(dev).wait_stream(side)
+    return best
+
+
+@pytest.mark.parametrize("n", [12, 4096, 32768])
+@pytest.mark.parametrize("norm", [False, True])
+def test_dn_create_picks_a_fused_shape_within_5_percent_of_the_best(n, norm, monkeypatch):
+    """the fused-launch shape is picked from tiles-per-CU crossovers calibrated on one 256-CU part, and the parity
+    tests mirror that table -- a wrong crossover would only be slower, never red.  Here every shape the configuration may legally take
+    (DN_WAVES = 1 2 3 4 5 8; a forced shape that does not exist for it falls back and is met once) is TIMED at BASELINE's three single-GPU
+    fleet sizes with the normaliser off and on -- 50 launches of the driver's K = 20 steps replayed from one hipGraph, best of three --
+    and dn_create's own pick must be within 5 % (+ 0.3 us of timer grain per launch) of the fastest."""
+    pkg = _gpu()
+    from drl_dronenavigation_amd import tracks
+    dev = torch.device("cuda:0")
+    K = 20
+    track = tracks.reaching() if n > 12 else tracks.circle(1, 4, 1)
+    n_pad = (n + 3) // 4 * 4                               # dn_step_many needs num_envs % 4 == 0
+    torch.manual_seed(n)
+    acts = torch.rand((K, n_pad, 4), device=dev) * 2 - 1
+    monkeypatch.delenv("DN_WAVES", raising=False)
+    env = pkg.DroneVecEnv(track, n_pad, normalize_obs=norm, device=dev)
+    env.reset_tensor()
+    pick = env.kernel_waves(fused=True)
+    times = {pick: _time_fused(env, acts)}
+    env.close()
+    for forced in ("1", "2", "3", "4", "5", "8"):
+        monkeypatch.setenv("DN_WAVES", forced)
+        e = pkg.DroneVecEnv(track, n_pad, normalize_obs=norm, device=dev)
+        shape = e.kernel_waves(fused=True)
+        if shape not in times or shape == pick:
+            e.reset_tensor()
+            t = _time_fused(e, acts)
+            times[shape] = min(times.get(shape, float("inf")), t)
+        e.close()
+    monkeypatch.delenv("DN_WAVES")
+    best_shape = min(times, key=times.get)
+    print(f"n={n} norm={norm}: pick {pick} {times[pick]:.2f} us per {K}-step launch; " + ", ".join(f"{s}: {t:.2f}" for s, t in sorted(times.items())))
+    assert times[pick] <= 1.05 * times[best_shape] + 0.3, (pick, best_shape, times)
