@@ -52,3 +52,30 @@ def test_valu_bound_is_computed_from_the_committed_counter_pass():
     assert "r06_instmix_k20" in v20["counters_from"]              # the driver's launch quotes the pass of the driver's own command
     assert v20["valu_insts_per_tile_step"] != v64["valu_insts_per_tile_step"]
     assert b.valu_bound("no such kernel", 32768, 20, 1.0) is None
+
+
+def _lookup(path, key):
+    full = os.path.join(ROOT, path)
+    if key.startswith("regex:"):
+        m = re.search(key[len("regex:"):], open(full).read(), flags=re.M)
+        assert m, (path, key)
+        return float(m.group(1))
+    obj = json.load(open(full))
+    for part in (key.split("|") if "|" in key else key.split(".")):
+        obj = obj[part]
+    return float(obj)
+
+
+def test_prose_quotes_the_committed_numbers():
+    """VERDICT r05 next #4a: README / DESIGN section 5 quote numbers; every such number listed in profiles/r06_claims.json must (1) appear in
+    the documents as quoted and (2) contain the value of the committed final file it names -- not the best box of an earlier round."""
+    claims = json.load(open(os.path.join(ROOT, "profiles", "r06_claims.json")))["claims"]
+    assert len(claims) >= 20
+    docs = {}
+    for c in claims:
+        for d in c["docs"]:
+            docs.setdefault(d, open(os.path.join(ROOT, d)).read())
+            assert c["text"] in docs[d], f"{d} does not quote {c['text']!r}"
+        for path, key in c["where"]:
+            v = _lookup(path, key)
+            assert c["lo"] <= v <= c["hi"], f"{c['text']!r}: {path} {key} = {v} is outside [{c['lo']}, {c['hi']}]"
