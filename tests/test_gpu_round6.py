@@ -374,3 +374,37 @@ def test_dn_create_picks_a_fused_shape_within_5_percent_of_the_best(n, norm, mon
     best_shape = min(times, key=times.get)
     print(f"n={n} norm={norm}: pick {pick} {times[pick]:.2f} us per {K}-step launch; " + ", ".join(f"{s}: {t:.2f}" for s, t in sorted(times.items())))
     assert times[pick] <= 1.05 * times[best_shape] + 0.3, (pick, best_shape, times)
+
+
+def test_statistics_round_trip_through_the_state_blob():
+    """The device carries the normaliser's second moment var x count (round 6); dn_get_state returns RunningMeanStd.var = M2 / count and
+    dn_set_state picks the second moment that reads back as the var it was given: a blob taken with get_state restores to statistics that
+    read back identically, an edited var is honoured, and a non-positive count is refused."""
+    pkg = _gpu()
+    from drl_dronenavigation_amd import tracks
+    dev = torch.device("cuda:0")
+    n = 2048
+    env = pkg.DroneVecEnv(tracks.reaching(), n, normalize_obs=True, max_steps=50, device=dev)
+    env.reset_tensor()
+    rng = np.random.default_rng(4)
+    acts = torch.from_numpy(rng.uniform(-1, 1, (70, n, 4)).astype(np.float32)).to(dev)
+    env.rollout_tensor(acts)
+    st = env.get_state()
+    assert (st["rms_count"] > 70).all() and (st["rms_var"] > 0).all()
+    twin = pkg.DroneVecEnv(tracks.reaching(), n, normalize_obs=True, max_steps=50, device=dev)
+    twin.set_state(st)
+    st2 = twin.get_state()
+    for k in ("rms_mean", "rms_var", "rms_count"):
+        assert np.array_equal(st[k], st2[k]), k
+    # ... and both continue alike: flags exact, observations to the last bits of the float32 output stage
+    twin.step_count = env.step_count
+    a, b = env.rollout_tensor(acts[:20].contiguous()), twin.rollout_tensor(acts[:20].contiguous())
+    assert torch.equal(a["done"], b["done"]) and torch.equal(a["reward"], b["reward"])
+    np.testing.assert_allclose(a["obs"].cpu().numpy(), b["obs"].cpu().numpy(), rtol=3e-7, atol=1e-9)
+    st["rms_var"][:, 3] = 0.25                             # an edited variance is what the next observation is normalised with
+    twin.set_state(st)
+    assert np.array_equal(twin.get_state()["rms_var"][:, 3], np.full(n, 0.25))
+    st["rms_count"][5] = 0.0
+    with pytest.raises(pkg.DroneNavError, match="rms_count"):
+        twin.set_state(st)
+    env.close(); twin.close()
