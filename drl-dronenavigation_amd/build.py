@@ -28,7 +28,12 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # are (nearly) alone on their SIMD (32768 drones, three waves: 1.48 -> 1.37 us per step).  So the multi-wave kernels
 # of the plain configuration are a translation unit of their own (dn_kernels_mw.hip includes dn_kernels.hip).
 NO_LICM = ["-mllvm", "-disable-machine-licm"]
-FLAGS_OF = {"dn_kernels_mw.hip": []}             # everything else: NO_LICM
+# The policy kernels keep their MFMA accumulators in architectural VGPRs (-amdgpu-mfma-vgpr-form): with AGPR accumulators every value of a
+# tile's epilogue is first copied out with v_accvgpr_read_b32 (664 of them per wave in the four-wave kernel, 833 in the float32-grade one)
+# before the vector ALU can touch it; in VGPR form the exp reads the accumulator directly and only finished operands are parked in AGPRs
+# (4 + 80 moves).  Interleaved A/B at 32 768 drones: 57.2 -> 55.7 us (bf16), 154.2 -> 151.6 us (float32 grade); profiles/r06_notes.md.
+MFMA_VGPR = ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]
+FLAGS_OF = {"dn_kernels_mw.hip": [], "dn_mlp.hip": NO_LICM + MFMA_VGPR, "dn_fused.hip": NO_LICM + MFMA_VGPR}   # everything else: NO_LICM
 
 
 EXTRA = os.environ.get("DN_EXTRA_HIPCC_FLAGS", "").split()

@@ -101,6 +101,9 @@ MLP_DEV unsigned pack2(float a, float b)
 // source order across K-steps -- fragment read issued RING steps ahead of its MFMA, one slice of the previous tile's epilogue
 // per step -- and leaves the order inside a step to the compiler.
 #define MLP_PIN() __builtin_amdgcn_sched_barrier(0)
+#ifndef DN_X3_LAZY_MERGE
+#define DN_X3_LAZY_MERGE 1    // float32-grade kernel: the partner's partial sums are ADDED where the epilogue consumes them, inside the K-loop, not before it
+#endif
 #ifndef DN_X3_DMA_SPREAD
 #define DN_X3_DMA_SPREAD 2    // float32-grade kernel: LDS-DMA pieces issued this many per K-step, between the MFMAs, instead of in one burst at the
                               // top of the tile (0 = burst).  Measured, interleaved A/B at 32 768 drones: 197.7 (burst) / 191 (1) / 187.7 us (2)
@@ -260,6 +263,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 constexpr int CHUNK = 32;                                  // fragments (KB) per LDS buffer
 constexpr int WAVES = 4;
 constexpr int LDS_RING = 8;
+constexpr int NBIAS = H1 + H2 + H3 + 32;                      // float32 biases of the four layers, staged in LDS
+// accumulator of an M-tile starts from its bias (staged in LDS): rows acc_row(m, g, 4j .. 4j + 3) are four consecutive floats
+MLP_DEV void bias_init(const float *lbias, const int m, const int g, f32x16 &acc)
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float4 b = *reinterpret_cast<const float4 *>(lbias + 32 * m + 4 * g + 8 * j);
+        acc[4 * j] = b.x; acc[4 * j + 1] = b.y; acc[4 * j + 2] = b.z; acc[4 * j + 3] = b.w;
+    }
+}
 
 // N (1, 2 or 4) weight pieces of 1 KB, 1 KB apart in global memory and in LDS alike (the instruction's immediate offset applies to both
 // addresses): `gbase` = the first piece's fragment (wave-uniform), `lds_dst` = its LDS byte address (wave-uniform -> M0).  The scalar-base
@@ -345,34 +358,45 @@ MLP_DEV void chunk_barrier_stamped(Stamp &s)
 #define CHUNK_BARRIER() chunk_barrier()
 #endif
 
-// A 512-input layer, weights through LDS: one chunk = the 32 fragments of one M-tile.  PAR = parity of the LDS buffer
-// that holds this layer's chunk 0 (requested by the previous layer, landed before its last barrier); `next` = the
-// following layer's weights, whose first NEXT_FR fragments are requested during this layer's last chunk.
-template <bool F16, int MT, int PAR, int NEXT_FR>
-MLP_DEV void layer_lds(const uint4 *__restrict__ w, const float *__restrict__ bias, const uint4 *__restrict__ next,
-                       const u32x4 (&in)[CHUNK], u32x4 (&out)[2 * MT], uint4 *lds, const int wave, const int lane STP_PARAM)
+// A 512-input layer, weights through LDS: one chunk = the 32 fragments of one M-tile.  PAR = parity of the LDS buffer that holds this layer's
+// chunk 0 (requested by the previous layer, landed before its last barrier); `next` = the following layer's weights, whose first NEXT_FR
+// fragments are requested during this layer's last chunk.  The layer is ONE fragment stream: the register ring (LDS_RING fragments ahead of
+// the MFMA that consumes them -- an LDS round trip is ~64-128 cycles, an MFMA 32) runs on across the tile boundary.
+//
+// Until round 6 every M-tile ended with `s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier` and the next one started with eight ring reads: between a
+// tile's last MFMA and the next tile's first the matrix pipe waited out the barrier and an LDS round trip.  Here the chunk barrier sits
+// INSIDE the K-loop, to the K-step whose ring refill is the first to read the next chunk (K-step CHUNK - LDS_RING): by then the
+// pieces requested at the top of the tile have had ~24 MFMAs to land, the barrier only says so (vmcnt(0), LDS reads stay in flight), the
+// refills of the last LDS_RING K-steps read the NEXT chunk, and the next tile's first MFMA follows this tile's last.  The same barrier is what
+// lets the following tile request its DMA into the buffer this tile read: every wave has issued its last read of it (K-step CHUNK -
+// LDS_RING - 1) before arriving, and a piece lands an L2 round trip after its request.  Biases come from LDS (bias_init), one tile ahead,
+// straight into the registers the next tile accumulates in.
+MLP_DEV void dma_landed_barrier()
 {
+    __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0) only
+    __builtin_amdgcn_s_barrier();
+}
+template <bool F16, int MT, int PAR, int NEXT_FR>
+MLP_DEV void layer_lds_c(const uint4 *__restrict__ w, const float *lbias, const uint4 *__restrict__ next,
+                         const u32x4 (&in)[CHUNK], u32x4 (&out)[2 * MT], uint4 *lds, const int wave, const int lane)
+{
+    constexpr int SYNC = CHUNK - LDS_RING;
     const int g = lane >> 5;
-    // biases one M-tile ahead, requested BEFORE the chunk's DMA: memory returns in order, so a bias load queued behind
-    // eight DMA pieces would hold the first MFMA of the chunk until they have all landed
     f32x16 bnext, prev;
+    bias_init(lbias, 0, g, bnext);
+    uint4 ring[LDS_RING];
+    {
+        const uint4 *c0 = lds + (PAR & 1) * (CHUNK * 64);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) bnext[r] = bias[acc_row(0, g, r)];
+        for (int kk = 0; kk < LDS_RING; ++kk) ring[kk] = c0[kk * 64 + lane];
+    }
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-        uint4 *cur = lds + ((PAR + m) & 1) * (CHUNK * 64);
+        const uint4 *cur = lds + ((PAR + m) & 1) * (CHUNK * 64);
         uint4 *nxt = lds + ((PAR + m + 1) & 1) * (CHUNK * 64);
         f32x16 acc = bnext;
-        if (m + 1 < MT) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) bnext[r] = bias[acc_row(m + 1, g, r)];
-            dma_chunk(w + (size_t)(m + 1) * CHUNK * 64, nxt, CHUNK, wave, lane);
-        } else dma_chunk(next, nxt, NEXT_FR, wave, lane);
-        // LDS -> register ring LDS_RING fragments ahead of the MFMA that consumes them (an LDS round trip is ~64-128 cycles,
-        // an MFMA 32): without it every MFMA waits for its own ds_read
-        uint4 ring[LDS_RING];
-#pragma unroll
-        for (int kk = 0; kk < LDS_RING; ++kk) ring[kk] = cur[kk * 64 + lane];
+        if (m + 1 < MT) dma_chunk(w + (size_t)(m + 1) * CHUNK * 64, nxt, CHUNK, wave, lane);
+        else dma_chunk(next, nxt, NEXT_FR, wave, lane);
         MLP_PIN();
         // The previous tile's epilogue as a three-stage software pipeline over the K-steps (one wave per SIMD: a dependent
         // exp -> add -> rcp -> fma chain inside one K-step stalls the wave past its MFMA's 32 cycles): element e has its exp at K-step 2e,
@@ -380,8 +404,11 @@ MLP_DEV void layer_lds(const uint4 *__restrict__ w, const float *__restrict__ bi
         float te = 0.0f, tr = 0.0f, tdone_even = 0.0f;       // in flight: exp result, rcp result, finished even element of a pair
 #pragma unroll
         for (int kk = 0; kk < CHUNK; ++kk) {
+            if (kk == SYNC) dma_landed_barrier();
+            if (kk == CHUNK / 2 && m + 1 < MT) bias_init(lbias, m + 1, g, bnext);
             const uint4 a = ring[kk % LDS_RING];
             if (kk + LDS_RING < CHUNK) ring[kk % LDS_RING] = cur[(kk + LDS_RING) * 64 + lane];
+            else if (m + 1 < MT) ring[kk % LDS_RING] = nxt[(kk + LDS_RING - CHUNK) * 64 + lane];
             acc = mfma16<F16>(a, in[kk], acc);
             if (m > 0) {
                 if (kk >= 2 && !(kk & 1)) {                  // stage C of element e = kk / 2 - 1
@@ -404,17 +431,18 @@ MLP_DEV void layer_lds(const uint4 *__restrict__ w, const float *__restrict__ bi
         }
         if (m + 1 < MT) prev = acc;
         else epilogue_t<F16>(acc, out[2 * m], out[2 * m + 1]);
-        CHUNK_BARRIER();                                    // everyone is done with `cur`; the next chunk has landed in `nxt`
     }
 }
 
+// grid = (workgroups of 128 drones, networks)
 template <bool F16>
 __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(1, 1))) void dn_mlp_lds_kernel(const MlpArgs a)
 {
     // ONE __shared__ object (a second one makes hipcc drain the LDS-DMA before every first ds_read of a chunk):
-    // 64 KB = two chunks, plus one uint4 for the masked-forward vote
-    __shared__ __attribute__((aligned(16))) uint4 lds[2 * CHUNK * 64 + 1];
-    int *s_any = reinterpret_cast<int *>(lds + 2 * CHUNK * 64);
+    // 64 KB = two chunks, the staged biases, one uint4 for the masked-forward vote
+    __shared__ __attribute__((aligned(16))) uint4 lds[2 * CHUNK * 64 + (NBIAS + 3) / 4 + 1];
+    float *lbias = reinterpret_cast<float *>(lds + 2 * CHUNK * 64);
+    int *s_any = reinterpret_cast<int *>(lds + 2 * CHUNK * 64 + (NBIAS + 3) / 4);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 5, col = lane & 31;
@@ -437,9 +465,10 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(1, 1
             return;
         }
     }
-#ifdef DN_MLP_STAMP
-    Stamp stp{0, wave, blockIdx.x == 0 && blockIdx.y == 0 && lane == 0};
-#endif
+    // biases -> LDS once (as in the pair / x3 / SAC kernels): the layers read them a tile ahead among the ring's LDS reads, in the counter the
+    // compiler tracks; a global load per tile shares the vector-memory counter with the LDS-DMA pieces, which it does not see
+    for (int i = threadIdx.x; i < NBIAS; i += 64 * WAVES)
+        lbias[i] = i < H1 ? net.b1[i] : i < H1 + H2 ? net.b2[i - H1] : i < H1 + H2 + H3 ? net.b3[i - H1 - H2] : net.bh[i - H1 - H2 - H3];
     dma_chunk(net.w1, lds, H1 / 32, wave, lane);            // layer 1 = one chunk of 16 fragments, into buffer 0
     u32x4 x0[1];
     {
@@ -450,31 +479,27 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(1, 1
             x0[0][q] = pack2t<F16>(k < a.obs_dim ? o[k] : 0.0f, k + 1 < a.obs_dim ? o[k + 1] : 0.0f);
         }
     }
-    CHUNK_BARRIER();
+    chunk_barrier();
     // LDS buffer parities: layer 1 (one chunk of 16 fragments) in buffer 0; layer 2's 16 chunks start in buffer 1;
     // layer 3's 8 chunks start at 1 + 16 -> buffer 1; the head (one chunk of 16 fragments) at 17 + 8 -> buffer 1
     u32x4 h1[H1 / 16];
-    {
-        dma_chunk(net.w2, lds + CHUNK * 64, CHUNK, wave, lane);          // layer 2, chunk 0 -> buffer 1
+    dma_chunk(net.w2, lds + CHUNK * 64, CHUNK, wave, lane);                  // layer 2, chunk 0 -> buffer 1
 #pragma unroll
-        for (int m = 0; m < H1 / 32; ++m) {                              // K = 16: one fragment per M-tile
-            f32x16 acc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = net.b1[acc_row(m, g, r)];
-            const uint4 w = lds[m * 64 + lane];
-            acc = mfma16<F16>(w, x0[0], acc);
-            epilogue_t<F16>(acc, h1[2 * m], h1[2 * m + 1]);
-        }
-        CHUNK_BARRIER();
+    for (int m = 0; m < H1 / 32; ++m) {                                      // K = 16: one fragment per M-tile
+        f32x16 acc;
+        bias_init(lbias, m, g, acc);
+        const uint4 w = lds[m * 64 + lane];
+        acc = mfma16<F16>(w, x0[0], acc);
+        epilogue_t<F16>(acc, h1[2 * m], h1[2 * m + 1]);
     }
+    chunk_barrier();
     u32x4 h2[H2 / 16];
-    layer_lds<F16, H2 / 32, 1, CHUNK>(net.w2, net.b2, net.w3, h1, h2, lds, wave, lane STP_ARG);
+    layer_lds_c<F16, H2 / 32, 1, CHUNK>(net.w2, lbias + H1, net.w3, h1, h2, lds, wave, lane);
     u32x4 h3[H3 / 16];
-    layer_lds<F16, H3 / 32, 1, H3 / 16>(net.w3, net.b3, net.wh, h2, h3, lds, wave, lane STP_ARG);
+    layer_lds_c<F16, H3 / 32, 1, H3 / 16>(net.w3, lbias + H1 + H2, net.wh, h2, h3, lds, wave, lane);
     // head: one M-tile of H3/16 = 16 fragments; float32 result straight from the accumulator
     f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = net.bh[acc_row(0, g, r)];
+    bias_init(lbias + H1 + H2 + H3, 0, g, acc);
     const uint4 *cur = lds + 1 * (CHUNK * 64);
 #pragma unroll
     for (int kk = 0; kk < H3 / 16; ++kk) {
@@ -511,7 +536,6 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(1, 1
 constexpr int PWAVES = 8;
 constexpr int DN_MLP_DEFAULT_SHAPE = 4;       // pi + vf at 32 768 drones, sustained (400 launches): 57.5 us (four waves, round 3: ring pinned, epilogue
                                               // software-pipelined) vs 59.0 us (pair) vs 79 us (one wave from L2); rounds 1-2: 77.9 / 68.9 / 79
-constexpr int NBIAS = H1 + H2 + H3 + 32;                      // float32 biases of the four layers, staged in LDS
 constexpr int XB_U4 = 4 * 2 * 4 * 64;                         // exchange: 4 pairs x 2 parities x (16 f32 per lane = 4 uint4) x 64 lanes
 constexpr int LDS_PAIR_U4 = 2 * CHUNK * 64 + XB_U4 + (NBIAS + 3) / 4 + 1;
 
@@ -528,15 +552,7 @@ MLP_DEV void park_partial(float4 *xb, const int parity, const int lane, const f3
 #pragma unroll
     for (int j = 0; j < 4; ++j) xb[(parity * 4 + j) * 64 + lane] = make_float4(acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]);
 }
-// owner: accumulator of an owned tile starts from the bias (staged in LDS), so that merging costs one add per value
-MLP_DEV void bias_init(const float *lbias, const int m, const int g, f32x16 &acc)
-{
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float4 b = *reinterpret_cast<const float4 *>(lbias + 32 * m + 4 * g + 8 * j);     // rows acc_row(m, g, 4j..4j+3)
-        acc[4 * j] = b.x; acc[4 * j + 1] = b.y; acc[4 * j + 2] = b.z; acc[4 * j + 3] = b.w;
-    }
-}
+// (owner: the accumulator of an owned tile starts from the bias -- bias_init above -- so that merging costs one add per value)
 MLP_DEV void merge_partial(const float4 *xb, const int parity, const int lane, f32x16 &acc)
 {
 #pragma unroll
@@ -801,13 +817,33 @@ MLP_DEV void layer_x3(const uint4 *__restrict__ w, const float *lbias, const uin
         else dma_x3<NEXT_FR>(next, nxt, wave, lane);
 #endif
         const bool fin = m > 0 && (((m - 1) >= MT / 2) == (HALF == 1));      // I own tile m-1: finish it under this tile's MFMAs
+#if DN_X3_LAZY_MERGE
+        // Nothing but LDS reads may stand between the chunk barrier and the tile's first MFMA: a merge here (four reads, their round trip, 16
+        // accumulator moves and adds) and an accumulator initialised from the bias (16 moves) held the matrix pipe idle for ~400 cycles of every
+        // ~2 400-cycle tile (ablation without the exchange: 154 -> 127 us).  So the partial sums stay in the registers their reads land in and
+        // are added where the epilogue consumes them, the OWNER's accumulator starts from zero (the first MFMA takes C = 0: no moves), and the
+        // bias rides in the partner's accumulator, whose initialisation sits in that wave's slack before the barrier.
+        float4 part[4];
+        if (fin) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) part[j] = xb[(((m - 1) & 1) * 4 + j) * 64 + lane];
+        }
+        f32x16 acc;
+        if ((m >= MT / 2) == (HALF == 1)) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        } else bias_init(lbias, m, g, acc);                                  // the partner's partial sum carries the bias
+#else
+#ifndef DN_ABL_X3_NOXCHG
         if (fin) merge_partial(xb, (m - 1) & 1, lane, prev);
+#endif
         f32x16 acc;
         if ((m >= MT / 2) == (HALF == 1)) bias_init(lbias, m, g, acc);       // mine: start from the bias
         else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
         }
+#endif
         constexpr int RG = 4;                                                // ring depth (fragment PAIRS in flight)
         uint4 rh[RG], rl[RG];
 #pragma unroll
@@ -833,15 +869,37 @@ MLP_DEV void layer_x3(const uint4 *__restrict__ w, const float *lbias, const uin
                 if (pc < NPER) dma_piece(nsrc + pc * 64, ndst + pc * 64, lane);
             }
 #endif
+#ifndef DN_ABL_X3_NOEPI
             if (fin && (kk & 1)) {
                 const int ml = (m - 1) - HALF * (MT / 2);
+#if DN_X3_LAZY_MERGE
+                const int q = kk >> 1;
+                const float4 pp = part[q >> 1];
+                prev[2 * q] += (q & 1) ? pp.z : pp.x;
+                prev[2 * q + 1] += (q & 1) ? pp.w : pp.y;
+#endif
                 epilogue3_pair(prev, kk >> 1, outh[2 * ml], outh[2 * ml + 1], outl[2 * ml], outl[2 * ml + 1]);
             }
+#else
+            if (fin && kk == 15) {                                            // timing ablation: no tanh, no split -- one dependence on prev
+                const int ml = (m - 1) - HALF * (MT / 2);
+                outh[2 * ml][0] = __float_as_uint(prev[0]); outh[2 * ml + 1][0] = __float_as_uint(prev[8]);
+                outl[2 * ml][0] = __float_as_uint(prev[1]); outl[2 * ml + 1][0] = __float_as_uint(prev[9]);
+            }
+#endif
             MLP_PIN();
         }
         if ((m >= MT / 2) == (HALF == 1)) prev = acc;                         // mine: keep, finish next round
+#ifndef DN_ABL_X3_NOXCHG
         else park_partial(xb, m & 1, lane, acc);                             // partner's: hand over through LDS
+#else
+        else prev[0] += acc[0];
+#endif
+#ifdef DN_ABL_X3_NOBAR
+        __builtin_amdgcn_s_waitcnt(0x0070);
+#else
         CHUNK_BARRIER();
+#endif
     }
     if (HALF == 1) {                                                         // the last tile belongs to half 1
         merge_partial(xb, (MT - 1) & 1, lane, prev);
@@ -1304,7 +1362,6 @@ hipError_t dn_launch_mlp(const dn_mlp_net *nets, int num_nets, const float *obs,
     } else {
         if (f16) hipLaunchKernelGGL(dn_mlp_lds_kernel<true>, dim3((tiles + WAVES - 1) / WAVES, num_nets), dim3(64 * WAVES), 0, stream, a);
         else hipLaunchKernelGGL(dn_mlp_lds_kernel<false>, dim3((tiles + WAVES - 1) / WAVES, num_nets), dim3(64 * WAVES), 0, stream, a);
-        dump_stamps("lds4");
     }
     return hipGetLastError();
 }
