@@ -358,25 +358,29 @@ MLP_DEV void chunk_barrier_stamped(Stamp &s)
 #define CHUNK_BARRIER() chunk_barrier()
 #endif
 
-// A 512-input layer, weights through LDS: one chunk = the 32 fragments of one M-tile.  PAR = parity of the LDS buffer that holds this layer's
-// chunk 0 (requested by the previous layer, landed before its last barrier); `next` = the following layer's weights, whose first NEXT_FR
-// fragments are requested during this layer's last chunk.  The layer is ONE fragment stream: the register ring (LDS_RING fragments ahead of
-// the MFMA that consumes them -- an LDS round trip is ~64-128 cycles, an MFMA 32) runs on across the tile boundary.
+// A 512-input layer, weights through LDS: one chunk = the 32 fragments of one M-tile, THREE chunk buffers.  BASE = the buffer that holds this
+// layer's chunk 0 (requested by the previous layer, landed before its last barrier): chunk m lives in buffer (BASE + m) % 3; `next` = the
+// following layer's weights, whose first NEXT_FR fragments are requested during this layer's last chunk into buffer (BASE + MT) % 3.
+// The layer is ONE fragment stream: the register ring (LDS_RING fragments ahead of the MFMA that consumes them -- an LDS round trip is
+// ~64-128 cycles, an MFMA 32) runs on across the tile boundary.
 //
 // Until round 6 every M-tile ended with `s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier` and the next one started with eight ring reads: between a
 // tile's last MFMA and the next tile's first the matrix pipe waited out the barrier and an LDS round trip.  Here the chunk barrier sits
-// INSIDE the K-loop, to the K-step whose ring refill is the first to read the next chunk (K-step CHUNK - LDS_RING): by then the
-// pieces requested at the top of the tile have had ~24 MFMAs to land, the barrier only says so (vmcnt(0), LDS reads stay in flight), the
-// refills of the last LDS_RING K-steps read the NEXT chunk, and the next tile's first MFMA follows this tile's last.  The same barrier is what
-// lets the following tile request its DMA into the buffer this tile read: every wave has issued its last read of it (K-step CHUNK -
-// LDS_RING - 1) before arriving, and a piece lands an L2 round trip after its request.  Biases come from LDS (bias_init), one tile ahead,
-// straight into the registers the next tile accumulates in.
+// INSIDE the K-loop, at the K-step whose ring refill is the first to read the next chunk (K-step CHUNK - LDS_RING): by then the pieces
+// requested at the top of the tile have had ~24 MFMAs to land, the barrier only says so (vmcnt(0); LDS reads stay in flight), the refills
+// of the last LDS_RING K-steps read the NEXT chunk, and the next tile's first MFMA follows this tile's last.
+// Why three buffers: tile m requests chunk m + 1 at its top.  With two buffers that is the buffer of chunk m - 1, whose last reads a slow
+// wave has issued (before the barrier inside tile m - 1) but perhaps not yet been served -- safe only because a DMA piece lands an L2 round
+// trip later.  With three it is the buffer of chunk m - 2: every wave consumed its last fragment of that chunk (K-step CHUNK - 1 of tile
+// m - 2) before it arrived at the barrier inside tile m - 1, which every wave has passed before any reaches the top of tile m.
+// Biases come from LDS (bias_init), one tile ahead, straight into the registers the next tile accumulates in.
 MLP_DEV void dma_landed_barrier()
 {
     __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0) only
     __builtin_amdgcn_s_barrier();
 }
-template <bool F16, int MT, int PAR, int NEXT_FR>
+constexpr int NBUF = 3;
+template <bool F16, int MT, int BASE, int NEXT_FR>
 MLP_DEV void layer_lds_c(const uint4 *__restrict__ w, const float *lbias, const uint4 *__restrict__ next,
                          const u32x4 (&in)[CHUNK], u32x4 (&out)[2 * MT], uint4 *lds, const int wave, const int lane)
 {
@@ -386,14 +390,14 @@ MLP_DEV void layer_lds_c(const uint4 *__restrict__ w, const float *lbias, const 
     bias_init(lbias, 0, g, bnext);
     uint4 ring[LDS_RING];
     {
-        const uint4 *c0 = lds + (PAR & 1) * (CHUNK * 64);
+        const uint4 *c0 = lds + (BASE % NBUF) * (CHUNK * 64);
 #pragma unroll
         for (int kk = 0; kk < LDS_RING; ++kk) ring[kk] = c0[kk * 64 + lane];
     }
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-        const uint4 *cur = lds + ((PAR + m) & 1) * (CHUNK * 64);
-        uint4 *nxt = lds + ((PAR + m + 1) & 1) * (CHUNK * 64);
+        const uint4 *cur = lds + ((BASE + m) % NBUF) * (CHUNK * 64);
+        uint4 *nxt = lds + ((BASE + m + 1) % NBUF) * (CHUNK * 64);
         f32x16 acc = bnext;
         if (m + 1 < MT) dma_chunk(w + (size_t)(m + 1) * CHUNK * 64, nxt, CHUNK, wave, lane);
         else dma_chunk(next, nxt, NEXT_FR, wave, lane);
@@ -439,10 +443,10 @@ template <bool F16>
 __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(1, 1))) void dn_mlp_lds_kernel(const MlpArgs a)
 {
     // ONE __shared__ object (a second one makes hipcc drain the LDS-DMA before every first ds_read of a chunk):
-    // 64 KB = two chunks, the staged biases, one uint4 for the masked-forward vote
-    __shared__ __attribute__((aligned(16))) uint4 lds[2 * CHUNK * 64 + (NBIAS + 3) / 4 + 1];
-    float *lbias = reinterpret_cast<float *>(lds + 2 * CHUNK * 64);
-    int *s_any = reinterpret_cast<int *>(lds + 2 * CHUNK * 64 + (NBIAS + 3) / 4);
+    // 96 KB = three chunks (layer_lds_c), the staged biases, one uint4 for the masked-forward vote
+    __shared__ __attribute__((aligned(16))) uint4 lds[NBUF * CHUNK * 64 + (NBIAS + 3) / 4 + 1];
+    float *lbias = reinterpret_cast<float *>(lds + NBUF * CHUNK * 64);
+    int *s_any = reinterpret_cast<int *>(lds + NBUF * CHUNK * 64 + (NBIAS + 3) / 4);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 5, col = lane & 31;
@@ -480,10 +484,11 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(1, 1
         }
     }
     chunk_barrier();
-    // LDS buffer parities: layer 1 (one chunk of 16 fragments) in buffer 0; layer 2's 16 chunks start in buffer 1;
-    // layer 3's 8 chunks start at 1 + 16 -> buffer 1; the head (one chunk of 16 fragments) at 17 + 8 -> buffer 1
+    // LDS buffers: layer 1 (one chunk of 16 fragments) in buffer 0; layer 2's 16 chunks start in buffer 1; layer 3's 8 chunks at
+    // (1 + 16) % 3 = 2; the head (one chunk of 16 fragments) at (2 + 8) % 3 = 1
+    constexpr int B2 = 1, B3 = (B2 + H2 / 32) % NBUF, BH = (B3 + H3 / 32) % NBUF;
     u32x4 h1[H1 / 16];
-    dma_chunk(net.w2, lds + CHUNK * 64, CHUNK, wave, lane);                  // layer 2, chunk 0 -> buffer 1
+    dma_chunk(net.w2, lds + B2 * CHUNK * 64, CHUNK, wave, lane);             // layer 2, chunk 0 -> buffer 1
 #pragma unroll
     for (int m = 0; m < H1 / 32; ++m) {                                      // K = 16: one fragment per M-tile
         f32x16 acc;
@@ -494,13 +499,13 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(1, 1
     }
     chunk_barrier();
     u32x4 h2[H2 / 16];
-    layer_lds_c<F16, H2 / 32, 1, CHUNK>(net.w2, lbias + H1, net.w3, h1, h2, lds, wave, lane);
+    layer_lds_c<F16, H2 / 32, B2, CHUNK>(net.w2, lbias + H1, net.w3, h1, h2, lds, wave, lane);
     u32x4 h3[H3 / 16];
-    layer_lds_c<F16, H3 / 32, 1, H3 / 16>(net.w3, lbias + H1 + H2, net.wh, h2, h3, lds, wave, lane);
+    layer_lds_c<F16, H3 / 32, B3, H3 / 16>(net.w3, lbias + H1 + H2, net.wh, h2, h3, lds, wave, lane);
     // head: one M-tile of H3/16 = 16 fragments; float32 result straight from the accumulator
     f32x16 acc;
     bias_init(lbias + H1 + H2 + H3, 0, g, acc);
-    const uint4 *cur = lds + 1 * (CHUNK * 64);
+    const uint4 *cur = lds + BH * (CHUNK * 64);
 #pragma unroll
     for (int kk = 0; kk < H3 / 16; ++kk) {
         const uint4 w = cur[kk * 64 + lane];

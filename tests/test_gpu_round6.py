@@ -408,3 +408,40 @@ def test_statistics_round_trip_through_the_state_blob():
     with pytest.raises(pkg.DroneNavError, match="rms_count"):
         twin.set_state(st)
     env.close(); twin.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("grade", ["bf16", "fp16", "fp32"])
+def test_policy_kernels_give_the_same_bits_launch_after_launch(grade):
+    """The four-wave policy kernel streams a layer's weight fragments as ONE ring that runs across the M-tile boundary: the chunk barrier sits
+    inside the K-loop, and the next chunk's LDS-DMA is requested into the buffer the current tile has just finished READING (dn_mlp.hip
+    layer_lds_c).  A barrier one K-step too early, or a DMA piece landing under a straggler's read, shows as a different float now and then,
+    not as a wrong answer every time: 150 back-to-back launches (weights hot in L2, the shortest DMA round trips) at a full and at a ragged
+    size must reproduce the first launch bit for bit, for every grade (the float32 grade covers dn_mlp_x3_kernel's in-loop merge)."""
+    pkg = _gpu()
+    import torch
+    from drl_dronenavigation_amd import policy_mfma as pm
+    dev = torch.device("cuda:0")
+    torch.manual_seed(11)
+    net = pkg.MlpActorCritic().to(dev)
+    actor = pkg.SacActor().to(dev)
+    for n in (32768, 4000):
+        obs = torch.randn(n, 13, device=dev).clamp_(-5, 5)
+        pol = pm.FusedMlpPolicy(net, n, dev, grade=grade)
+        mean, val = torch.zeros((n, 4), device=dev), torch.zeros((n, 1), device=dev)
+        pm.mlp_forward([pol.pi, pol.vf], obs, [mean, val])
+        ref_m, ref_v = mean.clone(), val.clone()
+        assert bool(torch.isfinite(ref_m).all()) and bool(torch.isfinite(ref_v).all()) and float(ref_m.abs().sum()) > 0
+        bad = torch.zeros((), dtype=torch.int64, device=dev)
+        for _ in range(150):
+            mean.zero_(); val.zero_()
+            pm.mlp_forward([pol.pi, pol.vf], obs, [mean, val])
+            bad += (mean != ref_m).sum() + (val != ref_v).sum()
+        assert int(bad) == 0, (grade, n, int(bad))
+        fa = pm.FusedSacActor(actor, n, dev, grade=grade)
+        m0, s0 = (t.clone() for t in fa.mean_log_std(obs))
+        bad.zero_()
+        for _ in range(50):
+            m, s = fa.mean_log_std(obs)
+            bad += (m != m0).sum() + (s != s0).sum()
+        assert int(bad) == 0, ("sac", grade, n, int(bad))
