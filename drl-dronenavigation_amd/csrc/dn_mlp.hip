@@ -1215,20 +1215,90 @@ MLP_DEV f32x16 sac_tile(const uint4 *chunk, const int off, const float *lbias, c
     return acc;
 }
 
+// Layer 2 and the stacked heads of the SAC actor as ONE stream of 9 M-tiles x 16 K-steps (the heads' K is layer 2's: 256): the register ring
+// runs on across tiles and chunks, the chunk barrier sits at the K-step whose refill is the first to read the next chunk, the next tile's bias
+// lands in its accumulator registers half a tile ahead, and a tile's ReLU / pack (/ split) is spread under the next tile's first eight
+// K-steps (layer-2 tile 7's under the heads', which need its output at K-steps 14 and 15).  Until round 6 every tile was bias reads -> ring
+// fill -> MFMAs -> epilogue -> barrier, one after the other: ~1 000 cycles a tile beside 512 (bf16) or 1 536 (float32 grade) of MFMAs, in a
+// kernel that is one dependent chain per SIMD at 32 768 drones.  Chunk c lives in buffer (1 + c) % NB (buffer 0 = layer 1); with three
+// buffers the DMA of chunk c + 1, requested at the top of chunk c, lands where chunk c - 2 was (see layer_lds_c); with two, where chunk
+// c - 1 was, behind a barrier of its own.
+template <bool X3, bool F16, int NB>
+MLP_DEV f32x16 sac_stream(const MlpNetDev &net, const float *lbias, uint4 *lds, const u32x4 (&h1h)[S1 / 16], const u32x4 (&h1l)[S1 / 16],
+                          const int wave, const int lane)
+{
+    constexpr int KS = S1 / 16, L2T = S2 / 32, NT = L2T + 1;               // 16 K-steps a tile; 8 layer-2 tiles + the heads
+    constexpr int PER = X3 ? 2 : 1, TPC = X3 ? 1 : 2, NL2 = L2T / TPC;     // layer-2 tiles per chunk, layer-2 chunks; the heads are chunk NL2
+    constexpr int RG = 4;                                                  // ring depth in K-steps
+    static_assert(S2 / 16 == KS, "the heads are streamed as a ninth tile of layer 2's K");
+    const int g = lane >> 5;
+    auto chunk_of = [](const int t) { return t < L2T ? t / TPC : NL2; };
+    auto off_of = [](const int t) { return t < L2T ? (t % TPC) * KS * PER : 0; };   // hi fragment kk at off + kk, lo at off + KS + kk
+    auto buf = [&](const int c) { return lds + ((1 + c) % NB) * (CHUNK * 64); };
+    u32x4 h2h[S2 / 16], h2l[S2 / 16];
+    uint4 rh[RG], rl[RG];
+#pragma unroll
+    for (int kk = 0; kk < RG; ++kk) {
+        rh[kk] = buf(0)[kk * 64 + lane];
+        if (X3) rl[kk] = buf(0)[(KS + kk) * 64 + lane];
+    }
+    f32x16 bnext, prev, acc;
+    bias_init(lbias + S1, 0, g, bnext);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int c = chunk_of(t);
+        acc = bnext;
+        if (off_of(t) == 0 && c + 1 <= NL2) {                              // first tile of chunk c: request chunk c + 1
+            // two buffers: the target held chunk c - 1, whose last fragments every wave has CONSUMED only once it stands here (the barrier
+            // inside chunk c - 1 came four K-steps before its end)
+            if (NB == 2 && c > 0) __builtin_amdgcn_s_barrier();
+            if (c + 1 < NL2) sac_dma<CHUNK>(net.w2 + (size_t)(c + 1) * CHUNK * 64, buf(c + 1), wave, lane);
+            else sac_dma<(S2 / 16) * PER>(net.wh, buf(c + 1), wave, lane);
+        }
+        MLP_PIN();
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            const uint4 ah = rh[kk % RG], al = rl[kk % RG];
+            const int tr = t + (kk + RG) / KS, kr = (kk + RG) % KS;        // the K-step the ring is refilled for
+            if (tr < NT) {
+                if (chunk_of(tr) != c && kr == 0) dma_landed_barrier();    // the first read of the next chunk: its pieces have landed
+                const uint4 *src = buf(chunk_of(tr)) + (off_of(tr) + kr) * 64 + lane;
+                rh[kk % RG] = src[0];
+                if (X3) rl[kk % RG] = src[KS * 64];
+            }
+            if (kk == KS / 2 && t + 1 < NT) bias_init(t + 1 < L2T ? lbias + S1 : lbias + S1 + S2, t + 1 < L2T ? t + 1 : 0, g, bnext);
+            const u32x4 &bh = t < L2T ? h1h[kk] : h2h[kk], &bl = t < L2T ? h1l[kk] : h2l[kk];
+            if (X3) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al), __builtin_bit_cast(bf16x8, bh), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bl), acc, 0, 0, 0);
+            }
+            acc = mfma16<F16>(ah, bh, acc);
+            if (t > 0 && kk < 8) {                                         // the previous tile's ReLU / pack / split, one pair a K-step
+                const int q = kk, m = t - 1;
+                const float v0 = fmaxf(prev[2 * q], 0.0f), v1 = fmaxf(prev[2 * q + 1], 0.0f);
+                unsigned hi, lo = 0u;
+                if (X3) split_pair(v0, v1, hi, lo); else hi = pack2t<F16>(v0, v1);
+                if (q < 4) { h2h[2 * m][q] = hi; if (X3) h2l[2 * m][q] = lo; }
+                else { h2h[2 * m + 1][q - 4] = hi; if (X3) h2l[2 * m + 1][q - 4] = lo; }
+            }
+            MLP_PIN();
+        }
+        if (t + 1 < NT) prev = acc;
+    }
+    return acc;
+}
+
 template <bool X3, bool F16>
 __global__ __launch_bounds__(64 * SAC_WAVES) void dn_mlp_sac_lds_kernel(const MlpArgs a)
 {
     constexpr int NB_SAC = S1 + S2 + 32;                   // float32 biases of the three layers, staged in LDS
-#ifdef DN_EXP_SAC_PAD
-    __shared__ __attribute__((aligned(16))) uint4 lds[2 * CHUNK * 64 + NB_SAC / 4 + 1 + 1280];   // > 80 KB: one workgroup per CU
-#else
-    __shared__ __attribute__((aligned(16))) uint4 lds[2 * CHUNK * 64 + NB_SAC / 4 + 1];     // ONE __shared__ object (see dn_mlp_lds_kernel)
-#endif
-    float *lbias = reinterpret_cast<float *>(lds + 2 * CHUNK * 64);
-    int *s_any = reinterpret_cast<int *>(lds + 2 * CHUNK * 64 + NB_SAC / 4);
+    // chunk buffers of sac_stream: three in the float32 grade (one wave per SIMD by its registers anyway), two in the 16-bit grades, where a
+    // second workgroup per CU is what large fleets run on (131 072 drones: 25 us with two buffers, 31 with three)
+    constexpr int NB = X3 ? 3 : 2;
+    __shared__ __attribute__((aligned(16))) uint4 lds[NB * CHUNK * 64 + NB_SAC / 4 + 1];    // ONE __shared__ object (see dn_mlp_lds_kernel)
+    float *lbias = reinterpret_cast<float *>(lds + NB * CHUNK * 64);
+    int *s_any = reinterpret_cast<int *>(lds + NB * CHUNK * 64 + NB_SAC / 4);
     constexpr int PER = X3 ? 2 : 1;
-    constexpr int TPC = X3 ? 1 : 2;                         // layer-2 M-tiles per 32-fragment chunk
-    constexpr int NL2 = (S2 / 32) / TPC;                    // layer-2 chunks
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 5, col = lane & 31;
@@ -1269,23 +1339,7 @@ __global__ __launch_bounds__(64 * SAC_WAVES) void dn_mlp_sac_lds_kernel(const Ml
         sac_epilogue<X3, F16>(acc, h1h[2 * m], h1h[2 * m + 1], h1l[2 * m], h1l[2 * m + 1]);
     }
     chunk_barrier();
-    u32x4 h2h[S2 / 16], h2l[S2 / 16];
-#pragma unroll
-    for (int c = 0; c < NL2; ++c) {
-        const uint4 *cur = lds + ((1 + c) & 1) * (CHUNK * 64);
-        uint4 *nxt = lds + ((2 + c) & 1) * (CHUNK * 64);
-        if (c + 1 < NL2) sac_dma<CHUNK>(net.w2 + (size_t)(c + 1) * CHUNK * 64, nxt, wave, lane);
-        else sac_dma<(S2 / 16) * PER>(net.wh, nxt, wave, lane);
-#pragma unroll
-        for (int j = 0; j < TPC; ++j) {
-            const int m = c * TPC + j;
-            const f32x16 acc = sac_tile<S1 / 16, X3, F16>(cur, j * (S1 / 16), lbias + S1, m, g, lane, h1h, h1l);
-            sac_epilogue<X3, F16>(acc, h2h[2 * m], h2h[2 * m + 1], h2l[2 * m], h2l[2 * m + 1]);
-        }
-        chunk_barrier();
-    }
-    // heads: one M-tile (8 rows used), float32 straight from the accumulator; its chunk is in buffer (1 + NL2) & 1
-    const f32x16 acc = sac_tile<S2 / 16, X3, F16>(lds + ((1 + NL2) & 1) * (CHUNK * 64), 0, lbias + S1 + S2, 0, g, lane, h2h, h2l);
+    const f32x16 acc = sac_stream<X3, F16, NB>(net, lbias, lds, h1h, h1l, wave, lane);     // layer 2 and the heads (float32 from the accumulator)
     if (live) {
         float *o = net.out + (row0 + col) * net.out_dim;
 #pragma unroll
