@@ -43,7 +43,7 @@ constexpr long long DN_CALIBRATION_CUS = 256;
 constexpr long long DN_TWO_WAVE_TILES_PER_CU = 4;   // 1024 tiles = 65536 drones on 256 CUs: one tile per SIMD
 constexpr long long DN_PQX_TILES_PER_CU = 4;        // three-wave single step: while the tiles alone leave SIMDs idle
 constexpr long long DN_FIVE_WAVE_TILES_PER_CU = 3;  // the same with the normaliser on a fifth wave: wherever the four-wave kernel would run (40 960 / 49 152 drones: 2.65 / 2.84 us per step against 2.95 / 3.28)
-constexpr long long DN_ROLE_PIPE_TILES_PER_CU = 3;  // role-pipelined fused step (eight roles per tile): up to three tiles per CU, see dn_create
+constexpr long long DN_ROLE_PIPE_TILES_PER_CU = 6;  // role-pipelined fused step (eight roles per tile): up to six tiles per CU, see dn_create
 constexpr long long DN_FOUR_WAVE_TILES_PER_CU = 3;  // four-wave fused step: up to three tiles per CU (768 tiles on 256 CUs)
 constexpr double DN_CONTACT_MARGIN = 0.02;          // Bullet's contact-breaking threshold (dn_kernels.hip collision_common)
 constexpr double DN_COLL_R = 0.06, DN_COLL_H = 0.025;   // base_link collision cylinder, cf2x.urdf:34
@@ -402,6 +402,9 @@ int32_t dn_create(const dn_config *cfg, dn_env **out)
     // -> eight roles up to one tile per CU and from two to three tiles per CU (where two of its workgroups fit a CU and the third tile
     // follows), five waves in between, where sixteen waves saturate the vector ALUs either way.  Without the normaliser the six-role form
     // lost to the four-wave kernel at every size (32 768 drones: 1.68 against 1.40) and was removed in round 5.
+    // Round 6, beyond three tiles per CU (one wave | eight roles, 64-step launches, the one-wave kernel 27 % faster than it was:
+    // profiles/r06_sweep_large.txt): 57 344 drones 3.41 | 2.53, 65 536 3.53 | 2.70, 81 920 4.56 | 3.37, 98 304 4.67 | 3.93, 114 688
+    // 4.76 | 4.58 (K = 20: 5.07 | 5.22), 131 072 4.86 | 5.16 -> eight roles up to six tiles per CU, one wave beyond.
     const bool rp_ok = plain && !cfg->ground_contact && !noisy;
     if (rp_ok && cfg->normalize_obs && (e->blocks <= e->num_cus || (e->blocks > 2 * e->num_cus && e->blocks <= DN_ROLE_PIPE_TILES_PER_CU * e->num_cus)))
         e->waves_fused = 8;

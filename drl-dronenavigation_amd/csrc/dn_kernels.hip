@@ -483,6 +483,33 @@ DN_DEV void normalize_obs_cols(Rms &r, float o[DN_OBS_DIM])
 }
 DN_DEV void normalize_obs(Rms &r, float o[DN_OBS_DIM]) { normalize_obs_cols<0, DN_OBS_DIM>(r, o); }
 // the statistics of columns [K0, K1) of the tile's drones: uniform column bases (SGPR pairs) + the lane's 32-bit offset
+// The same loads / stores with the column base WALKED in one scalar register pair (base += n per column, opaque to the optimiser): 27 uniform
+// bases computed up front are 54 SGPRs the single-step kernel does not have -- it then forms 27 per-lane 64-bit addresses (54 VGPRs) and
+// keeps them from the loads to the stores.  Walked, load and store each recompute their base from one pair and share the lane's 32-bit offset.
+DN_DEV void load_rms_walk(const DnParams &p, const long long tile_base, const unsigned li, Rms &r)
+{
+    const double *pm = p.st.rms_mean + tile_base, *pv = p.st.rms_m2 + tile_base;
+#pragma unroll
+    for (int k = 0; k < DN_OBS_DIM; ++k) {
+        r.mean[k] = pm[li];
+        r.m2[k] = pv[li];
+        pm += p.n; pv += p.n;
+        asm volatile("" : "+s"(pm), "+s"(pv));
+    }
+    r.count = (p.st.rms_count + tile_base)[li];
+}
+DN_DEV void store_rms_walk(const DnParams &p, const long long tile_base, const unsigned li, const Rms &r)
+{
+    double *pm = p.st.rms_mean + tile_base, *pv = p.st.rms_m2 + tile_base;
+#pragma unroll
+    for (int k = 0; k < DN_OBS_DIM; ++k) {
+        pm[li] = r.mean[k];
+        pv[li] = r.m2[k];
+        pm += p.n; pv += p.n;
+        asm volatile("" : "+s"(pm), "+s"(pv));
+    }
+    (p.st.rms_count + tile_base)[li] = r.count;
+}
 template <int K0, int K1>
 DN_DEV void load_rms_cols(const DnParams &p, const long long tile_base, const unsigned li, Rms &r)
 {
@@ -2073,7 +2100,7 @@ __global__ __launch_bounds__(DN_BLOCK) void dn_step_many_1w_kernel(const DnParam
     const R wp0[3] = {s_tab[DN_T_WP], s_tab[DN_T_WP + 1], s_tab[DN_T_WP + 2]};   // waypoint 0: every reset measures against it
     StatAcc acc;
     Rms rms;
-    if (NORM) load_rms(p, i, rms);
+    if (NORM) load_rms_walk(p, tile_base, li, rms);
     RewNorm rn = {0.0, 0.0, 1.0, 1e-4};
     if (XOPT && p.norm_rew) load_rewnorm(p, i, rn);
     double pid_st[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
@@ -2100,7 +2127,7 @@ __global__ __launch_bounds__(DN_BLOCK) void dn_step_many_1w_kernel(const DnParam
     }
     if (ONE) flush_stats_preloaded(p, slot0, acc, sc0 + 1ull, lane, (long long)blockIdx.x);
     else flush_stats(p, acc, sc0 + (unsigned long long)k_steps, lane);
-    if (NORM && active) store_rms(p, i, rms);
+    if (NORM && active) store_rms_walk(p, tile_base, li, rms);
     if (XOPT && p.norm_rew && active) store_rewnorm(p, i, rn);
     if (XOPT && p.pid_mode && active) {
 #pragma unroll

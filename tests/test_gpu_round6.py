@@ -339,13 +339,14 @@ def _time_fused(env, acts, launches=50, reps=3):
     return best
 
 
-@pytest.mark.parametrize("n", [12, 4096, 32768])
+@pytest.mark.parametrize("n", [12, 4096, 32768, 49152, 65536, 131072])
 @pytest.mark.parametrize("norm", [False, True])
 def test_dn_create_picks_a_fused_shape_within_5_percent_of_the_best(n, norm, monkeypatch):
     """the fused-launch shape is picked from tiles-per-CU crossovers calibrated on one 256-CU part, and the parity
     tests mirror that table -- a wrong crossover would only be slower, never red.  Here every shape the configuration may legally take
     (DN_WAVES = 1 2 3 4 5 8; a forced shape that does not exist for it falls back and is met once) is TIMED at BASELINE's three single-GPU
-    fleet sizes with the normaliser off and on -- 50 launches of the driver's K = 20 steps replayed from one hipGraph, best of three --
+    fleet sizes and at three sizes around and beyond the last crossover (49 152, 65 536, 131 072 drones: the one-wave kernel's territory,
+    which round 6 made 27 % faster) with the normaliser off and on -- 50 launches of the driver's K = 20 steps replayed from one hipGraph, best of three --
     and dn_create's own pick must be within 5 % (+ 0.3 us of timer grain per launch) of the fastest."""
     pkg = _gpu()
     from drl_dronenavigation_amd import tracks
