@@ -885,6 +885,31 @@ def main():
             else:
                 large = d_l
 
+    # the fused launch on larger single-GPU fleets (BASELINE configs[3] / [4] hold 131 072 / 262 144 drones in all: on one GPU they are one fleet,
+    # sharded they are the headline's 32 768 per GPU): dn_create's own shape pick per size, 64-step launches replayed from one hipGraph
+    fleet_sweep = None
+    if world == 1 and not args.profile_lite and args.mode == "many":
+        fleet_sweep = {"what": "us per vector step of the fused launch (64 steps per launch, 20 launches replayed from one hipGraph, best of 3) at larger "
+                               "fleets on ONE GPU, the shape dn_create picks at each size; workload as in the headline", "sizes": {}}
+        for n_f in (65536, 131072, 262144):
+            try:
+                torch.cuda.empty_cache()
+                env_f = pkg.DroneVecEnv(track, n_f, max_steps=max_steps, normalize_obs=args.normalize_obs, compute_dtype=args.compute_dtype, device=dev)
+                env_f.reset_tensor()
+                gf = torch.Generator(device="cpu").manual_seed(11)
+                acts_f = (torch.rand((64, n_f, 4), generator=gf, dtype=torch.float32) * 2 - 1).to(dev)
+                out_f = env_f.rollout_tensor(acts_f)
+                for _ in range(4):                                # into a mixed fleet state (episodes ending in every launch)
+                    env_f.rollout_tensor(acts_f, out=out_f)
+                us_f = time_launches(torch, dev, lambda: env_f.rollout_tensor(acts_f, out=out_f), reps=20, warm=2) / 64.0
+                wv_f = env_f.kernel_waves(fused=True)
+                fleet_sweep["sizes"][str(n_f)] = {"kernel": kernel_name(wv_f, args.compute_dtype, args.normalize_obs, True), "waves_per_64_drones": wv_f,
+                                                  "us_per_vector_step": round(us_f, 4), "value": round(n_f / (us_f * 1e-6), 1), "unit": "env-steps/s"}
+                env_f.close()
+                del acts_f, out_f
+            except Exception as exc:  # noqa: BLE001
+                fleet_sweep["sizes"][str(n_f)] = {"error": f"{type(exc).__name__}: {exc}"}
+
     # the SB3 NumPy surface (PCIe-inclusive: H2D actions, D2H obs/reward/done/found, N info dicts built in Python);
     # host bound, reported for the record only
     if world == 1 and not args.profile_lite:
@@ -1015,6 +1040,7 @@ def main():
             "hbm_bound_fleet": large,
             "hbm_copy_ceiling": copy_ceiling,
             "other_launch_shapes": others,
+            "fleet_sweep": fleet_sweep,
         }
         # the two side legs must never cost the headline line: a failure is reported in place of the numbers
         if world == 1 and not args.no_ppo_rollout:
