@@ -19,7 +19,8 @@ i=0
 FAILED=""
 for grp in "${GROUPS_[@]}"; do
     i=$((i+1))
-    rocprofv3 --kernel-trace --pmc $grp -d "$OUT/p$i" -o p$i -- python3 "$ROOT/$SCRIPT" "$@" > "$OUT/run_p$i.log" 2>&1 || FAILED="$FAILED p$i($grp)"
+    # (a pass that aborts inside rocprofv3 can hang in its signal handler for the rest of the call: bounded)
+    timeout -k 10 ${DN_PMC_PASS_TIMEOUT:-600} rocprofv3 --kernel-trace --pmc $grp -d "$OUT/p$i" -o p$i -- python3 "$ROOT/$SCRIPT" "$@" > "$OUT/run_p$i.log" 2>&1 || FAILED="$FAILED p$i($grp)"
 done
 cd "$ROOT"
 python3 - "$OUT" > "$ROOT/gpurun_out/pmc_$TAG.txt" <<'PY'
