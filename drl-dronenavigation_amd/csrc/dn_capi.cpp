@@ -42,8 +42,8 @@ inline double norm3d(const double v[3]) { return std::sqrt(v[0] * v[0] + v[1] * 
 constexpr long long DN_CALIBRATION_CUS = 256;
 constexpr long long DN_TWO_WAVE_TILES_PER_CU = 4;   // 1024 tiles = 65536 drones on 256 CUs: one tile per SIMD
 constexpr long long DN_PQX_TILES_PER_CU = 4;        // three-wave single step: while the tiles alone leave SIMDs idle
-constexpr long long DN_FIVE_WAVE_TILES_PER_CU = 3;  // the same with the normaliser on a fifth wave: wherever the four-wave kernel would run (40 960 / 49 152 drones: 2.65 / 2.84 us per step against 2.95 / 3.28)
-constexpr long long DN_ROLE_PIPE_TILES_PER_CU = 6;  // role-pipelined fused step (eight roles per tile): up to six tiles per CU, see dn_create
+constexpr long long DN_FIVE_WAVE_TILES_PER_CU = 2;  // the same with the normaliser on a fifth wave: up to two tiles per CU (round 6: beyond, the four-wave kernel's X wave carries the normaliser -- 149 registers since its statistics are addressed from a walked pair -- and wins: dn_create)
+constexpr long long DN_ROLE_PIPE_TILES_PER_CU = 6;  // role-pipelined fused step (eight roles per tile): up to one tile per CU and from three to six, see dn_create
 constexpr long long DN_FOUR_WAVE_TILES_PER_CU = 3;  // four-wave fused step: up to three tiles per CU (768 tiles on 256 CUs)
 constexpr double DN_CONTACT_MARGIN = 0.02;          // Bullet's contact-breaking threshold (dn_kernels.hip collision_common)
 constexpr double DN_COLL_R = 0.06, DN_COLL_H = 0.025;   // base_link collision cylinder, cf2x.urdf:34
@@ -406,7 +406,10 @@ int32_t dn_create(const dn_config *cfg, dn_env **out)
     // profiles/r06_sweep_large.txt): 57 344 drones 3.41 | 2.53, 65 536 3.53 | 2.70, 81 920 4.56 | 3.37, 98 304 4.67 | 3.93, 114 688
     // 4.76 | 4.58 (K = 20: 5.07 | 5.22), 131 072 4.86 | 5.16 -> eight roles up to six tiles per CU, one wave beyond.
     const bool rp_ok = plain && !cfg->ground_contact && !noisy;
-    if (rp_ok && cfg->normalize_obs && (e->blocks <= e->num_cus || (e->blocks > 2 * e->num_cus && e->blocks <= DN_ROLE_PIPE_TILES_PER_CU * e->num_cus)))
+    // ... and from two to three tiles per CU the four-wave kernel WITH the normaliser on its X wave, once its statistics are addressed from a walked
+    // scalar pair (195 -> 149 registers: three tiles = twelve waves per CU resident; four waves | five | eight roles, profiles/r06_sweep_4wnorm.txt):
+    // 34 816 drones 1.80 | 2.06 | 1.93, 40 960 1.83 | 2.13 | 1.96, 49 152 1.95 | 2.23 | 2.06, 53 248 2.66 | 3.14 | 2.44 -> four waves in (2, 3] tiles per CU.
+    if (rp_ok && cfg->normalize_obs && (e->blocks <= e->num_cus || (e->blocks > 3 * e->num_cus && e->blocks <= DN_ROLE_PIPE_TILES_PER_CU * e->num_cus)))
         e->waves_fused = 8;
     // dn_step (one control step per launch) is latency bound: 1.65 us of kernel boundary that an empty kernel already pays
     // (profiles/r03_dispatch_floor.txt; the 2.9 us of round 2 was the host's eager launch cadence), a ~1.2 us memory round trip

@@ -2889,7 +2889,7 @@ DN_DEV void step_many_4w_body(const DnParams &p, const DnStepIO &io0, const int 
     } else if (role == 4) {
         // ---- N (NW == 5): observation -> normaliser -> rows, the reset observation of a finished drone included
         Rms rms;
-        load_rms(p, i, rms);
+        load_rms(p, i, rms);                                               // (walked bases, load_rms_walk, cost this kernel 2 %: profiles/r06_notes.md section 12)
         block_lds_barrier(); MW_EDGE(1);                                   // P
 #pragma clang loop unroll(disable)
         for (int t = 0; t <= k_steps + 1; ++t) {
@@ -2912,7 +2912,7 @@ DN_DEV void step_many_4w_body(const DnParams &p, const DnStepIO &io0, const int 
         float4 G4 = b.g4[li], G5 = b.g5[li];                               // .w: Monitor return / length
         StatAcc acc;
         Rms rms;
-        if (NORM && NW == 4) load_rms(p, i, rms);
+        if (NORM && NW == 4) load_rms_walk(p, tile_base, li, rms);         // four waves with the normaliser: 195 -> 149 registers, three tiles per CU resident
         RewNorm rn = {0.0, 0.0, 1.0, 1e-4};
         const float4 *act = reinterpret_cast<const float4 *>(io0.actions) + tile_base;
         float4 A = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -2949,7 +2949,7 @@ DN_DEV void step_many_4w_body(const DnParams &p, const DnStepIO &io0, const int 
         }
         MW_EDGE(2);
         flush_stats(p, acc, sc0 + (unsigned long long)k_steps, lane);
-        if (NORM && NW == 4 && active) store_rms(p, i, rms);
+        if (NORM && NW == 4 && active) store_rms_walk(p, tile_base, li, rms);
         if (active) {
             reinterpret_cast<float *>(b.g4 + li)[3] = G4.w;
             reinterpret_cast<float *>(b.g5 + li)[3] = G5.w;

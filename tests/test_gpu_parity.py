@@ -1047,9 +1047,11 @@ def _expected_fused_waves(env, n, norm):
     tiles, cus = (n + 63) // 64, env.num_cus
     if not norm:
         return 4 if tiles <= 3 * cus else None
-    if tiles <= cus or 2 * cus < tiles <= 6 * cus:
-        return 8                                          # the role-pipelined kernel: up to one tile per CU and from two to six
-    return 5 if tiles <= 3 * cus else None
+    if tiles <= cus or 3 * cus < tiles <= 6 * cus:
+        return 8                                          # the role-pipelined kernel: up to one tile per CU and from three to six
+    if 2 * cus < tiles <= 3 * cus:
+        return 4                                          # four waves, the normaliser on the X wave (round 6: its statistics addressed from a walked pair)
+    return 5 if tiles <= 2 * cus else None
 
 
 @pytest.mark.parametrize("n,norm,K", [(32768, False, 64), (32768, True, 20), (32768, True, 64),
@@ -1059,7 +1061,7 @@ def test_baseline_full_size_fused_launch_matches_oracle(n, norm, K, monkeypatch)
     """The bench's own launches -- race track, K steps of U(-1,1)^4 actions in ONE dn_step_many (K = 20 is the driver's launch, 64 the
     default line's) -- against the oracle, every drone, every step, every output; then the mixed stream.  32 768 drones: the headline
     size (five waves with the normaliser, four without); 4 096 / 16 384 / 49 152 / 65 536 / 98 304 drones with the normaliser: sizes at which
-    dn_create picks the eight-role kernel, met here by the oracle DIRECTLY (long runs: the register-resident _current_position, second
+    dn_create picks the eight-role kernel (49 152: the four-wave kernel with the normaliser), met here by the oracle DIRECTLY (long runs: the register-resident _current_position, second
     episodes inside one launch), not only through bit-identity with the one-wave kernel.
 
     Free-running: both sides keep their own float32 state, so a drone whose yaw or roll sits within rounding of +-pi comes out on the
