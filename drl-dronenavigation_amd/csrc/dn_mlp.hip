@@ -385,6 +385,7 @@ MLP_DEV void layer_lds_c(const uint4 *__restrict__ w, const float *lbias, const 
                          const u32x4 (&in)[CHUNK], u32x4 (&out)[2 * MT], uint4 *lds, const int wave, const int lane)
 {
     constexpr int SYNC = CHUNK - LDS_RING;
+    static_assert(CHUNK % LDS_RING == 0, "the ring slot of K-step kk is kk % LDS_RING in EVERY tile: the ring must divide the chunk");
     const int g = lane >> 5;
     f32x16 bnext, prev;
     bias_init(lbias, 0, g, bnext);
@@ -1231,6 +1232,7 @@ MLP_DEV f32x16 sac_stream(const MlpNetDev &net, const float *lbias, uint4 *lds, 
     constexpr int PER = X3 ? 2 : 1, TPC = X3 ? 1 : 2, NL2 = L2T / TPC;     // layer-2 tiles per chunk, layer-2 chunks; the heads are chunk NL2
     constexpr int RG = 4;                                                  // ring depth in K-steps
     static_assert(S2 / 16 == KS, "the heads are streamed as a ninth tile of layer 2's K");
+    static_assert(KS % RG == 0, "the ring slot of K-step kk is kk % RG in every tile");
     const int g = lane >> 5;
     auto chunk_of = [](const int t) { return t < L2T ? t / TPC : NL2; };
     auto off_of = [](const int t) { return t < L2T ? (t % TPC) * KS * PER : 0; };   // hi fragment kk at off + kk, lo at off + KS + kk
